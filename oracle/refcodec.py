@@ -1,0 +1,200 @@
+"""ctypes driver for the COMPILED, UNMODIFIED reference (oracle/_ref/libsolo_ref_{fix,flp}.so).
+
+TEST INFRASTRUCTURE ONLY.  Nothing in solo_amd/ imports this module.  It is used by tests/,
+by __graft_entry__.smoke() and by bench.py's cpu_baseline leg as the checker / reported baseline.
+
+The library is built by `make -C oracle ref` from the sources where they lie under
+/root/reference (see oracle/Makefile); the built .so travels to the GPU box, the sources do not.
+
+Interface driven (reference file:line):
+  AGR_Sate_Encoder_Init / _Encode / _Uninit   JC1_SDK_SRC_ARM/interface/AGR_JC1_SDK_API.h:33-47
+  AGR_Sate_Decoder_Init / _Decode / _Uninit   JC1_SDK_SRC_ARM/interface/AGR_JC1_SDK_API.h:49-64
+Harness behaviour mirrored (framing, loss -> lostflag mapping):
+  JC1_SDK_SRC_ARM/test/enc_main.c:190-253, JC1_SDK_SRC_ARM/test/dec_main.c:202-378
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PACKET_SAMPLES = 640
+MAX_FRAME_BYTES = 1024
+
+
+class USER_Ctrl_enc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "targetRate_bps", "samplerate", "dtx_enable", "framesize_ms",
+        "joint_enable", "joint_mode", "useMDIndex")]
+
+
+class USER_Ctrl_dec(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "packetLoss_perc", "samplerate", "framesize_ms", "joint_enable", "joint_mode", "useMDIndex")]
+
+
+def ref_lib_path(kind="fix"):
+    return os.path.join(_HERE, "_ref", "libsolo_ref_%s.so" % kind)
+
+
+def have_ref(kind="fix"):
+    return os.path.exists(ref_lib_path(kind))
+
+
+_libs = {}
+
+
+def load_ref(kind="fix"):
+    if kind not in _libs:
+        lib = C.CDLL(ref_lib_path(kind))
+        lib.AGR_Sate_Encoder_Init.restype = C.c_void_p
+        lib.AGR_Sate_Encoder_Init.argtypes = [C.POINTER(USER_Ctrl_enc)]
+        lib.AGR_Sate_Encoder_Encode.restype = C.c_int32
+        lib.AGR_Sate_Encoder_Encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+        lib.AGR_Sate_Encoder_Uninit.argtypes = [C.c_void_p]
+        lib.AGR_Sate_Decoder_Init.restype = C.c_void_p
+        lib.AGR_Sate_Decoder_Init.argtypes = [C.POINTER(USER_Ctrl_dec)]
+        lib.AGR_Sate_Decoder_Decode.restype = C.c_int32
+        lib.AGR_Sate_Decoder_Decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+        lib.AGR_Sate_Decoder_Uninit.argtypes = [C.c_void_p]
+        _libs[kind] = lib
+    return _libs[kind]
+
+
+def default_enc_ctrl(rate=13600, use_md_index=0):
+    # defaults of the reference CLI: JC1_SDK_SRC_ARM/test/enc_main.c:92-99
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=0,
+                         framesize_ms=40, joint_enable=0, joint_mode=0, useMDIndex=use_md_index)
+
+
+def default_dec_ctrl(use_md_index=0):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=16000, framesize_ms=40,
+                         joint_enable=0, joint_mode=0, useMDIndex=use_md_index)
+
+
+class RefEncoder:
+    def __init__(self, kind="fix", rate=13600):
+        self.lib = load_ref(kind)
+        self.ctrl = default_enc_ctrl(rate)
+        self.h = self.lib.AGR_Sate_Encoder_Init(C.byref(self.ctrl))
+        assert self.h
+        self._bits = np.zeros(MAX_FRAME_BYTES, np.uint8)
+        self._nb = np.zeros(6, np.int16)
+
+    def encode(self, pcm640):
+        """-> (payload bytes, nBytes0 total, nBytes1 = len(MD2)+HB)"""
+        pcm = np.ascontiguousarray(pcm640, dtype=np.int16)
+        assert pcm.size == PACKET_SAMPLES
+        self._nb[:] = 0
+        n = self.lib.AGR_Sate_Encoder_Encode(self.h, pcm.ctypes.data, self._bits.ctypes.data,
+                                             MAX_FRAME_BYTES, self._nb.ctypes.data)
+        return self._bits[:n].tobytes(), int(self._nb[0]), int(self._nb[1])
+
+    def close(self):
+        if self.h:
+            self.lib.AGR_Sate_Encoder_Uninit(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+class RefDecoder:
+    def __init__(self, kind="fix"):
+        self.lib = load_ref(kind)
+        self.ctrl = default_dec_ctrl()
+        self.h = self.lib.AGR_Sate_Decoder_Init(C.byref(self.ctrl))
+        assert self.h
+        self._pcm = np.zeros(1920, np.int16)
+        self._ns = np.zeros(1, np.int16)
+        self._nb = np.zeros(6, np.int16)
+
+    def decode(self, payload, nbytes0, nbytes1, lostflag):
+        """payload: bytes handed to the decoder (already offset per the harness mapping)."""
+        buf = np.zeros(MAX_FRAME_BYTES, np.uint8)
+        pl = np.frombuffer(payload, np.uint8)
+        buf[:pl.size] = pl
+        self._nb[:] = 0
+        self._nb[0] = nbytes0
+        self._nb[1] = nbytes1
+        ret = self.lib.AGR_Sate_Decoder_Decode(self.h, self._pcm.ctypes.data, self._ns.ctypes.data,
+                                               buf.ctypes.data, self._nb.ctypes.data, int(lostflag))
+        return self._pcm[:PACKET_SAMPLES].copy(), ret
+
+    def close(self):
+        if self.h:
+            self.lib.AGR_Sate_Decoder_Uninit(self.h)
+            self.h = None
+
+    __del__ = close
+
+
+# ---------------------------------------------------------------------------------------------
+# harness-side helpers shared by the tests (pure data plumbing, no codec arithmetic)
+# ---------------------------------------------------------------------------------------------
+def map_loss(payload, n0, n1, lost_md1, lost_md2):
+    """(payload, nBytes0, nBytes1, lostflag) the decoder is called with for a given loss pattern.
+    Mirrors JC1_SDK_SRC_ARM/test/dec_main.c:255-378 (_SIMU1_ mapping; both branches are identical
+    in effect for the 2-description case)."""
+    if not lost_md1 and not lost_md2:
+        return payload, n0, n1, 4
+    if not lost_md1 and lost_md2:
+        return payload[:n0 - n1], n0 - n1, 0, 2
+    if lost_md1 and not lost_md2:
+        return payload[n0 - n1:], n1, 0, 3
+    return b"", n0, n1, 1
+
+
+def skp_rand(seed):
+    # JC1_SDK_SRC_ARM/test/dec_main.c:24 (int32 wrap-around)
+    return (907633515 + (seed * 196314165)) & 0xFFFFFFFF
+
+
+def cli_loss_pattern(n_packets, loss_perc, md_nbytes=None):
+    """The loss draws of the reference decoder CLI (`-loss P`): rand_seed=1, two draws on every
+    EVEN packet (run_count % 2 == 0), pattern reused for the following odd packet
+    (JC1_SDK_SRC_ARM/test/dec_main.c:236-252)."""
+    seed = 1
+    out = []
+    lost = [0, 0]
+    thr = np.float32(loss_perc) / np.float32(100.0)
+    for p in range(n_packets):
+        if p % 2 == 0:
+            for j in range(2):
+                seed = skp_rand(seed)
+                s = seed - (1 << 32) if seed & 0x80000000 else seed
+                v = np.float32((s >> 16) + (1 << 15)) / np.float32(65535.0)
+                if v >= thr:
+                    lost[j] = 1 if (md_nbytes is not None and md_nbytes[p][j] == 0) else 0
+                else:
+                    lost[j] = 1
+        out.append(tuple(lost))
+    return out
+
+
+def synth_stream(stream_index, n_packets, base_seed=0x50100000):
+    """Synthetic speech-like 16 kHz int16 stream (BASELINE.md section 4 generator)."""
+    rng = np.random.default_rng(base_seed + int(stream_index))
+    n = n_packets * PACKET_SAMPLES
+    fs = 16000.0
+    t = np.arange(n) / fs
+    f0 = rng.uniform(90.0, 250.0)
+    vib = 1.0 + 0.02 * np.sin(2 * np.pi * 3.0 * t + rng.uniform(0, 2 * np.pi))
+    phase = 2 * np.pi * np.cumsum(f0 * vib) / fs
+    sig = np.zeros(n)
+    h = 1
+    while h * f0 * 1.02 < 7500.0:
+        sig += np.sin(h * phase + rng.uniform(0, 2 * np.pi)) / h
+        h += 1
+    # syllabic on/off envelope, ~60 % active, 5 ms ramps
+    env = np.zeros(n)
+    pos = 0
+    while pos < n:
+        on = int(rng.uniform(0.12, 0.45) * fs)
+        off = int(rng.uniform(0.05, 0.30) * fs)
+        env[pos:pos + on] = rng.uniform(0.3, 1.0)
+        pos += on + off
+    k = int(0.005 * fs)
+    env = np.convolve(env, np.ones(k) / k, mode="same")
+    sig = sig * env
+    peak = np.max(np.abs(sig)) + 1e-9
+    sig = sig / peak * 12000.0 + rng.normal(0.0, 200.0, n)
+    return np.clip(np.rint(sig), -32768, 32767).astype(np.int16).reshape(n_packets, PACKET_SAMPLES)

@@ -1,0 +1,270 @@
+// solo_common.h -- small DSP building blocks shared by the encoder and decoder kernels
+// (LPC/NLSF conversions, stabilisers, energy with the reference's block-shift rule, short filters).
+// Wave-uniform unless a function says "wave-parallel".  Reference paths are relative to
+// JC1_SDK_SRC_ARM/src/libSATECodec/.
+#pragma once
+#include "solo_wave.h"
+
+#if defined(__HIPCC__)
+#define SOLO_TAB static __device__ const
+#else
+#define SOLO_TAB static const
+#endif
+#include "solo_tables.inc"
+
+#define SX_LPC 10          // predictLPCOrder at fs_kHz == 8   (SKP_Silk_control_codec_FIX.c:278)
+#define SX_MAX_LPC 16      // MAX_LPC_ORDER                    (SKP_Silk_define.h:200)
+#define SX_HB_LPC 8        // BWE_LPCOrder                     (libBWE/AGR_BWE_SDK_API.c:106)
+#define SX_FRAME 160       // 20 ms @ 8 kHz
+#define SX_SUBFR 40
+#define SX_NB_SUBFR 4
+#define SX_LTP_ORDER 5
+
+// SKP_Silk_bwexpander, SKP_Silk_bwexpander.c:31
+SX_HD void sx_bwexpander(i16* ar, int d, i32 chirp_Q16) {
+    i32 chirp_minus_one_Q16 = chirp_Q16 - 65536;
+    for (int i = 0; i < d - 1; i++) {
+        ar[i] = (i16)sx_rshift_round(sx_mul(chirp_Q16, ar[i]), 16);
+        chirp_Q16 = sx_add(chirp_Q16, sx_rshift_round(sx_mul(chirp_Q16, chirp_minus_one_Q16), 16));
+    }
+    ar[d - 1] = (i16)sx_rshift_round(sx_mul(chirp_Q16, ar[d - 1]), 16);
+}
+
+// SKP_Silk_bwexpander_32, SKP_Silk_bwexpander_32.c:31
+SX_HD void sx_bwexpander_32(i32* ar, int d, i32 chirp_Q16) {
+    i32 tmp = chirp_Q16;
+    for (int i = 0; i < d - 1; i++) {
+        ar[i] = sx_smulww(ar[i], tmp);
+        tmp = sx_smulww(chirp_Q16, tmp);
+    }
+    ar[d - 1] = sx_smulww(ar[d - 1], tmp);
+}
+
+// LPC_inverse_pred_gain_QA, SKP_Silk_LPC_inv_pred_gain.c:43.  A_QA holds the coefficients in Q16
+// in row (order & 1).  Returns 1 if unstable.
+SX_HD int sx_lpc_inv_pred_gain_QA(i32* invGain_Q30, i32 A_QA[2][SX_MAX_LPC], int order) {
+    const i32 A_LIMIT = 65520;  // SKP_FIX_CONST( 0.99975, 16 ) = (int)(65519.616 + 0.5)
+    i32* Anew = A_QA[order & 1];
+    *invGain_Q30 = 1 << 30;
+    for (int k = order - 1; k > 0; k--) {
+        if (Anew[k] > A_LIMIT || Anew[k] < -A_LIMIT) return 1;
+        i32 rc_Q31 = sx_neg(sx_shl(Anew[k], 31 - 16));
+        i32 rc_mult1_Q30 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+        i32 rc_mult2_Q16 = sx_inverse32_varQ(rc_mult1_Q30, 46);
+        *invGain_Q30 = sx_shl(sx_smmul(*invGain_Q30, rc_mult1_Q30), 2);
+        i32* Aold = Anew;
+        Anew = A_QA[k & 1];
+        int headrm = sx_clz32(rc_mult2_Q16) - 1;
+        rc_mult2_Q16 = sx_shl(rc_mult2_Q16, headrm);
+        for (int n = 0; n < k; n++) {
+            i32 tmp = sx_sub(Aold[n], sx_shl(sx_smmul(Aold[k - n - 1], rc_Q31), 1));
+            Anew[n] = sx_shl(sx_smmul(tmp, rc_mult2_Q16), 16 - headrm);
+        }
+    }
+    if (Anew[0] > A_LIMIT || Anew[0] < -A_LIMIT) return 1;
+    i32 rc_Q31 = sx_neg(sx_shl(Anew[0], 31 - 16));
+    i32 rc_mult1_Q30 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+    *invGain_Q30 = sx_shl(sx_smmul(*invGain_Q30, rc_mult1_Q30), 2);
+    return 0;
+}
+// SKP_Silk_LPC_inverse_pred_gain (Q12 input), SKP_Silk_LPC_inv_pred_gain.c:113
+SX_HD int sx_lpc_inv_pred_gain(i32* invGain_Q30, const i16* A_Q12, int order) {
+    i32 A[2][SX_MAX_LPC];
+    for (int k = 0; k < order; k++) A[order & 1][k] = sx_shl((i32)A_Q12[k], 4);
+    return sx_lpc_inv_pred_gain_QA(invGain_Q30, A, order);
+}
+// SKP_Silk_LPC_inverse_pred_gain_Q24, SKP_Silk_LPC_inv_pred_gain.c:134
+SX_HD int sx_lpc_inv_pred_gain_Q24(i32* invGain_Q30, const i32* A_Q24, int order) {
+    i32 A[2][SX_MAX_LPC];
+    for (int k = 0; k < order; k++) A[order & 1][k] = sx_rshift_round(A_Q24[k], 8);
+    return sx_lpc_inv_pred_gain_QA(invGain_Q30, A, order);
+}
+
+// SKP_Silk_NLSF2A_find_poly, SKP_Silk_NLSF2A.c:37
+SX_HD void sx_nlsf2a_find_poly(i32* out, const i32* cLSF, int dd) {
+    out[0] = 1 << 20;
+    out[1] = sx_neg(cLSF[0]);
+    for (int k = 1; k < dd; k++) {
+        i32 ftmp = cLSF[2 * k];
+        out[k + 1] = sx_sub(sx_shl(out[k - 1], 1), (i32)sx_rshift_round64(sx_smull(ftmp, out[k]), 20));
+        for (int n = k; n > 1; n--)
+            out[n] = sx_add(out[n], sx_sub(out[n - 2], (i32)sx_rshift_round64(sx_smull(ftmp, out[n - 1]), 20)));
+        out[1] = sx_sub(out[1], ftmp);
+    }
+}
+
+// SKP_Silk_NLSF2A, SKP_Silk_NLSF2A.c:59   (d even, <= 16)
+SX_HD void sx_nlsf2a(i16* a, const i32* NLSF, int d) {
+    i32 cos_LSF_Q20[SX_MAX_LPC], P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1], a32[SX_MAX_LPC];
+    for (int k = 0; k < d; k++) {
+        i32 f_int = NLSF[k] >> 8;
+        i32 f_frac = NLSF[k] - (f_int << 8);
+        i32 cos_val = T_lsf_cos_Q12[f_int];
+        i32 delta = T_lsf_cos_Q12[f_int + 1] - cos_val;
+        cos_LSF_Q20[k] = sx_add(sx_shl(cos_val, 8), sx_mul(delta, f_frac));
+    }
+    int dd = d >> 1;
+    sx_nlsf2a_find_poly(P, &cos_LSF_Q20[0], dd);
+    sx_nlsf2a_find_poly(Q, &cos_LSF_Q20[1], dd);
+    for (int k = 0; k < dd; k++) {
+        i32 Ptmp = sx_add(P[k + 1], P[k]);
+        i32 Qtmp = sx_sub(Q[k + 1], Q[k]);
+        a32[k] = sx_neg(sx_rshift_round(sx_add(Ptmp, Qtmp), 9));
+        a32[d - k - 1] = sx_rshift_round(sx_sub(Qtmp, Ptmp), 9);
+    }
+    int i;
+    for (i = 0; i < 10; i++) {
+        i32 maxabs = 0, idx = 0;
+        for (int k = 0; k < d; k++) {
+            i32 av = sx_abs(a32[k]);
+            if (av > maxabs) { maxabs = av; idx = k; }
+        }
+        if (maxabs > 32767) {
+            maxabs = sx_min(maxabs, 98369);
+            i32 sc_Q16 = 65470 - sx_mul(65470 >> 2, maxabs - 32767) / (sx_mul(maxabs, idx + 1) >> 2);
+            sx_bwexpander_32(a32, d, sc_Q16);
+        } else {
+            break;
+        }
+    }
+    if (i == 10) {
+        for (int k = 0; k < d; k++) a32[k] = sx_sat16(a32[k]);
+    }
+    for (int k = 0; k < d; k++) a[k] = (i16)a32[k];
+}
+
+// SKP_Silk_NLSF2A_stable, SKP_Silk_NLSF2A_stable.c:31
+SX_HD void sx_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF, int order) {
+    i32 invGain_Q30;
+    sx_nlsf2a(pAR_Q12, pNLSF, order);
+    int i;
+    for (i = 0; i < 20; i++) {
+        if (sx_lpc_inv_pred_gain(&invGain_Q30, pAR_Q12, order) == 1)
+            sx_bwexpander(pAR_Q12, order, 65536 - sx_smulbb(10 + i, i));
+        else
+            break;
+    }
+    if (i == 20) {
+        for (i = 0; i < order; i++) pAR_Q12[i] = 0;
+    }
+}
+
+// SKP_Silk_NLSF_stabilize, SKP_Silk_NLSF_stabilize.c:42   (NDeltaMin has L+1 entries)
+SX_HD void sx_nlsf_stabilize(i32* NLSF_Q15, const i32* NDeltaMin_Q15, int L) {
+    int loops;
+    for (loops = 0; loops < 20; loops++) {
+        i32 min_diff = NLSF_Q15[0] - NDeltaMin_Q15[0];
+        int I = 0;
+        for (int i = 1; i <= L - 1; i++) {
+            i32 diff = NLSF_Q15[i] - (NLSF_Q15[i - 1] + NDeltaMin_Q15[i]);
+            if (diff < min_diff) { min_diff = diff; I = i; }
+        }
+        i32 diff = (1 << 15) - (NLSF_Q15[L - 1] + NDeltaMin_Q15[L]);
+        if (diff < min_diff) { min_diff = diff; I = L; }
+        if (min_diff >= 0) return;
+        if (I == 0) {
+            NLSF_Q15[0] = NDeltaMin_Q15[0];
+        } else if (I == L) {
+            NLSF_Q15[L - 1] = (1 << 15) - NDeltaMin_Q15[L];
+        } else {
+            i32 min_center = 0;
+            for (int k = 0; k < I; k++) min_center += NDeltaMin_Q15[k];
+            min_center += NDeltaMin_Q15[I] >> 1;
+            i32 max_center = 1 << 15;
+            for (int k = L; k > I; k--) max_center -= NDeltaMin_Q15[k];
+            max_center -= (NDeltaMin_Q15[I] - (NDeltaMin_Q15[I] >> 1));
+            i32 center = sx_limit(sx_rshift_round(NLSF_Q15[I - 1] + NLSF_Q15[I], 1), min_center, max_center);
+            NLSF_Q15[I - 1] = center - (NDeltaMin_Q15[I] >> 1);
+            NLSF_Q15[I] = NLSF_Q15[I - 1] + NDeltaMin_Q15[I];
+        }
+    }
+    // fall-back (SKP_Silk_NLSF_stabilize.c:117-137): insertion sort, then clamp both ways
+    for (int i = 1; i < L; i++) {
+        i32 value = NLSF_Q15[i];
+        int j;
+        for (j = i - 1; j >= 0 && value < NLSF_Q15[j]; j--) NLSF_Q15[j + 1] = NLSF_Q15[j];
+        NLSF_Q15[j + 1] = value;
+    }
+    NLSF_Q15[0] = sx_max(NLSF_Q15[0], NDeltaMin_Q15[0]);
+    for (int i = 1; i < L; i++) NLSF_Q15[i] = sx_max(NLSF_Q15[i], NLSF_Q15[i - 1] + NDeltaMin_Q15[i]);
+    NLSF_Q15[L - 1] = sx_min(NLSF_Q15[L - 1], (1 << 15) - NDeltaMin_Q15[L]);
+    for (int i = L - 2; i >= 0; i--) NLSF_Q15[i] = sx_min(NLSF_Q15[i], NLSF_Q15[i + 1] - NDeltaMin_Q15[i + 1]);
+}
+
+// SKP_Silk_NLSF_VQ_weights_laroia, SKP_Silk_NLSF_VQ_weights_laroia.c:40   (D even)
+SX_HD void sx_nlsf_weights_laroia(i32* pW_Q6, const i32* pNLSF_Q15, int D) {
+    i32 t1 = sx_max(pNLSF_Q15[0], 3);
+    t1 = (1 << 21) / t1;
+    i32 t2 = sx_max(pNLSF_Q15[1] - pNLSF_Q15[0], 3);
+    t2 = (1 << 21) / t2;
+    pW_Q6[0] = sx_min(t1 + t2, 32767);
+    for (int k = 1; k < D - 1; k += 2) {
+        t1 = sx_max(pNLSF_Q15[k + 1] - pNLSF_Q15[k], 3);
+        t1 = (1 << 21) / t1;
+        pW_Q6[k] = sx_min(t1 + t2, 32767);
+        t2 = sx_max(pNLSF_Q15[k + 2] - pNLSF_Q15[k + 1], 3);
+        t2 = (1 << 21) / t2;
+        pW_Q6[k + 1] = sx_min(t1 + t2, 32767);
+    }
+    t1 = sx_max((1 << 15) - pNLSF_Q15[D - 1], 3);
+    t1 = (1 << 21) / t1;
+    pW_Q6[D - 1] = sx_min(t1 + t2, 32767);
+}
+
+// SKP_Silk_sum_sqr_shift, SKP_Silk_sum_sqr_shift.c:40.  The reference's result depends on whether
+// the int16 pointer is 4-byte aligned (it then accumulates in sample PAIRS and tests for overflow
+// once per pair); `odd_start` = 1 reproduces the "pointer & 2" branch.  Wave-uniform, serial.
+SX_HD void sx_sum_sqr_shift(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
+    i32 nrg, nrg_tmp;
+    int i, shft = 0;
+    if (odd_start) { nrg = sx_smulbb(x[0], x[0]); i = 1; } else { nrg = 0; i = 0; }
+    len--;
+    while (i < len) {
+        nrg = sx_add(nrg, sx_smulbb(x[i], x[i]));
+        nrg = sx_add(nrg, sx_smulbb(x[i + 1], x[i + 1]));
+        i += 2;
+        if (nrg < 0) { nrg = (i32)((u32)nrg >> 2); shft = 2; break; }
+    }
+    for (; i < len; i += 2) {
+        nrg_tmp = sx_smulbb(x[i], x[i]);
+        nrg_tmp = sx_add(nrg_tmp, sx_smulbb(x[i + 1], x[i + 1]));
+        nrg = (i32)((u32)nrg + ((u32)nrg_tmp >> shft));
+        if (nrg < 0) { nrg = (i32)((u32)nrg >> 2); shft += 2; }
+    }
+    if (i == len) {
+        nrg_tmp = sx_smulbb(x[i], x[i]);
+        nrg = (i32)((u32)nrg + ((u32)nrg_tmp >> shft));
+    }
+    if (nrg & 0xC0000000) { nrg = (i32)((u32)nrg >> 2); shft += 2; }
+    *shift = shft;
+    *energy = nrg;
+}
+
+// SKP_Silk_LPC_analysis_filter, SKP_Silk_MA.c:70 with a ZERO initial state, as a direct-form FIR:
+//   out[k] = sat16( rshift_round( sub_sat32( in[k] << 12, sum_j B[j] * in[k-1-j] ), 12 ) ),  in[<0] = 0
+// (the reference's delay-line update is a plain shift, and its SMLABB accumulation wraps, so the
+// tap order is irrelevant).  Wave-parallel over k; caller must wv_sync() afterwards.
+SX_HD void sx_lpc_analysis_filter_zero_state(const i16* in, const i16* B, i16* out, int len, int order) {
+    SX_PAR(k, len) {
+        i32 acc = 0;
+        for (int j = 0; j < order; j++) {
+            int t = k - 1 - j;
+            if (t >= 0) acc = sx_smlabb(acc, in[t], B[j]);
+        }
+        i32 o = sx_sub_sat32(sx_shl((i32)in[k], 12), acc);
+        out[k] = (i16)sx_sat16(sx_rshift_round(o, 12));
+    }
+}
+
+// SKP_Silk_sigm_Q15, SKP_Silk_sigm_Q15.c:54
+SX_HD i32 sx_sigm_Q15(i32 in_Q5) {
+    if (in_Q5 < 0) {
+        in_Q5 = -in_Q5;
+        if (in_Q5 >= 6 * 32) return 0;
+        int ind = in_Q5 >> 5;
+        return T_sigm_neg_Q15[ind] - sx_smulbb(T_sigm_slope_Q10[ind], in_Q5 & 0x1F);
+    }
+    if (in_Q5 >= 6 * 32) return 32767;
+    int ind = in_Q5 >> 5;
+    return T_sigm_pos_Q15[ind] + sx_smulbb(T_sigm_slope_Q10[ind], in_Q5 & 0x1F);
+}

@@ -1,0 +1,874 @@
+// solo_dec.h -- SOLO decoder hot path (AGR_Sate_Decoder_Decode), one wavefront per stream.
+//
+// Rows D0-D8 of SURVEY.md section 8(a): range decoding of one or two descriptions, inverse NSQ
+// (single-description rescale / two-description merge), LTP + LPC synthesis, PLC, CNG, high-band
+// resynthesis and 64-tap QMF synthesis.  Specialised to the live configuration (16 kHz API rate,
+// SILK running NB at 8 kHz, LPC order 10, 2 descriptions, 2 x 20 ms frames per 40 ms packet).
+//
+// Reference files restated here (JC1_SDK_SRC_ARM/src/...):
+//   libBWE/AGR_BWE_SDK_API.c:249-280, libBWE/AGR_BWE_decode_frame_FIX.c:40-197, libBWE/AGR_BWE_qmf.c:86-182,
+//   libBWE/AGR_BWE_LPC_synthesizer.c:56-136, libBWE/AGR_BWE_quant_highband.c:106-121, libBWE/AGR_BWE_bits.c:135
+//   libSATECodec/SKP_Silk_dec_API.c:76-188, SKP_Silk_decode_frame.c:33-395, SKP_Silk_decode_parameters.c:31-261,
+//   SKP_Silk_decode_pulses.c:33, SKP_Silk_shell_coder.c:59-155, SKP_Silk_code_signs.c:64, SKP_Silk_gain_quant.c:110,
+//   SKP_Silk_NLSF_MSVQ_decode.c:31, SKP_Silk_decode_pitch.c:34, SKP_Silk_decode_core.c:43-288, SKP_Silk_PLC.c:36-417,
+//   SKP_Silk_CNG.c:31-149, SKP_Silk_MA.c:40, SKP_Silk_LPC_synthesis_filter.c:37, SKP_Silk_decoder_set_fs.c:31,
+//   SKP_Silk_create_init_destroy.c:34
+#pragma once
+#include "solo_common.h"
+#include "solo_rc.h"
+
+#define SX_PACKET 640            // 40 ms @ 16 kHz
+#define SX_BAND 320              // samples per band per packet
+#define SX_HB_BYTES 8            // 2 x HB_BYTE (libBWE/AGR_BWE_defines.h:39)
+#define SX_QMF_HIST 32           // synthesis memory per band (M2)
+
+// ---- persistent per-stream decoder state (HBM) ---------------------------------------------------
+struct SxDecDesc {               // SKP_Silk_md_decoder_state, SKP_Silk_structs.h:295 (live fields)
+    i32 LastGainIndex;
+    i32 prevNLSF_Q15[SX_LPC];
+    i32 typeOffsetPrev;
+    i32 prevDeltaGainIndex;
+};
+struct SxPLC {                   // SKP_Silk_PLC_struct, SKP_Silk_structs.h:268
+    i32 pitchL_Q8;
+    i16 LTPCoef_Q14[SX_LTP_ORDER];
+    i16 prevLPC_Q12[SX_LPC];
+    i32 last_frame_lost;
+    i32 rand_seed;
+    i16 randScale_Q14;
+    i16 prevLTP_scale_Q14;
+    i32 conc_energy;
+    i32 conc_energy_shift;
+    i32 prevGain_Q16[SX_NB_SUBFR];
+    i32 fs_kHz;
+};
+struct SxCNG {                   // SKP_Silk_CNG_struct, SKP_Silk_structs.h:283
+    i32 exc_buf_Q10[SX_FRAME];
+    i32 smth_NLSF_Q15[SX_LPC];
+    i32 synth_state[SX_LPC];
+    i32 smth_Gain_Q16;
+    i32 rand_seed;
+    i32 fs_kHz;
+};
+struct SxDecState {
+    SxDecDesc md[2];
+    i32 prev_inv_gain_Q16;
+    i32 sLTP_Q16[2 * SX_FRAME];
+    i32 sLPC_Q14[SX_MAX_LPC];
+    i32 exc_Q10[SX_FRAME];
+    i16 outBuf[2 * SX_FRAME];
+    i32 lagPrev;
+    i32 first_frame_after_reset;
+    i32 nFramesDecoded;
+    i32 moreInternalDecoderFrames;
+    i32 FrameTermination;
+    i32 vadFlag;
+    i32 lossCnt;
+    i32 prev_sigtype;
+    i32 nBytesLeft0;
+    i32 started;                 // 0 until the first received packet switched the decoder to 8 kHz
+    SxCNG cng;
+    SxPLC plc;
+    // high band + QMF (AGR_Sate_decoder_hb_state_FIX / AGR_Sate_HB_decoder_control_FIX)
+    i32 hb_lossCnt;
+    i32 hb_first;
+    i32 HB_prev_NLSFq[SX_HB_LPC];
+    i32 HB_synth_state[SX_HB_LPC];
+    i32 HB_prev_Gain;
+    i16 qmf_lo_hist[SX_QMF_HIST];   // last 32 low-band samples, time order (g0_mem of the reference, re-laid-out)
+    i16 qmf_hi_hist[SX_QMF_HIST];
+    i32 last_error;
+};
+
+// ---- per-packet working set (LDS) ----------------------------------------------------------------
+struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h:362
+    i32 pitchL[SX_NB_SUBFR];
+    i32 Gains_Q16[SX_NB_SUBFR];
+    i32 DeltaGains_Q16;
+    i32 Seed;
+    i16 PredCoef_Q12[2][SX_MAX_LPC];
+    i16 LTPCoef_Q14[SX_LTP_ORDER * SX_NB_SUBFR];
+    i32 LTP_scale_Q14;
+    i32 PERIndex, RateLevelIndex, QuantOffsetType, sigtype, MDIndex, NLSFInterpCoef_Q2;
+};
+struct SxDecWork {
+    SxDecCtrl ctrl;
+    i32 pulses[2][SX_FRAME];
+    i32 res_Q10[SX_FRAME];          // LPC residual of the current frame
+    i32 sLPC_Q14[SX_MAX_LPC + SX_SUBFR];
+    i32 sig_Q10[SX_FRAME];          // PLC / scratch
+    i16 sLTP[SX_FRAME];             // re-whitened history
+    i16 tmp16[SX_FRAME];            // exc_buf (PLC) / CNG_sig
+    i32 exc_pkt_Q10[SX_BAND];       // low-band excitation of both frames -> high-band regeneration
+    i16 lo[SX_QMF_HIST + SX_BAND];  // [history | packet] low band
+    i16 hi[SX_QMF_HIST + SX_BAND];  // [history | packet] high band
+};
+
+// SKP_Silk_init_decoder + first decoder_set_fs(8) folded together (create_init_destroy.c:34,
+// decoder_set_fs.c:31).  The reference starts at 24 kHz and switches to 8 kHz when the first
+// payload is parsed; every field touched by that switch has the same value here, so the state after
+// the first received packet is identical.  (A LOST first packet would run the 24 kHz PLC + resampler
+// in the reference; that corner is out of scope -- see DESIGN.md.)
+SX_HD void sx_dec_state_init(SxDecState* st) {
+    u8* p = (u8*)st;
+    SX_PAR(i, (int)sizeof(SxDecState)) p[i] = 0;
+    wv_sync();
+    st->lagPrev = 100;
+    st->first_frame_after_reset = 1;
+    st->prev_inv_gain_Q16 = 65536;
+    st->md[0].LastGainIndex = 1;
+    st->md[1].LastGainIndex = 1;
+    st->hb_first = 1;
+    // CNG / PLC are (re)initialised on the first call because their fs_kHz field is 0
+    wv_sync();
+}
+
+// SKP_Silk_gains_dequant, SKP_Silk_gain_quant.c:110 (md_enable = 1)
+SX_HD void sx_gains_dequant(i32* gain_Q16, const i32* ind, i32* prev_ind, int conditional, int ind2, i32* DeltaGains_Q16) {
+    const i32 OFFSET = (6 * 128) / 6 + 16 * 128;                                  // gain_quant.c:30
+    const i32 INV_SCALE_Q16 = (65536 * (((86 - 6) * 128) / 6)) / (64 - 1);        // gain_quant.c:32
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        if (k == 0 && conditional == 0) *prev_ind = ind[k];
+        else *prev_ind += ind[k] + (-4);
+        gain_Q16[k] = sx_log2lin(sx_min(sx_smulwb(INV_SCALE_Q16, *prev_ind) + OFFSET, 3967));
+    }
+    i32 inv_gain_Q16 = (ind2 + 1) * (32768 / 8) + 32767;                           // gain_quant.c:138-139
+    *DeltaGains_Q16 = sx_inverse32_varQ(sx_max(inv_gain_Q16, 1), 32);
+}
+
+// decode_split + SKP_Silk_shell_decoder, SKP_Silk_shell_coder.c:59-155 (scalars stay in registers)
+SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* table) {
+    if (p > 0) {
+        *c1 = sx_rc_dec(rc, &table[T_shell_offsets[p]], p >> 1);
+        *c2 = p - *c1;
+    } else {
+        *c1 = 0;
+        *c2 = 0;
+    }
+}
+SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4) {
+    i32 p3[2], p2[4], p1[8], a, b;
+    sx_shell_split(&p3[0], &p3[1], rc, pulses4, T_cdf_shell3);
+    sx_shell_split(&p2[0], &p2[1], rc, p3[0], T_cdf_shell2);
+    sx_shell_split(&p1[0], &p1[1], rc, p2[0], T_cdf_shell1);
+    sx_shell_split(&a, &b, rc, p1[0], T_cdf_shell0); q[0] = a; q[1] = b;
+    sx_shell_split(&a, &b, rc, p1[1], T_cdf_shell0); q[2] = a; q[3] = b;
+    sx_shell_split(&p1[2], &p1[3], rc, p2[1], T_cdf_shell1);
+    sx_shell_split(&a, &b, rc, p1[2], T_cdf_shell0); q[4] = a; q[5] = b;
+    sx_shell_split(&a, &b, rc, p1[3], T_cdf_shell0); q[6] = a; q[7] = b;
+    sx_shell_split(&p2[2], &p2[3], rc, p3[1], T_cdf_shell2);
+    sx_shell_split(&p1[4], &p1[5], rc, p2[2], T_cdf_shell1);
+    sx_shell_split(&a, &b, rc, p1[4], T_cdf_shell0); q[8] = a; q[9] = b;
+    sx_shell_split(&a, &b, rc, p1[5], T_cdf_shell0); q[10] = a; q[11] = b;
+    sx_shell_split(&p1[6], &p1[7], rc, p2[3], T_cdf_shell1);
+    sx_shell_split(&a, &b, rc, p1[6], T_cdf_shell0); q[12] = a; q[13] = b;
+    sx_shell_split(&a, &b, rc, p1[7], T_cdf_shell0); q[14] = a; q[15] = b;
+}
+
+// SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64)
+SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q) {
+    const int iter = SX_FRAME / 16;
+    i32 sum_pulses[SX_FRAME / 16], nLshifts[SX_FRAME / 16];
+    c->RateLevelIndex = sx_rc_dec(rc, &T_cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
+    const u16* cdf_ptr = &T_cdf_pulses_per_block[c->RateLevelIndex * 21];
+    for (int i = 0; i < iter; i++) {
+        nLshifts[i] = 0;
+        sum_pulses[i] = sx_rc_dec(rc, cdf_ptr, T_CDF_MID_PULSES_PER_BLOCK);
+        while (sum_pulses[i] == 18 + 1) {
+            nLshifts[i]++;
+            sum_pulses[i] = sx_rc_dec(rc, &T_cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
+            if (rc->error) break;   // (reference would spin on the zero returned after an error only until != 19; 0 != 19)
+        }
+    }
+    for (int i = 0; i < iter; i++) {
+        if (sum_pulses[i] > 0) {
+            sx_shell_decoder(&q[i * 16], rc, sum_pulses[i]);
+        } else {
+            for (int k = 0; k < 16; k++) q[i * 16 + k] = 0;
+        }
+    }
+    for (int i = 0; i < iter; i++) {
+        if (nLshifts[i] > 0) {
+            int nLS = nLshifts[i];
+            for (int k = 0; k < 16; k++) {
+                i32 abs_q = q[i * 16 + k];
+                for (int j = 0; j < nLS; j++) {
+                    abs_q = sx_shl(abs_q, 1);
+                    abs_q += sx_rc_dec(rc, T_cdf_lsb, 1);
+                }
+                q[i * 16 + k] = abs_q;
+            }
+        }
+    }
+    // signs
+    u16 cdf[3];
+    cdf[0] = 0;
+    cdf[1] = T_cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
+    cdf[2] = 65535;
+    for (int i = 0; i < SX_FRAME; i++) {
+        if (q[i] > 0) {
+            i32 data = sx_rc_dec(rc, cdf, 1);
+            q[i] *= (data << 1) - 1;
+        }
+    }
+}
+
+// SKP_Silk_NLSF_MSVQ_decode, SKP_Silk_NLSF_MSVQ_decode.c:31 (order 10, 6 stages)
+SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
+    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+    const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
+    const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
+    const i16* e = &cb[idx[0] * SX_LPC];
+    for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] = e[i];
+    int base = nvec[0];
+    for (int s = 1; s < 6; s++) {
+        e = &cb[(base + idx[s]) * SX_LPC];
+        for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] += e[i];
+        base += nvec[s];
+    }
+    sx_nlsf_stabilize(pNLSF_Q15, sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15, SX_LPC);
+}
+
+// SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
+SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex) {
+    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], pNLSF_Q15[SX_LPC], pNLSF0_Q15[SX_LPC], DeltaGainIndices;
+    SxDecDesc* md = &st->md[kDesp];
+    if (st->nFramesDecoded == 0) {
+        if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, T_cdf_mdindex, T_CDF_MID_MDINDEX);
+        Ix = sx_rc_dec(rc, T_cdf_fs, T_CDF_MID_FS);
+        if (Ix != 0) {  // only the 8 kHz NB mode exists in this build (reference: decoder_set_fs to 12/16/24 kHz)
+            if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
+            return;
+        }
+        Ix = sx_rc_dec(rc, T_cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
+    } else {
+        Ix = sx_rc_dec(rc, &T_cdf_type_offset_joint[md->typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
+    }
+    c->sigtype = Ix >> 1;
+    c->QuantOffsetType = Ix & 1;
+    md->typeOffsetPrev = Ix;
+
+    if (st->nFramesDecoded == 0) GainsIndices[0] = sx_rc_dec(rc, &T_cdf_gain[c->sigtype * 65], T_CDF_MID_GAIN);
+    else GainsIndices[0] = sx_rc_dec(rc, T_cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    for (int i = 1; i < SX_NB_SUBFR; i++) GainsIndices[i] = sx_rc_dec(rc, T_cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    if (st->nFramesDecoded == 0) {
+        DeltaGainIndices = sx_rc_dec(rc, T_cdf_md_delta_gain, T_CDF_MID_MD_DELTA_GAIN);
+        md->prevDeltaGainIndex = DeltaGainIndices;
+    } else {
+        DeltaGainIndices = md->prevDeltaGainIndex;
+    }
+    sx_gains_dequant(c->Gains_Q16, GainsIndices, &md->LastGainIndex, st->nFramesDecoded, DeltaGainIndices, &c->DeltaGains_Q16);
+
+    // NLSF path: 6 stages, per-stage CDFs laid out back to back (nvec+1 entries each)
+    {
+        const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+        const i32* nvec = c->sigtype == 0 ? nvec0 : nvec1;
+        const u16* cdf = c->sigtype == 0 ? T_nlsf_cb0_cdf : T_nlsf_cb1_cdf;
+        const i32* mid = c->sigtype == 0 ? T_nlsf_cb0_cdf_mid : T_nlsf_cb1_cdf_mid;
+        int off = 0;
+        for (int s = 0; s < 6; s++) {
+            NLSFIndices[s] = sx_rc_dec(rc, cdf + off, mid[s]);
+            off += nvec[s] + 1;
+        }
+    }
+    sx_nlsf_msvq_decode(pNLSF_Q15, c->sigtype, NLSFIndices);
+    c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, T_cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
+    if (st->first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
+
+    sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
+    if (c->NLSFInterpCoef_Q2 < 4) {
+        for (int i = 0; i < SX_LPC; i++)
+            pNLSF0_Q15[i] = md->prevNLSF_Q15[i] + (sx_mul(c->NLSFInterpCoef_Q2, pNLSF_Q15[i] - md->prevNLSF_Q15[i]) >> 2);
+        sx_nlsf2a_stable(c->PredCoef_Q12[0], pNLSF0_Q15, SX_LPC);
+    } else {
+        for (int i = 0; i < SX_LPC; i++) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+    }
+    for (int i = 0; i < SX_LPC; i++) md->prevNLSF_Q15[i] = pNLSF_Q15[i];
+    if (st->lossCnt) {
+        sx_bwexpander(c->PredCoef_Q12[0], SX_LPC, 63570);
+        sx_bwexpander(c->PredCoef_Q12[1], SX_LPC, 63570);
+    }
+
+    if (c->sigtype == 0) {
+        i32 lagIx = sx_rc_dec(rc, T_cdf_pitch_lag_nb, T_CDF_MID_PITCH_LAG_NB);
+        i32 conIx = sx_rc_dec(rc, T_cdf_pitch_contour_nb, T_CDF_MID_PITCH_CONTOUR_NB);
+        i32 lag = 2 * 8 + lagIx;   // SKP_Silk_decode_pitch.c:43-50
+        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_stage2[i * 11 + conIx];
+        c->PERIndex = sx_rc_dec(rc, T_cdf_ltp_per, T_CDF_MID_LTP_PER);
+        const i16* cbk = c->PERIndex == 0 ? T_ltp_vq0_Q14 : (c->PERIndex == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+        const u16* gcdf = c->PERIndex == 0 ? T_cdf_ltp_gain0 : (c->PERIndex == 1 ? T_cdf_ltp_gain1 : T_cdf_ltp_gain2);
+        for (int k = 0; k < SX_NB_SUBFR; k++) {
+            Ix = sx_rc_dec(rc, gcdf, T_cdf_mid_ltp_gain[c->PERIndex]);
+            for (int i = 0; i < SX_LTP_ORDER; i++) c->LTPCoef_Q14[k * SX_LTP_ORDER + i] = cbk[Ix * SX_LTP_ORDER + i];
+        }
+        Ix = sx_rc_dec(rc, T_cdf_ltpscale, T_CDF_MID_LTPSCALE);
+        c->LTP_scale_Q14 = T_ltp_scales_Q14[Ix];
+    } else {
+        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = 0;
+        for (int i = 0; i < SX_LTP_ORDER * SX_NB_SUBFR; i++) c->LTPCoef_Q14[i] = 0;
+        c->PERIndex = 0;
+        c->LTP_scale_Q14 = 0;
+    }
+    c->Seed = sx_rc_dec(rc, T_cdf_seed, T_CDF_MID_SEED);
+    sx_decode_pulses(rc, c, q);
+    st->vadFlag = sx_rc_dec(rc, T_cdf_vadflag, T_CDF_MID_VADFLAG);
+    st->FrameTermination = sx_rc_dec(rc, T_cdf_frame_term, T_CDF_MID_FRAME_TERM);
+
+    i32 nBytesUsed;
+    sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytesUsed);
+    i32 left = rc->bufferLength - nBytesUsed;
+    if (kDesp == 0) st->nBytesLeft0 = left;
+    if (left < 0) rc->error = SX_RC_READ_BEYOND_BUFFER;
+    if (left == 0) sx_rc_check_after_decoding(rc);
+}
+
+// SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
+SX_HD void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
+    SxDecCtrl* c = &w->ctrl;
+    const int NLSF_interpolation_flag = c->NLSFInterpCoef_Q2 < 4 ? 1 : 0;
+    i32* pexc_Q10 = st->exc_Q10;
+    i32* pres_Q10 = w->res_Q10;
+    i16* pxq = &st->outBuf[SX_FRAME];
+    int sLTP_buf_idx = SX_FRAME;
+    int lag = 0;
+    SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = st->sLPC_Q14[i];
+    wv_sync();
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        const i16* A_Q12 = c->PredCoef_Q12[k >> 1];
+        i16* B_Q14 = &c->LTPCoef_Q14[k * SX_LTP_ORDER];
+        i32 Gain_Q16 = c->Gains_Q16[k];
+        int sigtype = c->sigtype;
+        i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
+        inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
+        i32 gain_adj_Q16 = 1 << 16;
+        if (inv_gain_Q16 != st->prev_inv_gain_Q16) gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, st->prev_inv_gain_Q16, 16);
+
+        if (st->lossCnt && st->prev_sigtype == 0 && c->sigtype == 1 && k < 2) {
+            for (int i = 0; i < SX_LTP_ORDER; i++) B_Q14[i] = 0;
+            B_Q14[SX_LTP_ORDER / 2] = (i16)(1 << 12);
+            sigtype = 0;
+            c->pitchL[k] = st->lagPrev;
+        }
+        if (sigtype == 0) {
+            lag = c->pitchL[k];
+            if ((k & (3 - (NLSF_interpolation_flag << 1))) == 0) {
+                // re-whitening: only the last lag+2 outputs of the reference's MA_Prediction run are
+                // consumed, and every one of them has a complete 10-sample history, so the filter is
+                // evaluated directly per output sample (wrapping sums: tap order irrelevant)
+                const i16* in = &st->outBuf[k * SX_SUBFR];   // in[j] == outBuf[j + k*40], j < 160
+                i32 inv_gain_Q32 = sx_shl(inv_gain_Q16, 16);
+                if (k == 0) inv_gain_Q32 = sx_shl(sx_smulwb(inv_gain_Q32, c->LTP_scale_Q14), 2);
+                const int n = lag + SX_LTP_ORDER / 2;
+                SX_PAR(i, n) {
+                    int j = SX_FRAME - 1 - i;
+                    i32 acc = 0;
+                    for (int d = 0; d < SX_LPC; d++) acc = sx_smlabb(acc, in[j - 1 - d], A_Q12[d]);
+                    i32 o = sx_rshift_round(sx_sub(sx_shl((i32)in[j], 12), acc), 12);
+                    st->sLTP_Q16[sLTP_buf_idx - i - 1] = sx_smulwb(inv_gain_Q32, sx_sat16(o));
+                }
+                wv_sync();
+            } else if (gain_adj_Q16 != (1 << 16)) {
+                const int n = lag + SX_LTP_ORDER / 2;
+                SX_PAR(i, n) st->sLTP_Q16[sLTP_buf_idx - i - 1] = sx_smulww(gain_adj_Q16, st->sLTP_Q16[sLTP_buf_idx - i - 1]);
+                wv_sync();
+            }
+        }
+        SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = sx_smulww(gain_adj_Q16, w->sLPC_Q14[i]);
+        wv_sync();
+        st->prev_inv_gain_Q16 = inv_gain_Q16;
+
+        if (sigtype == 0) {
+            i32* pred_lag_ptr = &st->sLTP_Q16[sLTP_buf_idx - lag + SX_LTP_ORDER / 2];
+            for (int i = 0; i < SX_SUBFR; i++) {
+                i32 p = sx_smulwb(pred_lag_ptr[0], B_Q14[0]);
+                p = sx_smlawb(p, pred_lag_ptr[-1], B_Q14[1]);
+                p = sx_smlawb(p, pred_lag_ptr[-2], B_Q14[2]);
+                p = sx_smlawb(p, pred_lag_ptr[-3], B_Q14[3]);
+                p = sx_smlawb(p, pred_lag_ptr[-4], B_Q14[4]);
+                pred_lag_ptr++;
+                i32 r = sx_add(pexc_Q10[i], sx_rshift_round(p, 4));
+                pres_Q10[i] = r;
+                st->sLTP_Q16[sLTP_buf_idx] = sx_shl(r, 6);
+                sLTP_buf_idx++;
+            }
+        } else {
+            SX_PAR(i, SX_SUBFR) pres_Q10[i] = pexc_Q10[i];
+            wv_sync();
+        }
+        // short-term prediction (decode_core.c:188-288), serial recursion
+        for (int i = 0; i < SX_SUBFR; i++) {
+            i32 p = 0;
+            for (int j = 0; j < SX_LPC; j++) p = sx_smlawb(p, w->sLPC_Q14[SX_MAX_LPC + i - j - 1], A_Q12[j]);
+            i32 v = sx_add(pres_Q10[i], p);
+            w->sLPC_Q14[SX_MAX_LPC + i] = sx_shl(v, 4);
+            pxq[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(v, Gain_Q16), 10));
+        }
+        for (int i = 0; i < SX_MAX_LPC; i++) {
+            i32 t = w->sLPC_Q14[SX_SUBFR + i];
+            w->sLPC_Q14[i] = t;
+        }
+        pexc_Q10 += SX_SUBFR;
+        pres_Q10 += SX_SUBFR;
+        pxq += SX_SUBFR;
+    }
+    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->sLPC_Q14[i];
+    SX_PAR(i, SX_FRAME) xq[i] = st->outBuf[SX_FRAME + i];
+    wv_sync();
+}
+
+// SKP_Silk_PLC_update, SKP_Silk_PLC.c:75
+SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
+    SxPLC* p = &st->plc;
+    st->prev_sigtype = c->sigtype;
+    i32 LTP_Gain_Q14 = 0;
+    if (c->sigtype == 0) {
+        for (int j = 0; j * SX_SUBFR < c->pitchL[SX_NB_SUBFR - 1]; j++) {
+            i32 t = 0;
+            for (int i = 0; i < SX_LTP_ORDER; i++) t += c->LTPCoef_Q14[(SX_NB_SUBFR - 1 - j) * SX_LTP_ORDER + i];
+            if (t > LTP_Gain_Q14) {
+                LTP_Gain_Q14 = t;
+                for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = c->LTPCoef_Q14[(SX_NB_SUBFR - 1 - j) * SX_LTP_ORDER + i];
+                p->pitchL_Q8 = sx_shl(c->pitchL[SX_NB_SUBFR - 1 - j], 8);
+            }
+        }
+        // USE_SINGLE_TAP (SKP_Silk_PLC.h:38)
+        for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = 0;
+        p->LTPCoef_Q14[SX_LTP_ORDER / 2] = (i16)LTP_Gain_Q14;
+        if (LTP_Gain_Q14 < 11469) {
+            i32 scale_Q10 = (11469 << 10) / sx_max(LTP_Gain_Q14, 1);
+            for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = (i16)(sx_smulbb(p->LTPCoef_Q14[i], scale_Q10) >> 10);
+        } else if (LTP_Gain_Q14 > 15565) {
+            i32 scale_Q14 = (15565 << 14) / sx_max(LTP_Gain_Q14, 1);
+            for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = (i16)(sx_smulbb(p->LTPCoef_Q14[i], scale_Q14) >> 14);
+        }
+    } else {
+        p->pitchL_Q8 = sx_shl(sx_smulbb(8, 18), 8);
+        for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = 0;
+    }
+    for (int i = 0; i < SX_LPC; i++) p->prevLPC_Q12[i] = c->PredCoef_Q12[1][i];
+    p->prevLTP_scale_Q14 = (i16)c->LTP_scale_Q14;
+    for (int i = 0; i < SX_NB_SUBFR; i++) p->prevGain_Q16[i] = c->Gains_Q16[i];
+}
+
+// SKP_Silk_PLC_conceal, SKP_Silk_PLC.c:146
+SX_HD void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
+    SxPLC* p = &st->plc;
+    SxDecCtrl* c = &w->ctrl;
+    i16* exc_buf = w->tmp16;
+    i32* sig_Q10 = w->sig_Q10;
+    // shift LTP buffer (source and destination halves do not overlap)
+    SX_PAR(i, SX_FRAME) st->sLTP_Q16[i] = st->sLTP_Q16[SX_FRAME + i];
+    wv_sync();
+    sx_bwexpander(p->prevLPC_Q12, SX_LPC, 64880);
+    SX_PAR(t, 2 * SX_SUBFR) {
+        int k = 2 + t / SX_SUBFR, i = t % SX_SUBFR;
+        exc_buf[t] = (i16)(sx_smulww(st->exc_Q10[i + k * SX_SUBFR], p->prevGain_Q16[k]) >> 10);
+    }
+    wv_sync();
+    i32 energy1, energy2, shift1, shift2;
+    sx_sum_sqr_shift(&energy1, &shift1, exc_buf, SX_SUBFR, 0);
+    sx_sum_sqr_shift(&energy2, &shift2, &exc_buf[SX_SUBFR], SX_SUBFR, 0);
+    const i32* rand_ptr;
+    if ((energy1 >> shift2) < (energy2 >> shift1)) rand_ptr = &st->exc_Q10[sx_max(0, 3 * SX_SUBFR - 128)];
+    else rand_ptr = &st->exc_Q10[sx_max(0, SX_FRAME - 128)];
+
+    i16* B_Q14 = p->LTPCoef_Q14;
+    i32 rand_scale_Q14 = p->randScale_Q14;
+    const int att = sx_min(1, st->lossCnt);
+    const i32 HARM_ATT_Q15[2] = {32440, 31130}, RAND_ATT_V_Q15[2] = {31130, 26214}, RAND_ATT_UV_Q15[2] = {32440, 29491};
+    i32 harm_Gain_Q15 = HARM_ATT_Q15[att];
+    i32 rand_Gain_Q15 = st->prev_sigtype == 0 ? RAND_ATT_V_Q15[att] : RAND_ATT_UV_Q15[att];
+    if (st->lossCnt == 0) {
+        rand_scale_Q14 = 1 << 14;
+        if (st->prev_sigtype == 0) {
+            for (int i = 0; i < SX_LTP_ORDER; i++) rand_scale_Q14 = (i16)(rand_scale_Q14 - B_Q14[i]);
+            rand_scale_Q14 = (i16)sx_max(3277, (i16)rand_scale_Q14);
+            rand_scale_Q14 = (i16)(sx_smulbb(rand_scale_Q14, p->prevLTP_scale_Q14) >> 14);
+        }
+        if (st->prev_sigtype == 1) {
+            i32 invGain_Q30, down_scale_Q30;
+            sx_lpc_inv_pred_gain(&invGain_Q30, p->prevLPC_Q12, SX_LPC);
+            down_scale_Q30 = sx_min((1 << 30) >> 3, invGain_Q30);
+            down_scale_Q30 = sx_max((1 << 30) >> 8, down_scale_Q30);
+            down_scale_Q30 = sx_shl(down_scale_Q30, 3);
+            rand_Gain_Q15 = sx_smulwb(down_scale_Q30, rand_Gain_Q15) >> 14;
+        }
+    }
+    i32 rand_seed = p->rand_seed;
+    int lag = sx_rshift_round(p->pitchL_Q8, 8);
+    int sLTP_buf_idx = SX_FRAME;
+    i32* sig_ptr = sig_Q10;
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        i32* pred_lag_ptr = &st->sLTP_Q16[sLTP_buf_idx - lag + SX_LTP_ORDER / 2];
+        for (int i = 0; i < SX_SUBFR; i++) {
+            rand_seed = sx_rand(rand_seed);
+            int idx = (rand_seed >> 25) & 127;
+            i32 pr = sx_smulwb(pred_lag_ptr[0], B_Q14[0]);
+            pr = sx_smlawb(pr, pred_lag_ptr[-1], B_Q14[1]);
+            pr = sx_smlawb(pr, pred_lag_ptr[-2], B_Q14[2]);
+            pr = sx_smlawb(pr, pred_lag_ptr[-3], B_Q14[3]);
+            pr = sx_smlawb(pr, pred_lag_ptr[-4], B_Q14[4]);
+            pred_lag_ptr++;
+            i32 e = sx_shl(sx_smulwb(rand_ptr[idx], rand_scale_Q14), 2);
+            e = sx_add(e, sx_rshift_round(pr, 4));
+            st->sLTP_Q16[sLTP_buf_idx] = sx_shl(e, 6);
+            sLTP_buf_idx++;
+            sig_ptr[i] = e;
+        }
+        sig_ptr += SX_SUBFR;
+        for (int j = 0; j < SX_LTP_ORDER; j++) B_Q14[j] = (i16)(sx_smulbb(harm_Gain_Q15, B_Q14[j]) >> 15);
+        rand_scale_Q14 = (i16)(sx_smulbb(rand_scale_Q14, rand_Gain_Q15) >> 15);
+        p->pitchL_Q8 += sx_smulwb(p->pitchL_Q8, 655);
+        p->pitchL_Q8 = sx_min(p->pitchL_Q8, sx_shl(sx_smulbb(18, 8), 8));
+        lag = sx_rshift_round(p->pitchL_Q8, 8);
+    }
+    // LPC synthesis
+    SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = st->sLPC_Q14[i];
+    wv_sync();
+    sig_ptr = sig_Q10;
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        for (int i = 0; i < SX_SUBFR; i++) {
+            i32 pr = 0;
+            for (int j = 0; j < SX_LPC; j++) pr = sx_smlawb(pr, w->sLPC_Q14[SX_MAX_LPC + i - j - 1], p->prevLPC_Q12[j]);
+            i32 v = sx_add(sig_ptr[i], pr);
+            sig_ptr[i] = v;
+            w->sLPC_Q14[SX_MAX_LPC + i] = sx_shl(v, 4);
+        }
+        sig_ptr += SX_SUBFR;
+        for (int i = 0; i < SX_MAX_LPC; i++) {
+            i32 t = w->sLPC_Q14[SX_SUBFR + i];
+            w->sLPC_Q14[i] = t;
+        }
+    }
+    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->sLPC_Q14[i];
+    SX_PAR(i, SX_FRAME) signal[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(sig_Q10[i], p->prevGain_Q16[SX_NB_SUBFR - 1]), 10));
+    wv_sync();
+    p->rand_seed = rand_seed;
+    p->randScale_Q14 = (i16)rand_scale_Q14;
+    for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag;
+}
+
+// SKP_Silk_PLC, SKP_Silk_PLC.c:43
+SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
+    if (st->plc.fs_kHz != 8) {
+        st->plc.pitchL_Q8 = SX_FRAME >> 1;   // SKP_Silk_PLC_Reset
+        st->plc.fs_kHz = 8;
+    }
+    if (lost) {
+        sx_plc_conceal(st, w, signal);
+        st->lossCnt++;
+    } else {
+        sx_plc_update(st, &w->ctrl);
+    }
+}
+
+// SKP_Silk_PLC_glue_frames, SKP_Silk_PLC.c:363.  `odd` = int16 offset of `signal` from a 4-byte
+// aligned base, modulo 2 (sum_sqr_shift's alignment branch); the low-band buffer of the reference is
+// a stack array advanced by 160 samples per frame, i.e. always even.
+SX_HD void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
+    SxPLC* p = &st->plc;
+    if (st->lossCnt) {
+        sx_sum_sqr_shift(&p->conc_energy, &p->conc_energy_shift, signal, length, 0);
+        p->last_frame_lost = 1;
+    } else {
+        if (p->last_frame_lost) {
+            i32 energy, energy_shift;
+            sx_sum_sqr_shift(&energy, &energy_shift, signal, length, 0);
+            if (energy_shift > p->conc_energy_shift) p->conc_energy = p->conc_energy >> (energy_shift - p->conc_energy_shift);
+            else if (energy_shift < p->conc_energy_shift) energy = energy >> (p->conc_energy_shift - energy_shift);
+            if (energy > p->conc_energy) {
+                i32 LZ = sx_clz32(p->conc_energy) - 1;
+                p->conc_energy = sx_shl(p->conc_energy, LZ);
+                energy = energy >> sx_max(24 - LZ, 0);
+                i32 frac_Q24 = p->conc_energy / sx_max(energy, 1);
+                i32 gain_Q12 = sx_sqrt_approx(frac_Q24);
+                i32 slope_Q12 = ((1 << 12) - gain_Q12) / length;
+                // serial ramp (rare path: first good frame after a loss); uniform code, all lanes identical
+                for (int i = 0; i < length; i++) {
+                    signal[i] = (i16)(sx_mul(gain_Q12, signal[i]) >> 12);
+                    gain_Q12 += slope_Q12;
+                    gain_Q12 = sx_min(gain_Q12, 1 << 12);
+                }
+                wv_sync();
+            }
+        }
+        p->last_frame_lost = 0;
+    }
+}
+
+// SKP_Silk_LPC_synthesis_filter, SKP_Silk_LPC_synthesis_filter.c:37 (order 10), in-place capable
+SX_HD void sx_lpc_synthesis_filter(const i16* in, const i16* A_Q12, i32 Gain_Q26, i32* S, i16* out, int len, int Order) {
+    // S[Order-1] is the newest state sample; the reference shifts the delay line by swapping pairs
+    i32 hist[SX_MAX_LPC];
+    for (int j = 0; j < Order; j++) hist[j] = S[Order - 1 - j];   // hist[0] newest
+    for (int k = 0; k < len; k++) {
+        i32 acc = 0;
+        for (int j = 0; j < Order; j++) acc = sx_smlawb(acc, hist[j], A_Q12[j]);
+        acc = sx_add_sat32(acc, sx_smulwb(Gain_Q26, in[k]));
+        out[k] = (i16)sx_sat16(sx_rshift_round(acc, 10));
+        for (int j = Order - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = sx_lshift_sat32(acc, 4);
+    }
+    for (int j = 0; j < Order; j++) S[Order - 1 - j] = hist[j];
+}
+
+// SKP_Silk_CNG, SKP_Silk_CNG.c:75
+SX_HD void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
+    SxCNG* g = &st->cng;
+    SxDecCtrl* c = &w->ctrl;
+    if (g->fs_kHz != 8) {
+        i32 step = 32767 / (SX_LPC + 1), acc = 0;      // SKP_Silk_CNG_Reset, CNG.c:58
+        for (int i = 0; i < SX_LPC; i++) { acc += step; g->smth_NLSF_Q15[i] = acc; }
+        g->smth_Gain_Q16 = 0;
+        g->rand_seed = 3176576;
+        g->fs_kHz = 8;
+    }
+    if (st->lossCnt == 0 && st->vadFlag == 0) {
+        for (int i = 0; i < SX_LPC; i++)
+            g->smth_NLSF_Q15[i] += sx_smulwb(st->md[0].prevNLSF_Q15[i] - g->smth_NLSF_Q15[i], 16348);
+        i32 max_Gain_Q16 = 0;
+        int subfr = 0;
+        for (int i = 0; i < SX_NB_SUBFR; i++) {
+            if (c->Gains_Q16[i] > max_Gain_Q16) { max_Gain_Q16 = c->Gains_Q16[i]; subfr = i; }
+        }
+        // memmove( &buf[40], buf, 120 ) then memcpy( buf, &exc[subfr*40], 40 ): read everything first
+        i32 v0 = 0, v1 = 0, v2 = 0;
+        const int l = SX_LANE;
+        if (SX_NLANES == 1) {
+            for (int i = 3 * SX_SUBFR - 1; i >= 0; i--) g->exc_buf_Q10[SX_SUBFR + i] = g->exc_buf_Q10[i];
+        } else {
+            if (l < 3 * SX_SUBFR) v0 = g->exc_buf_Q10[l];
+            if (l + 64 < 3 * SX_SUBFR) v1 = g->exc_buf_Q10[l + 64];
+            (void)v2;
+            wv_sync();
+            if (l < 3 * SX_SUBFR) g->exc_buf_Q10[SX_SUBFR + l] = v0;
+            if (l + 64 < 3 * SX_SUBFR) g->exc_buf_Q10[SX_SUBFR + l + 64] = v1;
+        }
+        wv_sync();
+        SX_PAR(i, SX_SUBFR) g->exc_buf_Q10[i] = st->exc_Q10[subfr * SX_SUBFR + i];
+        wv_sync();
+        for (int i = 0; i < SX_NB_SUBFR; i++)
+            g->smth_Gain_Q16 += sx_smulwb(c->Gains_Q16[i] - g->smth_Gain_Q16, 4634);
+    }
+    if (st->lossCnt) {
+        i16* CNG_sig = w->tmp16;
+        int exc_mask = 255;
+        while (exc_mask > length) exc_mask >>= 1;
+        // CNG_exc (CNG.c:31): the seed recurrence is a pure LCG, so every lane regenerates it serially
+        i32 seed = g->rand_seed;
+        for (int i = 0; i < length; i++) {
+            seed = sx_rand(seed);
+            int idx = (seed >> 24) & exc_mask;
+            CNG_sig[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(g->exc_buf_Q10[idx], g->smth_Gain_Q16), 10));
+        }
+        g->rand_seed = seed;
+        i16 LPC_buf[SX_MAX_LPC];
+        sx_nlsf2a_stable(LPC_buf, g->smth_NLSF_Q15, SX_LPC);
+        sx_lpc_synthesis_filter(CNG_sig, LPC_buf, 1 << 26, g->synth_state, CNG_sig, length, SX_LPC);
+        SX_PAR(i, length) signal[i] = (i16)sx_sat16((i32)signal[i] + (i32)CNG_sig[i]);
+        wv_sync();
+    } else {
+        for (int i = 0; i < SX_LPC; i++) g->synth_state[i] = 0;
+    }
+}
+
+// One 20 ms low-band frame: SKP_Silk_SDK_Decode + SKP_Silk_decode_frame + AgoraSateDecodeTwoDesps.
+// rc[] persists across the two frames of a packet.  Returns 0, or a negative SILK error code
+// (SKP_Silk_errors.h) on a corrupt payload.
+SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
+                               i32 nB0, i32 nB1, int useMDIndex, i16* pOut) {
+    int ret = 0;
+    SxDecCtrl* c = &w->ctrl;
+    if (st->moreInternalDecoderFrames == 0) st->nFramesDecoded = 0;
+    c->LTP_scale_Q14 = 0;
+    int used = 0;
+    if (action == 1) {
+        sx_plc(st, w, pOut, 1);
+    } else {
+        const int desp_type = action - 2;
+        if (st->nFramesDecoded == 0) {
+            sx_rc_dec_init(&rc[0], payload, nB0);
+            if (desp_type > 1) sx_rc_dec_init(&rc[1], payload + nB0, nB1);
+        }
+        sx_decode_parameters(st, c, &rc[0], w->pulses[0], 0, useMDIndex);
+        if (desp_type > 1) sx_decode_parameters(st, c, &rc[1], w->pulses[1], 1, useMDIndex);
+
+        i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
+        i32 inv_gain_p1_Q16 = inv_gain_Q16;
+        i32 inv_gain_p2_Q16 = 65536 - inv_gain_Q16;
+        i32 DeltaGains_p1_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p1_Q16, 1), 32);
+        i32 DeltaGains_p2_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p2_Q16, 1), 32);
+        i32 offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
+        i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);
+        i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
+
+        if (rc[0].error || (desp_type > 1 && rc[1].error)) {
+            st->nBytesLeft0 = 0;
+            used = rc[0].bufferLength;
+            ret = rc[0].error == SX_RC_DEC_PAYLOAD_TOO_LONG ? -11 : -12;   // SKP_SILK_DEC_PAYLOAD_TOO_LARGE / _ERROR
+            st->moreInternalDecoderFrames = 0;
+        } else {
+            st->nFramesDecoded++;
+            used = rc[0].bufferLength - st->nBytesLeft0;
+            // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
+            i32 rand_seed = c->Seed;
+            if (desp_type == 2) {
+                for (int i = 0; i < SX_FRAME; i++) {
+                    rand_seed = sx_rand(rand_seed);
+                    i32 dither = rand_seed >> 31;
+                    i32 q_Q10 = sx_add(sx_shl(w->pulses[0][i], 10), sx_shl(w->pulses[1][i], 10));
+                    q_Q10 = sx_add(offset_p1_Q10 + offset_p2_Q10, q_Q10);
+                    st->exc_Q10[i] = (q_Q10 ^ dither) - dither;
+                }
+            } else {
+                for (int i = 0; i < SX_FRAME; i++) {
+                    rand_seed = sx_rand(rand_seed);
+                    i32 dither = rand_seed >> 31;
+                    int first_half = (i % (SX_SUBFR << 1)) < SX_SUBFR;
+                    int use_p1 = desp_type == 0 ? first_half : !first_half;
+                    i32 q_Q10 = sx_add(use_p1 ? offset_p1_Q10 : offset_p2_Q10, sx_shl(w->pulses[0][i], 10));
+                    i32 e = (q_Q10 ^ dither) - dither;
+                    st->exc_Q10[i] = sx_smulww(use_p1 ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16, e);
+                }
+            }
+            sx_decode_core(st, w, pOut);
+            sx_plc(st, w, pOut, 0);
+            st->lossCnt = 0;
+            st->prev_sigtype = c->sigtype;
+            st->first_frame_after_reset = 0;
+        }
+    }
+    if (ret < 0) return ret;   // corrupt payload: the reference returns before producing output
+    SX_PAR(i, SX_FRAME) st->outBuf[i] = pOut[i];
+    wv_sync();
+    sx_plc_glue_frames(st, pOut, SX_FRAME);
+    sx_cng(st, w, pOut, SX_FRAME);
+    // (output HP filter: guard nFramesDecoded > 2 can never hold with 2 frames per packet, decode_frame.c:381)
+    st->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
+    // SKP_Silk_SDK_Decode bookkeeping, dec_API.c:125-150
+    if (used) {
+        if (st->nBytesLeft0 > 0 && st->FrameTermination == 1 && st->nFramesDecoded < 5) st->moreInternalDecoderFrames = 1;
+        else st->moreInternalDecoderFrames = 0;
+    }
+    return 0;
+}
+
+// MSB-first bit reader over the 8 high-band bytes (libBWE/AGR_BWE_bits.c:135)
+SX_HD u32 sx_hb_unpack(const u8* hb, int* bitpos, int nbBits) {
+    u32 d = 0;
+    for (int i = 0; i < nbBits; i++) {
+        int bp = *bitpos + i;
+        d = (d << 1) | ((hb[bp >> 3] >> (7 - (bp & 7))) & 1);
+    }
+    *bitpos += nbBits;
+    return d;
+}
+
+// AGR_Sate_LPC_synthesis_filter_fix, libBWE/AGR_BWE_LPC_synthesizer.c:56 (order 8, int32 Q10 input)
+SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16, i32* S, i16* out, int len) {
+    i32 hist[SX_HB_LPC];
+    for (int j = 0; j < SX_HB_LPC; j++) hist[j] = S[SX_HB_LPC - 1 - j];
+    for (int k = 0; k < len; k++) {
+        i32 acc = 0;
+        for (int j = 0; j < SX_HB_LPC; j++) acc = sx_smlawb(acc, hist[j], A_Q12[j]);
+        acc = sx_add_sat32(acc, sx_smulww(Gain_Q16, in_Q10[k]));
+        out[k] = (i16)sx_sat16(sx_rshift_round(acc, 10));
+        for (int j = SX_HB_LPC - 1; j > 0; j--) hist[j] = hist[j - 1];
+        hist[0] = sx_lshift_sat32(acc, 4);
+    }
+    for (int j = 0; j < SX_HB_LPC; j++) S[SX_HB_LPC - 1 - j] = hist[j];
+}
+
+// AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40.  hb == NULL-equivalent when lost.
+SX_HD void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* OutHigh, const i32* residue_Q10, int lostflag) {
+    i32 QHB_LSP[SX_HB_LPC];
+    i32 QGain[4];
+    i16 lpc[SX_MAX_LPC];
+    const int lost = (lostflag == 1 || lostflag == 2);
+    if (lost) {
+        for (int i = 0; i < SX_HB_LPC; i++) QHB_LSP[i] = st->HB_prev_NLSFq[i];
+        for (int s = 0; s < 4; s++) QGain[s] = st->HB_prev_Gain;
+        st->hb_lossCnt++;
+    } else {
+        u32 idx = sx_hb_unpack(hb, bitpos, 12);
+        u32 idx1 = idx & 0xFF, idx2 = idx >> 8;
+        for (int i = 0; i < SX_HB_LPC; i++) QHB_LSP[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i];
+        for (int s = 0; s < 4; s++) QGain[s] = T_hb_gain_cb[sx_hb_unpack(hb, bitpos, 5)];
+        if (st->hb_first) {
+            for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
+            st->HB_prev_Gain = QGain[3];
+        }
+        st->hb_lossCnt = 0;
+    }
+    sx_nlsf2a_stable(lpc, QHB_LSP, SX_HB_LPC);     // identical for all 4 subframes (same NLSF vector)
+    for (int s = 0; s < 4; s++) {
+        // excitation = low-band excitation (zero when the high band is lost: decode_frame_FIX.c:65)
+        i32 zero[SX_SUBFR];
+        const i32* ex = &residue_Q10[s * SX_SUBFR];
+        if (lost) { for (int i = 0; i < SX_SUBFR; i++) zero[i] = 0; ex = zero; }
+        sx_hb_lpc_synthesis(ex, lpc, sx_mul(-2867, (i32)(i16)QGain[s]), st->HB_synth_state, &OutHigh[s * SX_SUBFR], SX_SUBFR);
+    }
+    if (lostflag == 0 || lostflag == 4 || lostflag == 3) {
+        st->HB_prev_Gain = QGain[3];
+        for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
+    }
+    st->hb_first = 0;
+}
+
+// AGR_Sate_qmf_synth, libBWE/AGR_BWE_qmf.c:86, as a direct polyphase form (wave-parallel):
+//   y[2k]   = sat( pshr15( sum_m a[2m]   * s1[k-m] + (-a[2m]) * s2[k-m] ) )
+//   y[2k+1] = sat( pshr15( sum_m a[2m+1] * s1[k-m] +   a[2m+1] * s2[k-m] ) )      m = 0..31
+// lo/hi hold [32 history | 320 new] samples.  32-bit accumulation wraps, so summation order is free.
+SX_HD void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
+    SX_PAR(k, SX_BAND) {
+        i32 y0 = 0, y1 = 0;
+        const i16* s1 = lo + SX_QMF_HIST + k;
+        const i16* s2 = hi + SX_QMF_HIST + k;
+        for (int m = 0; m < 32; m++) {
+            i32 a0 = T_qmf_taps[2 * m], a1 = T_qmf_taps[2 * m + 1];
+            i32 x1 = s1[-m], x2 = s2[-m];
+            y0 = sx_add(y0, sx_mul(a0, x1));
+            y0 = sx_add(y0, sx_mul((i32)(i16)(-a0), x2));
+            y1 = sx_add(y1, sx_mul(a1, x1));
+            y1 = sx_add(y1, sx_mul(a1, x2));
+        }
+        y[2 * k] = (i16)sx_saturate(sx_pshr32(y0, 15), 32767);
+        y[2 * k + 1] = (i16)sx_saturate(sx_pshr32(y1, 15), 32767);
+    }
+}
+
+// AGR_Sate_Decoder_Decode + AGR_Sate_decode_process for one 40 ms packet (libBWE/AGR_BWE_SDK_API.c:249,
+// libBWE/AGR_BWE_decode_frame_FIX.c:118).  `bits`/`nBytes*` follow the reference's calling convention:
+//   lostflag 4: bits = MD1|MD2|HB, nBytes0 = total, nBytes1 = len(MD2)+8
+//   lostflag 2: bits = MD1,        nBytes0 = len(MD1), nBytes1 = 0
+//   lostflag 3: bits = MD2|HB,     nBytes0 = len(MD2)+8, nBytes1 = 0
+//   lostflag 1: packet lost (bits ignored)
+// Returns 0 / -1 / negative SILK code like the reference.
+SX_HD int sx_decode_packet(SxDecState* st, SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes1, int lostflag,
+                           int useMDIndex, i16* pcm_out) {
+    if (nBytes0 <= 0) return -1;
+    i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - SX_HB_BYTES;
+    i32 nB1 = nBytes1 ? nBytes1 - SX_HB_BYTES : 0;
+    const i32 hb_pos = nB0;
+    nB0 -= nB1;
+    SxRangeDec rc[2];
+    rc[0].error = 0; rc[1].error = 0;
+    rc[0].bufferLength = 0; rc[1].bufferLength = 0;
+    rc[0].buf = bits; rc[1].buf = bits;
+    SX_PAR(i, SX_QMF_HIST) { w->lo[i] = st->qmf_lo_hist[i]; w->hi[i] = st->qmf_hi_hist[i]; }
+    wv_sync();
+    for (int f = 0; f < 2; f++) {
+        int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME]);
+        if (ret < 0) { st->last_error = ret; return ret; }
+        SX_PAR(i, SX_FRAME) w->exc_pkt_Q10[f * SX_FRAME + i] = st->exc_Q10[i];
+        wv_sync();
+    }
+    int bitpos = 0;
+    for (int f = 0; f < 2; f++)
+        sx_hb_decode_frame(st, bits + hb_pos, &bitpos, &w->hi[SX_QMF_HIST + f * SX_FRAME], &w->exc_pkt_Q10[f * SX_FRAME], lostflag);
+    wv_sync();
+    sx_qmf_synth(w->lo, w->hi, pcm_out);
+    SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->hi[SX_BAND + i]; }
+    wv_sync();
+    return 0;
+}

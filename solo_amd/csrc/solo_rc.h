@@ -1,0 +1,196 @@
+// solo_rc.h -- SILK range coder (encoder + decoder), wave-uniform scalar code.
+//
+// Restates  SKP_Silk_range_coder.c:31-372  (range_encoder, range_decoder, enc/dec_init, get_length,
+// enc_wrap_up, check_after_decoding).  The coder state lives in registers (a small struct); the byte
+// buffer is a plain pointer (LDS for the encoder, the packet itself in HBM for the decoder).
+// Every lane executes the identical instruction stream on identical data (see solo_wave.h).
+#pragma once
+#include "solo_wave.h"
+
+#define SX_MAX_ARITHM_BYTES 1024
+// error codes: SKP_Silk_define.h:159-166
+#define SX_RC_WRITE_BEYOND_BUFFER (-1)
+#define SX_RC_CDF_OUT_OF_RANGE (-2)
+#define SX_RC_NORMALIZATION_FAILED (-3)
+#define SX_RC_ZERO_INTERVAL_WIDTH (-4)
+#define SX_RC_DECODER_CHECK_FAILED (-5)
+#define SX_RC_READ_BEYOND_BUFFER (-6)
+#define SX_RC_ILLEGAL_SAMPLING_RATE (-7)
+#define SX_RC_DEC_PAYLOAD_TOO_LONG (-8)
+
+struct SxRangeDec {
+    const u8* buf;      // payload bytes of this description (inside the packet, HBM)
+    i32 bufferLength;   // bytes that belong to this description
+    i32 bufferIx;       // read index, counted from byte 4 (the first 4 bytes pre-load base_Q32)
+    u32 base_Q32;
+    u32 range_Q16;
+    i32 error;
+};
+
+// Bytes past the end of a description read as 0.  (The reference reads whatever its internal buffer
+// held there from earlier packets -- SKP_Silk_range_coder.c:129,205-216 -- which cannot change any
+// decoded symbol of a valid stream: the encoder's wrap-up makes the stream uniquely decodable for
+// every continuation.)
+SX_HD u32 sx_rc_byte(const SxRangeDec* rc, i32 pos) { return pos < rc->bufferLength ? (u32)rc->buf[pos] : 0u; }
+
+// SKP_Silk_range_dec_init, SKP_Silk_range_coder.c:262
+SX_HD void sx_rc_dec_init(SxRangeDec* rc, const u8* buf, i32 len) {
+    rc->buf = buf;
+    if (len > SX_MAX_ARITHM_BYTES || len < 0) { rc->error = SX_RC_DEC_PAYLOAD_TOO_LONG; rc->bufferLength = 0; return; }
+    rc->bufferLength = len;
+    rc->bufferIx = 0;
+    rc->base_Q32 = (sx_rc_byte(rc, 0) << 24) | (sx_rc_byte(rc, 1) << 16) | (sx_rc_byte(rc, 2) << 8) | sx_rc_byte(rc, 3);
+    rc->range_Q16 = 0x0000FFFF;
+    rc->error = 0;
+}
+
+// SKP_Silk_range_decoder, SKP_Silk_range_coder.c:115.  Returns the decoded symbol (0 on error).
+SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
+    u32 low_Q16 = 0, high_Q16, base_tmp, range_Q32;
+    u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16;
+    i32 bufferIx = rc->bufferIx;
+    if (rc->error) return 0;
+
+    high_Q16 = prob[probIx];
+    base_tmp = range_Q16 * high_Q16;
+    if (base_tmp > base_Q32) {
+        for (;;) {
+            low_Q16 = prob[--probIx];
+            base_tmp = range_Q16 * low_Q16;
+            if (base_tmp <= base_Q32) break;
+            high_Q16 = low_Q16;
+            if (high_Q16 == 0) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        }
+    } else {
+        for (;;) {
+            low_Q16 = high_Q16;
+            high_Q16 = prob[++probIx];
+            base_tmp = range_Q16 * high_Q16;
+            if (base_tmp > base_Q32) { probIx--; break; }
+            if (high_Q16 == 0xFFFF) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        }
+    }
+    base_Q32 -= range_Q16 * low_Q16;
+    range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+
+    if (range_Q32 & 0xFF000000) {
+        range_Q16 = range_Q32 >> 16;
+    } else {
+        if (range_Q32 & 0xFFFF0000) {
+            range_Q16 = range_Q32 >> 8;
+            if (base_Q32 >> 24) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }
+        } else {
+            range_Q16 = range_Q32;
+            // reference: SKP_RSHIFT( base_Q32, 16 ) on an unsigned value => logical shift
+            if (base_Q32 >> 16) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }
+            base_Q32 <<= 8;
+            if (bufferIx < rc->bufferLength) base_Q32 |= sx_rc_byte(rc, 4 + bufferIx++);
+        }
+        base_Q32 <<= 8;
+        if (bufferIx < rc->bufferLength) base_Q32 |= sx_rc_byte(rc, 4 + bufferIx++);
+    }
+    if (range_Q16 == 0) { rc->error = SX_RC_ZERO_INTERVAL_WIDTH; return 0; }
+    rc->base_Q32 = base_Q32;
+    rc->range_Q16 = range_Q16;
+    rc->bufferIx = bufferIx;
+    return probIx;
+}
+
+// SKP_Silk_range_coder_get_length, SKP_Silk_range_coder.c:288 (shared by both directions)
+SX_HD i32 sx_rc_length_bits(i32 bufferIx, u32 range_Q16, i32* nBytes) {
+    i32 nBits = (bufferIx << 3) + sx_clz32((i32)(range_Q16 - 1)) - 14;
+    *nBytes = (nBits + 7) >> 3;
+    return nBits;
+}
+
+// SKP_Silk_range_coder_check_after_decoding, SKP_Silk_range_coder.c:350.
+// NOTE the reference indexes its internal buffer from byte 0 here (not from byte 4).
+SX_HD void sx_rc_check_after_decoding(SxRangeDec* rc) {
+    i32 nBytes;
+    i32 bits = sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytes);
+    if (nBytes - 1 >= rc->bufferLength) { rc->error = SX_RC_DECODER_CHECK_FAILED; return; }
+    if (bits & 7) {
+        i32 mask = 0xFF >> (bits & 7);
+        if (((i32)sx_rc_byte(rc, nBytes - 1) & mask) != mask) { rc->error = SX_RC_DECODER_CHECK_FAILED; return; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// encoder
+// ---------------------------------------------------------------------------------------------------
+struct SxRangeEnc {
+    u8* buf;            // SX_MAX_ARITHM_BYTES bytes of workspace
+    i32 bufferLength;
+    i32 bufferIx;
+    u32 base_Q32;
+    u32 range_Q16;
+    i32 error;
+};
+
+// SKP_Silk_range_enc_init, SKP_Silk_range_coder.c:249
+SX_HD void sx_rc_enc_init(SxRangeEnc* rc, u8* buf) {
+    rc->buf = buf;
+    rc->bufferLength = SX_MAX_ARITHM_BYTES;
+    rc->range_Q16 = 0x0000FFFF;
+    rc->bufferIx = 0;
+    rc->base_Q32 = 0;
+    rc->error = 0;
+}
+
+// SKP_Silk_range_encoder, SKP_Silk_range_coder.c:31
+SX_HD void sx_rc_enc(SxRangeEnc* rc, i32 data, const u16* prob) {
+    if (rc->error) return;
+    u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16;
+    i32 bufferIx = rc->bufferIx;
+    u8* buffer = rc->buf;
+    u32 low_Q16 = prob[data], high_Q16 = prob[data + 1];
+    u32 base_tmp = base_Q32;
+    base_Q32 += range_Q16 * low_Q16;
+    u32 range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+    if (base_Q32 < base_tmp) {  // carry: propagate into the bytes already written
+        i32 ix = bufferIx;
+        while ((++buffer[--ix]) == 0) {}
+    }
+    if (range_Q32 & 0xFF000000) {
+        range_Q16 = range_Q32 >> 16;
+    } else {
+        if (range_Q32 & 0xFFFF0000) {
+            range_Q16 = range_Q32 >> 8;
+        } else {
+            range_Q16 = range_Q32;
+            if (bufferIx >= rc->bufferLength) { rc->error = SX_RC_WRITE_BEYOND_BUFFER; return; }
+            buffer[bufferIx++] = (u8)(base_Q32 >> 24);
+            base_Q32 <<= 8;
+        }
+        if (bufferIx >= rc->bufferLength) { rc->error = SX_RC_WRITE_BEYOND_BUFFER; return; }
+        buffer[bufferIx++] = (u8)(base_Q32 >> 24);
+        base_Q32 <<= 8;
+    }
+    rc->base_Q32 = base_Q32;
+    rc->range_Q16 = range_Q16;
+    rc->bufferIx = bufferIx;
+}
+
+// SKP_Silk_range_enc_wrap_up, SKP_Silk_range_coder.c:305
+SX_HD void sx_rc_enc_wrap_up(SxRangeEnc* rc) {
+    i32 nBytes;
+    u32 base_Q24 = rc->base_Q32 >> 8;
+    i32 bits_in_stream = sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytes);
+    i32 bits_to_store = bits_in_stream - (rc->bufferIx << 3);
+    base_Q24 += 0x00800000u >> (bits_to_store - 1);
+    base_Q24 &= 0xFFFFFFFFu << (24 - bits_to_store);
+    if (base_Q24 & 0x01000000) {
+        i32 ix = rc->bufferIx;
+        while ((++(rc->buf[--ix])) == 0) {}
+    }
+    if (rc->bufferIx < rc->bufferLength) {
+        rc->buf[rc->bufferIx++] = (u8)(base_Q24 >> 16);
+        if (bits_to_store > 8) {
+            if (rc->bufferIx < rc->bufferLength) rc->buf[rc->bufferIx++] = (u8)(base_Q24 >> 8);
+        }
+    }
+    if (bits_in_stream & 7) {
+        i32 mask = 0xFF >> (bits_in_stream & 7);
+        if (nBytes - 1 < rc->bufferLength) rc->buf[nBytes - 1] |= (u8)mask;
+    }
+}

@@ -1,0 +1,94 @@
+// solo_wave.h -- execution model of the SOLO kernels: ONE 64-lane wavefront owns ONE stream.
+//
+// All codec code is written "wave-uniform": control flow and scalars are identical in every lane
+// (the compiler keeps provably uniform values in SGPRs), arrays live in LDS / HBM, and the
+// data-parallel loops are strided over the lanes:
+//
+//     SX_PAR(i, n) { out[i] = f(in[i]); }      // lane l handles i = l, l+64, ...
+//     wv_sync();                               // make the stores visible to the whole wave
+//     s = wv_sum(partial);                     // wrapping int32 add => bit-exact tree reduction
+//
+// The workgroup is exactly one wavefront (blockDim.x == 64), so wv_sync() is a wave-level
+// barrier + LDS/global fence (hipcc drops the s_barrier for single-wave groups).
+//
+// Host build (SOLO_HOST_EMU): SX_NLANES == 1, the same source runs serially -- used only by the
+// CPU-side tests to check the kernel source against the reference without a GPU.
+#pragma once
+#include "solo_fix.h"
+
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SX_NLANES 64
+#define SX_LANE ((int)(threadIdx.x & 63))
+SX_DEV __forceinline__ void wv_sync() { __syncthreads(); }
+SX_DEV __forceinline__ i32 wv_sum(i32 v) {   // sum over the 64 lanes, result in every lane
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = sx_add(v, __shfl_xor(v, o, 64));
+    return v;
+}
+SX_DEV __forceinline__ i64 wv_sum64(i64 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+SX_DEV __forceinline__ i32 wv_max(i32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { i32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
+    return v;
+}
+SX_DEV __forceinline__ i32 wv_min(i32 v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { i32 t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
+    return v;
+}
+// broadcast lane `src`'s value
+SX_DEV __forceinline__ i32 wv_bcast(i32 v, int src) { return __shfl(v, src, 64); }
+// (value, index) arg-min with "first index wins on ties" (matches a serial `<` scan)
+SX_DEV __forceinline__ void wv_argmin(i32* v, i32* idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
+        if (tv < *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
+    }
+}
+// (value, index) arg-max with "first index wins on ties" (matches a serial `>` scan)
+SX_DEV __forceinline__ void wv_argmax(i32* v, i32* idx) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
+        if (tv > *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
+    }
+}
+#else
+#define SX_NLANES 1
+#define SX_LANE 0
+static inline void wv_sync() {}
+static inline i32 wv_sum(i32 v) { return v; }
+static inline i64 wv_sum64(i64 v) { return v; }
+static inline i32 wv_max(i32 v) { return v; }
+static inline i32 wv_min(i32 v) { return v; }
+static inline i32 wv_bcast(i32 v, int) { return v; }
+static inline void wv_argmin(i32*, i32*) {}
+static inline void wv_argmax(i32*, i32*) {}
+#endif
+
+// lane-strided parallel loop
+#define SX_PAR(i, n) for (int i = SX_LANE; i < (int)(n); i += SX_NLANES)
+
+// wave-cooperative memcpy / memset / memmove helpers (element-wise, any POD type)
+template <typename T>
+SX_HD void wv_copy(T* dst, const T* src, int n) { SX_PAR(i, n) dst[i] = src[i]; }
+template <typename T>
+SX_HD void wv_fill(T* dst, T v, int n) { SX_PAR(i, n) dst[i] = v; }
+// overlapping move towards LOWER addresses (dst < src): chunked so every lane reads before any lane
+// of a later chunk writes.  Reads of chunk c happen-before writes of chunk c within the wave.
+template <typename T>
+SX_HD void wv_move_down(T* dst, const T* src, int n) {
+    for (int base = 0; base < n; base += SX_NLANES) {
+        int i = base + SX_LANE;
+        T v = T();
+        if (i < n) v = src[i];
+        wv_sync();
+        if (i < n) dst[i] = v;
+        wv_sync();
+    }
+}
