@@ -1,0 +1,110 @@
+/* solo_mi355x.h -- C ABI of libsolo_mi355x.so, the MI355X-native drop-in for the SOLO hot path.
+ *
+ * Part 1 re-declares, unchanged, the six entry points of the reference's public header
+ *   JC1_SDK_SRC_ARM/interface/AGR_JC1_SDK_API.h:11-64   (identical in JC1_SDK_SRC_FLP/interface/)
+ * so the reference's own callers (test/enc_main.c:190-274, test/dec_main.c:188-392, or a media
+ * engine) link against this library instead of libJC1Codec.a without source changes.  Each handle is
+ * a batch of ONE stream whose codec state lives in HBM; every call launches the same gfx950 kernels
+ * as the batched API (there is no host-side codec arithmetic and no CPU fallback: if no HIP device is
+ * usable, Init returns NULL and Encode/Decode return -1).
+ *
+ * Part 2 is the additive batched API: N independent streams per handle, device pointers in,
+ * device pointers out, one wavefront per stream.  This is what a server-side integration binds
+ * (see INTEGRATION.md for the ctypes / cgo style stubs).
+ */
+#ifndef SOLO_MI355X_H
+#define SOLO_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 1: reference-compatible surface (types from interface/SKP_Silk_typedef.h: SKP_int16=short,
+ * SKP_int32=int, SKP_uint8=unsigned char)
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct {            /* AGR_JC1_SDK_API.h:11-21 */
+    int32_t mode;           /* ignored by the library (as in the reference)            */
+    int32_t targetRate_bps; /* <=0 -> 15600 (AGR_BWE_SDK_API.c:35-37); CLI default 13600 */
+    int32_t samplerate;     /* 16000 (the only rate this build implements)             */
+    int32_t dtx_enable;     /* 0                                                        */
+    int32_t framesize_ms;   /* 40                                                       */
+    int32_t joint_enable;   /* 0                                                        */
+    int32_t joint_mode;
+    int32_t useMDIndex;     /* 0/1: one extra description-index symbol per description  */
+} USER_Ctrl_enc;
+
+typedef struct {            /* AGR_JC1_SDK_API.h:23-31 */
+    int32_t packetLoss_perc;
+    int32_t samplerate;
+    int32_t framesize_ms;
+    int32_t joint_enable;
+    int32_t joint_mode;
+    int32_t useMDIndex;
+} USER_Ctrl_dec;
+
+/* AGR_JC1_SDK_API.h:33  (impl. libBWE/AGR_BWE_SDK_API.c:11).  NULL if the configuration is not the
+ * live one (samplerate 16000, framesize 40, joint off, dtx off) or no GPU is available. */
+void *AGR_Sate_Encoder_Init(USER_Ctrl_enc *enc_Ctrl);
+/* AGR_JC1_SDK_API.h:37  (impl. AGR_BWE_SDK_API.c:129).  pcm: 640 samples; returns total bytes,
+ * nBytesOut[0] = total, nBytesOut[1] = len(MD2)+8 (MD1 = first nBytesOut[0]-nBytesOut[1] bytes). */
+int32_t AGR_Sate_Encoder_Encode(void *SATEEnc_State, const int16_t *AGR_Sate_PCM, uint8_t *AGR_Sate_Bit,
+                                int32_t AGR_Sate_Buf_Size, int16_t *nBytesOut);
+/* AGR_JC1_SDK_API.h:45 */
+int AGR_Sate_Encoder_Uninit(void *SATEEnc_State);
+/* AGR_JC1_SDK_API.h:49  (impl. AGR_BWE_SDK_API.c:166) */
+void *AGR_Sate_Decoder_Init(USER_Ctrl_dec *dec_Ctrl);
+/* AGR_JC1_SDK_API.h:53  (impl. AGR_BWE_SDK_API.c:249).  lostflag: 1 lost, 2 MD1 only, 3 MD2(+HB) only,
+ * 4 both.  Like the reference, nBytes[0..1] are overwritten with the low-band description lengths. */
+int32_t AGR_Sate_Decoder_Decode(void *SATEDec_State, int16_t *AGR_Sate_PCM, int16_t *nSamplesOut,
+                                const uint8_t *AGR_Sate_Bit, int16_t nBytes[], int32_t lostflag);
+/* AGR_JC1_SDK_API.h:62 */
+int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
+
+/* ------------------------------------------------------------------------------------------------
+ * Part 2: batched device API.  All d_* pointers are DEVICE pointers (HBM) of the current HIP device.
+ *
+ *   d_pcm      int16  [n_streams][n_packets][640]      stream-major 16 kHz PCM
+ *   d_bits     uint8  [n_streams][n_packets][slot]     one fixed-size slot per packet: MD1|MD2|HB
+ *   d_nbytes   int16  [n_streams][n_packets][2]        {total, len(MD2)+8}  (the reference's nBytesOut[0..1])
+ *   d_recv     uint8  [n_streams][n_packets]           bit0: MD1 arrived, bit1: MD2(+HB) arrived
+ *                                                      (3 -> lostflag 4, 1 -> 2, 2 -> 3, 0 -> 1; the
+ *                                                       pointer/length mapping of test/dec_main.c:255-378
+ *                                                       is done on the device)
+ *   d_status   int32  [n_streams]                      0, or the first negative SILK error of the call
+ *
+ * Streams keep their codec state in HBM inside the handle between calls (a call with n_packets = P
+ * is identical to P calls with n_packets = 1).  Work is enqueued on `hip_stream` (a hipStream_t, may
+ * be NULL for the default stream) and is asynchronous; no host synchronisation is performed.
+ * Return value: 0 or a negative hipError_t.
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct solo_batch solo_batch_t;
+
+#define SOLO_PACKET_SAMPLES 640
+#define SOLO_DEFAULT_SLOT_BYTES 512
+
+/* Creates encoder and/or decoder state for n_streams streams (pass NULL to skip one direction). */
+solo_batch_t *solo_batch_create(int32_t n_streams, const USER_Ctrl_enc *enc, const USER_Ctrl_dec *dec,
+                                int32_t slot_bytes);
+void solo_batch_destroy(solo_batch_t *b);
+/* Re-initialises all stream states (same as destroy + create). */
+int32_t solo_batch_reset(solo_batch_t *b, void *hip_stream);
+int32_t solo_batch_encode(solo_batch_t *b, const int16_t *d_pcm, int32_t n_packets, uint8_t *d_bits,
+                          int16_t *d_nbytes, int32_t *d_status, void *hip_stream);
+int32_t solo_batch_decode(solo_batch_t *b, const uint8_t *d_bits, const int16_t *d_nbytes,
+                          const uint8_t *d_recv, int32_t n_packets, int16_t *d_pcm, int32_t *d_status,
+                          void *hip_stream);
+/* Geometry / introspection */
+int32_t solo_batch_n_streams(const solo_batch_t *b);
+int32_t solo_batch_slot_bytes(const solo_batch_t *b);
+/* Name of the dominant kernel of the last encode / decode launch (for profiling tools). */
+const char *solo_kernel_name(int32_t which /* 0 = encode, 1 = decode */);
+/* Library version string. */
+const char *solo_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

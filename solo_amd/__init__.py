@@ -1,0 +1,162 @@
+"""solo_amd -- thin Python binding of libsolo_mi355x.so (the MI355X-native SOLO encode/decode path).
+
+PyTorch is used only as plumbing: device memory (tensors), HIP streams and torch.distributed.
+All codec arithmetic runs in the hand-written gfx950 kernels of solo_amd/csrc/; there is no CPU
+fallback -- importing works everywhere (so the ABI can be inspected on a CPU-only box), but creating
+a `SoloBatch` without the built library or without a GPU raises.
+
+The C ABI bound here is declared in include/solo_mi355x.h (the six AGR_Sate_* entry points of the
+reference's interface/AGR_JC1_SDK_API.h plus the batched device-pointer API).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsolo_mi355x.so")
+
+PACKET_SAMPLES = 640
+DEFAULT_SLOT_BYTES = 512
+
+ABI_SYMBOLS = [
+    "AGR_Sate_Encoder_Init", "AGR_Sate_Encoder_Encode", "AGR_Sate_Encoder_Uninit",
+    "AGR_Sate_Decoder_Init", "AGR_Sate_Decoder_Decode", "AGR_Sate_Decoder_Uninit",
+    "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
+    "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version",
+]
+
+
+class USER_Ctrl_enc(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "mode", "targetRate_bps", "samplerate", "dtx_enable", "framesize_ms",
+        "joint_enable", "joint_mode", "useMDIndex")]
+
+
+class USER_Ctrl_dec(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "packetLoss_perc", "samplerate", "framesize_ms", "joint_enable", "joint_mode", "useMDIndex")]
+
+
+_lib = None
+
+
+def load_library():
+    """Loads libsolo_mi355x.so (raises if it has not been built: see __graft_entry__.build())."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("libsolo_mi355x.so is not built (%s). Run `python -c 'import __graft_entry__ as g; g.build()'`; "
+                           "this package has no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    lib.solo_batch_create.restype = C.c_void_p
+    lib.solo_batch_create.argtypes = [C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.solo_batch_destroy.argtypes = [C.c_void_p]
+    lib.solo_batch_reset.argtypes = [C.c_void_p, C.c_void_p]
+    lib.solo_batch_reset.restype = C.c_int32
+    lib.solo_batch_encode.restype = C.c_int32
+    lib.solo_batch_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.solo_batch_decode.restype = C.c_int32
+    lib.solo_batch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.solo_batch_n_streams.argtypes = [C.c_void_p]
+    lib.solo_batch_slot_bytes.argtypes = [C.c_void_p]
+    lib.solo_kernel_name.restype = C.c_char_p
+    lib.solo_kernel_name.argtypes = [C.c_int32]
+    lib.solo_version.restype = C.c_char_p
+    lib.AGR_Sate_Encoder_Init.restype = C.c_void_p
+    lib.AGR_Sate_Encoder_Init.argtypes = [C.c_void_p]
+    lib.AGR_Sate_Encoder_Encode.restype = C.c_int32
+    lib.AGR_Sate_Encoder_Encode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
+    lib.AGR_Sate_Encoder_Uninit.argtypes = [C.c_void_p]
+    lib.AGR_Sate_Decoder_Init.restype = C.c_void_p
+    lib.AGR_Sate_Decoder_Init.argtypes = [C.c_void_p]
+    lib.AGR_Sate_Decoder_Decode.restype = C.c_int32
+    lib.AGR_Sate_Decoder_Decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32]
+    lib.AGR_Sate_Decoder_Uninit.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def default_enc_ctrl(rate=13600, use_md_index=0):
+    """Defaults of the reference CLI (JC1_SDK_SRC_ARM/test/enc_main.c:92-99)."""
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=0, framesize_ms=40,
+                         joint_enable=0, joint_mode=0, useMDIndex=use_md_index)
+
+
+def default_dec_ctrl(use_md_index=0):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=16000, framesize_ms=40, joint_enable=0, joint_mode=0,
+                         useMDIndex=use_md_index)
+
+
+class SoloBatch:
+    """N independent SOLO streams on the current HIP device (one wavefront per stream)."""
+
+    def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0):
+        import torch
+        if not torch.cuda.is_available():
+            raise RuntimeError("solo_amd needs a HIP device (MI355X); there is no CPU path")
+        self.torch = torch
+        self.lib = load_library()
+        self.n_streams = int(n_streams)
+        self.slot = int(slot_bytes)
+        self._enc = default_enc_ctrl(rate, use_md_index) if encoder else None
+        self._dec = default_dec_ctrl(use_md_index) if decoder else None
+        self.h = self.lib.solo_batch_create(self.n_streams, C.byref(self._enc) if encoder else None,
+                                            C.byref(self._dec) if decoder else None, self.slot)
+        if not self.h:
+            raise RuntimeError("solo_batch_create failed (unsupported configuration, no GPU, or out of memory)")
+        self.device = torch.device("cuda", torch.cuda.current_device())
+
+    def _stream(self):
+        return C.c_void_p(self.torch.cuda.current_stream().cuda_stream)
+
+    def reset(self):
+        r = self.lib.solo_batch_reset(self.h, self._stream())
+        if r:
+            raise RuntimeError("solo_batch_reset -> %d" % r)
+
+    def encode(self, pcm, bits=None, nbytes=None, status=None):
+        """pcm: int16 CUDA tensor [N, P, 640] -> (bits uint8 [N,P,slot], nbytes int16 [N,P,2], status int32 [N])"""
+        t = self.torch
+        assert pcm.is_cuda and pcm.dtype == t.int16 and pcm.is_contiguous()
+        N, P, L = pcm.shape
+        assert N == self.n_streams and L == PACKET_SAMPLES
+        if bits is None:
+            bits = t.zeros((N, P, self.slot), dtype=t.uint8, device=pcm.device)
+        if nbytes is None:
+            nbytes = t.zeros((N, P, 2), dtype=t.int16, device=pcm.device)
+        if status is None:
+            status = t.zeros((N,), dtype=t.int32, device=pcm.device)
+        r = self.lib.solo_batch_encode(self.h, pcm.data_ptr(), P, bits.data_ptr(), nbytes.data_ptr(), status.data_ptr(), self._stream())
+        if r:
+            raise RuntimeError("solo_batch_encode -> %d" % r)
+        return bits, nbytes, status
+
+    def decode(self, bits, nbytes, recv=None, pcm=None, status=None):
+        """bits uint8 [N,P,slot], nbytes int16 [N,P,2], recv uint8 [N,P] (bit0 MD1, bit1 MD2) -> pcm int16 [N,P,640]"""
+        t = self.torch
+        assert bits.is_cuda and bits.dtype == t.uint8 and bits.is_contiguous()
+        assert nbytes.dtype == t.int16 and nbytes.is_contiguous()
+        N, P, S = bits.shape
+        assert N == self.n_streams and S == self.slot
+        if recv is not None:
+            assert recv.dtype == t.uint8 and recv.is_contiguous() and tuple(recv.shape) == (N, P)
+        if pcm is None:
+            pcm = t.zeros((N, P, PACKET_SAMPLES), dtype=t.int16, device=bits.device)
+        if status is None:
+            status = t.zeros((N,), dtype=t.int32, device=bits.device)
+        r = self.lib.solo_batch_decode(self.h, bits.data_ptr(), nbytes.data_ptr(), recv.data_ptr() if recv is not None else None,
+                                       P, pcm.data_ptr(), status.data_ptr(), self._stream())
+        if r:
+            raise RuntimeError("solo_batch_decode -> %d" % r)
+        return pcm, status
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.lib.solo_batch_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,280 @@
+// solo_api.hip -- gfx950 kernels + the C ABI of libsolo_mi355x.so (include/solo_mi355x.h).
+//
+// Execution model: one 64-lane wavefront (= one workgroup) owns one stream and walks its packets in
+// order; thousands of streams run concurrently.  Persistent codec state is an array of per-stream
+// structs in HBM; the per-packet working set lives in LDS.  No host-side codec arithmetic exists in
+// this library: without a usable HIP device every entry point fails.
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <new>
+
+#include "../../include/solo_mi355x.h"
+#include "solo_dec.h"
+#ifdef SOLO_WITH_ENCODER
+#include "solo_enc.h"
+#endif
+
+#define SOLO_CHECK(expr)                                        \
+    do {                                                        \
+        hipError_t e_ = (expr);                                 \
+        if (e_ != hipSuccess) return -(int32_t)e_;              \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------
+// kernels
+// ---------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(64) solo_dec_init_kernel(SxDecState* states, int n_streams) {
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    sx_dec_state_init(&states[s]);
+}
+
+// Decoder: rows D0-D8.  blockIdx.x = stream.
+__global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, const u8* __restrict__ bits,
+                                                         const i16* __restrict__ nbytes, const u8* __restrict__ recv,
+                                                         int n_streams, int n_packets, int slot, int useMDIndex,
+                                                         i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SxDecState* st = &states[s];
+    i32 first_err = 0;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const u8* b = bits + pk * (size_t)slot;
+        const i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
+        const int m = recv ? (recv[pk] & 3) : 3;
+        // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
+        int lostflag;
+        i32 a0, a1;
+        const u8* ptr = b;
+        if (m == 3) { lostflag = 4; a0 = n0; a1 = n1; }
+        else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
+        else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
+        else { lostflag = 1; a0 = n0; a1 = n1; }
+        i16* out = pcm + pk * SX_PACKET;
+        int ret = sx_decode_packet(st, &w, ptr, a0, a1, lostflag, useMDIndex, out);
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    if (status && SX_LANE == 0) status[s] = first_err;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// host side: handle + C ABI
+// ---------------------------------------------------------------------------------------------------
+struct solo_batch {
+    int32_t n_streams;
+    int32_t slot;
+    int have_enc, have_dec;
+    USER_Ctrl_enc enc_ctrl;
+    USER_Ctrl_dec dec_ctrl;
+    void* d_enc_state;
+    void* d_enc_work;
+    SxDecState* d_dec_state;
+};
+
+static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
+    return c->samplerate == 16000 && c->framesize_ms == 40 && c->joint_enable == 0 && c->dtx_enable == 0;
+}
+static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
+    return c->samplerate == 16000 && c->framesize_ms == 40 && c->joint_enable == 0;
+}
+
+#ifdef SOLO_WITH_ENCODER
+int32_t solo_enc_alloc(solo_batch* b);
+int32_t solo_enc_reset(solo_batch* b, hipStream_t s);
+void solo_enc_free(solo_batch* b);
+#endif
+
+extern "C" {
+
+const char* solo_version(void) { return "solo_mi355x 0.1 (gfx950)"; }
+
+const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : "solo_decode_kernel"; }
+
+int32_t solo_batch_n_streams(const solo_batch_t* b) { return b ? b->n_streams : 0; }
+int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
+
+int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
+    if (!b) return -1;
+    hipStream_t s = (hipStream_t)hip_stream;
+    if (b->have_dec) {
+        hipLaunchKernelGGL(solo_dec_init_kernel, dim3(b->n_streams), dim3(64), 0, s, b->d_dec_state, b->n_streams);
+        SOLO_CHECK(hipGetLastError());
+    }
+#ifdef SOLO_WITH_ENCODER
+    if (b->have_enc) {
+        int32_t r = solo_enc_reset(b, s);
+        if (r) return r;
+    }
+#endif
+    return 0;
+}
+
+solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, const USER_Ctrl_dec* dec, int32_t slot_bytes) {
+    if (n_streams <= 0) return NULL;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) {
+        fprintf(stderr, "solo_mi355x: no HIP device available -- this library has no CPU path\n");
+        return NULL;
+    }
+    if (enc && !ctrl_enc_supported(enc)) return NULL;
+    if (dec && !ctrl_dec_supported(dec)) return NULL;
+    solo_batch* b = new (std::nothrow) solo_batch();
+    if (!b) return NULL;
+    memset(b, 0, sizeof(*b));
+    b->n_streams = n_streams;
+    b->slot = slot_bytes > 0 ? slot_bytes : SOLO_DEFAULT_SLOT_BYTES;
+    if (enc) {
+#ifdef SOLO_WITH_ENCODER
+        b->have_enc = 1;
+        b->enc_ctrl = *enc;
+        if (b->enc_ctrl.targetRate_bps <= 0) b->enc_ctrl.targetRate_bps = 15600;  // AGR_BWE_SDK_API.c:35
+        if (solo_enc_alloc(b) != 0) { solo_batch_destroy(b); return NULL; }
+#else
+        delete b;
+        return NULL;
+#endif
+    }
+    if (dec) {
+        b->have_dec = 1;
+        b->dec_ctrl = *dec;
+        if (hipMalloc((void**)&b->d_dec_state, sizeof(SxDecState) * (size_t)n_streams) != hipSuccess) { solo_batch_destroy(b); return NULL; }
+    }
+    if (solo_batch_reset(b, NULL) != 0 || hipDeviceSynchronize() != hipSuccess) { solo_batch_destroy(b); return NULL; }
+    return b;
+}
+
+void solo_batch_destroy(solo_batch_t* b) {
+    if (!b) return;
+    if (b->d_dec_state) (void)hipFree(b->d_dec_state);
+#ifdef SOLO_WITH_ENCODER
+    solo_enc_free(b);
+#endif
+    delete b;
+}
+
+int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
+                          int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
+    if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
+    hipLaunchKernelGGL(solo_decode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state,
+                       d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot, b->dec_ctrl.useMDIndex, d_pcm, d_status);
+    SOLO_CHECK(hipGetLastError());
+    return 0;
+}
+
+#ifndef SOLO_WITH_ENCODER
+int32_t solo_batch_encode(solo_batch_t*, const int16_t*, int32_t, uint8_t*, int16_t*, int32_t*, void*) { return -1; }
+#endif
+
+// ---- the reference's six entry points: a batch of one stream, staged through device buffers ----------
+struct solo_single {
+    solo_batch* b;
+    int16_t* d_pcm;
+    uint8_t* d_bits;
+    int16_t* d_nbytes;
+    uint8_t* d_recv;
+    int32_t* d_status;
+    int is_enc;
+};
+
+static void single_free(solo_single* h) {
+    if (!h) return;
+    if (h->d_pcm) (void)hipFree(h->d_pcm);
+    if (h->d_bits) (void)hipFree(h->d_bits);
+    if (h->d_nbytes) (void)hipFree(h->d_nbytes);
+    if (h->d_recv) (void)hipFree(h->d_recv);
+    if (h->d_status) (void)hipFree(h->d_status);
+    solo_batch_destroy(h->b);
+    free(h);
+}
+
+static solo_single* single_new(const USER_Ctrl_enc* e, const USER_Ctrl_dec* d) {
+    solo_single* h = (solo_single*)calloc(1, sizeof(solo_single));
+    if (!h) return NULL;
+    h->is_enc = e != NULL;
+    h->b = solo_batch_create(1, e, d, 1024 + 64);   // MAX_FRAME_BYTES of the reference harness + slack
+    if (!h->b || hipMalloc((void**)&h->d_pcm, SX_PACKET * 2) != hipSuccess || hipMalloc((void**)&h->d_bits, h->b->slot) != hipSuccess ||
+        hipMalloc((void**)&h->d_nbytes, 4) != hipSuccess || hipMalloc((void**)&h->d_recv, 4) != hipSuccess ||
+        hipMalloc((void**)&h->d_status, 4) != hipSuccess) {
+        single_free(h);
+        return NULL;
+    }
+    return h;
+}
+
+void* AGR_Sate_Encoder_Init(USER_Ctrl_enc* enc_Ctrl) {
+    if (!enc_Ctrl) return NULL;
+    if (enc_Ctrl->targetRate_bps <= 0) enc_Ctrl->targetRate_bps = 15600;   // the reference rewrites the caller's struct
+    return single_new(enc_Ctrl, NULL);
+}
+
+int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int32_t bufSize, int16_t* nBytesOut) {
+    solo_single* h = (solo_single*)st;
+    if (!h || !h->is_enc) return -1;
+    if (hipMemcpy(h->d_pcm, pcm, SX_PACKET * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
+    int16_t nb[2];
+    if (hipMemcpy(nb, h->d_nbytes, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    int32_t n = nb[0];
+    if (n > bufSize) n = bufSize;                                            // AGR_Sate_bits_write truncates to max_nbytes
+    if (n > 0 && hipMemcpy(bits, h->d_bits, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    nBytesOut[0] = nb[0];
+    nBytesOut[1] = nb[1];
+    return n;
+}
+
+int AGR_Sate_Encoder_Uninit(void* st) {
+    if (!st) return -1;
+    single_free((solo_single*)st);
+    return 0;
+}
+
+void* AGR_Sate_Decoder_Init(USER_Ctrl_dec* dec_Ctrl) {
+    if (!dec_Ctrl) return NULL;
+    return single_new(NULL, dec_Ctrl);
+}
+
+// single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
+__global__ void __launch_bounds__(64) solo_decode_raw_kernel(SxDecState* st, const u8* bits, int n0, int n1, int lostflag,
+                                                             int useMDIndex, i16* pcm, i32* status) {
+    __shared__ SxDecWork w;
+    int ret = sx_decode_packet(st, &w, bits, n0, n1, lostflag, useMDIndex, pcm);
+    if (SX_LANE == 0) *status = ret;
+}
+
+int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, const uint8_t* bits, int16_t nBytes[], int32_t lostflag) {
+    solo_single* h = (solo_single*)st;
+    if (!h || h->is_enc) return -1;
+    if (nBytes[0] <= 0) return -1;                                           // AGR_BWE_SDK_API.c:266
+    if (lostflag < 1 || lostflag > 4) return -1;
+    int32_t n0 = nBytes[0], n1 = nBytes[1];
+    if (lostflag != 1) {
+        if (n0 > h->b->slot) return -11;                                      // SKP_SILK_DEC_PAYLOAD_TOO_LARGE
+        if (hipMemcpy(h->d_bits, bits, n0, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    }
+    hipLaunchKernelGGL(solo_decode_raw_kernel, dim3(1), dim3(64), 0, 0, h->b->d_dec_state, h->d_bits, n0, n1, lostflag,
+                       h->b->dec_ctrl.useMDIndex, h->d_pcm, h->d_status);
+    int32_t ret = 0;
+    if (hipMemcpy(&ret, h->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    // the reference rewrites the caller's nBytes[] with the low-band lengths (AGR_BWE_decode_frame_FIX.c:150-169)
+    int32_t nb0 = (lostflag == 2) ? n0 : n0 - SX_HB_BYTES;
+    int32_t nb1 = n1 ? n1 - SX_HB_BYTES : 0;
+    nBytes[0] = (int16_t)(nb0 - nb1);
+    nBytes[1] = (int16_t)nb1;
+    if (ret < 0) return ret;
+    if (hipMemcpy(pcm, h->d_pcm, SX_PACKET * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *nSamplesOut = SX_PACKET;
+    return 0;
+}
+
+int32_t AGR_Sate_Decoder_Uninit(void* st) {
+    if (!st) return -1;
+    single_free((solo_single*)st);
+    return 0;
+}
+
+}  // extern "C"

@@ -19,57 +19,57 @@
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SX_NLANES 64
 #define SX_LANE ((int)(threadIdx.x & 63))
-SX_DEV __forceinline__ void wv_sync() { __syncthreads(); }
-SX_DEV __forceinline__ i32 wv_sum(i32 v) {   // sum over the 64 lanes, result in every lane
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = sx_add(v, __shfl_xor(v, o, 64));
-    return v;
+#define SX_XOR_REDUCE(v, OP)                                              \
+    _Pragma("unroll") for (int o_ = 32; o_ > 0; o_ >>= 1) { auto t_ = __shfl_xor(v, o_, 64); v = OP; }
+#else
+#define SX_NLANES 1
+#define SX_LANE 0
+#define SX_XOR_REDUCE(v, OP)
+#endif
+
+// (under hipcc these are __host__ __device__ so that the host pass of a .hip file still parses
+// kernels that call them; the host bodies are the 1-lane identities used by the emulation build)
+SX_HD void wv_sync() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    __syncthreads();
+#endif
 }
-SX_DEV __forceinline__ i64 wv_sum64(i64 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+SX_HD i32 wv_sum(i32 v) { SX_XOR_REDUCE(v, sx_add(v, t_)) return v; }   // sum over the lanes, result in every lane
+SX_HD i64 wv_sum64(i64 v) { SX_XOR_REDUCE(v, v + t_) return v; }
+SX_HD i32 wv_max(i32 v) { SX_XOR_REDUCE(v, (t_ > v ? t_ : v)) return v; }
+SX_HD i32 wv_min(i32 v) { SX_XOR_REDUCE(v, (t_ < v ? t_ : v)) return v; }
+SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __shfl(v, src, 64);
+#else
+    (void)src;
     return v;
+#endif
 }
-SX_DEV __forceinline__ i32 wv_max(i32 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { i32 t = __shfl_xor(v, o, 64); v = t > v ? t : v; }
-    return v;
-}
-SX_DEV __forceinline__ i32 wv_min(i32 v) {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { i32 t = __shfl_xor(v, o, 64); v = t < v ? t : v; }
-    return v;
-}
-// broadcast lane `src`'s value
-SX_DEV __forceinline__ i32 wv_bcast(i32 v, int src) { return __shfl(v, src, 64); }
 // (value, index) arg-min with "first index wins on ties" (matches a serial `<` scan)
-SX_DEV __forceinline__ void wv_argmin(i32* v, i32* idx) {
+SX_HD void wv_argmin(i32* v, i32* idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
         if (tv < *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
     }
+#else
+    (void)v; (void)idx;
+#endif
 }
 // (value, index) arg-max with "first index wins on ties" (matches a serial `>` scan)
-SX_DEV __forceinline__ void wv_argmax(i32* v, i32* idx) {
+SX_HD void wv_argmax(i32* v, i32* idx) {
+#if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
         if (tv > *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
     }
-}
 #else
-#define SX_NLANES 1
-#define SX_LANE 0
-static inline void wv_sync() {}
-static inline i32 wv_sum(i32 v) { return v; }
-static inline i64 wv_sum64(i64 v) { return v; }
-static inline i32 wv_max(i32 v) { return v; }
-static inline i32 wv_min(i32 v) { return v; }
-static inline i32 wv_bcast(i32 v, int) { return v; }
-static inline void wv_argmin(i32*, i32*) {}
-static inline void wv_argmax(i32*, i32*) {}
+    (void)v; (void)idx;
 #endif
+}
 
 // lane-strided parallel loop
 #define SX_PAR(i, n) for (int i = SX_LANE; i < (int)(n); i += SX_NLANES)

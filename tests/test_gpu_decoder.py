@@ -1,0 +1,112 @@
+"""GPU parity of the decoder (rows D0-D8) through the C ABI: HIP kernels vs the committed golden
+vectors and, when oracle/_ref travelled with the snapshot, vs the compiled reference itself."""
+import numpy as np
+import pytest
+
+import refcodec as R
+import solo_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+def _gpu_decode(torch, bits, nb, recv):
+    import solo_amd
+    N, P, S = bits.shape
+    b = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=S)
+    dev = b.device
+    pcm, status = b.decode(torch.from_numpy(bits).to(dev), torch.from_numpy(nb).to(dev),
+                           None if recv is None else torch.from_numpy(recv).to(dev))
+    torch.cuda.synchronize()
+    assert int(status.abs().max()) == 0
+    return pcm.cpu().numpy()
+
+
+def test_synthetic_goldens_clean_and_lossy(torch_cuda):
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    out = _gpu_decode(torch_cuda, z["bits"], z["nbytes"], None)
+    assert np.array_equal(out, z["dec_clean"])
+    out = _gpu_decode(torch_cuda, z["bits"], z["nbytes"], z["recv"])
+    assert np.array_equal(out, z["dec_loss"])
+
+
+def test_ch_f1_md5_cli_loss(torch_cuda):
+    g = T.golden_json()
+    recs = T.parse_bit_container(open(T.GOLDEN + "/ch_f1.bit", "rb").read())
+    bits, nb = T.pack_slots([recs])
+    for loss in (0, 30):
+        recv = T.recv_mask_from_pattern(R.cli_loss_pattern(len(recs), loss))[None, :]
+        out = _gpu_decode(torch_cuda, bits, nb, np.ascontiguousarray(recv))
+        assert T.md5(out) == g["ch_f1_dec_loss%d_md5" % loss]
+
+
+def test_packetwise_calls_equal_one_call(torch_cuda):
+    """State carries in HBM between launches: P calls of 1 packet == 1 call of P packets."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    bits, nb, recv = z["bits"], z["nbytes"], z["recv"]
+    N, P, S = bits.shape
+    b = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=S)
+    outs = []
+    for p in range(P):
+        pcm, st = b.decode(torch.from_numpy(np.ascontiguousarray(bits[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(nb[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(recv[:, p:p + 1])).to(b.device))
+        outs.append(pcm.cpu().numpy())
+    assert np.array_equal(np.concatenate(outs, axis=1), z["dec_loss"])
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_many_streams_vs_compiled_reference(torch_cuda):
+    """256 streams x 12 packets, 30 % Bernoulli description loss (config 4 shape, reduced count)."""
+    N, P = 256, 12
+    streams = []
+    for i in range(N):
+        e = R.RefEncoder("fix")
+        pcm = R.synth_stream(1000 + i, P)
+        streams.append([e.encode(pcm[p]) for p in range(P)])
+    bits, nb = T.pack_slots(streams)
+    recv = T.bernoulli_recv(N, P, 0.3, 99)
+    out = _gpu_decode(torch_cuda, bits, nb, recv)
+    for i in range(N):
+        d = R.RefDecoder("fix")
+        for p, (pl, n0, n1) in enumerate(streams[i]):
+            m = int(recv[i, p])
+            x, ret = d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert np.array_equal(out[i, p], x), (i, p, m)
+
+
+def test_legacy_single_stream_api(torch_cuda):
+    """The six AGR_Sate_* symbols (decoder side) driven exactly like test/dec_main.c does."""
+    import ctypes as C
+    import solo_amd
+    lib = solo_amd.load_library()
+    g = T.golden_json()
+    recs = T.parse_bit_container(open(T.GOLDEN + "/ch_f1.bit", "rb").read())
+    ctrl = solo_amd.default_dec_ctrl()
+    h = lib.AGR_Sate_Decoder_Init(C.byref(ctrl))
+    assert h
+    pat = R.cli_loss_pattern(len(recs), 30)
+    out = []
+    pcm = np.zeros(1920, np.int16)
+    ns = np.zeros(1, np.int16)
+    for p, (pl, n0, n1) in enumerate(recs[:60]):
+        payload, a0, a1, flag = R.map_loss(pl, n0, n1, *pat[p])
+        buf = np.zeros(1100, np.uint8)
+        buf[:len(payload)] = np.frombuffer(payload, np.uint8)
+        nbv = np.array([a0, a1, 0, 0, 0, 0], np.int16)
+        ret = lib.AGR_Sate_Decoder_Decode(h, pcm.ctypes.data, ns.ctypes.data, buf.ctypes.data, nbv.ctypes.data, flag)
+        assert ret == 0 and ns[0] == 640
+        out.append(pcm[:640].copy())
+    lib.AGR_Sate_Decoder_Uninit(h)
+    ref = T.EmuDecoder()
+    for p, (pl, n0, n1) in enumerate(recs[:60]):
+        x, _ = ref.decode(*R.map_loss(pl, n0, n1, *pat[p]))
+        assert np.array_equal(out[p], x)
