@@ -12,7 +12,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsolo_mi355x.so")
+LIB_PATH = os.environ.get("SOLO_LIB_OVERRIDE") or os.path.join(_HERE, "libsolo_mi355x.so")
 
 PACKET_SAMPLES = 640
 DEFAULT_SLOT_BYTES = 512

@@ -134,7 +134,7 @@ SX_HD void sx_nlsf2a(i16* a, const i32* NLSF, int d) {
 }
 
 // SKP_Silk_NLSF2A_stable, SKP_Silk_NLSF2A_stable.c:31
-SX_HD void sx_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF, int order) {
+SX_FN void sx_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF, int order) {
     i32 invGain_Q30;
     sx_nlsf2a(pAR_Q12, pNLSF, order);
     int i;
@@ -150,7 +150,7 @@ SX_HD void sx_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF, int order) {
 }
 
 // SKP_Silk_NLSF_stabilize, SKP_Silk_NLSF_stabilize.c:42   (NDeltaMin has L+1 entries)
-SX_HD void sx_nlsf_stabilize(i32* NLSF_Q15, const i32* NDeltaMin_Q15, int L) {
+SX_FN void sx_nlsf_stabilize(i32* NLSF_Q15, const i32* NDeltaMin_Q15, int L) {
     int loops;
     for (loops = 0; loops < 20; loops++) {
         i32 min_diff = NLSF_Q15[0] - NDeltaMin_Q15[0];
@@ -214,7 +214,7 @@ SX_HD void sx_nlsf_weights_laroia(i32* pW_Q6, const i32* pNLSF_Q15, int D) {
 // SKP_Silk_sum_sqr_shift, SKP_Silk_sum_sqr_shift.c:40.  The reference's result depends on whether
 // the int16 pointer is 4-byte aligned (it then accumulates in sample PAIRS and tests for overflow
 // once per pair); `odd_start` = 1 reproduces the "pointer & 2" branch.  Wave-uniform, serial.
-SX_HD void sx_sum_sqr_shift(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
+SX_FN void sx_sum_sqr_shift(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
     i32 nrg, nrg_tmp;
     int i, shft = 0;
     if (odd_start) { nrg = sx_smulbb(x[0], x[0]); i = 1; } else { nrg = 0; i = 0; }

@@ -21,6 +21,17 @@
 #define SX_BAND 320              // samples per band per packet
 #define SX_HB_BYTES 8            // 2 x HB_BYTE (libBWE/AGR_BWE_defines.h:39)
 #define SX_QMF_HIST 32           // synthesis memory per band (M2)
+// first-failure trace of the range decoder (debug aid, costs one compare per stage)
+#ifndef SX_TRACE_ALWAYS
+#define SX_TRACE_ALWAYS 0
+#endif
+#define SX_TRACE(stage)                                                                            \
+    do {                                                                                           \
+        if ((rc->error && st->dbg[0] == 0) || SX_TRACE_ALWAYS) {                                                        \
+            st->dbg[0] = (stage); st->dbg[1] = rc->error; st->dbg[2] = rc->bufferIx; st->dbg[3] = rc->bufferLength; \
+            st->dbg[4] = (i32)rc->range_Q16; st->dbg[5] = (i32)rc->base_Q32; st->dbg[6] = st->nFramesDecoded; st->dbg[7] = kDesp; \
+        }                                                                                          \
+    } while (0)
 
 // ---- persistent per-stream decoder state (HBM) ---------------------------------------------------
 struct SxDecDesc {               // SKP_Silk_md_decoder_state, SKP_Silk_structs.h:295 (live fields)
@@ -78,6 +89,10 @@ struct SxDecState {
     i16 qmf_lo_hist[SX_QMF_HIST];   // last 32 low-band samples, time order (g0_mem of the reference, re-laid-out)
     i16 qmf_hi_hist[SX_QMF_HIST];
     i32 last_error;
+#ifdef SX_RC_LOG
+    i32 rclog[512];
+#endif
+    i32 dbg[8];                  // first-failure trace: {stage, rc error, bufferIx, bufferLength, range, base, frame, desc}
 };
 
 // ---- per-packet working set (LDS) ----------------------------------------------------------------
@@ -166,7 +181,7 @@ SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4) {
 }
 
 // SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64)
-SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q) {
+SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q) {
     const int iter = SX_FRAME / 16;
     i32 sum_pulses[SX_FRAME / 16], nLshifts[SX_FRAME / 16];
     c->RateLevelIndex = sx_rc_dec(rc, &T_cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
@@ -230,7 +245,7 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 }
 
 // SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
-SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex) {
+SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex) {
     i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], pNLSF_Q15[SX_LPC], pNLSF0_Q15[SX_LPC], DeltaGainIndices;
     SxDecDesc* md = &st->md[kDesp];
     if (st->nFramesDecoded == 0) {
@@ -244,6 +259,7 @@ SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     } else {
         Ix = sx_rc_dec(rc, &T_cdf_type_offset_joint[md->typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
     }
+    SX_TRACE(1);
     c->sigtype = Ix >> 1;
     c->QuantOffsetType = Ix & 1;
     md->typeOffsetPrev = Ix;
@@ -257,6 +273,7 @@ SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     } else {
         DeltaGainIndices = md->prevDeltaGainIndex;
     }
+    SX_TRACE(2);
     sx_gains_dequant(c->Gains_Q16, GainsIndices, &md->LastGainIndex, st->nFramesDecoded, DeltaGainIndices, &c->DeltaGains_Q16);
 
     // NLSF path: 6 stages, per-stage CDFs laid out back to back (nvec+1 entries each)
@@ -271,6 +288,7 @@ SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
             off += nvec[s] + 1;
         }
     }
+    SX_TRACE(3);
     sx_nlsf_msvq_decode(pNLSF_Q15, c->sigtype, NLSFIndices);
     c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, T_cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
     if (st->first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
@@ -309,8 +327,11 @@ SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
         c->PERIndex = 0;
         c->LTP_scale_Q14 = 0;
     }
+    SX_TRACE(4);
     c->Seed = sx_rc_dec(rc, T_cdf_seed, T_CDF_MID_SEED);
+    SX_TRACE(5);
     sx_decode_pulses(rc, c, q);
+    SX_TRACE(6);
     st->vadFlag = sx_rc_dec(rc, T_cdf_vadflag, T_CDF_MID_VADFLAG);
     st->FrameTermination = sx_rc_dec(rc, T_cdf_frame_term, T_CDF_MID_FRAME_TERM);
 
@@ -320,10 +341,11 @@ SX_HD void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     if (kDesp == 0) st->nBytesLeft0 = left;
     if (left < 0) rc->error = SX_RC_READ_BEYOND_BUFFER;
     if (left == 0) sx_rc_check_after_decoding(rc);
+    SX_TRACE(7);
 }
 
 // SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
-SX_HD void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
+SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
     SxDecCtrl* c = &w->ctrl;
     const int NLSF_interpolation_flag = c->NLSFInterpCoef_Q2 < 4 ? 1 : 0;
     i32* pexc_Q10 = st->exc_Q10;
@@ -451,7 +473,7 @@ SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
 }
 
 // SKP_Silk_PLC_conceal, SKP_Silk_PLC.c:146
-SX_HD void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
+SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
     SxPLC* p = &st->plc;
     SxDecCtrl* c = &w->ctrl;
     i16* exc_buf = w->tmp16;
@@ -565,7 +587,7 @@ SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
 // SKP_Silk_PLC_glue_frames, SKP_Silk_PLC.c:363.  `odd` = int16 offset of `signal` from a 4-byte
 // aligned base, modulo 2 (sum_sqr_shift's alignment branch); the low-band buffer of the reference is
 // a stack array advanced by 160 samples per frame, i.e. always even.
-SX_HD void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
+SX_FN void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
     SxPLC* p = &st->plc;
     if (st->lossCnt) {
         sx_sum_sqr_shift(&p->conc_energy, &p->conc_energy_shift, signal, length, 0);
@@ -613,7 +635,7 @@ SX_HD void sx_lpc_synthesis_filter(const i16* in, const i16* A_Q12, i32 Gain_Q26
 }
 
 // SKP_Silk_CNG, SKP_Silk_CNG.c:75
-SX_HD void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
+SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
     SxCNG* g = &st->cng;
     SxDecCtrl* c = &w->ctrl;
     if (g->fs_kHz != 8) {
@@ -675,7 +697,7 @@ SX_HD void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
 // One 20 ms low-band frame: SKP_Silk_SDK_Decode + SKP_Silk_decode_frame + AgoraSateDecodeTwoDesps.
 // rc[] persists across the two frames of a packet.  Returns 0, or a negative SILK error code
 // (SKP_Silk_errors.h) on a corrupt payload.
-SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
+SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
                                i32 nB0, i32 nB1, int useMDIndex, i16* pOut) {
     int ret = 0;
     SxDecCtrl* c = &w->ctrl;
@@ -780,7 +802,7 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
 }
 
 // AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40.  hb == NULL-equivalent when lost.
-SX_HD void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* OutHigh, const i32* residue_Q10, int lostflag) {
+SX_FN void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* OutHigh, const i32* residue_Q10, int lostflag) {
     i32 QHB_LSP[SX_HB_LPC];
     i32 QGain[4];
     i16 lpc[SX_MAX_LPC];
@@ -819,7 +841,7 @@ SX_HD void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* Ou
 //   y[2k]   = sat( pshr15( sum_m a[2m]   * s1[k-m] + (-a[2m]) * s2[k-m] ) )
 //   y[2k+1] = sat( pshr15( sum_m a[2m+1] * s1[k-m] +   a[2m+1] * s2[k-m] ) )      m = 0..31
 // lo/hi hold [32 history | 320 new] samples.  32-bit accumulation wraps, so summation order is free.
-SX_HD void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
+SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
     SX_PAR(k, SX_BAND) {
         i32 y0 = 0, y1 = 0;
         const i16* s1 = lo + SX_QMF_HIST + k;
@@ -855,6 +877,9 @@ SX_HD int sx_decode_packet(SxDecState* st, SxDecWork* w, const u8* bits, i32 nBy
     rc[0].error = 0; rc[1].error = 0;
     rc[0].bufferLength = 0; rc[1].bufferLength = 0;
     rc[0].buf = bits; rc[1].buf = bits;
+#ifdef SX_RC_LOG
+    rc[0].log = st->rclog; rc[0].nlog = 0; rc[1].log = 0; rc[1].nlog = 0;
+#endif
     SX_PAR(i, SX_QMF_HIST) { w->lo[i] = st->qmf_lo_hist[i]; w->hi[i] = st->qmf_hi_hist[i]; }
     wv_sync();
     for (int f = 0; f < 2; f++) {

@@ -14,9 +14,23 @@
 #if defined(__HIPCC__)
 #define SX_HD __host__ __device__ __forceinline__
 #define SX_DEV __device__
+// large stage functions: real calls (keeps register pressure and code size per kernel in check)
+#if defined(SX_INLINE_ALL)
+#define SX_FN __host__ __device__ __forceinline__
+#else
+#define SX_FN static __host__ __device__ __attribute__((noinline))
+#endif
 #else
 #define SX_HD static inline
 #define SX_DEV
+#define SX_FN static
+#endif
+
+// keep a scalar search loop exactly as written (no vectorisation / interleaving / unrolling)
+#if defined(__clang__)
+#define SX_PLAIN_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")
+#else
+#define SX_PLAIN_LOOP
 #endif
 
 typedef int32_t i32;

@@ -25,6 +25,9 @@ struct SxRangeDec {
     u32 base_Q32;
     u32 range_Q16;
     i32 error;
+#ifdef SX_RC_LOG
+    i32* log; i32 nlog;
+#endif
 };
 
 // Bytes past the end of a description read as 0.  (The reference reads whatever its internal buffer
@@ -46,27 +49,32 @@ SX_HD void sx_rc_dec_init(SxRangeDec* rc, const u8* buf, i32 len) {
 
 // SKP_Silk_range_decoder, SKP_Silk_range_coder.c:115.  Returns the decoded symbol (0 on error).
 SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
-    u32 low_Q16 = 0, high_Q16, base_tmp, range_Q32;
+    u32 low_Q16 = 0, high_Q16, range_Q32;
     u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16;
     i32 bufferIx = rc->bufferIx;
     if (rc->error) return 0;
 
+    // CDF search from the start index.  probIx always names the entry holding low_Q16.  (Written
+    // without the reference's ++/-- overshoot and with loop vectorisation disabled: hipcc 7.2 at
+    // -O2/-O3 mis-compiled the overshooting form of this early-exit search on gfx950 -- the symbol
+    // came out one too high after long upward scans -- found by GPU-vs-host symbol traces.)
     high_Q16 = prob[probIx];
-    base_tmp = range_Q16 * high_Q16;
-    if (base_tmp > base_Q32) {
+    if (range_Q16 * high_Q16 > base_Q32) {
+        SX_PLAIN_LOOP
         for (;;) {
-            low_Q16 = prob[--probIx];
-            base_tmp = range_Q16 * low_Q16;
-            if (base_tmp <= base_Q32) break;
+            probIx--;
+            low_Q16 = prob[probIx];
+            if (range_Q16 * low_Q16 <= base_Q32) break;
             high_Q16 = low_Q16;
             if (high_Q16 == 0) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
         }
     } else {
+        SX_PLAIN_LOOP
         for (;;) {
             low_Q16 = high_Q16;
-            high_Q16 = prob[++probIx];
-            base_tmp = range_Q16 * high_Q16;
-            if (base_tmp > base_Q32) { probIx--; break; }
+            high_Q16 = prob[probIx + 1];
+            if (range_Q16 * high_Q16 > base_Q32) break;
+            probIx++;
             if (high_Q16 == 0xFFFF) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
         }
     }
@@ -93,6 +101,9 @@ SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
     rc->base_Q32 = base_Q32;
     rc->range_Q16 = range_Q16;
     rc->bufferIx = bufferIx;
+#ifdef SX_RC_LOG
+    if (rc->log && rc->nlog < 500) { rc->log[rc->nlog++] = probIx; }
+#endif
     return probIx;
 }
 

@@ -16,7 +16,7 @@
 #pragma once
 #include "solo_fix.h"
 
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SX_FORCE_SERIAL)
 #define SX_NLANES 64
 #define SX_LANE ((int)(threadIdx.x & 63))
 #define SX_XOR_REDUCE(v, OP)                                              \

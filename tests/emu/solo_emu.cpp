@@ -27,3 +27,6 @@ int emu_sizeof_dec_state() { return (int)sizeof(SxDecState); }
 int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
 
 }  // extern "C"
+
+// debug aid: raw view of the decoder state (tests only)
+extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
