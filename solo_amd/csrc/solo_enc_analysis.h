@@ -1,0 +1,1275 @@
+// solo_enc_analysis.h -- noise-shape analysis, prefilter, LTP/LPC prediction analysis, NLSF MSVQ,
+// gain processing.  Rows E5d-E5g of SURVEY.md section 8(a).  Reference (JC1_SDK_SRC_ARM/src/libSATECodec/):
+//   SKP_Silk_noise_shape_analysis_FIX.c:33-531, SKP_Silk_warped_autocorrelation_FIX.c:36, SKP_Silk_schur64.c:42,
+//   SKP_Silk_k2a_Q16.c:40, SKP_Silk_prefilter_FIX.c:43-224, SKP_Silk_find_pred_coefs_FIX.c:31,
+//   SKP_Silk_find_LTP_FIX.c:39-243, SKP_Silk_corrMatrix_FIX.c:35-152, SKP_Silk_solve_LS_FIX.c:71-241,
+//   SKP_Silk_regularize_correlations_FIX.c:31, SKP_Silk_residual_energy16_FIX.c:31, SKP_Silk_quant_LTP_gains_FIX.c:30,
+//   SKP_Silk_VQ_nearest_neighbor_FIX.c:31, SKP_Silk_LTP_scale_ctrl_FIX.c:39, SKP_Silk_LTP_analysis_filter_FIX.c:30,
+//   SKP_Silk_find_LPC_FIX.c:32, SKP_Silk_burg_modified.c:49, SKP_Silk_A2NLSF.c:46-287, SKP_Silk_process_NLSFs_FIX.c:31,
+//   SKP_Silk_NLSF_MSVQ_encode_FIX.c:33, SKP_Silk_NLSF_VQ_rate_distortion_FIX.c:31, SKP_Silk_NLSF_VQ_sum_error_FIX.c:33,
+//   SKP_Silk_residual_energy_FIX.c:32, SKP_Silk_process_gains_FIX.c:32, SKP_Silk_gain_quant.c:42
+#pragma once
+#include "solo_enc_front.h"
+#include "solo_dec.h"   // sx_nlsf_msvq_decode (shared with the decoder)
+
+// ---------------------------------------------------------------------------------------------------
+// noise shape analysis
+// ---------------------------------------------------------------------------------------------------
+// SKP_Silk_warped_autocorrelation_FIX, SKP_Silk_warped_autocorrelation_FIX.c:36 (order 16, serial chain)
+SX_FN void sx_warped_autocorr(i32* corr, i32* scale, const i16* input, i32 warping_Q16, int length) {
+    const int order = SX_SHAPE_ORDER;
+    i32 state[SX_SHAPE_ORDER + 1];
+    i64 corr_QC[SX_SHAPE_ORDER + 1];
+    for (int i = 0; i <= order; i++) { state[i] = 0; corr_QC[i] = 0; }
+    for (int n = 0; n < length; n++) {
+        i32 tmp1 = sx_shl((i32)input[n], 14), tmp2;
+        for (int i = 0; i < order; i += 2) {
+            tmp2 = sx_smlawb(state[i], state[i + 1] - tmp1, warping_Q16);
+            state[i] = tmp1;
+            corr_QC[i] += sx_smull(tmp1, state[0]) >> 18;
+            tmp1 = sx_smlawb(state[i + 1], state[i + 2] - tmp2, warping_Q16);
+            state[i + 1] = tmp2;
+            corr_QC[i + 1] += sx_smull(tmp2, state[0]) >> 18;
+        }
+        state[order] = tmp1;
+        corr_QC[order] += sx_smull(tmp1, state[0]) >> 18;
+    }
+    int lsh = sx_clz64(corr_QC[0]) - 35;
+    lsh = sx_limit(lsh, -12 - 10, 30 - 10);
+    *scale = -(10 + lsh);
+    if (lsh >= 0) {
+        for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] << lsh);
+    } else {
+        for (int i = 0; i <= order; i++) corr[i] = (i32)(corr_QC[i] >> (-lsh));
+    }
+}
+
+// SKP_Silk_schur64, SKP_Silk_schur64.c:42
+SX_HD i32 sx_schur64(i32* rc_Q16, const i32* c, int order) {
+    i32 C[SX_MAX_LPC + 1][2];
+    if (c[0] <= 0) {
+        for (int k = 0; k < order; k++) rc_Q16[k] = 0;
+        return 0;
+    }
+    for (int k = 0; k < order + 1; k++) C[k][0] = C[k][1] = c[k];
+    for (int k = 0; k < order; k++) {
+        i32 rc_Q31 = sx_div32_varQ(sx_neg(C[k + 1][0]), C[0][1], 31);
+        rc_Q16[k] = sx_rshift_round(rc_Q31, 15);
+        for (int n = 0; n < order - k; n++) {
+            i32 t1 = C[n + k + 1][0], t2 = C[n][1];
+            C[n + k + 1][0] = sx_add(t1, sx_smmul(sx_shl(t2, 1), rc_Q31));
+            C[n][1] = sx_add(t2, sx_smmul(sx_shl(t1, 1), rc_Q31));
+        }
+    }
+    return C[0][1];
+}
+
+// SKP_Silk_k2a_Q16, SKP_Silk_k2a_Q16.c:40
+SX_HD void sx_k2a_Q16(i32* A_Q24, const i32* rc_Q16, int order) {
+    i32 Atmp[SX_MAX_LPC];
+    for (int k = 0; k < order; k++) {
+        for (int n = 0; n < k; n++) Atmp[n] = A_Q24[n];
+        for (int n = 0; n < k; n++) A_Q24[n] = sx_smlaww(A_Q24[n], Atmp[k - n - 1], rc_Q16[k]);
+        A_Q24[k] = sx_neg(sx_shl(rc_Q16[k], 8));
+    }
+}
+
+// warped_gain, noise_shape_analysis_FIX.c:33
+SX_HD i32 sx_warped_gain(const i32* coefs_Q24, i32 lambda_Q16, int order) {
+    lambda_Q16 = -lambda_Q16;
+    i32 gain_Q24 = coefs_Q24[order - 1];
+    for (int i = order - 2; i >= 0; i--) gain_Q24 = sx_smlawb(coefs_Q24[i], gain_Q24, lambda_Q16);
+    gain_Q24 = sx_smlawb(K_1p0_Q24, gain_Q24, -lambda_Q16);
+    return sx_inverse32_varQ(gain_Q24, 40);
+}
+
+// limit_warped_coefs, noise_shape_analysis_FIX.c:52
+SX_FN void sx_limit_warped_coefs(i32* syn, i32* ana, i32 lambda_Q16, i32 limit_Q24, int order) {
+    int ind = 0;
+    i32 nom_Q16, den_Q24, gain_syn_Q16, gain_ana_Q16;
+    lambda_Q16 = -lambda_Q16;
+    for (int i = order - 1; i > 0; i--) {
+        syn[i - 1] = sx_smlawb(syn[i - 1], syn[i], lambda_Q16);
+        ana[i - 1] = sx_smlawb(ana[i - 1], ana[i], lambda_Q16);
+    }
+    lambda_Q16 = -lambda_Q16;
+    nom_Q16 = sx_smlawb(K_1p0_Q16, -lambda_Q16, lambda_Q16);
+    den_Q24 = sx_smlawb(K_1p0_Q24, syn[0], lambda_Q16);
+    gain_syn_Q16 = sx_div32_varQ(nom_Q16, den_Q24, 24);
+    den_Q24 = sx_smlawb(K_1p0_Q24, ana[0], lambda_Q16);
+    gain_ana_Q16 = sx_div32_varQ(nom_Q16, den_Q24, 24);
+    for (int i = 0; i < order; i++) {
+        syn[i] = sx_smulww(gain_syn_Q16, syn[i]);
+        ana[i] = sx_smulww(gain_ana_Q16, ana[i]);
+    }
+    for (int iter = 0; iter < 10; iter++) {
+        i32 maxabs_Q24 = -1;
+        for (int i = 0; i < order; i++) {
+            i32 a = (syn[i] ^ (syn[i] >> 31)) - (syn[i] >> 31), b = (ana[i] ^ (ana[i] >> 31)) - (ana[i] >> 31);
+            i32 tmp = sx_max(a, b);
+            if (tmp > maxabs_Q24) { maxabs_Q24 = tmp; ind = i; }
+        }
+        if (maxabs_Q24 <= limit_Q24) return;
+        for (int i = 1; i < order; i++) {
+            syn[i - 1] = sx_smlawb(syn[i - 1], syn[i], lambda_Q16);
+            ana[i - 1] = sx_smlawb(ana[i - 1], ana[i], lambda_Q16);
+        }
+        gain_syn_Q16 = sx_inverse32_varQ(gain_syn_Q16, 32);
+        gain_ana_Q16 = sx_inverse32_varQ(gain_ana_Q16, 32);
+        for (int i = 0; i < order; i++) {
+            syn[i] = sx_smulww(gain_syn_Q16, syn[i]);
+            ana[i] = sx_smulww(gain_ana_Q16, ana[i]);
+        }
+        i32 chirp_Q16 = K_0p99_Q16 - sx_div32_varQ(sx_smulwb(maxabs_Q24 - limit_Q24, sx_smlabb(K_0p8_Q10, K_0p1_Q10, iter)),
+                                                  sx_mul(maxabs_Q24, ind + 1), 22);
+        sx_bwexpander_32(syn, order, chirp_Q16);
+        sx_bwexpander_32(ana, order, chirp_Q16);
+        lambda_Q16 = -lambda_Q16;
+        for (int i = order - 1; i > 0; i--) {
+            syn[i - 1] = sx_smlawb(syn[i - 1], syn[i], lambda_Q16);
+            ana[i - 1] = sx_smlawb(ana[i - 1], ana[i], lambda_Q16);
+        }
+        lambda_Q16 = -lambda_Q16;
+        nom_Q16 = sx_smlawb(K_1p0_Q16, -lambda_Q16, lambda_Q16);
+        den_Q24 = sx_smlawb(K_1p0_Q24, syn[0], lambda_Q16);
+        gain_syn_Q16 = sx_div32_varQ(nom_Q16, den_Q24, 24);
+        den_Q24 = sx_smlawb(K_1p0_Q24, ana[0], lambda_Q16);
+        gain_ana_Q16 = sx_div32_varQ(nom_Q16, den_Q24, 24);
+        for (int i = 0; i < order; i++) {
+            syn[i] = sx_smulww(gain_syn_Q16, syn[i]);
+            ana[i] = sx_smulww(gain_ana_Q16, ana[i]);
+        }
+    }
+}
+
+// float island of the "fixed point" encoder (noise_shape_analysis_FIX.c:407): IEEE single division
+SX_HD float sx_fdiv(float a, float b) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __fdiv_rn(a, b);
+#else
+    volatile float r = a / b;
+    return r;
+#endif
+}
+
+// SKP_Silk_noise_shape_analysis_FIX, noise_shape_analysis_FIX.c:137.
+// pitch_res = res_pitch + frame_length; x = x_buf + frame_length; x_windowed: 120-sample scratch (LDS)
+SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, i16* x_windowed) {
+    i32 auto_corr[SX_SHAPE_ORDER + 1], refl_coef_Q16[SX_SHAPE_ORDER], AR1_Q24[SX_SHAPE_ORDER], AR2_Q24[SX_SHAPE_ORDER];
+    i32 scale = 0, nrg, pre_nrg_Q30, tmp32;
+    const i16* x_ptr = x - SX_LA_SHAPE;
+    c->current_SNR_dB_Q7 = st->SNR_dB_Q7;                 // DISABLE_BUF_RD (SKP_Silk_define.h:53)
+    c->current_SNRPerMD_dB_Q7 = st->SNRPerMD_dB_Q7;
+    // (inBandFEC_SNR_comp_Q8 == 0: LBRR disabled)
+    c->input_quality_Q14 = (c->input_quality_bands_Q15[0] + c->input_quality_bands_Q15[1]) >> 2;
+    c->coding_quality_Q14 = sx_sigm_Q15(sx_rshift_round(c->current_SNR_dB_Q7 - K_18p0_Q7, 4)) >> 1;
+    i32 b_Q8 = K_1p0_Q8 - st->speech_activity_Q8;
+    b_Q8 = sx_smulwb(sx_shl(b_Q8, 8), b_Q8);
+    i32 SNR_adj_dB_Q7 = sx_smlawb(c->current_SNR_dB_Q7, sx_smulbb(K_mBG_SNR_DECR_dB_Q7 >> 5, b_Q8),
+                                  sx_smulwb(K_1p0_Q14 + c->input_quality_Q14, c->coding_quality_Q14));
+    if (c->sigtype == 0) {
+        SNR_adj_dB_Q7 = sx_smlawb(SNR_adj_dB_Q7, K_HARM_SNR_INCR_dB_Q8, st->LTPCorr_Q15);
+    } else {
+        SNR_adj_dB_Q7 = sx_smlawb(SNR_adj_dB_Q7, sx_smlawb(K_6p0_Q9, -K_0p4_Q18, c->current_SNR_dB_Q7), K_1p0_Q14 - c->input_quality_Q14);
+    }
+    i32 md_input_quality_Q14 = sx_sigm_Q15(sx_rshift_round(c->current_SNRPerMD_dB_Q7 - K_18p0_Q7, 4)) >> 1;
+    i32 md_SNR_adj_dB_Q7 = sx_smlawb(c->current_SNRPerMD_dB_Q7, sx_smulbb(K_mBG_SNR_DECR_dB_Q7 >> 5, b_Q8),
+                                     sx_smulwb(K_1p0_Q14 + md_input_quality_Q14, c->coding_quality_Q14));
+    if (c->sigtype == 0) {
+        md_SNR_adj_dB_Q7 = sx_smlawb(md_SNR_adj_dB_Q7, K_HARM_SNR_INCR_dB_Q8, st->LTPCorr_Q15);
+    } else {
+        md_SNR_adj_dB_Q7 = sx_smlawb(md_SNR_adj_dB_Q7, sx_smlawb(K_6p0_Q9, -K_0p4_Q18, c->current_SNRPerMD_dB_Q7),
+                                     K_1p0_Q14 - c->input_quality_Q14);
+    }
+    // sparseness
+    if (c->sigtype == 0) {
+        c->QuantOffsetType = 0;
+        c->sparseness_Q8 = 0;
+    } else {
+        const int nSamples = 16;
+        i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
+        for (int k = 0; k < 10; k++) {
+            i32 e, sh;
+            sx_sum_sqr_shift(&e, &sh, pitch_res + k * nSamples, nSamples, 0);
+            e += nSamples >> sh;
+            i32 log_energy_Q7 = sx_lin2log(e);
+            if (k > 0) energy_variation_Q7 += sx_abs(log_energy_Q7 - log_energy_prev_Q7);
+            log_energy_prev_Q7 = log_energy_Q7;
+        }
+        c->sparseness_Q8 = sx_sigm_Q15(sx_smulwb(energy_variation_Q7 - K_5p0_Q7, K_0p1_Q16)) >> 7;
+        c->QuantOffsetType = c->sparseness_Q8 > K_SPARSENESS_THRESHOLD_QNT_OFFSET_Q8 ? 0 : 1;
+        SNR_adj_dB_Q7 = sx_smlawb(SNR_adj_dB_Q7, K_SPARSE_SNR_INCR_dB_Q15, c->sparseness_Q8 - K_0p5_Q8);
+        md_SNR_adj_dB_Q7 = sx_smlawb(md_SNR_adj_dB_Q7, K_SPARSE_SNR_INCR_dB_Q15, c->sparseness_Q8 - K_0p5_Q8);
+    }
+    // bandwidth expansion
+    i32 strength_Q16 = sx_smulwb(c->predGain_Q16, K_FIND_PITCH_WHITE_NOISE_FRACTION_Q16);
+    i32 BWExp1_Q16, BWExp2_Q16;
+    BWExp1_Q16 = BWExp2_Q16 = sx_div32_varQ(K_BANDWIDTH_EXPANSION_Q16, sx_smlaww(K_1p0_Q16, strength_Q16, strength_Q16), 16);
+    i32 delta_Q16 = sx_smulwb(K_1p0_Q16 - sx_smulbb(3, c->coding_quality_Q14), K_LOW_RATE_BANDWIDTH_EXPANSION_DELTA_Q16);
+    BWExp1_Q16 = sx_sub(BWExp1_Q16, delta_Q16);
+    BWExp2_Q16 = sx_add(BWExp2_Q16, delta_Q16);
+    BWExp1_Q16 = sx_shl(BWExp1_Q16, 14) / (BWExp2_Q16 >> 2);
+    i32 warping_Q16 = sx_smlawb(SX_WARPING_Q16, c->coding_quality_Q14, K_0p01_Q18);
+    // per-subframe shaping filters
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        const int flat_part = 40, slope_part = (SX_SHAPE_WIN - flat_part) >> 1;
+        sx_apply_sine_window(x_windowed, x_ptr, 1, slope_part);
+        SX_PAR(i, flat_part) x_windowed[slope_part + i] = x_ptr[slope_part + i];
+        sx_apply_sine_window(x_windowed + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
+        wv_sync();
+        x_ptr += SX_SUBFR;
+        sx_warped_autocorr(auto_corr, &scale, x_windowed, (i16)warping_Q16, SX_SHAPE_WIN);
+        auto_corr[0] = sx_add(auto_corr[0], sx_max(sx_smulwb(auto_corr[0] >> 4, K_SHAPE_WHITE_NOISE_FRACTION_Q20), 1));
+        nrg = sx_schur64(refl_coef_Q16, auto_corr, SX_SHAPE_ORDER);
+        sx_k2a_Q16(AR2_Q24, refl_coef_Q16, SX_SHAPE_ORDER);
+        int Qnrg = -scale;
+        if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
+        tmp32 = sx_sqrt_approx(nrg);
+        Qnrg >>= 1;
+        c->Gains_Q16[k] = sx_lshift_sat32(tmp32, 16 - Qnrg);
+        {
+            i32 gain_mult_Q16 = sx_warped_gain(AR2_Q24, warping_Q16, SX_SHAPE_ORDER);
+            c->Gains_Q16[k] = sx_smulww(c->Gains_Q16[k], gain_mult_Q16);
+            if (c->Gains_Q16[k] < 0) c->Gains_Q16[k] = SX_I32_MAX;
+        }
+        sx_bwexpander_32(AR2_Q24, SX_SHAPE_ORDER, BWExp2_Q16);
+        for (int i = 0; i < SX_SHAPE_ORDER; i++) AR1_Q24[i] = AR2_Q24[i];
+        sx_bwexpander_32(AR1_Q24, SX_SHAPE_ORDER, BWExp1_Q16);
+        sx_lpc_inv_pred_gain_Q24(&pre_nrg_Q30, AR2_Q24, SX_SHAPE_ORDER);
+        sx_lpc_inv_pred_gain_Q24(&nrg, AR1_Q24, SX_SHAPE_ORDER);
+        pre_nrg_Q30 = sx_shl(sx_smulwb(pre_nrg_Q30, K_0p7_Q15), 1);
+        c->GainsPre_Q14[k] = K_0p3_Q14 + sx_div32_varQ(pre_nrg_Q30, nrg, 14);
+        sx_limit_warped_coefs(AR2_Q24, AR1_Q24, warping_Q16, K_3p999_Q24, SX_SHAPE_ORDER);
+        for (int i = 0; i < SX_SHAPE_ORDER; i++) {
+            c->AR1_Q13[k * SX_SHAPE_ORDER + i] = (i16)sx_sat16(sx_rshift_round(AR1_Q24[i], 11));
+            c->AR2_Q13[k * SX_SHAPE_ORDER + i] = (i16)sx_sat16(sx_rshift_round(AR2_Q24[i], 11));
+        }
+    }
+    // gain tweaking
+    i32 md_gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, md_SNR_adj_dB_Q7, K_0p16_Q16)));
+    i32 gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, SNR_adj_dB_Q7, K_0p16_Q16)));
+    c->md_delta_gain_par = sx_fdiv((float)gain_mult_Q16, (float)md_gain_mult_Q16);
+    i32 gain_add_Q16 = sx_log2lin(sx_smlawb(K_16p0_Q7, K_NOISE_FLOOR_dB_Q7, K_0p16_Q16));
+    tmp32 = sx_log2lin(sx_smlawb(K_16p0_Q7, K_RELATIVE_MIN_GAIN_dB_Q7, K_0p16_Q16));
+    tmp32 = sx_smulww(st->avgGain_Q16, tmp32);
+    gain_add_Q16 = sx_add_sat32(gain_add_Q16, tmp32);
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        c->Gains_Q16[k] = sx_smulww(c->Gains_Q16[k], gain_mult_Q16);
+        if (c->Gains_Q16[k] < 0) c->Gains_Q16[k] = SX_I32_MAX;
+    }
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        c->Gains_Q16[k] = sx_add_pos_sat32(c->Gains_Q16[k], gain_add_Q16);
+        st->avgGain_Q16 = sx_add_sat32(st->avgGain_Q16, sx_smulwb(c->Gains_Q16[k] - st->avgGain_Q16,
+                                       sx_rshift_round(sx_smulbb(st->speech_activity_Q8, K_GAIN_SMOOTHING_COEF_Q10), 2)));
+    }
+    // de-essing: only for fs 16 / 24 kHz -> nothing at 8 kHz
+    gain_mult_Q16 = K_1p0_Q16 + sx_rshift_round(sx_add(K_INPUT_TILT_Q26, sx_mul(c->coding_quality_Q14, K_HIGH_RATE_INPUT_TILT_Q12)), 10);
+    for (int k = 0; k < SX_NB_SUBFR; k++) c->GainsPre_Q14[k] = sx_smulwb(gain_mult_Q16, c->GainsPre_Q14[k]);
+    // low-frequency shaping and tilt
+    strength_Q16 = sx_mul(K_LOW_FREQ_SHAPING_Q0, K_1p0_Q16 + sx_smulbb(K_LOW_QUALITY_LOW_FREQ_SHAPING_DECR_Q1,
+                                                                        c->input_quality_bands_Q15[0] - K_1p0_Q15));
+    i32 Tilt_Q16;
+    if (c->sigtype == 0) {
+        i32 fs_kHz_inv = K_0p2_Q14 / 8;
+        for (int k = 0; k < SX_NB_SUBFR; k++) {
+            i32 b_Q14 = fs_kHz_inv + K_3p0_Q14 / c->pitchL[k];
+            c->LF_shp_Q14[k] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, b_Q14), 16);
+            c->LF_shp_Q14[k] |= (i32)(u16)(b_Q14 - K_1p0_Q14);
+        }
+        Tilt_Q16 = -K_HP_NOISE_COEF_Q16 - sx_smulwb(K_1p0_Q16 - K_HP_NOISE_COEF_Q16, sx_smulwb(K_HARM_HP_NOISE_COEF_Q24, st->speech_activity_Q8));
+    } else {
+        i32 b_Q14 = 21299 / 8;
+        c->LF_shp_Q14[0] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, sx_smulwb(K_0p6_Q16, b_Q14)), 16);
+        c->LF_shp_Q14[0] |= (i32)(u16)(b_Q14 - K_1p0_Q14);
+        for (int k = 1; k < SX_NB_SUBFR; k++) c->LF_shp_Q14[k] = c->LF_shp_Q14[0];
+        Tilt_Q16 = -K_HP_NOISE_COEF_Q16;
+    }
+    // harmonic shaping
+    i32 HarmBoost_Q16 = sx_smulwb(sx_smulwb(K_1p0_Q17 - sx_shl(c->coding_quality_Q14, 3), st->LTPCorr_Q15), K_LOW_RATE_HARMONIC_BOOST_Q16);
+    HarmBoost_Q16 = sx_smlawb(HarmBoost_Q16, K_1p0_Q16 - sx_shl(c->input_quality_Q14, 2), K_LOW_INPUT_QUALITY_HARMONIC_BOOST_Q16);
+    i32 HarmShapeGain_Q16;
+    if (c->sigtype == 0) {
+        HarmShapeGain_Q16 = sx_smlawb(K_HARMONIC_SHAPING_Q16,
+                                      K_1p0_Q16 - sx_smulwb(K_1p0_Q18 - sx_shl(c->coding_quality_Q14, 4), c->input_quality_Q14),
+                                      K_HIGH_RATE_OR_LOW_QUALITY_HARMONIC_SHAPING_Q16);
+        HarmShapeGain_Q16 = sx_smulwb(sx_shl(HarmShapeGain_Q16, 1), sx_sqrt_approx(sx_shl(st->LTPCorr_Q15, 15)));
+    } else {
+        HarmShapeGain_Q16 = 0;
+    }
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        st->HarmBoost_smth_Q16 = sx_smlawb(st->HarmBoost_smth_Q16, HarmBoost_Q16 - st->HarmBoost_smth_Q16, K_SUBFR_SMTH_COEF_Q16);
+        st->HarmShapeGain_smth_Q16 = sx_smlawb(st->HarmShapeGain_smth_Q16, HarmShapeGain_Q16 - st->HarmShapeGain_smth_Q16, K_SUBFR_SMTH_COEF_Q16);
+        st->Tilt_smth_Q16 = sx_smlawb(st->Tilt_smth_Q16, Tilt_Q16 - st->Tilt_smth_Q16, K_SUBFR_SMTH_COEF_Q16);
+        c->HarmBoost_Q14[k] = sx_rshift_round(st->HarmBoost_smth_Q16, 2);
+        c->HarmShapeGain_Q14[k] = sx_rshift_round(st->HarmShapeGain_smth_Q16, 2);
+        c->Tilt_Q14[k] = sx_rshift_round(st->Tilt_smth_Q16, 2);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// prefilter
+// ---------------------------------------------------------------------------------------------------
+// SKP_Silk_prefilter_FIX + warped_LPC_analysis_filter_FIX + prefilt_FIX, SKP_Silk_prefilter_FIX.c:43-224
+SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x) {
+    i32 x_filt_Q12[SX_SUBFR];
+    i16 st_res[SX_SUBFR];
+    const i16* px = x;
+    i16* pxw = xw;
+    int lag = st->pf_lagPrev;
+    const i32 lambda_Q16 = (i16)SX_WARPING_Q16;
+    i32 state[SX_SHAPE_ORDER + 1];
+    for (int i = 0; i <= SX_SHAPE_ORDER; i++) state[i] = st->pf_sAR_shp[i];
+    i32 sLF_AR = st->pf_sLF_AR_shp_Q12, sLF_MA = st->pf_sLF_MA_shp_Q12;
+    int buf_idx = st->pf_sLTP_shp_buf_idx;
+    i32 sHarmHP = st->pf_sHarmHP;
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        if (c->sigtype == 0) lag = c->pitchL[k];
+        i32 HarmShapeGain_Q12 = sx_smulwb(c->HarmShapeGain_Q14[k], 16384 - c->HarmBoost_Q14[k]);
+        i32 HarmShapeFIRPacked_Q12 = HarmShapeGain_Q12 >> 2;
+        HarmShapeFIRPacked_Q12 |= sx_shl(HarmShapeGain_Q12 >> 1, 16);
+        i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k];
+        const i16* coef_Q13 = &c->AR1_Q13[k * SX_SHAPE_ORDER];
+        // warped LPC analysis filter
+        for (int n = 0; n < SX_SUBFR; n++) {
+            i32 tmp2 = sx_smlawb(state[0], state[1], lambda_Q16);
+            state[0] = sx_shl((i32)px[n], 14);
+            i32 tmp1 = sx_smlawb(state[1], state[2] - tmp2, lambda_Q16);
+            state[1] = tmp2;
+            i32 acc_Q11 = sx_smulwb(tmp2, coef_Q13[0]);
+            for (int i = 2; i < SX_SHAPE_ORDER; i += 2) {
+                tmp2 = sx_smlawb(state[i], state[i + 1] - tmp1, lambda_Q16);
+                state[i] = tmp1;
+                acc_Q11 = sx_smlawb(acc_Q11, tmp1, coef_Q13[i - 1]);
+                tmp1 = sx_smlawb(state[i + 1], state[i + 2] - tmp2, lambda_Q16);
+                state[i + 1] = tmp2;
+                acc_Q11 = sx_smlawb(acc_Q11, tmp2, coef_Q13[i]);
+            }
+            state[SX_SHAPE_ORDER] = tmp1;
+            acc_Q11 = sx_smlawb(acc_Q11, tmp1, coef_Q13[SX_SHAPE_ORDER - 1]);
+            st_res[n] = (i16)sx_sat16((i32)px[n] - sx_rshift_round(acc_Q11, 11));
+        }
+        i32 B_lo = sx_rshift_round(c->GainsPre_Q14[k], 2);
+        i32 tmp_32 = sx_smlabb(K_INPUT_TILT_Q26, c->HarmBoost_Q14[k], HarmShapeGain_Q12);
+        tmp_32 = sx_smlabb(tmp_32, c->coding_quality_Q14, K_HIGH_RATE_INPUT_TILT_Q12);
+        tmp_32 = sx_smulwb(tmp_32, -c->GainsPre_Q14[k]);
+        tmp_32 = sx_rshift_round(tmp_32, 12);
+        i32 B_hi = sx_sat16(tmp_32);
+        x_filt_Q12[0] = sx_add(sx_smulbb(st_res[0], B_lo), sx_smulbb(sHarmHP, B_hi));
+        for (int j = 1; j < SX_SUBFR; j++) x_filt_Q12[j] = sx_add(sx_smulbb(st_res[j], B_lo), sx_smulbb(st_res[j - 1], B_hi));
+        sHarmHP = st_res[SX_SUBFR - 1];
+        // prefilt_FIX
+        for (int i = 0; i < SX_SUBFR; i++) {
+            i32 n_LTP_Q12 = 0;
+            if (lag > 0) {
+                int idx = lag + buf_idx;
+                n_LTP_Q12 = sx_smulbb(st->pf_sLTP_shp[(idx - 2) & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+                n_LTP_Q12 = sx_add(n_LTP_Q12, sx_smulbt(st->pf_sLTP_shp[(idx - 1) & SX_LTP_MASK], HarmShapeFIRPacked_Q12));
+                n_LTP_Q12 = sx_smlabb(n_LTP_Q12, st->pf_sLTP_shp[idx & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+            }
+            i32 n_Tilt_Q10 = sx_smulwb(sLF_AR, Tilt_Q14);
+            i32 n_LF_Q10 = sx_smlawb(sx_smulwt(sLF_AR, LF_shp_Q14), sLF_MA, LF_shp_Q14);
+            sLF_AR = sx_sub(x_filt_Q12[i], sx_shl(n_Tilt_Q10, 2));
+            sLF_MA = sx_sub(sLF_AR, sx_shl(n_LF_Q10, 2));
+            buf_idx = (buf_idx - 1) & SX_LTP_MASK;
+            st->pf_sLTP_shp[buf_idx] = (i16)sx_sat16(sx_rshift_round(sLF_MA, 12));
+            pxw[i] = (i16)sx_sat16(sx_rshift_round(sx_sub(sLF_MA, n_LTP_Q12), 12));
+        }
+        px += SX_SUBFR;
+        pxw += SX_SUBFR;
+    }
+    for (int i = 0; i <= SX_SHAPE_ORDER; i++) st->pf_sAR_shp[i] = state[i];
+    st->pf_sLF_AR_shp_Q12 = sLF_AR;
+    st->pf_sLF_MA_shp_Q12 = sLF_MA;
+    st->pf_sLTP_shp_buf_idx = buf_idx;
+    st->pf_sHarmHP = sHarmHP;
+    st->pf_lagPrev = c->pitchL[SX_NB_SUBFR - 1];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LTP analysis
+// ---------------------------------------------------------------------------------------------------
+// SKP_Silk_corrMatrix_FIX + corrVector_FIX, SKP_Silk_corrMatrix_FIX.c:35-152 (order 5, L = 40)
+SX_FN void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* XX, i32* rshifts, int x_odd) {
+    i32 energy, rshifts_local;
+    sx_sum_sqr_shift(&energy, &rshifts_local, x, L + order - 1, x_odd);
+    int head_room_rshifts = sx_max(head_room - sx_clz32(energy), 0);
+    energy = energy >> head_room_rshifts;
+    rshifts_local += head_room_rshifts;
+    for (int i = 0; i < order - 1; i++) energy -= sx_smulbb(x[i], x[i]) >> rshifts_local;
+    if (rshifts_local < *rshifts) {
+        energy = energy >> (*rshifts - rshifts_local);
+        rshifts_local = *rshifts;
+    }
+    XX[0] = energy;
+    const i16* ptr1 = &x[order - 1];
+    for (int j = 1; j < order; j++) {
+        energy = sx_sub(energy, sx_smulbb(ptr1[L - j], ptr1[L - j]) >> rshifts_local);
+        energy = sx_add(energy, sx_smulbb(ptr1[-j], ptr1[-j]) >> rshifts_local);
+        XX[j * order + j] = energy;
+    }
+    const i16* ptr2 = &x[order - 2];
+    for (int lag = 1; lag < order; lag++) {
+        energy = 0;
+        if (rshifts_local > 0) {
+            for (int i = 0; i < L; i++) energy += sx_smulbb(ptr1[i], ptr2[i]) >> rshifts_local;
+        } else {
+            for (int i = 0; i < L; i++) energy = sx_smlabb(energy, ptr1[i], ptr2[i]);
+        }
+        XX[lag * order] = energy;
+        XX[lag] = energy;
+        for (int j = 1; j < order - lag; j++) {
+            energy = sx_sub(energy, sx_smulbb(ptr1[L - j], ptr2[L - j]) >> rshifts_local);
+            energy = sx_add(energy, sx_smulbb(ptr1[-j], ptr2[-j]) >> rshifts_local);
+            XX[(lag + j) * order + j] = energy;
+            XX[j * order + lag + j] = energy;
+        }
+        ptr2--;
+    }
+    *rshifts = rshifts_local;
+}
+SX_HD void sx_corr_vector(const i16* x, const i16* t, int L, int order, i32* Xt, int rshifts) {
+    const i16* ptr1 = &x[order - 1];
+    for (int lag = 0; lag < order; lag++) {
+        i32 ip = 0;
+        if (rshifts > 0) {
+            for (int i = 0; i < L; i++) ip += sx_smulbb(ptr1[i], t[i]) >> rshifts;
+        } else {
+            for (int i = 0; i < L; i++) ip = sx_smlabb(ip, ptr1[i], t[i]);
+        }
+        Xt[lag] = ip;
+        ptr1--;
+    }
+}
+
+// SKP_Silk_solve_LDL_FIX and helpers, SKP_Silk_solve_LS_FIX.c:71-241 (M = 5)
+SX_FN void sx_solve_LDL(i32* A, int M, const i32* b, i32* x_Q16) {
+    i32 L_Q16[25], Y[5], inv_D_Q36[5], inv_D_Q48[5], v_Q0[5], D_Q0[5];
+    int status = 1;
+    i32 diag_min_value = sx_max(sx_smmul(sx_add_sat32(A[0], A[M * M - 1]), K_FIND_LTP_COND_FAC_Q31), 1 << 9);
+    for (int loop_count = 0; loop_count < M && status == 1; loop_count++) {
+        status = 0;
+        for (int j = 0; j < M; j++) {
+            const i32* ptr1 = &L_Q16[j * M];
+            i32 tmp_32 = 0;
+            for (int i = 0; i < j; i++) {
+                v_Q0[i] = sx_smulww(D_Q0[i], ptr1[i]);
+                tmp_32 = sx_smlaww(tmp_32, v_Q0[i], ptr1[i]);
+            }
+            tmp_32 = sx_sub(A[j * M + j], tmp_32);
+            if (tmp_32 < diag_min_value) {
+                tmp_32 = sx_sub(sx_smulbb(loop_count + 1, diag_min_value), tmp_32);
+                for (int i = 0; i < M; i++) A[i * M + i] = sx_add(A[i * M + i], tmp_32);
+                status = 1;
+                break;
+            }
+            D_Q0[j] = tmp_32;
+            i32 one_div_diag_Q36 = sx_inverse32_varQ(tmp_32, 36);
+            i32 one_div_diag_Q40 = sx_shl(one_div_diag_Q36, 4);
+            i32 err = sx_sub(1 << 24, sx_smulww(tmp_32, one_div_diag_Q40));
+            i32 one_div_diag_Q48 = sx_smulww(err, one_div_diag_Q40);
+            inv_D_Q36[j] = one_div_diag_Q36;
+            inv_D_Q48[j] = one_div_diag_Q48;
+            L_Q16[j * M + j] = 65536;
+            ptr1 = &A[j * M];
+            const i32* ptr2 = &L_Q16[(j + 1) * M];
+            for (int i = j + 1; i < M; i++) {
+                tmp_32 = 0;
+                for (int k = 0; k < j; k++) tmp_32 = sx_smlaww(tmp_32, v_Q0[k], ptr2[k]);
+                tmp_32 = sx_sub(ptr1[i], tmp_32);
+                L_Q16[i * M + j] = sx_add(sx_smmul(tmp_32, one_div_diag_Q48), sx_smulww(tmp_32, one_div_diag_Q36) >> 4);
+                ptr2 += M;
+            }
+        }
+    }
+    for (int i = 0; i < M; i++) {   // SolveFirst
+        i32 tmp_32 = 0;
+        for (int j = 0; j < i; j++) tmp_32 = sx_smlaww(tmp_32, L_Q16[i * M + j], Y[j]);
+        Y[i] = sx_sub(b[i], tmp_32);
+    }
+    for (int i = 0; i < M; i++) {   // divide
+        i32 t = Y[i];
+        Y[i] = sx_add(sx_smmul(t, inv_D_Q48[i]), sx_smulww(t, inv_D_Q36[i]) >> 4);
+    }
+    for (int i = M - 1; i >= 0; i--) {   // SolveLast
+        i32 tmp_32 = 0;
+        for (int j = M - 1; j > i; j--) tmp_32 = sx_smlaww(tmp_32, L_Q16[j * M + i], x_Q16[j]);
+        x_Q16[i] = sx_sub(Y[i], tmp_32);
+    }
+}
+
+// SKP_Silk_residual_energy16_covar_FIX, SKP_Silk_residual_energy16_FIX.c:31 (cQ = 14, D = 5)
+SX_HD i32 sx_residual_energy16_covar(const i16* cvec, const i32* wXX, const i32* wXx, i32 wxx, int D, int cQ) {
+    i32 cn[SX_MAX_LPC];
+    int lshifts = 16 - cQ, Qxtra = lshifts;
+    i32 c_max = 0;
+    for (int i = 0; i < D; i++) c_max = sx_max(c_max, sx_abs((i32)cvec[i]));
+    Qxtra = sx_min(Qxtra, sx_clz32(c_max) - 17);
+    i32 w_max = sx_max(wXX[0], wXX[D * D - 1]);
+    Qxtra = sx_min(Qxtra, sx_clz32(sx_mul(D, sx_smulwb(w_max, c_max) >> 4)) - 5);
+    Qxtra = sx_max(Qxtra, 0);
+    for (int i = 0; i < D; i++) cn[i] = sx_shl((i32)cvec[i], Qxtra);
+    lshifts -= Qxtra;
+    i32 tmp = 0;
+    for (int i = 0; i < D; i++) tmp = sx_smlawb(tmp, wXx[i], cn[i]);
+    i32 nrg = (wxx >> (1 + lshifts)) - tmp;
+    i32 tmp2 = 0;
+    for (int i = 0; i < D; i++) {
+        tmp = 0;
+        const i32* pRow = &wXX[i * D];
+        for (int j = i + 1; j < D; j++) tmp = sx_smlawb(tmp, pRow[j], cn[j]);
+        tmp = sx_smlawb(tmp, pRow[i] >> 1, cn[i]);
+        tmp2 = sx_smlawb(tmp2, tmp, cn[i]);
+    }
+    nrg = sx_add(nrg, sx_shl(tmp2, lshifts));
+    if (nrg < 1) nrg = 1;
+    else if (nrg > (SX_I32_MAX >> (lshifts + 2))) nrg = SX_I32_MAX >> 1;
+    else nrg = sx_shl(nrg, lshifts + 1);
+    return nrg;
+}
+
+// SKP_Silk_find_LTP_FIX, SKP_Silk_find_LTP_FIX.c:39.  res_pitch: LPC residual buffer (336 samples)
+SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15) {
+    const int subfr_length = SX_SUBFR, mem_offset = SX_FRAME, HEAD = 2;
+    i32 b_Q16[5], delta_b_Q14[5], d_Q14[4], nrg[4], w[4], Rr[5], rr[4], corr_rshifts[4];
+    i16* b_Q14_ptr = b_Q14;
+    i32* WLTP_ptr = WLTP;
+    for (int k = 0; k < 4; k++) {
+        // r_first = res_pitch, r_last = res_pitch + frame_length/2: r_ptr = base[mem_offset + 40*k] resp. base2[...]
+        const i16* r_ptr = (k < 2 ? res_pitch : res_pitch + (SX_FRAME >> 1)) + mem_offset + (k < 2 ? k : k) * 0 + 0;
+        r_ptr = res_pitch + mem_offset + k * subfr_length;     // both halves address the same timeline
+        const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
+        i32 rr_shifts;
+        sx_sum_sqr_shift(&rr[k], &rr_shifts, r_ptr, subfr_length, 0);
+        int LZs = sx_clz32(rr[k]);
+        if (LZs < HEAD) {
+            rr[k] = sx_rshift_round(rr[k], HEAD - LZs);
+            rr_shifts += HEAD - LZs;
+        }
+        corr_rshifts[k] = rr_shifts;
+        sx_corr_matrix(lag_ptr, subfr_length, SX_LTP_ORDER, HEAD, WLTP_ptr, &corr_rshifts[k], lag[k] & 1);
+        sx_corr_vector(lag_ptr, r_ptr, subfr_length, SX_LTP_ORDER, Rr, corr_rshifts[k]);
+        if (corr_rshifts[k] > rr_shifts) rr[k] = rr[k] >> (corr_rshifts[k] - rr_shifts);
+        i32 regu = 1;
+        regu = sx_smlawb(regu, rr[k], K_LTP_DAMPING_DIV3_Q16);
+        regu = sx_smlawb(regu, WLTP_ptr[0], K_LTP_DAMPING_DIV3_Q16);
+        regu = sx_smlawb(regu, WLTP_ptr[24], K_LTP_DAMPING_DIV3_Q16);
+        for (int i = 0; i < 5; i++) WLTP_ptr[i * 5 + i] = sx_add(WLTP_ptr[i * 5 + i], regu);
+        rr[k] += regu;
+        sx_solve_LDL(WLTP_ptr, SX_LTP_ORDER, Rr, b_Q16);
+        for (int i = 0; i < 5; i++) b_Q14_ptr[i] = (i16)sx_sat16(sx_rshift_round(b_Q16[i], 2));
+        nrg[k] = sx_residual_energy16_covar(b_Q14_ptr, WLTP_ptr, Rr, rr[k], SX_LTP_ORDER, 14);
+        int extra_shifts = sx_min(corr_rshifts[k], HEAD);
+        i32 denom32 = sx_add(sx_lshift_sat32(sx_smulwb(nrg[k], Wght_Q15[k]), 1 + extra_shifts),
+                             sx_smulwb(subfr_length, 655) >> (corr_rshifts[k] - extra_shifts));
+        denom32 = sx_max(denom32, 1);
+        i32 temp32 = sx_shl(Wght_Q15[k], 16) / denom32;
+        temp32 = temp32 >> (31 + corr_rshifts[k] - extra_shifts - 26);
+        i32 WLTP_max = 0;
+        for (int i = 0; i < 25; i++) WLTP_max = sx_max(WLTP_ptr[i], WLTP_max);
+        int lshift = sx_clz32(WLTP_max) - 1 - 3;
+        if (26 - 18 + lshift < 31) temp32 = sx_min(temp32, sx_shl(1, 26 - 18 + lshift));
+        for (int i = 0; i < 25; i++) WLTP_ptr[i] = (i32)(sx_smull(WLTP_ptr[i], temp32) >> 8);
+        w[k] = WLTP_ptr[2 * 5 + 2];
+        b_Q14_ptr += 5;
+        WLTP_ptr += 25;
+    }
+    int maxRshifts = 0;
+    for (int k = 0; k < 4; k++) maxRshifts = sx_max(corr_rshifts[k], maxRshifts);
+    {
+        i32 LPC_LTP_res_nrg = 0, LPC_res_nrg = 0;
+        for (int k = 0; k < 4; k++) {
+            LPC_res_nrg = sx_add(LPC_res_nrg, sx_add(sx_smulwb(rr[k], Wght_Q15[k]), 1) >> (1 + (maxRshifts - corr_rshifts[k])));
+            LPC_LTP_res_nrg = sx_add(LPC_LTP_res_nrg, sx_add(sx_smulwb(nrg[k], Wght_Q15[k]), 1) >> (1 + (maxRshifts - corr_rshifts[k])));
+        }
+        LPC_LTP_res_nrg = sx_max(LPC_LTP_res_nrg, 1);
+        i32 div_Q16 = sx_div32_varQ(LPC_res_nrg, LPC_LTP_res_nrg, 16);
+        *LTPredCodGain_Q7 = sx_smulbb(3, sx_lin2log(div_Q16) - (16 << 7));
+    }
+    b_Q14_ptr = b_Q14;
+    for (int k = 0; k < 4; k++) {
+        d_Q14[k] = 0;
+        for (int i = 0; i < 5; i++) d_Q14[k] += b_Q14_ptr[i];
+        b_Q14_ptr += 5;
+    }
+    i32 max_abs_d_Q14 = 0, max_w_bits = 0;
+    for (int k = 0; k < 4; k++) {
+        max_abs_d_Q14 = sx_max(max_abs_d_Q14, sx_abs(d_Q14[k]));
+        max_w_bits = sx_max(max_w_bits, 32 - sx_clz32(w[k]) + corr_rshifts[k] - maxRshifts);
+    }
+    int extra_shifts = max_w_bits + 32 - sx_clz32(max_abs_d_Q14) - 14;
+    extra_shifts -= (32 - 1 - 2 + maxRshifts);
+    extra_shifts = sx_max(extra_shifts, 0);
+    int maxRshifts_wxtra = maxRshifts + extra_shifts;
+    i32 temp32 = (262 >> (maxRshifts + extra_shifts)) + 1;
+    i32 wd = 0;
+    for (int k = 0; k < 4; k++) {
+        temp32 = sx_add(temp32, w[k] >> (maxRshifts_wxtra - corr_rshifts[k]));
+        wd = sx_add(wd, sx_shl(sx_smulww(w[k] >> (maxRshifts_wxtra - corr_rshifts[k]), d_Q14[k]), 2));
+    }
+    i32 m_Q12 = sx_div32_varQ(wd, temp32, 12);
+    b_Q14_ptr = b_Q14;
+    for (int k = 0; k < 4; k++) {
+        if (2 - corr_rshifts[k] > 0) temp32 = w[k] >> (2 - corr_rshifts[k]);
+        else temp32 = sx_lshift_sat32(w[k], corr_rshifts[k] - 2);
+        i32 g_Q26 = sx_mul(K_LTP_SMOOTHING_Q26 / ((K_LTP_SMOOTHING_Q26 >> 10) + temp32),
+                           sx_lshift_sat32(sx_sub_sat32(m_Q12, d_Q14[k] >> 2), 4));
+        temp32 = 0;
+        for (int i = 0; i < 5; i++) {
+            delta_b_Q14[i] = sx_max(b_Q14_ptr[i], 1638);
+            temp32 += delta_b_Q14[i];
+        }
+        temp32 = g_Q26 / temp32;
+        for (int i = 0; i < 5; i++)
+            b_Q14_ptr[i] = (i16)sx_limit((i32)b_Q14_ptr[i] + sx_smulwb(sx_lshift_sat32(temp32, 4), delta_b_Q14[i]), -16000, 28000);
+        b_Q14_ptr += 5;
+    }
+}
+
+// SKP_Silk_VQ_WMat_EC_FIX, SKP_Silk_VQ_nearest_neighbor_FIX.c:31 (generic, non-packed form of the arithmetic)
+SX_HD void sx_vq_wmat_ec(i32* ind, i32* rate_dist_Q14, const i16* in_Q14, const i32* W, const i16* cb_Q14, const i16* cl_Q6, i32 mu_Q8, int L) {
+    *rate_dist_Q14 = SX_I32_MAX;
+    for (int k = 0; k < L; k++) {
+        const i16* row = &cb_Q14[k * 5];
+        i32 d0 = (i16)(in_Q14[0] - row[0]), d1 = (i16)(in_Q14[1] - row[1]), d2 = (i16)(in_Q14[2] - row[2]),
+            d3 = (i16)(in_Q14[3] - row[3]), d4 = (i16)(in_Q14[4] - row[4]);
+        i32 sum1 = sx_smulbb(mu_Q8, cl_Q6[k]), sum2;
+        sum2 = sx_smulwb(W[1], d1); sum2 = sx_smlawb(sum2, W[2], d2); sum2 = sx_smlawb(sum2, W[3], d3); sum2 = sx_smlawb(sum2, W[4], d4);
+        sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[0], d0); sum1 = sx_smlawb(sum1, sum2, d0);
+        sum2 = sx_smulwb(W[7], d2); sum2 = sx_smlawb(sum2, W[8], d3); sum2 = sx_smlawb(sum2, W[9], d4);
+        sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[6], d1); sum1 = sx_smlawb(sum1, sum2, d1);
+        sum2 = sx_smulwb(W[13], d3); sum2 = sx_smlawb(sum2, W[14], d4);
+        sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[12], d2); sum1 = sx_smlawb(sum1, sum2, d2);
+        sum2 = sx_smulwb(W[19], d4);
+        sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[18], d3); sum1 = sx_smlawb(sum1, sum2, d3);
+        sum2 = sx_smulwb(W[24], d4); sum1 = sx_smlawb(sum1, sum2, d4);
+        if (sum1 < *rate_dist_Q14) { *rate_dist_Q14 = sum1; *ind = k; }
+    }
+}
+
+// SKP_Silk_quant_LTP_gains_FIX, SKP_Silk_quant_LTP_gains_FIX.c:30 (lowComplexity = 0)
+SX_FN void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8) {
+    i32 temp_idx[4], min_rate_dist = SX_I32_MAX;
+    for (int k = 0; k < 3; k++) {
+        const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
+        const i16* cbk = k == 0 ? T_ltp_vq0_Q14 : (k == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+        int cbk_size = T_ltp_vq_sizes[k];
+        i32 rate_dist = 0;
+        for (int j = 0; j < 4; j++) {
+            i32 rd;
+            sx_vq_wmat_ec(&temp_idx[j], &rd, &B_Q14[j * 5], &W_Q18[j * 25], cbk, cl, mu_Q8, cbk_size);
+            rate_dist = sx_add_pos_sat32(rate_dist, rd);
+        }
+        rate_dist = sx_min(SX_I32_MAX - 1, rate_dist);
+        if (rate_dist < min_rate_dist) {
+            min_rate_dist = rate_dist;
+            for (int j = 0; j < 4; j++) cbk_index[j] = temp_idx[j];
+            *periodicity_index = k;
+        }
+    }
+    const i16* cbk = *periodicity_index == 0 ? T_ltp_vq0_Q14 : (*periodicity_index == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+    for (int j = 0; j < 4; j++)
+        for (int k = 0; k < 5; k++) B_Q14[j * 5 + k] = cbk[cbk_index[j] * 5 + k];
+}
+
+// SKP_Silk_LTP_scale_ctrl_FIX, SKP_Silk_LTP_scale_ctrl_FIX.c:39 (PacketLoss_perc = 0, PacketSize_ms = 40)
+SX_HD void sx_LTP_scale_ctrl(SxEncState* st, SxEncCtrl* c) {
+    st->HPLTPredCodGain_Q7 = sx_max(c->LTPredCodGain_Q7 - st->prevLTPredCodGain_Q7, 0) + sx_rshift_round(st->HPLTPredCodGain_Q7, 1);
+    st->prevLTPredCodGain_Q7 = c->LTPredCodGain_Q7;
+    i32 g_out_Q5 = sx_rshift_round((c->LTPredCodGain_Q7 >> 1) + (st->HPLTPredCodGain_Q7 >> 1), 3);
+    i32 g_limit_Q15 = sx_sigm_Q15(g_out_Q5 - (3 << 5));
+    c->LTP_scaleIndex = 0;
+    if (st->nFramesInPayloadBuf == 0) {
+        int round_loss = 0 + (40 / 20) - 1;
+        i32 thrld1 = T_ltp_scale_thresholds_Q15[sx_min(round_loss, 10)];
+        i32 thrld2 = T_ltp_scale_thresholds_Q15[sx_min(round_loss + 1, 10)];
+        if (g_limit_Q15 > thrld1) c->LTP_scaleIndex = 2;
+        else if (g_limit_Q15 > thrld2) c->LTP_scaleIndex = 1;
+    }
+    c->LTP_scale_Q14 = T_ltp_scales_Q14[c->LTP_scaleIndex];
+}
+
+// SKP_Silk_LTP_analysis_filter_FIX, SKP_Silk_LTP_analysis_filter_FIX.c:30 (wave-parallel over the 4 x 50 outputs)
+SX_HD void sx_LTP_analysis_filter(i16* LTP_res, const i16* x, const i16* LTPCoef_Q14, const i32* pitchL, const i32* invGains_Q16) {
+    const int n = SX_SUBFR + SX_LPC;
+    SX_PAR(t, 4 * n) {
+        int k = t / n, i = t - k * n;
+        const i16* x_ptr = x + k * SX_SUBFR;
+        const i16* x_lag_ptr = x_ptr - pitchL[k] + i;
+        const i16* B = &LTPCoef_Q14[k * 5];
+        i32 est = sx_smulbb(x_lag_ptr[2], B[0]);
+        for (int j = 1; j < 5; j++) est = sx_smlabb(est, x_lag_ptr[2 - j], B[j]);
+        est = sx_rshift_round(est, 14);
+        i32 r = sx_sat16((i32)x_ptr[i] - est);
+        LTP_res[k * n + i] = (i16)sx_smulwb(invGains_Q16[k], r);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// LPC analysis: Burg, A2NLSF, interpolation search
+// ---------------------------------------------------------------------------------------------------
+// SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49
+SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16* x, int subfr_length, int nb_subfr, i32 WhiteNoiseFrac_Q32, int D) {
+    const int QA = 25, MAX_RSHIFTS = 32 - 25, MIN_RSHIFTS = -16;
+    i32 C0, rshifts, C_first_row[SX_MAX_LPC], C_last_row[SX_MAX_LPC], Af_QA[SX_MAX_LPC], CAf[SX_MAX_LPC + 1], CAb[SX_MAX_LPC + 1];
+    sx_sum_sqr_shift(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
+    if (rshifts > MAX_RSHIFTS) {
+        C0 = sx_shl(C0, rshifts - MAX_RSHIFTS);
+        rshifts = MAX_RSHIFTS;
+    } else {
+        int lz = sx_clz32(C0) - 1;
+        int rshifts_extra = 2 - lz;
+        if (rshifts_extra > 0) {
+            rshifts_extra = sx_min(rshifts_extra, MAX_RSHIFTS - rshifts);
+            C0 = C0 >> rshifts_extra;
+        } else {
+            rshifts_extra = sx_max(rshifts_extra, MIN_RSHIFTS - rshifts);
+            C0 = sx_shl(C0, -rshifts_extra);
+        }
+        rshifts += rshifts_extra;
+    }
+    for (int i = 0; i < SX_MAX_LPC; i++) { C_first_row[i] = 0; Af_QA[i] = 0; }
+    for (int s = 0; s < nb_subfr; s++) {
+        const i16* x_ptr = x + s * subfr_length;
+        for (int n = 1; n < D + 1; n++) {
+            if (rshifts > 0) C_first_row[n - 1] += (i32)(sx_inner_prod64(x_ptr, x_ptr + n, subfr_length - n) >> rshifts);
+            else C_first_row[n - 1] += sx_shl(sx_inner_prod32(x_ptr, x_ptr + n, subfr_length - n), -rshifts);
+        }
+    }
+    for (int i = 0; i < SX_MAX_LPC; i++) C_last_row[i] = C_first_row[i];
+    CAb[0] = CAf[0] = sx_add(sx_add(C0, sx_smmul(WhiteNoiseFrac_Q32, C0)), 1);
+    int n;
+    for (n = 0; n < D; n++) {
+        i32 tmp1, tmp2;
+        if (rshifts > -2) {
+            for (int s = 0; s < nb_subfr; s++) {
+                const i16* x_ptr = x + s * subfr_length;
+                i32 x1 = sx_neg(sx_shl((i32)x_ptr[n], 16 - rshifts));
+                i32 x2 = sx_neg(sx_shl((i32)x_ptr[subfr_length - n - 1], 16 - rshifts));
+                tmp1 = sx_shl((i32)x_ptr[n], QA - 16);
+                tmp2 = sx_shl((i32)x_ptr[subfr_length - n - 1], QA - 16);
+                for (int k = 0; k < n; k++) {
+                    C_first_row[k] = sx_smlawb(C_first_row[k], x1, x_ptr[n - k - 1]);
+                    C_last_row[k] = sx_smlawb(C_last_row[k], x2, x_ptr[subfr_length - n + k]);
+                    i32 Atmp_QA = Af_QA[k];
+                    tmp1 = sx_smlawb(tmp1, Atmp_QA, x_ptr[n - k - 1]);
+                    tmp2 = sx_smlawb(tmp2, Atmp_QA, x_ptr[subfr_length - n + k]);
+                }
+                tmp1 = sx_shl(sx_neg(tmp1), 32 - QA - rshifts);
+                tmp2 = sx_shl(sx_neg(tmp2), 32 - QA - rshifts);
+                for (int k = 0; k <= n; k++) {
+                    CAf[k] = sx_smlawb(CAf[k], tmp1, x_ptr[n - k]);
+                    CAb[k] = sx_smlawb(CAb[k], tmp2, x_ptr[subfr_length - n + k - 1]);
+                }
+            }
+        } else {
+            for (int s = 0; s < nb_subfr; s++) {
+                const i16* x_ptr = x + s * subfr_length;
+                i32 x1 = sx_neg(sx_shl((i32)x_ptr[n], -rshifts));
+                i32 x2 = sx_neg(sx_shl((i32)x_ptr[subfr_length - n - 1], -rshifts));
+                tmp1 = sx_shl((i32)x_ptr[n], 17);
+                tmp2 = sx_shl((i32)x_ptr[subfr_length - n - 1], 17);
+                for (int k = 0; k < n; k++) {
+                    C_first_row[k] = sx_add(C_first_row[k], sx_mul(x1, x_ptr[n - k - 1]));
+                    C_last_row[k] = sx_add(C_last_row[k], sx_mul(x2, x_ptr[subfr_length - n + k]));
+                    i32 Atmp1 = sx_rshift_round(Af_QA[k], QA - 17);
+                    tmp1 = sx_add(tmp1, sx_mul(x_ptr[n - k - 1], Atmp1));
+                    tmp2 = sx_add(tmp2, sx_mul(x_ptr[subfr_length - n + k], Atmp1));
+                }
+                tmp1 = sx_neg(tmp1);
+                tmp2 = sx_neg(tmp2);
+                for (int k = 0; k <= n; k++) {
+                    CAf[k] = sx_smlaww(CAf[k], tmp1, sx_shl((i32)x_ptr[n - k], -rshifts - 1));
+                    CAb[k] = sx_smlaww(CAb[k], tmp2, sx_shl((i32)x_ptr[subfr_length - n + k - 1], -rshifts - 1));
+                }
+            }
+        }
+        tmp1 = C_first_row[n];
+        tmp2 = C_last_row[n];
+        i32 num = 0;
+        i32 nrg = sx_add(CAb[0], CAf[0]);
+        for (int k = 0; k < n; k++) {
+            i32 Atmp_QA = Af_QA[k];
+            int lz = sx_clz32(sx_abs(Atmp_QA)) - 1;
+            lz = sx_min(32 - QA, lz);
+            i32 Atmp1 = sx_shl(Atmp_QA, lz);
+            tmp1 = sx_add(tmp1, sx_shl(sx_smmul(C_last_row[n - k - 1], Atmp1), 32 - QA - lz));
+            tmp2 = sx_add(tmp2, sx_shl(sx_smmul(C_first_row[n - k - 1], Atmp1), 32 - QA - lz));
+            num = sx_add(num, sx_shl(sx_smmul(CAb[n - k], Atmp1), 32 - QA - lz));
+            nrg = sx_add(nrg, sx_shl(sx_smmul(sx_add(CAb[k + 1], CAf[k + 1]), Atmp1), 32 - QA - lz));
+        }
+        CAf[n + 1] = tmp1;
+        CAb[n + 1] = tmp2;
+        num = sx_add(num, tmp2);
+        num = sx_shl(sx_neg(num), 1);
+        i32 rc_Q31;
+        if (sx_abs(num) < nrg) {
+            rc_Q31 = sx_div32_varQ(num, nrg, 31);
+        } else {
+            for (int k = n; k < D; k++) Af_QA[k] = 0;
+            break;
+        }
+        for (int k = 0; k < (n + 1) >> 1; k++) {
+            tmp1 = Af_QA[k];
+            tmp2 = Af_QA[n - k - 1];
+            Af_QA[k] = sx_add(tmp1, sx_shl(sx_smmul(tmp2, rc_Q31), 1));
+            Af_QA[n - k - 1] = sx_add(tmp2, sx_shl(sx_smmul(tmp1, rc_Q31), 1));
+        }
+        Af_QA[n] = rc_Q31 >> (31 - QA);
+        for (int k = 0; k <= n + 1; k++) {
+            tmp1 = CAf[k];
+            tmp2 = CAb[n - k + 1];
+            CAf[k] = sx_add(tmp1, sx_shl(sx_smmul(tmp2, rc_Q31), 1));
+            CAb[n - k + 1] = sx_add(tmp2, sx_shl(sx_smmul(tmp1, rc_Q31), 1));
+        }
+    }
+    i32 nrg = CAf[0];
+    i32 tmp1 = 1 << 16;
+    for (int k = 0; k < D; k++) {
+        i32 Atmp1 = sx_rshift_round(Af_QA[k], QA - 16);
+        nrg = sx_smlaww(nrg, CAf[k + 1], Atmp1);
+        tmp1 = sx_smlaww(tmp1, Atmp1, Atmp1);
+        A_Q16[k] = sx_neg(Atmp1);
+    }
+    *res_nrg = sx_smlaww(nrg, sx_smmul(WhiteNoiseFrac_Q32, C0), sx_neg(tmp1));
+    *res_nrg_Q = -rshifts;
+}
+
+// A2NLSF helpers, SKP_Silk_A2NLSF.c:46-123
+SX_HD void sx_a2nlsf_trans_poly(i32* p, int dd) {
+    for (int k = 2; k <= dd; k++) {
+        for (int n = dd; n > k; n--) p[n - 2] -= p[n];
+        p[k - 2] -= sx_shl(p[k], 1);
+    }
+}
+SX_HD i32 sx_a2nlsf_eval_poly(const i32* p, i32 x, int dd) {
+    i32 y32 = p[dd], x_Q16 = sx_shl(x, 4);
+    for (int n = dd - 1; n >= 0; n--) y32 = sx_smlaww(p[n], y32, x_Q16);
+    return y32;
+}
+SX_HD void sx_a2nlsf_init(const i32* a_Q16, i32* P, i32* Q, int dd) {
+    P[dd] = 1 << 16;
+    Q[dd] = 1 << 16;
+    for (int k = 0; k < dd; k++) {
+        P[k] = sx_sub(sx_neg(a_Q16[dd - k - 1]), a_Q16[dd + k]);
+        Q[k] = sx_add(sx_neg(a_Q16[dd - k - 1]), a_Q16[dd + k]);
+    }
+    for (int k = dd; k > 0; k--) {
+        P[k - 1] -= P[k];
+        Q[k - 1] += Q[k];
+    }
+    sx_a2nlsf_trans_poly(P, dd);
+    sx_a2nlsf_trans_poly(Q, dd);
+}
+// SKP_Silk_A2NLSF, SKP_Silk_A2NLSF.c:127
+SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d) {
+    i32 P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1];
+    const int dd = d >> 1;
+    sx_a2nlsf_init(a_Q16, P, Q, dd);
+    i32* p = P;
+    i32 xlo = T_lsf_cos_Q12[0], ylo = sx_a2nlsf_eval_poly(p, xlo, dd), xhi, yhi;
+    int root_ix;
+    if (ylo < 0) {
+        NLSF[0] = 0;
+        p = Q;
+        ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
+        root_ix = 1;
+    } else {
+        root_ix = 0;
+    }
+    int k = 1, i = 0;
+    for (;;) {
+        xhi = T_lsf_cos_Q12[k];
+        yhi = sx_a2nlsf_eval_poly(p, xhi, dd);
+        if ((ylo <= 0 && yhi >= 0) || (ylo >= 0 && yhi <= 0)) {
+            i32 ffrac = -256;
+            for (int m = 0; m < 3; m++) {
+                i32 xmid = sx_rshift_round(xlo + xhi, 1);
+                i32 ymid = sx_a2nlsf_eval_poly(p, xmid, dd);
+                if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) {
+                    xhi = xmid;
+                    yhi = ymid;
+                } else {
+                    xlo = xmid;
+                    ylo = ymid;
+                    ffrac = ffrac + (128 >> m);
+                }
+            }
+            if (sx_abs(ylo) < 65536) {
+                i32 den = ylo - yhi;
+                i32 nom = sx_shl(ylo, 8 - 3) + (den >> 1);
+                if (den != 0) ffrac += nom / den;
+            } else {
+                ffrac += ylo / ((ylo - yhi) >> (8 - 3));
+            }
+            NLSF[root_ix] = sx_min(sx_shl(k, 8) + ffrac, 32767);
+            root_ix++;
+            if (root_ix >= d) break;
+            p = (root_ix & 1) ? Q : P;
+            xlo = T_lsf_cos_Q12[k - 1];
+            ylo = sx_shl(1 - (root_ix & 2), 12);
+        } else {
+            k++;
+            xlo = xhi;
+            ylo = yhi;
+            if (k > 128) {
+                i++;
+                if (i > 30) {
+                    NLSF[0] = (1 << 15) / (d + 1);
+                    for (k = 1; k < d; k++) NLSF[k] = sx_smulbb(k + 1, NLSF[0]);
+                    return;
+                }
+                sx_bwexpander_32(a_Q16, d, 65536 - sx_smulbb(10 + i, i));
+                sx_a2nlsf_init(a_Q16, P, Q, dd);
+                p = P;
+                xlo = T_lsf_cos_Q12[0];
+                ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
+                if (ylo < 0) {
+                    NLSF[0] = 0;
+                    p = Q;
+                    ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
+                    root_ix = 1;
+                } else {
+                    root_ix = 0;
+                }
+                k = 1;
+            }
+        }
+    }
+}
+
+// SKP_Silk_find_LPC_FIX, SKP_Silk_find_LPC_FIX.c:32.  x: nb_subfr blocks of subfr_length samples (incl. `order` pre-samples)
+// LPC_res: scratch of 2*subfr_length samples (LDS)
+SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q15, int useInterp, int order, const i16* x,
+                       int subfr_length, i16* LPC_res) {
+    i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
+    i16 a_tmp_Q12[SX_MAX_LPC];
+    i32 res_nrg, res_tmp_nrg, res_nrg_Q, res_tmp_nrg_Q;
+    *interpIndex = 4;
+    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order);
+    sx_bwexpander_32(a_Q16, order, K_FIND_LPC_CHIRP_Q16);
+    if (useInterp == 1) {
+        sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order);
+        sx_bwexpander_32(a_tmp_Q16, order, K_FIND_LPC_CHIRP_Q16);
+        int shift = res_tmp_nrg_Q - res_nrg_Q;
+        if (shift >= 0) {
+            if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift);
+        } else {
+            res_nrg = (res_nrg >> (-shift)) - res_tmp_nrg;
+            res_nrg_Q = res_tmp_nrg_Q;
+        }
+        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order);
+        for (int k = 3; k >= 0; k--) {
+            for (int i = 0; i < order; i++) NLSF0_Q15[i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
+            sx_nlsf2a_stable(a_tmp_Q12, NLSF0_Q15, order);
+            sx_lpc_analysis_filter_zero_state(x, a_tmp_Q12, LPC_res, 2 * subfr_length, order);
+            wv_sync();
+            i32 res_nrg0, res_nrg1, rshift0, rshift1, res_nrg_interp, res_nrg_interp_Q;
+            sx_sum_sqr_shift(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order, 0);
+            sx_sum_sqr_shift(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order, 0);
+            shift = rshift0 - rshift1;
+            if (shift >= 0) {
+                res_nrg1 = res_nrg1 >> shift;
+                res_nrg_interp_Q = -rshift0;
+            } else {
+                res_nrg0 = res_nrg0 >> (-shift);
+                res_nrg_interp_Q = -rshift1;
+            }
+            res_nrg_interp = sx_add(res_nrg0, res_nrg1);
+            shift = res_nrg_interp_Q - res_nrg_Q;
+            int isInterpLower;
+            if (shift >= 0) {
+                isInterpLower = (res_nrg_interp >> shift) < res_nrg;
+            } else {
+                isInterpLower = (-shift < 32) ? (res_nrg_interp < (res_nrg >> (-shift))) : 0;
+            }
+            if (isInterpLower) {
+                res_nrg = res_nrg_interp;
+                res_nrg_Q = res_nrg_interp_Q;
+                *interpIndex = k;
+            }
+        }
+    }
+    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// NLSF MSVQ
+// ---------------------------------------------------------------------------------------------------
+struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 vectors per later stage; 64 in stage 0)
+    i32 RateDist_Q18[256];
+    i32 Rate_Q5[16], Rate_new_Q5[16];
+    i32 TempIndices[16];
+    i32 Path[16 * 6], Path_new[16 * 6];
+    i32 Res_Q15[16 * SX_LPC], Res_new_Q15[16 * SX_LPC];
+};
+
+// SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
+SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
+                               i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
+    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+    const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
+    const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
+    const i16* rates = sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5;
+    const int nStages = 6, S = SX_MSVQ_SURVIVORS;
+    for (int i = 0; i < S; i++) w->Rate_Q5[i] = 0;
+    for (int i = 0; i < SX_LPC; i++) w->Res_Q15[i] = pNLSF_Q15[i];
+    int prev_survivors = 1, cur_survivors = 0;
+    const int min_survivors = S / 2;
+    int cb_base = 0;
+    for (int s = 0; s < nStages; s++) {
+        const int K = nvec[s];
+        const i16* cbs = cb + cb_base * SX_LPC;
+        const i16* rts = rates + cb_base;
+        cur_survivors = sx_min(S, sx_smulbb(prev_survivors, K));
+        // rate-distortion of every (survivor, codebook vector) pair: wave-parallel
+        const int total = prev_survivors * K;
+        SX_PAR(t, total) {
+            int n = t / K, i = t - n * K;
+            const i32* in = &w->Res_Q15[n * SX_LPC];
+            const i16* cv = &cbs[i * SX_LPC];
+            i32 sum_error = 0;
+            for (int m = 0; m < SX_LPC; m++) {
+                i32 diff = in[m] - cv[m];
+                sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
+            }
+            w->RateDist_Q18[t] = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
+        }
+        wv_sync();
+        // insertion_sort_increasing, K best of `total` (value asc, index asc): rank by counting, wave-parallel
+        SX_PAR(t, total) {
+            i32 v = w->RateDist_Q18[t];
+            int rank = 0;
+            for (int j = 0; j < total; j++) {
+                i32 u = w->RateDist_Q18[j];
+                rank += (u < v || (u == v && j < t)) ? 1 : 0;
+            }
+            if (rank < cur_survivors) { w->Path_new[rank] = v; w->TempIndices[rank] = t; }   // Path_new reused as sorted-value scratch
+        }
+        wv_sync();
+        for (int r = 0; r < cur_survivors; r++) w->RateDist_Q18[r] = w->Path_new[r];
+        if (w->RateDist_Q18[0] < SX_I32_MAX / 16) {
+            i32 thr = sx_smlawb(w->RateDist_Q18[0], sx_mul(S, w->RateDist_Q18[0]), K_NLSF_MSVQ_SURV_MAX_REL_RD_Q16);
+            while (w->RateDist_Q18[cur_survivors - 1] > thr && cur_survivors > min_survivors) cur_survivors--;
+        }
+        for (int k = 0; k < cur_survivors; k++) {
+            int input_index, cb_index;
+            if (s > 0) {
+                input_index = w->TempIndices[k] / K;
+                cb_index = w->TempIndices[k] - input_index * K;
+            } else {
+                input_index = 0;
+                cb_index = w->TempIndices[k];
+            }
+            const i32* pin = &w->Res_Q15[input_index * SX_LPC];
+            const i16* pcb = &cbs[cb_index * SX_LPC];
+            for (int i = 0; i < SX_LPC; i++) w->Res_new_Q15[k * SX_LPC + i] = pin[i] - (i32)pcb[i];
+            w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
+            for (int i = 0; i < s; i++) w->Path_new[k * nStages + i] = w->Path[input_index * nStages + i];
+            w->Path_new[k * nStages + s] = cb_index;
+        }
+        if (s < nStages - 1) {
+            for (int i = 0; i < cur_survivors * SX_LPC; i++) w->Res_Q15[i] = w->Res_new_Q15[i];
+            for (int i = 0; i < cur_survivors; i++) w->Rate_Q5[i] = w->Rate_new_Q5[i];
+            for (int i = 0; i < cur_survivors * nStages; i++) w->Path[i] = w->Path_new[i];
+        }
+        prev_survivors = cur_survivors;
+        cb_base += K;
+    }
+    int bestIndex = 0;
+    if (deactivate_fluc_red != 1) {
+        i32 bestRateDist_Q20 = SX_I32_MAX;
+        for (int s = 0; s < cur_survivors; s++) {
+            sx_nlsf_msvq_decode(pNLSF_Q15, sigtype, &w->Path_new[s * nStages]);
+            i32 wsse_Q20 = 0;
+            for (int i = 0; i < SX_LPC; i++) {
+                i32 se = pNLSF_Q15[i] - prev_q_Q15[i];
+                wsse_Q20 = sx_smlawb(wsse_Q20, sx_smulbb(se, se), pW_Q6[i]);
+            }
+            wsse_Q20 = sx_add_pos_sat32(w->RateDist_Q18[s], sx_smulwb(wsse_Q20, mu_fluc_red_Q16));
+            if (wsse_Q20 < bestRateDist_Q20) { bestRateDist_Q20 = wsse_Q20; bestIndex = s; }
+        }
+    }
+    for (int i = 0; i < nStages; i++) NLSFIndices[i] = w->Path_new[bestIndex * nStages + i];
+    sx_nlsf_msvq_decode(pNLSF_Q15, sigtype, NLSFIndices);
+}
+
+// SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
+SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
+    i32 pNLSFW_Q6[SX_LPC], pNLSF0_temp_Q15[SX_LPC], pNLSFW0_temp_Q6[SX_LPC], NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
+    if (c->sigtype == 0) {
+        NLSF_mu_Q15 = sx_smlawb(66, -8388, st->speech_activity_Q8);
+        NLSF_mu_fluc_red_Q16 = sx_smlawb(6554, -838848, st->speech_activity_Q8);
+    } else {
+        NLSF_mu_Q15 = sx_smlawb(164, -33554, st->speech_activity_Q8);
+        NLSF_mu_fluc_red_Q16 = sx_smlawb(13107, -1677696, st->speech_activity_Q8 + c->sparseness_Q8);
+    }
+    NLSF_mu_Q15 = sx_max(NLSF_mu_Q15, 1);
+    sx_nlsf_weights_laroia(pNLSFW_Q6, pNLSF_Q15, SX_LPC);
+    const int doInterpolate = c->NLSFInterpCoef_Q2 < 4;     // useInterpolatedNLSFs == 1
+    if (doInterpolate) {
+        for (int i = 0; i < SX_LPC; i++)
+            pNLSF0_temp_Q15[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], c->NLSFInterpCoef_Q2) >> 2);
+        sx_nlsf_weights_laroia(pNLSFW0_temp_Q6, pNLSF0_temp_Q15, SX_LPC);
+        i32 i_sqr_Q15 = sx_shl(sx_smulbb(c->NLSFInterpCoef_Q2, c->NLSFInterpCoef_Q2), 11);
+        for (int i = 0; i < SX_LPC; i++) pNLSFW_Q6[i] = sx_smlawb(pNLSFW_Q6[i] >> 1, pNLSFW0_temp_Q6[i], i_sqr_Q15);
+    }
+    sx_nlsf_msvq_encode(c->NLSFIndices, pNLSF_Q15, c->sigtype, st->prev_NLSFq_Q15, pNLSFW_Q6, NLSF_mu_Q15, NLSF_mu_fluc_red_Q16,
+                        st->first_frame_after_reset, w);
+    sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
+    if (doInterpolate) {
+        for (int i = 0; i < SX_LPC; i++)
+            pNLSF0_temp_Q15[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], c->NLSFInterpCoef_Q2) >> 2);
+        sx_nlsf2a_stable(c->PredCoef_Q12[0], pNLSF0_temp_Q15, SX_LPC);
+    } else {
+        for (int i = 0; i < SX_LPC; i++) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+    }
+}
+
+// SKP_Silk_residual_energy_FIX, SKP_Silk_residual_energy_FIX.c:32.  LPC_res: 100-sample scratch
+SX_FN void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][SX_MAX_LPC], const i32* gains, i16* LPC_res) {
+    const int offset = SX_LPC + SX_SUBFR;
+    const i16* x_ptr = x;
+    for (int i = 0; i < 2; i++) {
+        sx_lpc_analysis_filter_zero_state(x_ptr, a_Q12[i], LPC_res, 2 * offset, SX_LPC);
+        wv_sync();
+        for (int j = 0; j < 2; j++) {
+            i32 rshift;
+            sx_sum_sqr_shift(&nrgs[i * 2 + j], &rshift, LPC_res + SX_LPC + j * offset, SX_SUBFR, 0);
+            nrgsQ[i * 2 + j] = -rshift;
+        }
+        x_ptr += 2 * offset;
+        wv_sync();
+    }
+    for (int i = 0; i < 4; i++) {
+        int lz1 = sx_clz32(nrgs[i]) - 1, lz2 = sx_clz32(gains[i]) - 1;
+        i32 tmp32 = sx_shl(gains[i], lz2);
+        tmp32 = sx_smmul(tmp32, tmp32);
+        nrgs[i] = sx_smmul(tmp32, sx_shl(nrgs[i], lz1));
+        nrgsQ[i] += lz1 + 2 * lz2 - 32 - 32;
+    }
+}
+
+struct SxPredWork {                   // LDS scratch of find_pred_coefs
+    i32 WLTP[4 * 25];
+    i16 LPC_in_pre[4 * (SX_SUBFR + SX_LPC)];
+    i16 LPC_res[2 * (SX_SUBFR + SX_LPC)];
+    SxMsvqWork msvq;
+};
+
+// SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
+SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* res_pitch, SxPredWork* w) {
+    i32 invGains_Q16[4], local_gains[4], Wght_Q15[4], NLSF_Q15[SX_MAX_LPC];
+    i32 min_gain_Q16 = SX_I32_MAX >> 6;
+    for (int i = 0; i < 4; i++) min_gain_Q16 = sx_min(min_gain_Q16, c->Gains_Q16[i]);
+    for (int i = 0; i < 4; i++) {
+        invGains_Q16[i] = sx_div32_varQ(min_gain_Q16, c->Gains_Q16[i], 16 - 2);
+        invGains_Q16[i] = sx_max(invGains_Q16[i], 363);
+        i32 tmp = sx_smulwb(invGains_Q16[i], invGains_Q16[i]);
+        Wght_Q15[i] = tmp >> 1;
+        local_gains[i] = (1 << 16) / invGains_Q16[i];
+    }
+    if (c->sigtype == 0) {
+        sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15);
+        sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8);
+        sx_LTP_scale_ctrl(st, c);
+        sx_LTP_analysis_filter(w->LPC_in_pre, st->x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
+        wv_sync();
+    } else {
+        const int n = SX_SUBFR + SX_LPC;
+        const i16* x_ptr = st->x_buf + SX_FRAME - SX_LPC;
+        SX_PAR(t, 4 * n) {
+            int k = t / n, i = t - k * n;
+            w->LPC_in_pre[t] = (i16)sx_smulwb(invGains_Q16[k], x_ptr[k * SX_SUBFR + i]);
+        }
+        wv_sync();
+        for (int i = 0; i < 20; i++) c->LTPCoef_Q14[i] = 0;
+        c->LTPredCodGain_Q7 = 0;
+    }
+    sx_find_LPC(NLSF_Q15, &c->NLSFInterpCoef_Q2, st->prev_NLSFq_Q15, 1 - st->first_frame_after_reset, SX_LPC, w->LPC_in_pre,
+                SX_SUBFR + SX_LPC, w->LPC_res);
+    sx_process_NLSFs(st, c, NLSF_Q15, &w->msvq);
+    sx_residual_energy(c->ResNrg, c->ResNrgQ, w->LPC_in_pre, c->PredCoef_Q12, local_gains, w->LPC_res);
+    for (int i = 0; i < SX_LPC; i++) st->prev_NLSFq_Q15[i] = NLSF_Q15[i];
+}
+
+// ---------------------------------------------------------------------------------------------------
+// gains
+// ---------------------------------------------------------------------------------------------------
+// SKP_Silk_gains_quant, SKP_Silk_gain_quant.c:42 (md_enable = 1)
+SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditional, i32* ind2, i32* DeltaGains_Q16) {
+    const i32 OFFSET = (6 * 128) / 6 + 16 * 128;
+    const i32 SCALE_Q16 = (65536 * (64 - 1)) / (((86 - 6) * 128) / 6);
+    const i32 INV_SCALE_Q16 = (65536 * (((86 - 6) * 128) / 6)) / (64 - 1);
+    const i32 AlphaDis_Q16 = 32768 / 8;
+    i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(*DeltaGains_Q16, 1), 32);
+    inv_gain_Q16 -= 32767;
+    *ind2 = 0;
+    for (int k = 0; k < 8; k++) {
+        if (inv_gain_Q16 > k * AlphaDis_Q16 && inv_gain_Q16 <= (k + 1) * AlphaDis_Q16) {
+            *ind2 = k;
+            inv_gain_Q16 = (k + 1) * AlphaDis_Q16;
+        }
+    }
+    inv_gain_Q16 += 32767;
+    *DeltaGains_Q16 = sx_inverse32_varQ(sx_max(inv_gain_Q16, 1), 32);
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        ind[k] = sx_smulwb(SCALE_Q16, sx_lin2log(gain_Q16[k]) - OFFSET);
+        if (ind[k] < *prev_ind) ind[k]++;
+        if (k == 0 && conditional == 0) {
+            ind[k] = sx_limit(ind[k], 0, 63);
+            ind[k] = sx_max(ind[k], *prev_ind + (-4));
+            *prev_ind = ind[k];
+        } else {
+            ind[k] = sx_limit(ind[k] - *prev_ind, -4, 40);
+            *prev_ind += ind[k];
+            ind[k] -= -4;
+        }
+        gain_Q16[k] = sx_log2lin(sx_min(sx_smulwb(INV_SCALE_Q16, *prev_ind) + OFFSET, 3967));
+    }
+}
+
+// SKP_Silk_process_gains_FIX, SKP_Silk_process_gains_FIX.c:32
+SX_FN void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
+    if (c->sigtype == 0) {
+        i32 s_Q16 = -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4));
+        for (int k = 0; k < 4; k++) c->Gains_Q16[k] = sx_smlawb(c->Gains_Q16[k], c->Gains_Q16[k], s_Q16);
+    }
+    i32 InvMaxSqrVal_Q16 = sx_log2lin(sx_smulwb(K_70p0_Q7 - c->current_SNR_dB_Q7, K_0p33_Q16)) / SX_SUBFR;
+    for (int k = 0; k < 4; k++) {
+        i32 ResNrg = c->ResNrg[k];
+        i32 ResNrgPart = sx_smulww(ResNrg, InvMaxSqrVal_Q16);
+        if (c->ResNrgQ[k] > 0) {
+            if (c->ResNrgQ[k] < 32) ResNrgPart = sx_rshift_round(ResNrgPart, c->ResNrgQ[k]);
+            else ResNrgPart = 0;
+        } else if (c->ResNrgQ[k] != 0) {
+            if (ResNrgPart > (SX_I32_MAX >> (-c->ResNrgQ[k]))) ResNrgPart = SX_I32_MAX;
+            else ResNrgPart = sx_shl(ResNrgPart, -c->ResNrgQ[k]);
+        }
+        i32 gain = c->Gains_Q16[k];
+        i32 gain_squared = sx_add_sat32(ResNrgPart, sx_smmul(gain, gain));
+        if (gain_squared < 32767) {
+            gain_squared = sx_smlaww(sx_shl(ResNrgPart, 16), gain, gain);
+            gain = sx_sqrt_approx(gain_squared);
+            c->Gains_Q16[k] = sx_lshift_sat32(gain, 8);
+        } else {
+            gain = sx_sqrt_approx(gain_squared);
+            c->Gains_Q16[k] = sx_lshift_sat32(gain, 16);
+        }
+    }
+    // MD delta gain: float / double island (process_gains_FIX.c:90-92)
+    float tmp_float = sx_fdiv(1.0f, c->md_delta_gain_par);
+    tmp_float = tmp_float * 65536.0f;
+    tmp_float = tmp_float > 131072.0f ? 131072.0f : (tmp_float < -131072.0f ? -131072.0f : tmp_float);
+    double dd = (double)tmp_float - (0.05 * 65536.0f);
+    i32 Delta_Gains_Q16 = (i32)(dd > 0 ? dd + 0.5 : dd - 0.5);
+    sx_gains_quant(c->GainsIndices, c->Gains_Q16, &st->LastGainIndex, st->nFramesInPayloadBuf, &c->DeltaGainsIndices, &Delta_Gains_Q16);
+    c->DeltaGains_Q16 = Delta_Gains_Q16;
+    if (c->sigtype == 0) {
+        if (c->LTPredCodGain_Q7 + (c->input_tilt_Q15 >> 8) > K_1p0_Q7) c->QuantOffsetType = 0;
+        else c->QuantOffsetType = 1;
+    }
+    i32 quant_offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
+    c->Lambda_Q10 = K_LAMBDA_OFFSET_Q10 + sx_smulbb(K_LAMBDA_DELAYED_DECISIONS_Q10, SX_DD_STATES) +
+                    sx_smulwb(K_LAMBDA_SPEECH_ACT_Q18, st->speech_activity_Q8) + sx_smulwb(K_LAMBDA_INPUT_QUALITY_Q12, c->input_quality_Q14) +
+                    sx_smulwb(K_LAMBDA_CODING_QUALITY_Q12, c->coding_quality_Q14) + sx_smulwb(K_LAMBDA_QUANT_OFFSET_Q16, quant_offset_Q10);
+}

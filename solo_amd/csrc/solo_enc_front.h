@@ -1,0 +1,533 @@
+// solo_enc_front.h -- encoder front end: QMF band split, VAD, adaptive high-pass, pitch analysis.
+// Rows E2, E5a, E5b, E5c of SURVEY.md section 8(a).  Reference (JC1_SDK_SRC_ARM/src/...):
+//   libBWE/AGR_BWE_qmf.c:38-80, libSATECodec/SKP_Silk_VAD.c:75-318, SKP_Silk_ana_filt_bank_1.c:45,
+//   SKP_Silk_HP_variable_cutoff_FIX.c:37, SKP_Silk_biquad_alt.c:38, SKP_Silk_find_pitch_lags_FIX.c:32,
+//   SKP_Silk_pitch_analysis_core.c:65-706, SKP_Silk_apply_sine_window.c:47, SKP_Silk_autocorr.c:40,
+//   SKP_Silk_schur.c:40, SKP_Silk_k2a.c:40, SKP_Silk_resampler_down2.c:41, SKP_Silk_sort.c:80
+#pragma once
+#include "solo_enc_state.h"
+
+// AGR_Sate_qmf_decomp (libBWE/AGR_BWE_qmf.c:38) in direct form, wave-parallel over the 320 output pairs.
+//   x[t] = in[t] >> 1 on a continuous timeline (63 samples of history), taps reversed (a[j] = aa[63-j]):
+//   y1[k] = sat( pshr15( sum_{j<32} a[j] * (int16)( x[2k+j-63] + x[2k-j] ) ) )
+//   y2[k] = sat( pshr15( sum_{j<32} (j even ? -1 : +1) * a[j] * ( x[2k+j-63] - x[2k-j] ) ) )
+// `tl` is a 63+640 sample scratch timeline (LDS).
+SX_FN void sx_qmf_decomp(SxEncState* st, const i16* pcm, i16* tl, i16* lo, i16* hi) {
+    SX_PAR(i, 63) tl[i] = st->qmf_hist[i];
+    SX_PAR(i, SX_PACKET) tl[63 + i] = (i16)(pcm[i] >> 1);
+    wv_sync();
+    SX_PAR(k, SX_BAND) {
+        i32 y1 = 0, y2 = 0;
+        const i16* xa = tl + 2 * k;          // x[2k + j - 63]  -> tl[63 + 2k + j - 63]
+        const i16* xb = tl + 63 + 2 * k;     // x[2k - j]
+        for (int j = 0; j < 32; j++) {
+            i32 a = T_qmf_taps[63 - j];
+            i32 p = xa[j], q = xb[-j];
+            y1 = sx_add(y1, sx_mul(a, (i32)(i16)(p + q)));
+            i32 d = sx_mul(a, (i32)(i16)(p - q));
+            y2 = (j & 1) ? sx_add(y2, d) : sx_sub(y2, d);
+        }
+        lo[k] = (i16)sx_saturate(sx_pshr32(y1, 15), 32767);
+        hi[k] = (i16)sx_saturate(sx_pshr32(y2, 15), 32767);
+    }
+    wv_sync();
+    SX_PAR(i, 63) st->qmf_hist[i] = tl[SX_PACKET + i];
+    wv_sync();
+}
+
+// SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
+SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
+    const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
+    i32 s0 = S[0], s1 = S[1];
+    for (int k = 0; k < (N >> 1); k++) {
+        i32 in32 = sx_shl((i32)in[2 * k], 10);
+        i32 Y = sx_sub(in32, s0);
+        i32 X = sx_smlawb(Y, Y, A21);
+        i32 out_1 = sx_add(s0, X);
+        s0 = sx_add(in32, X);
+        in32 = sx_shl((i32)in[2 * k + 1], 10);
+        Y = sx_sub(in32, s1);
+        X = sx_smulwb(Y, A20);
+        i32 out_2 = sx_add(s1, X);
+        s1 = sx_add(in32, X);
+        outL[k] = (i16)sx_sat16(sx_rshift_round(sx_add(out_2, out_1), 11));
+        outH[k] = (i16)sx_sat16(sx_rshift_round(sx_sub(out_2, out_1), 11));
+    }
+    S[0] = s0;
+    S[1] = s1;
+}
+
+// SKP_Silk_VAD_GetSA_Q8 (+ GetNoiseLevels), SKP_Silk_VAD.c:75-318.  X is a 4 x 80 int16 scratch (LDS).
+SX_FN void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSNR_dB_Q7) {
+    SxVAD* v = &st->vad;
+    i16* X0 = X, *X1 = X + 80, *X2 = X + 160, *X3 = X + 240;
+    i32 Xnrg[4], NrgToNoiseRatio_Q8[4];
+    sx_ana_filt_bank_1(pIn, v->AnaState, X0, X3, SX_FRAME);
+    sx_ana_filt_bank_1(X0, v->AnaState1, X0, X2, SX_FRAME >> 1);
+    sx_ana_filt_bank_1(X0, v->AnaState2, X0, X1, SX_FRAME >> 2);
+    // HP filter on lowest band (differentiator)
+    int dfl = SX_FRAME >> 3;
+    X0[dfl - 1] = (i16)(X0[dfl - 1] >> 1);
+    i16 HPstateTmp = X0[dfl - 1];
+    for (int i = dfl - 1; i > 0; i--) {
+        X0[i - 1] = (i16)(X0[i - 1] >> 1);
+        X0[i] = (i16)(X0[i] - X0[i - 1]);
+    }
+    X0[0] = (i16)(X0[0] - (i16)v->HPstate);
+    v->HPstate = HPstateTmp;
+    // band energies
+    for (int b = 0; b < 4; b++) {
+        const i16* Xb = X + 80 * b;
+        int dec_len = SX_FRAME >> sx_min(4 - b, 3);
+        int sub_len = dec_len >> 2, off = 0;
+        i32 sumSquared = 0;
+        Xnrg[b] = v->XnrgSubfr[b];
+        for (int s = 0; s < 4; s++) {
+            sumSquared = 0;
+            for (int i = 0; i < sub_len; i++) {
+                i32 x_tmp = Xb[i + off] >> 3;
+                sumSquared = sx_smlabb(sumSquared, x_tmp, x_tmp);
+            }
+            if (s < 3) Xnrg[b] = sx_add_pos_sat32(Xnrg[b], sumSquared);
+            else Xnrg[b] = sx_add_pos_sat32(Xnrg[b], sumSquared >> 1);
+            off += sub_len;
+        }
+        v->XnrgSubfr[b] = sumSquared;
+    }
+    // noise levels (SKP_Silk_VAD_GetNoiseLevels, VAD.c:260)
+    {
+        i32 min_coef = v->counter < 1000 ? 32767 / ((v->counter >> 4) + 1) : 0;
+        for (int k = 0; k < 4; k++) {
+            i32 nl = v->NL[k];
+            i32 nrg = sx_add_pos_sat32(Xnrg[k], v->NoiseLevelBias[k]);
+            i32 inv_nrg = SX_I32_MAX / nrg;
+            i32 coef;
+            if (nrg > sx_shl(nl, 3)) coef = 1024 >> 3;
+            else if (nrg < nl) coef = 1024;
+            else coef = sx_smulwb(sx_smulww(inv_nrg, nl), 1024 << 1);
+            coef = sx_max(coef, min_coef);
+            v->inv_NL[k] = sx_smlawb(v->inv_NL[k], inv_nrg - v->inv_NL[k], coef);
+            nl = SX_I32_MAX / v->inv_NL[k];
+            nl = sx_min(nl, 0x00FFFFFF);
+            v->NL[k] = nl;
+        }
+        v->counter++;
+    }
+    i32 sumSquared = 0, input_tilt = 0;
+    for (int b = 0; b < 4; b++) {
+        i32 speech_nrg = Xnrg[b] - v->NL[b];
+        if (speech_nrg > 0) {
+            if ((Xnrg[b] & 0xFF800000) == 0) NrgToNoiseRatio_Q8[b] = sx_shl(Xnrg[b], 8) / (v->NL[b] + 1);
+            else NrgToNoiseRatio_Q8[b] = Xnrg[b] / ((v->NL[b] >> 8) + 1);
+            i32 SNR_Q7 = sx_lin2log(NrgToNoiseRatio_Q8[b]) - 8 * 128;
+            sumSquared = sx_smlabb(sumSquared, SNR_Q7, SNR_Q7);
+            if (speech_nrg < (1 << 20)) SNR_Q7 = sx_smulwb(sx_shl(sx_sqrt_approx(speech_nrg), 6), SNR_Q7);
+            input_tilt = sx_smlawb(input_tilt, T_vad_tilt_weights[b], SNR_Q7);
+        } else {
+            NrgToNoiseRatio_Q8[b] = 256;
+        }
+    }
+    sumSquared = sumSquared / 4;
+    *pSNR_dB_Q7 = (i16)(3 * sx_sqrt_approx(sumSquared));
+    i32 SA_Q15 = sx_sigm_Q15(sx_smulwb(45000, *pSNR_dB_Q7) - 128);
+    c->input_tilt_Q15 = sx_shl(sx_sigm_Q15(input_tilt) - 16384, 1);
+    i32 speech_nrg = 0;
+    for (int b = 0; b < 4; b++) speech_nrg += (b + 1) * ((Xnrg[b] - v->NL[b]) >> 4);
+    if (speech_nrg <= 0) {
+        SA_Q15 = SA_Q15 >> 1;
+    } else if (speech_nrg < 32768) {
+        speech_nrg = sx_sqrt_approx(sx_shl(speech_nrg, 15));
+        SA_Q15 = sx_smulwb(32768 + speech_nrg, SA_Q15);
+    }
+    st->speech_activity_Q8 = sx_min(SA_Q15 >> 7, 255);
+    i32 smooth_coef_Q16 = (i16)sx_smulwb(4096, sx_smulwb(SA_Q15, SA_Q15));
+    for (int b = 0; b < 4; b++) {
+        v->NrgRatioSmth_Q8[b] = sx_smlawb(v->NrgRatioSmth_Q8[b], NrgToNoiseRatio_Q8[b] - v->NrgRatioSmth_Q8[b], smooth_coef_Q16);
+        i32 SNR_Q7 = 3 * (sx_lin2log(v->NrgRatioSmth_Q8[b]) - 8 * 128);
+        c->input_quality_bands_Q15[b] = sx_sigm_Q15((SNR_Q7 - 16 * 128) >> 4);
+    }
+}
+
+// SKP_Silk_HP_variable_cutoff_FIX (HP_variable_cutoff_FIX.c:37) + SKP_Silk_biquad_alt (biquad_alt.c:38)
+SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in) {
+    if (st->prev_sigtype == 0) {
+        i32 pitch_freq_Hz_Q16 = sx_shl(8 * 1000, 16) / st->prevLag;
+        i32 pitch_freq_log_Q7 = sx_lin2log(pitch_freq_Hz_Q16) - (16 << 7);
+        i32 quality_Q15 = c->input_quality_bands_Q15[0];
+        pitch_freq_log_Q7 = sx_sub(pitch_freq_log_Q7, sx_smulwb(sx_smulwb(sx_shl(quality_Q15, 2), quality_Q15), pitch_freq_log_Q7 - 809));
+        pitch_freq_log_Q7 = sx_add(pitch_freq_log_Q7, (K_0p6_Q15 - quality_Q15) >> 9);
+        i32 delta_freq_Q7 = pitch_freq_log_Q7 - (st->variable_HP_smth1_Q15 >> 8);
+        if (delta_freq_Q7 < 0) delta_freq_Q7 = sx_mul(delta_freq_Q7, 3);
+        delta_freq_Q7 = sx_limit(delta_freq_Q7, -K_VARIABLE_HP_MAX_DELTA_FREQ_Q7, K_VARIABLE_HP_MAX_DELTA_FREQ_Q7);
+        st->variable_HP_smth1_Q15 = sx_smlawb(st->variable_HP_smth1_Q15,
+                                              sx_mul(sx_shl(st->speech_activity_Q8, 1), delta_freq_Q7), K_VARIABLE_HP_SMTH_COEF1_Q16);
+    }
+    st->variable_HP_smth2_Q15 = sx_smlawb(st->variable_HP_smth2_Q15, st->variable_HP_smth1_Q15 - st->variable_HP_smth2_Q15,
+                                          K_VARIABLE_HP_SMTH_COEF2_Q16);
+    c->pitch_freq_low_Hz = sx_log2lin(st->variable_HP_smth2_Q15 >> 8);
+    c->pitch_freq_low_Hz = sx_limit(c->pitch_freq_low_Hz, K_VARIABLE_HP_MIN_FREQ_Q0, K_VARIABLE_HP_MAX_FREQ_Q0);
+    i32 Fc_Q19 = sx_smulbb(1482, c->pitch_freq_low_Hz) / 8;
+    i32 r_Q28 = K_1p0_Q28 - sx_mul(K_0p92_Q9, Fc_Q19);
+    i32 B0 = r_Q28, B1 = sx_shl(sx_neg(r_Q28), 1), B2 = r_Q28;
+    i32 r_Q22 = r_Q28 >> 6;
+    i32 A0 = sx_smulww(r_Q22, sx_smulww(Fc_Q19, Fc_Q19) - K_2p0_Q22);
+    i32 A1 = sx_smulww(r_Q22, r_Q22);
+    // biquad_alt (direct form II transposed), serial
+    i32 A0_L = sx_neg(A0) & 0x3FFF, A0_U = sx_neg(A0) >> 14;
+    i32 A1_L = sx_neg(A1) & 0x3FFF, A1_U = sx_neg(A1) >> 14;
+    i32 S0 = st->In_HP_State[0], S1 = st->In_HP_State[1];
+    for (int k = 0; k < SX_FRAME; k++) {
+        i32 inval = in[k];
+        i32 out32_Q14 = sx_shl(sx_smlawb(S0, B0, inval), 2);
+        S0 = sx_add(S1, sx_rshift_round(sx_smulwb(out32_Q14, A0_L), 14));
+        S0 = sx_smlawb(S0, out32_Q14, A0_U);
+        S0 = sx_smlawb(S0, B1, inval);
+        S1 = sx_rshift_round(sx_smulwb(out32_Q14, A1_L), 14);
+        S1 = sx_smlawb(S1, out32_Q14, A1_U);
+        S1 = sx_smlawb(S1, B2, inval);
+        out[k] = (i16)sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14);
+    }
+    st->In_HP_State[0] = S0;
+    st->In_HP_State[1] = S1;
+}
+
+// SKP_Silk_apply_sine_window, SKP_Silk_apply_sine_window.c:47 (serial recursion, 4 samples per step)
+SX_HD void sx_apply_sine_window(i16* px_win, const i16* px, int win_type, int length) {
+    int k = (length >> 2) - 4;
+    i32 f_Q16 = T_sine_win_freq_Q16[k];
+    i32 c_Q16 = sx_smulwb(f_Q16, -f_Q16);
+    i32 S0, S1;
+    if (win_type == 1) {
+        S0 = 0;
+        S1 = f_Q16 + (length >> 3);
+    } else {
+        S0 = 1 << 16;
+        S1 = (1 << 16) + (c_Q16 >> 1) + (length >> 4);
+    }
+    for (k = 0; k < length; k += 4) {
+        px_win[k] = (i16)sx_smulwb((S0 + S1) >> 1, px[k]);
+        px_win[k + 1] = (i16)sx_smulwb(S1, px[k + 1]);
+        S0 = sx_smulwb(S1, c_Q16) + sx_shl(S1, 1) - S0 + 1;
+        S0 = sx_min(S0, 1 << 16);
+        px_win[k + 2] = (i16)sx_smulwb((S0 + S1) >> 1, px[k + 2]);
+        px_win[k + 3] = (i16)sx_smulwb(S0, px[k + 3]);
+        S1 = sx_smulwb(S0, c_Q16) + sx_shl(S0, 1) - S1;
+        S1 = sx_min(S1, 1 << 16);
+    }
+}
+
+// int64 inner product of two int16 vectors, wave-parallel + reduction (inner_prod16_aligned_64)
+SX_HD i64 sx_inner_prod64(const i16* a, const i16* b, int len) {
+    i64 s = 0;
+    SX_PAR(i, len) s += (i64)((i32)a[i] * (i32)b[i]);
+    return wv_sum64(s);
+}
+// wrapping int32 inner product (inner_prod_aligned: SMLABB chain), wave-parallel + reduction
+SX_HD i32 sx_inner_prod32(const i16* a, const i16* b, int len) {
+    i32 s = 0;
+    SX_PAR(i, len) s = sx_smlabb(s, a[i], b[i]);
+    return wv_sum(s);
+}
+SX_HD i32 sx_clz64(i64 x) {
+    i32 hi = (i32)(x >> 32);
+    return hi == 0 ? 32 + sx_clz32((i32)x) : sx_clz32(hi);
+}
+
+// SKP_Silk_autocorr, SKP_Silk_autocorr.c:40
+SX_HD void sx_autocorr(i32* results, i32* scale, const i16* x, int n, int count) {
+    int corrCount = sx_min(n, count);
+    i64 corr64 = sx_inner_prod64(x, x, n) + 1;
+    int lz = sx_clz64(corr64);
+    int nRightShifts = 35 - lz;
+    *scale = nRightShifts;
+    if (nRightShifts <= 0) {
+        results[0] = sx_shl((i32)corr64, -nRightShifts);
+        for (int i = 1; i < corrCount; i++) results[i] = sx_shl(sx_inner_prod32(x, x + i, n - i), -nRightShifts);
+    } else {
+        results[0] = (i32)(corr64 >> nRightShifts);
+        for (int i = 1; i < corrCount; i++) results[i] = (i32)(sx_inner_prod64(x, x + i, n - i) >> nRightShifts);
+    }
+}
+
+// SKP_Silk_schur, SKP_Silk_schur.c:40
+SX_HD i32 sx_schur(i16* rc_Q15, const i32* c, int order) {
+    i32 C[SX_MAX_LPC + 1][2];
+    int lz = sx_clz32(c[0]);
+    if (lz < 2) {
+        for (int k = 0; k < order + 1; k++) C[k][0] = C[k][1] = c[k] >> 1;
+    } else if (lz > 2) {
+        lz -= 2;
+        for (int k = 0; k < order + 1; k++) C[k][0] = C[k][1] = sx_shl(c[k], lz);
+    } else {
+        for (int k = 0; k < order + 1; k++) C[k][0] = C[k][1] = c[k];
+    }
+    for (int k = 0; k < order; k++) {
+        i32 rc = sx_neg(C[k + 1][0] / sx_max(C[0][1] >> 15, 1));
+        rc = sx_sat16(rc);
+        rc_Q15[k] = (i16)rc;
+        for (int n = 0; n < order - k; n++) {
+            i32 t1 = C[n + k + 1][0], t2 = C[n][1];
+            C[n + k + 1][0] = sx_smlawb(t1, sx_shl(t2, 1), rc);
+            C[n][1] = sx_smlawb(t2, sx_shl(t1, 1), rc);
+        }
+    }
+    return C[0][1];
+}
+
+// SKP_Silk_k2a, SKP_Silk_k2a.c:40
+SX_HD void sx_k2a(i32* A_Q24, const i16* rc_Q15, int order) {
+    i32 Atmp[SX_MAX_LPC];
+    for (int k = 0; k < order; k++) {
+        for (int n = 0; n < k; n++) Atmp[n] = A_Q24[n];
+        for (int n = 0; n < k; n++) A_Q24[n] = sx_smlawb(A_Q24[n], sx_shl(Atmp[k - n - 1], 1), rc_Q15[k]);
+        A_Q24[k] = sx_neg(sx_shl((i32)rc_Q15[k], 9));
+    }
+}
+
+// SKP_Silk_resampler_down2, SKP_Silk_resampler_down2.c:41 (zero initial state, serial)
+SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
+    i32 S0 = 0, S1 = 0;
+    const i32 c0 = T_down2_c0[0], c1 = T_down2_c1[0];
+    for (int k = 0; k < (inLen >> 1); k++) {
+        i32 in32 = sx_shl((i32)in[2 * k], 10);
+        i32 Y = sx_sub(in32, S0);
+        i32 X = sx_smlawb(Y, Y, c1);
+        i32 out32 = sx_add(S0, X);
+        S0 = sx_add(in32, X);
+        in32 = sx_shl((i32)in[2 * k + 1], 10);
+        Y = sx_sub(in32, S1);
+        X = sx_smulwb(Y, c0);
+        out32 = sx_add(out32, S1);
+        out32 = sx_add(out32, X);
+        S1 = sx_add(in32, X);
+        out[k] = (i16)sx_sat16(sx_rshift_round(out32, 11));
+    }
+}
+
+// SKP_Silk_int16_array_maxabs (array_maxabs.c:41) -> SKP_FIX_P_Ana_find_scaling (pitch_analysis_core.c:681)
+SX_HD i32 sx_pitch_find_scaling(const i16* sig, int len, int sum_sqr_len) {
+    // the reference scans for the largest SQUARE and returns |x| there, clamped to 32767: same as max |x| clamped
+    i32 m = 0;
+    SX_PAR(i, len) { i32 v = sig[i] < 0 ? -(i32)sig[i] : (i32)sig[i]; m = v > m ? v : m; }
+    m = wv_max(m);
+    i32 x_max = sx_min(m, 32767);
+    i32 nbits;
+    if (x_max < 32767) nbits = 32 - sx_clz32(sx_smulbb(x_max, x_max));
+    else nbits = 30;
+    nbits += 17 - sx_clz16((i16)sum_sqr_len);
+    return nbits < 31 ? 0 : nbits - 30;
+}
+
+struct SxPitchWork {                 // LDS scratch of the pitch analysis
+    i16 sig8[320];
+    i16 sig4[160];
+    i16 C[4][221];
+    i16 d_comp[221];
+    i32 d_srch[24];
+    i32 tmp32[160];
+};
+
+// SKP_Silk_pitch_analysis_core, SKP_Silk_pitch_analysis_core.c:65, Fs = 8 kHz, complexity 2 (so the
+// third stage is skipped and the extended 11-entry stage-2 codebook is used).  Returns sigtype.
+SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagIndex, i32* contourIndex, i32* LTPCorr_Q15,
+                                 i32 prevLag, i32 search_thres1_Q16, i32 search_thres2_Q15, SxPitchWork* w) {
+    const int min_lag_4 = 8, max_lag_4 = 72, min_lag_8 = 16, max_lag_8 = 144, sf8 = 40;
+    SX_PAR(i, 4 * 221) (&w->C[0][0])[i] = 0;
+    SX_PAR(i, 320) w->sig8[i] = signal[i];
+    wv_sync();
+    sx_down2_zero_state(w->sig4, w->sig8, 320);
+    for (int i = 159; i > 0; i--) w->sig4[i] = (i16)sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]);
+    i32 shift = sx_pitch_find_scaling(w->sig4, 160, sx_max(sf8, 80));
+    if (shift > 0) {
+        SX_PAR(i, 160) w->sig4[i] = (i16)(w->sig4[i] >> shift);
+        wv_sync();
+    }
+    // ---- first stage (4 kHz): normalised correlation of two 10 ms targets against lags 8..72 ----
+    for (int k = 0; k < 2; k++) {
+        const i16* target = &w->sig4[80 + k * sf8];
+        // energies of the basis window at every lag: E(d) = sum_{n<40} b_d[n]^2, b_d = target - d
+        // reference: N(8) = add_sat32(E(8), 40*4000), N(d) = N(d-1) + b_d[0]^2 - b_d[40]^2 (wrapping) = N(8) + E(d) - E(8)
+        i32 E8 = 0;
+        {
+            const i16* b = target - min_lag_4;
+            for (int n = 0; n < sf8; n++) E8 = sx_smlabb(E8, b[n], b[n]);
+        }
+        i32 N8 = sx_add_sat32(E8, sx_smulbb(sf8, 4000));
+        SX_PAR(d, max_lag_4 + 1) {
+            if (d >= min_lag_4) {
+                const i16* b = target - d;
+                i32 cc = 0, E = 0;
+                for (int n = 0; n < sf8; n++) { cc = sx_smlabb(cc, target[n], b[n]); E = sx_smlabb(E, b[n], b[n]); }
+                i32 normalizer = sx_add(N8, sx_sub(E, E8));
+                i32 t = cc / (sx_sqrt_approx(normalizer) + 1);
+                w->C[k][d] = (i16)sx_sat16(t);
+            }
+        }
+        wv_sync();
+    }
+    SX_PAR(i, max_lag_4 + 1) {
+        if (i >= min_lag_4) {
+            i32 sum = ((i32)w->C[0][i] + (i32)w->C[1][i]) >> 1;
+            sum = sx_smlawb(sum, sum, sx_shl(-i, 4));
+            w->tmp32[i] = sum;
+        }
+    }
+    wv_sync();
+    // insertion_sort_decreasing_int16 of C[0][8..72], top-8 (value desc, index asc): rank by counting
+    int length_d_srch = 4 + 2 * 2;
+    const int L = max_lag_4 - min_lag_4 + 1;
+    SX_PAR(i, L) {
+        i32 v = (i16)w->tmp32[min_lag_4 + i];
+        int rank = 0;
+        for (int j = 0; j < L; j++) {
+            i32 u = (i16)w->tmp32[min_lag_4 + j];
+            rank += (u > v || (u == v && j < i)) ? 1 : 0;
+        }
+        if (rank < length_d_srch) { w->C[0][min_lag_4 + rank] = (i16)v; w->d_srch[rank] = i; }
+    }
+    wv_sync();
+    const i16* target = &w->sig4[80];
+    i32 energy = 0;
+    for (int n = 0; n < 80; n++) energy = sx_smlabb(energy, target[n], target[n]);
+    energy = sx_add_pos_sat32(energy, 1000);
+    i32 Cmax = w->C[0][min_lag_4];
+    i32 threshold = sx_smulbb(Cmax, Cmax);
+    if ((energy >> 6) > threshold) {
+        for (int k = 0; k < 4; k++) pitch_out[k] = 0;
+        *LTPCorr_Q15 = 0; *lagIndex = 0; *contourIndex = 0;
+        return 1;
+    }
+    threshold = sx_smulwb(search_thres1_Q16, Cmax);
+    for (int i = 0; i < length_d_srch; i++) {
+        if (w->C[0][min_lag_4 + i] > threshold) w->d_srch[i] = (w->d_srch[i] + min_lag_4) << 1;
+        else { length_d_srch = i; break; }
+    }
+    for (int i = min_lag_8 - 5; i < max_lag_8 + 5; i++) w->d_comp[i] = 0;
+    for (int i = 0; i < length_d_srch; i++) w->d_comp[w->d_srch[i]] = 1;
+    for (int i = max_lag_8 + 3; i >= min_lag_8; i--) w->d_comp[i] = (i16)(w->d_comp[i] + w->d_comp[i - 1] + w->d_comp[i - 2]);
+    length_d_srch = 0;
+    for (int i = min_lag_8; i < max_lag_8 + 1; i++) {
+        if (w->d_comp[i + 1] > 0) { w->d_srch[length_d_srch] = i; length_d_srch++; }
+    }
+    for (int i = max_lag_8 + 3; i >= min_lag_8; i--)
+        w->d_comp[i] = (i16)(w->d_comp[i] + w->d_comp[i - 1] + w->d_comp[i - 2] + w->d_comp[i - 3]);
+    int length_d_comp = 0;
+    for (int i = min_lag_8; i < max_lag_8 + 4; i++) {
+        if (w->d_comp[i] > 0) { w->d_comp[length_d_comp] = (i16)(i - 2); length_d_comp++; }
+    }
+    // ---- second stage (8 kHz) ----
+    shift = sx_pitch_find_scaling(w->sig8, 320, sf8);
+    if (shift > 0) {
+        SX_PAR(i, 320) w->sig8[i] = (i16)(w->sig8[i] >> shift);
+    }
+    SX_PAR(i, 4 * 221) (&w->C[0][0])[i] = 0;
+    wv_sync();
+    SX_PAR(t, 4 * length_d_comp) {
+        int k = t / length_d_comp, j = t - k * length_d_comp;
+        const i16* tp = &w->sig8[160 + k * sf8];
+        int d = w->d_comp[j];
+        const i16* bp = tp - d;
+        i32 cross = 0, eb = 0, et = 0;
+        for (int n = 0; n < sf8; n++) {
+            cross = sx_smlabb(cross, tp[n], bp[n]);
+            eb = sx_smlabb(eb, bp[n], bp[n]);
+            et = sx_smlabb(et, tp[n], tp[n]);
+        }
+        i32 r = 0;
+        if (cross > 0) {
+            i32 en = sx_max(et, eb);
+            i32 lz = sx_clz32(cross);
+            i32 lshift = sx_limit(lz - 1, 0, 15);
+            i32 t32 = sx_shl(cross, lshift) / ((en >> (15 - lshift)) + 1);
+            t32 = sx_smulwb(cross, t32);
+            t32 = sx_add_sat32(t32, t32);
+            lz = sx_clz32(t32);
+            lshift = sx_limit(lz - 1, 0, 15);
+            en = sx_min(et, eb);
+            r = sx_shl(t32, lshift) / ((en >> (15 - lshift)) + 1);
+        }
+        w->C[k][d] = (i16)r;
+    }
+    wv_sync();
+    i32 CCmax = SX_I32_MIN, CCmax_b = SX_I32_MIN;
+    int CBimax = 0, lag = -1;
+    i32 prevLag_log2_Q7 = prevLag > 0 ? sx_lin2log(prevLag) : 0;
+    i32 corr_thres_Q15 = sx_smulbb(search_thres2_Q15, search_thres2_Q15) >> 13;
+    const int nb_cbks = 11;
+    for (int k = 0; k < length_d_srch; k++) {
+        int d = w->d_srch[k];
+        i32 CCmax_new = SX_I32_MIN;
+        int CBimax_new = 0;
+        for (int j = 0; j < nb_cbks; j++) {
+            i32 cc = 0;
+            for (int i = 0; i < 4; i++) cc += (i32)w->C[i][d + T_pitch_cb_stage2[i * 11 + j]];
+            if (cc > CCmax_new) { CCmax_new = cc; CBimax_new = j; }
+        }
+        i32 lag_log2_Q7 = sx_lin2log(d);
+        i32 CCmax_new_b = CCmax_new - (sx_smulbb(4 * 6554, lag_log2_Q7) >> 7);
+        if (prevLag > 0) {
+            i32 dl = lag_log2_Q7 - prevLag_log2_Q7;
+            dl = sx_smulbb(dl, dl) >> 7;
+            i32 bias = sx_smulbb(4 * 6554, *LTPCorr_Q15) >> 15;
+            bias = sx_mul(bias, dl) / (dl + (1 << 6));
+            CCmax_new_b -= bias;
+        }
+        if (CCmax_new_b > CCmax_b && CCmax_new > corr_thres_Q15 && T_pitch_cb_stage2[CBimax_new] <= min_lag_8) {
+            CCmax_b = CCmax_new_b;
+            CCmax = CCmax_new;
+            lag = d;
+            CBimax = CBimax_new;
+        }
+    }
+    if (lag == -1) {
+        for (int k = 0; k < 4; k++) pitch_out[k] = 0;
+        *LTPCorr_Q15 = 0; *lagIndex = 0; *contourIndex = 0;
+        return 1;
+    }
+    CCmax = sx_max(CCmax, 0);
+    *LTPCorr_Q15 = sx_sqrt_approx(sx_shl(CCmax, 13));
+    for (int k = 0; k < 4; k++) pitch_out[k] = lag + T_pitch_cb_stage2[k * 11 + CBimax];
+    *lagIndex = lag - min_lag_8;
+    *contourIndex = CBimax;
+    return 0;
+}
+
+// SKP_Silk_find_pitch_lags_FIX, SKP_Silk_find_pitch_lags_FIX.c:32.  x = x_buf + frame_length.
+// res: 336 samples (LDS).  Wsig: 192 samples scratch.
+SX_FN void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, i16* res, i16* Wsig, SxPitchWork* pw) {
+    const i16* x_buf = st->x_buf;                          // == x - frame_length
+    const int buf_len = SX_LA_PITCH + 2 * SX_FRAME;        // 336
+    i32 auto_corr[SX_MAX_LPC + 1], A_Q24[SX_MAX_LPC], scale;
+    i16 rc_Q15[SX_MAX_LPC], A_Q12[SX_MAX_LPC];
+    const i16* x_ptr = x_buf + buf_len - SX_PITCH_LPC_WIN;
+    sx_apply_sine_window(Wsig, x_ptr, 1, SX_LA_PITCH);
+    SX_PAR(i, SX_PITCH_LPC_WIN - 2 * SX_LA_PITCH) Wsig[SX_LA_PITCH + i] = x_ptr[SX_LA_PITCH + i];
+    sx_apply_sine_window(Wsig + SX_PITCH_LPC_WIN - SX_LA_PITCH, x_ptr + SX_PITCH_LPC_WIN - SX_LA_PITCH, 2, SX_LA_PITCH);
+    wv_sync();
+    sx_autocorr(auto_corr, &scale, Wsig, SX_PITCH_LPC_WIN, SX_PITCH_LPC_ORDER + 1);
+    auto_corr[0] = sx_smlawb(auto_corr[0], auto_corr[0], K_FIND_PITCH_WHITE_NOISE_FRACTION_Q16);
+    i32 res_nrg = sx_schur(rc_Q15, auto_corr, SX_PITCH_LPC_ORDER);
+    c->predGain_Q16 = sx_div32_varQ(auto_corr[0], sx_max(res_nrg, 1), 16);
+    sx_k2a(A_Q24, rc_Q15, SX_PITCH_LPC_ORDER);
+    for (int i = 0; i < SX_PITCH_LPC_ORDER; i++) A_Q12[i] = (i16)sx_sat16(A_Q24[i] >> 12);
+    sx_bwexpander(A_Q12, SX_PITCH_LPC_ORDER, K_FIND_PITCH_BANDWITH_EXPANSION_Q16);
+    // MA_Prediction with zero state over the whole buffer (SKP_Silk_MA.c:40), FIR form, then zero the first `order` outputs
+    SX_PAR(k, buf_len) {
+        i32 acc = 0;
+        for (int d = 0; d < SX_PITCH_LPC_ORDER; d++) {
+            int t = k - 1 - d;
+            if (t >= 0) acc = sx_smlabb(acc, x_buf[t], A_Q12[d]);
+        }
+        i32 o = sx_rshift_round(sx_sub(sx_shl((i32)x_buf[k], 12), acc), 12);
+        res[k] = k < SX_PITCH_LPC_ORDER ? (i16)0 : (i16)sx_sat16(o);
+    }
+    wv_sync();
+    i32 thr = K_0p45_Q15;
+    thr = sx_smlabb(thr, K_m0p004_Q15, SX_PITCH_LPC_ORDER);
+    thr = sx_smlabb(thr, K_m0p1_Q7, st->speech_activity_Q8);
+    thr = sx_smlabb(thr, K_0p15_Q15, st->prev_sigtype);
+    thr = sx_smlawb(thr, K_m0p1_Q16, c->input_tilt_Q15);
+    thr = sx_sat16(thr);
+    c->sigtype = sx_pitch_analysis_core(res, c->pitchL, &c->lagIndex, &c->contourIndex, &st->LTPCorr_Q15, st->prevLag,
+                                        K_FIND_PITCH_CORRELATION_THRESHOLD_HC_MODE_Q16, (i16)thr, pw);
+}
