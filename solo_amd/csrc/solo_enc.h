@@ -1,0 +1,392 @@
+// solo_enc.h -- parameter / pulse entropy coding, high-band (BWE) encoder and the packet-level encoder
+// `sx_encode_packet` = AGR_Sate_Encoder_Encode for one 40 ms packet of one stream.  Rows E0-E9 of SURVEY.md 8(a).
+// Reference (JC1_SDK_SRC_ARM/src/): libBWE/AGR_BWE_SDK_API.c:129 (AGR_Sate_Encoder_Encode),
+//   libBWE/AGR_BWE_encode_frame_FIX.c:8-179, libBWE/AGR_BWE_find_HB_LPC_FIX.c:4, libBWE/AGR_BWE_quant_highband.c:24-147,
+//   libBWE/AGR_BWE_bits.c:77, libSATECodec/SKP_Silk_enc_API.c:104-275, SKP_Silk_encode_frame_FIX.c:33,
+//   SKP_Silk_encode_parameters.c:33, SKP_Silk_encode_pulses.c:55, SKP_Silk_shell_coder.c:84, SKP_Silk_code_signs.c:40
+#pragma once
+#include "solo_enc_analysis.h"
+#include "solo_enc_nsq.h"
+
+// what the parameter coder needs of one frame (kept from both frames until the packet is assembled)
+struct SxFrameIdx {
+    i32 sigtype, QuantOffsetType;
+    i32 GainsIndices[SX_NB_SUBFR], DeltaGainsIndices;
+    i32 NLSFIndices[6], NLSFInterpCoef_Q2;
+    i32 lagIndex, contourIndex, PERIndex, LTPIndex[SX_NB_SUBFR], LTP_scaleIndex;
+    i32 Seed, vadFlag;
+};
+
+struct SxCodeWork {                  // LDS: range-coder byte buffers of the two descriptions
+    u8 buf[2][SX_MAX_ARITHM_BYTES];
+};
+
+struct SxFrontWork {                 // LDS scratch of the per-frame analysis chain
+    i16 res_pitch[2 * SX_FRAME + SX_LA_PITCH];
+    i16 Wsig[SX_PITCH_LPC_WIN];      // also: VAD band buffer (4 x 80) and shaping window (120)
+    i16 hp[SX_FRAME];
+    union {
+        SxPitchWork pitch;
+        SxPredWork pred;
+    } u;
+};
+
+struct SxEncWork {
+    // persistent over the packet
+    i16 lo[SX_BAND], hi[SX_BAND];
+    SxEncCtrl ctrl;
+    SxFrameIdx idx[2];
+    i8 q[2][SX_N_TRACKS][SX_FRAME];
+    i16 xfw[SX_FRAME];
+    i32 r[SX_FRAME];
+    u8 hb_bytes[8];
+    // phase-local
+    union {
+        i16 qmf_tl[63 + SX_PACKET];
+        SxFrontWork front;
+        SxNsqWork nsq;
+        SxCodeWork code;
+        i16 hb_lpc_in[4 * 88];
+    } u;
+};
+
+// ---------------------------------------------------------------------------------------------------
+// entropy coding
+// ---------------------------------------------------------------------------------------------------
+SX_HD void sx_enc_split(SxRangeEnc* rc, int p_child1, int p, const u16* shell_table) {
+    if (p > 0) sx_rc_enc(rc, p_child1, &shell_table[T_shell_offsets[p]]);
+}
+
+// SKP_Silk_shell_encoder, SKP_Silk_shell_coder.c:84
+SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i32* p0) {
+    i32 p1[8], p2[4], p3[2], p4;
+    for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
+    for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
+    for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
+    p4 = p3[0] + p3[1];
+    sx_enc_split(rc, p3[0], p4, T_cdf_shell3);
+    for (int h = 0; h < 2; h++) {
+        sx_enc_split(rc, p2[2 * h], p3[h], T_cdf_shell2);
+        for (int g = 0; g < 2; g++) {
+            const int m = 2 * h + g;
+            sx_enc_split(rc, p1[2 * m], p2[m], T_cdf_shell1);
+            sx_enc_split(rc, p0[4 * m], p1[2 * m], T_cdf_shell0);
+            sx_enc_split(rc, p0[4 * m + 2], p1[2 * m + 1], T_cdf_shell0);
+        }
+    }
+}
+
+// SKP_Silk_encode_pulses + SKP_Silk_encode_signs, SKP_Silk_encode_pulses.c:55, SKP_Silk_code_signs.c:40
+SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q) {
+    const int iter = SX_FRAME / 16;
+    i32 abs_pulses[SX_FRAME], sum_pulses[SX_FRAME / 16], nRshifts[SX_FRAME / 16];
+    for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = q[i] < 0 ? -(i32)q[i] : (i32)q[i];
+    for (int i = 0; i < iter; i++) {
+        i32* ap = &abs_pulses[i * 16];
+        nRshifts[i] = 0;
+        for (;;) {
+            // combine_and_check: 1+1 (max 3), 2+2 (max 6), 4+4 (max 8), 8+8 (max 12); the reference aborts each level at
+            // the first overflow, which leaves its `pulses_comb` partly stale -- but any overflow forces another
+            // pass, so only the overflow count of a clean pass is observable
+            i32 c1[8], c2[4], c3[2];
+            int scale_down = 0, bad;
+            bad = 0;
+            for (int k = 0; k < 8; k++) { c1[k] = ap[2 * k] + ap[2 * k + 1]; bad |= c1[k] > T_max_pulses[0]; }
+            scale_down += bad;
+            bad = 0;
+            for (int k = 0; k < 4; k++) { c2[k] = c1[2 * k] + c1[2 * k + 1]; bad |= c2[k] > T_max_pulses[1]; }
+            scale_down += bad;
+            bad = 0;
+            for (int k = 0; k < 2; k++) { c3[k] = c2[2 * k] + c2[2 * k + 1]; bad |= c3[k] > T_max_pulses[2]; }
+            scale_down += bad;
+            sum_pulses[i] = c3[0] + c3[1];
+            if (sum_pulses[i] > T_max_pulses[3]) scale_down++;
+            if (!scale_down) break;
+            nRshifts[i]++;
+            for (int k = 0; k < 16; k++) ap[k] >>= 1;
+        }
+    }
+    int RateLevelIndex = 0;
+    i32 minSumBits_Q6 = SX_I32_MAX;
+    for (int k = 0; k < 9; k++) {
+        const i16* nBits = &T_bits_pulses_per_block_Q6[k * 20];
+        i32 sumBits_Q6 = T_bits_rate_levels_Q6[sigtype * 9 + k];
+        for (int i = 0; i < iter; i++) sumBits_Q6 += nRshifts[i] > 0 ? nBits[18 + 1] : nBits[sum_pulses[i]];
+        if (sumBits_Q6 < minSumBits_Q6) { minSumBits_Q6 = sumBits_Q6; RateLevelIndex = k; }
+    }
+    sx_rc_enc(rc, RateLevelIndex, &T_cdf_rate_levels[sigtype * 10]);
+    const u16* cdf_ptr = &T_cdf_pulses_per_block[RateLevelIndex * 21];
+    for (int i = 0; i < iter; i++) {
+        if (nRshifts[i] == 0) {
+            sx_rc_enc(rc, sum_pulses[i], cdf_ptr);
+        } else {
+            sx_rc_enc(rc, 18 + 1, cdf_ptr);
+            for (int k = 0; k < nRshifts[i] - 1; k++) sx_rc_enc(rc, 18 + 1, &T_cdf_pulses_per_block[9 * 21]);
+            sx_rc_enc(rc, sum_pulses[i], &T_cdf_pulses_per_block[9 * 21]);
+        }
+    }
+    for (int i = 0; i < iter; i++)
+        if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16]);
+    for (int i = 0; i < iter; i++) {
+        if (nRshifts[i] > 0) {
+            const i8* pp = &q[i * 16];
+            const int nLS = nRshifts[i] - 1;
+            for (int k = 0; k < 16; k++) {
+                i32 abs_q = (i8)(pp[k] < 0 ? -pp[k] : pp[k]);
+                for (int j = nLS; j > 0; j--) sx_rc_enc(rc, (abs_q >> j) & 1, T_cdf_lsb);
+                sx_rc_enc(rc, abs_q & 1, T_cdf_lsb);
+            }
+        }
+    }
+    u16 cdf[3];
+    cdf[0] = 0;
+    cdf[1] = T_cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
+    cdf[2] = 65535;
+    for (int i = 0; i < SX_FRAME; i++)
+        if (q[i] != 0) sx_rc_enc(rc, ((i32)q[i] >> 15) + 1, cdf);
+}
+
+// SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`)
+SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q) {
+    if (frame == 0) {
+        if (writeMDIndex == 1) sx_rc_enc(rc, md, T_cdf_mdindex);
+        sx_rc_enc(rc, 0, T_cdf_fs);                          // SamplingRates_table[0] == 8
+    }
+    const int typeOffset = 2 * x->sigtype + x->QuantOffsetType;
+    if (frame == 0) sx_rc_enc(rc, typeOffset, T_cdf_type_offset);
+    else sx_rc_enc(rc, typeOffset, &T_cdf_type_offset_joint[typeOffsetPrev * 5]);
+    if (frame == 0) sx_rc_enc(rc, x->GainsIndices[0], &T_cdf_gain[x->sigtype * 65]);
+    else sx_rc_enc(rc, x->GainsIndices[0], T_cdf_delta_gain);
+    for (int i = 1; i < SX_NB_SUBFR; i++) sx_rc_enc(rc, x->GainsIndices[i], T_cdf_delta_gain);
+    if (frame == 0) sx_rc_enc(rc, x->DeltaGainsIndices, T_cdf_md_delta_gain);
+    {
+        const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+        const i32* nvec = x->sigtype == 0 ? nvec0 : nvec1;
+        const u16* cdf = x->sigtype == 0 ? T_nlsf_cb0_cdf : T_nlsf_cb1_cdf;
+        int off = 0;
+        for (int s = 0; s < 6; s++) {
+            sx_rc_enc(rc, x->NLSFIndices[s], cdf + off);
+            off += nvec[s] + 1;
+        }
+    }
+    sx_rc_enc(rc, x->NLSFInterpCoef_Q2, T_cdf_nlsf_interp);
+    if (x->sigtype == 0) {
+        sx_rc_enc(rc, x->lagIndex, T_cdf_pitch_lag_nb);
+        sx_rc_enc(rc, x->contourIndex, T_cdf_pitch_contour_nb);
+        sx_rc_enc(rc, x->PERIndex, T_cdf_ltp_per);
+        const u16* gcdf = x->PERIndex == 0 ? T_cdf_ltp_gain0 : (x->PERIndex == 1 ? T_cdf_ltp_gain1 : T_cdf_ltp_gain2);
+        for (int k = 0; k < SX_NB_SUBFR; k++) sx_rc_enc(rc, x->LTPIndex[k], gcdf);
+        sx_rc_enc(rc, x->LTP_scaleIndex, T_cdf_ltpscale);
+    }
+    sx_rc_enc(rc, x->Seed, T_cdf_seed);
+    sx_encode_pulses(rc, x->sigtype, x->QuantOffsetType, q);
+    sx_rc_enc(rc, x->vadFlag, T_cdf_vadflag);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// high band
+// ---------------------------------------------------------------------------------------------------
+// AGR_Bwe_encode_frame_FIX (AGR_BWE_encode_frame_FIX.c:8) for one 20 ms high-band frame; writes its 4 payload bytes.
+// `high`: 160 new high-band samples, `residue`: centre excitation Q10 of the matching SILK frame, lpc_in: 4 x 88 scratch (LDS)
+SX_FN void sx_hb_encode_frame(SxEncState* st, const i16* high, const i32* residue, i16* lpc_in, i16* exc /*40, LDS*/, u8* out4) {
+    i16* xb = st->x_hb_buf;
+    SX_PAR(i, SX_FRAME) xb[SX_FRAME + 40 + i] = high[i];
+    wv_sync();
+    // AGR_Sate_find_HB_LPC_FIX: four 10 ms blocks, each with 8 samples of history; the window runs past the
+    // written part of the reference's buffer (zeros)
+    SX_PAR(t, 4 * 88) {
+        const int k = t / 88, j = t - k * 88;
+        const int src = SX_FRAME - SX_HB_LPC + k * 80 + j;
+        lpc_in[t] = src < SX_HB_XBUF ? xb[src] : (i16)0;
+    }
+    wv_sync();
+    i32 a_Q16[SX_MAX_LPC], NLSF_Q15[SX_MAX_LPC], weight[SX_MAX_LPC], res_nrg, res_nrg_Q;
+    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, 88, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC);
+    sx_bwexpander_32(a_Q16, SX_HB_LPC, K_FIND_LPC_CHIRP_Q16);
+    sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC);
+    // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
+    sx_nlsf_weights_laroia(weight, NLSF_Q15, SX_HB_LPC);
+    i32 best = SX_I32_MAX;
+    int idx1 = 0;
+    {
+        i32 my_best = SX_I32_MAX;
+        int my_idx = 0;
+        SX_PAR(i, 256) {
+            i32 dist = 0;
+            for (int j = 0; j < SX_HB_LPC; j++) {
+                i32 tmp = NLSF_Q15[j] - T_hb_lsp_cb1[i * SX_HB_LPC + j];
+                dist = sx_smlabb(dist, tmp, tmp);
+            }
+            if (dist < my_best) { my_best = dist; my_idx = i; }
+        }
+        wv_argmin(&my_best, &my_idx);
+        idx1 = my_idx;
+    }
+    for (int j = 0; j < SX_HB_LPC; j++) NLSF_Q15[j] -= T_hb_lsp_cb1[idx1 * SX_HB_LPC + j];
+    int idx2 = 0;
+    best = SX_I32_MAX;
+    for (int i = 0; i < 16; i++) {
+        i32 dist = 0;
+        for (int j = 0; j < SX_HB_LPC; j++) {
+            i32 tmp = sx_sub(NLSF_Q15[j], T_hb_lsp_cb2[i * SX_HB_LPC + j]);
+            dist = sx_smlawb(dist, sx_smulbb(tmp, tmp), weight[j]);
+        }
+        if (dist < best) { best = dist; idx2 = i; }
+    }
+    for (int j = 0; j < SX_HB_LPC; j++) NLSF_Q15[j] = (i32)T_hb_lsp_cb1[idx1 * SX_HB_LPC + j] + (i32)T_hb_lsp_cb2[idx2 * SX_HB_LPC + j];
+    const i32 hb_lsp_idx = (idx2 << 8) + idx1;
+    i16 A_Q12[SX_MAX_LPC];
+    sx_nlsf2a_stable(A_Q12, NLSF_Q15, SX_HB_LPC);
+    u32 word = (u32)hb_lsp_idx << 20;
+    for (int sub = 0; sub < 4; sub++) {
+        const i16* p_hb = xb + SX_FRAME + sub * 40;
+        sx_lpc_analysis_filter_zero_state(p_hb, A_Q12, exc, 40, SX_HB_LPC);
+        wv_sync();
+        i32 res_nrg0 = 0, res_nrg1 = 0;
+        for (int i = 0; i < 40; i++) {
+            res_nrg0 = sx_add(res_nrg0, sx_mul((i32)exc[i], (i32)exc[i]));
+            i32 tmp = residue[sub * 40 + i] >> 10;
+            res_nrg1 = sx_smlabb(res_nrg1, tmp, tmp);
+        }
+        res_nrg0 = sx_sqrt_approx(res_nrg0);
+        res_nrg1 = sx_sqrt_approx(res_nrg1);
+        const i16 gain = (i16)(sx_shl(res_nrg0 + 1, 4) / (res_nrg1 + 1));
+        i32 min_dist = SX_I32_MAX;
+        int gidx = 0;
+        for (int i = 0; i < 32; i++) {
+            i16 tmp = (i16)(gain - T_hb_gain_cb[i]);
+            i32 dist = sx_smulbb(tmp, tmp);
+            if (dist < min_dist) { min_dist = dist; gidx = i; }
+        }
+        word |= (u32)gidx << (15 - 5 * sub);
+        wv_sync();
+    }
+    out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
+    // slide the buffer: keep the last 200 samples
+    wv_move_down(xb, xb + SX_FRAME, 200);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// frame and packet level
+// ---------------------------------------------------------------------------------------------------
+#ifndef SX_ENC_TAP
+#define SX_ENC_TAP(stage, st, w, sig)   // test hook (tests/emu): nothing in the product build
+#endif
+
+// SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
+// frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
+SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int frame) {
+    SxEncCtrl* c = &w->ctrl;
+    SxFrontWork* f = &w->u.front;
+    c->Seed = st->frameCounter++ & 3;
+    i32 SNR_dB_Q7;
+    sx_vad(st, c, pIn, f->Wsig, &SNR_dB_Q7);
+    wv_sync();
+    sx_hp_variable_cutoff(st, c, f->hp, pIn);
+    wv_sync();
+    SX_PAR(i, SX_FRAME) st->x_buf[SX_FRAME + SX_LA_SHAPE + i] = f->hp[i];
+    wv_sync();
+    sx_find_pitch_lags(st, c, f->res_pitch, f->Wsig, &f->u.pitch);
+    wv_sync();
+    SX_ENC_TAP(1, st, w, f->hp);
+    sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, st->x_buf + SX_FRAME, f->Wsig);
+    wv_sync();
+    SX_ENC_TAP(2, st, w, f->res_pitch + SX_FRAME);
+    sx_prefilter(st, c, w->xfw, st->x_buf + SX_FRAME);
+    wv_sync();
+    SX_ENC_TAP(3, st, w, w->xfw);
+    sx_find_pred_coefs(st, c, f->res_pitch, &f->u.pred);
+    wv_sync();
+    SX_ENC_TAP(4, st, w, w->xfw);
+    sx_process_gains(st, c);
+    wv_sync();
+    SX_ENC_TAP(5, st, w, w->xfw);
+    sx_nsq_del_dec(st, c, w->xfw, &w->q[frame][0][0], w->r, &w->u.nsq);
+    wv_sync();
+    SX_ENC_TAP(6 + 16 * frame, st, w, w->xfw);
+    // VAD / DTX flags (encode_frame_FIX.c:155-171)
+    if (st->speech_activity_Q8 < K_SPEECH_ACTIVITY_DTX_THRES_Q8) {
+        st->vadFlag = 0;
+        st->noSpeechCounter++;
+        if (st->noSpeechCounter > 5) st->inDTX = 1;
+        if (st->noSpeechCounter > 20 + 5) { st->noSpeechCounter = 5; st->inDTX = 0; }
+    } else {
+        st->noSpeechCounter = 0;
+        st->inDTX = 0;
+        st->vadFlag = 1;
+    }
+    SxFrameIdx* x = &w->idx[frame];
+    x->sigtype = c->sigtype; x->QuantOffsetType = c->QuantOffsetType;
+    for (int i = 0; i < 4; i++) { x->GainsIndices[i] = c->GainsIndices[i]; x->LTPIndex[i] = c->LTPIndex[i]; }
+    x->DeltaGainsIndices = c->DeltaGainsIndices;
+    for (int i = 0; i < 6; i++) x->NLSFIndices[i] = c->NLSFIndices[i];
+    x->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
+    x->lagIndex = c->lagIndex; x->contourIndex = c->contourIndex; x->PERIndex = c->PERIndex;
+    x->LTP_scaleIndex = c->LTP_scaleIndex;
+    x->Seed = c->Seed;
+    x->vadFlag = st->vadFlag;
+    // update input buffer and cross-frame parameters (encode_frame_FIX.c:203-212)
+    wv_move_down(st->x_buf, st->x_buf + SX_FRAME, SX_FRAME + SX_LA_SHAPE);
+    st->prev_sigtype = c->sigtype;
+    st->prevLag = c->pitchL[SX_NB_SUBFR - 1];
+    st->first_frame_after_reset = 0;
+    st->nFramesInPayloadBuf = frame == 0 ? 1 : 0;
+    wv_sync();
+}
+
+// AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129) for one packet: 640 samples @ 16 kHz -> MD1 || MD2 || HB(8).
+// nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.  Returns the total byte count, or a negative status if the
+// payload does not fit `buf_size`.
+SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+    sx_qmf_decomp(st, pcm, w->u.qmf_tl, w->lo, w->hi);
+    wv_sync();
+    for (int frame = 0; frame < 2; frame++) {
+        sx_encode_frame(st, w, w->lo + frame * SX_FRAME, frame);
+        sx_hb_encode_frame(st, w->hi + frame * SX_FRAME, w->r, w->u.hb_lpc_in, w->xfw, &w->hb_bytes[4 * frame]);
+        wv_sync();
+    }
+    // range coding of the two descriptions: description md on lane md
+    i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};
+#if SX_NLANES == 1
+    for (int md = 0; md < 2; md++)
+#else
+    const int md = SX_LANE & 1;
+#endif
+    {
+        SxRangeEnc rc;
+        sx_rc_enc_init(&rc, w->u.code.buf[md]);
+        for (int frame = 0; frame < 2; frame++) {
+            const int prev = frame == 0 ? 0 : 2 * w->idx[0].sigtype + w->idx[0].QuantOffsetType;
+            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->q[frame][1 + md][0]);
+            sx_rc_enc(&rc, frame == 0 ? 1 : 0, T_cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
+        }
+        i32 nb;
+        sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
+        sx_rc_enc_wrap_up(&rc);
+#if SX_NLANES == 1
+        nBytes_md[md] = nb;
+        err_md[md] = rc.error;
+#else
+        nBytes_md[0] = wv_bcast(nb, 0); nBytes_md[1] = wv_bcast(nb, 1);
+        err_md[0] = wv_bcast(rc.error, 0); err_md[1] = wv_bcast(rc.error, 1);
+#endif
+    }
+    wv_sync();
+    const i32 total = nBytes_md[0] + nBytes_md[1] + 8;
+    if (err_md[0] || err_md[1] || total > buf_size || nBytes_md[0] > SX_MAX_ARITHM_BYTES || nBytes_md[1] > SX_MAX_ARITHM_BYTES) {
+        nBytesOut[0] = 0;
+        nBytesOut[1] = 0;
+        return -1;
+    }
+    SX_PAR(i, total) {
+        u8 b;
+        if (i < nBytes_md[0]) b = w->u.code.buf[0][i];
+        else if (i < nBytes_md[0] + nBytes_md[1]) b = w->u.code.buf[1][i - nBytes_md[0]];
+        else b = w->hb_bytes[i - nBytes_md[0] - nBytes_md[1]];
+        bits[i] = b;
+    }
+    nBytesOut[0] = (i16)total;
+    nBytesOut[1] = (i16)(nBytes_md[1] + 8);
+    wv_sync();
+    return total;
+}

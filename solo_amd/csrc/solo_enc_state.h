@@ -6,6 +6,7 @@
 #pragma once
 #include "solo_common.h"
 #include "solo_consts.inc"
+#include "solo_dec.h"     // SX_PACKET / SX_BAND, sx_nlsf_msvq_decode (shared with the decoder)
 
 #define SX_SHAPE_ORDER 16            // shapingLPCOrder (setup_complexity.h:76)
 #define SX_LA_SHAPE 40               // la_shape = 5 * fs_kHz
@@ -34,7 +35,7 @@ struct SxVAD {                       // SKP_Silk_VAD_state, SKP_Silk_structs.h:6
 
 struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:44 (q_Q10 / rand_seed are dead)
     i16 xq[2 * SX_FRAME];
-    i32 sLTP_shp_Q10[2 * SX_FRAME];
+    i32 sLTP_shp_Q10[2 * SX_FRAME + 8];   // +8: a side track with lag 0 reads one entry past the frame (always 0)
     i32 sLPC_Q14[SX_MAX_LPC];        // newest 16 of the reference's 32-entry tail (only the last 10 are ever read)
     i32 sAR2_Q14[SX_SHAPE_ORDER];
     i32 sLF_AR_shp_Q12;

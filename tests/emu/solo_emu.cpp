@@ -6,7 +6,12 @@
 // library (solo_amd/csrc/solo_api.hip) links or calls this file.
 #include <stdlib.h>
 #include <string.h>
+#include <stdint.h>
+struct SxEncState; struct SxEncWork;
+static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const int16_t* sig);
+#define SX_ENC_TAP(stage, st, w, sig) emu_tap(stage, st, w, sig)
 #include "../../solo_amd/csrc/solo_dec.h"
+#include "../../solo_amd/csrc/solo_enc.h"
 
 extern "C" {
 
@@ -30,3 +35,63 @@ int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
 
 // debug aid: raw view of the decoder state (tests only)
 extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
+
+// ---- encoder ----
+extern "C" {
+struct EmuEnc { SxEncState st; SxEncWork w; };
+void* emu_enc_create(int rate_bps, int useMDIndex) {
+    EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
+    sx_enc_state_init(&e->st, rate_bps - 1600, useMDIndex);   // AGR_BWE_SDK_API.c:119: SILK rate = target - 1600
+    return e;
+}
+void emu_enc_destroy(void* h) { free(h); }
+int emu_enc_packet(void* h, const int16_t* pcm, uint8_t* bits, int buf_size, int16_t* nBytesOut) {
+    EmuEnc* e = (EmuEnc*)h;
+    return sx_encode_packet(&e->st, &e->w, pcm, bits, buf_size, nBytesOut);
+}
+int emu_sizeof_enc_state() { return (int)sizeof(SxEncState); }
+int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
+// debug taps (tests only): last frame's control block, pulses and residual
+const void* emu_enc_ctrl_ptr(void* h) { return &((EmuEnc*)h)->w.ctrl; }
+int emu_sizeof_enc_ctrl() { return (int)sizeof(SxEncCtrl); }
+const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->w.q[0][0][0]; }
+const void* emu_enc_idx_ptr(void* h) { return &((EmuEnc*)h)->w.idx[0]; }
+const void* emu_enc_state_ptr(void* h) { return &((EmuEnc*)h)->st; }
+}
+
+// ---- stage taps: same canonical record as oracle/ref_taps.c ----
+#define TAP_REC 1024
+#define TAP_MAX 64
+extern "C" { int solo_tap_n = 0; int solo_tap_buf[TAP_MAX][TAP_REC]; }
+template <typename T> static int* tput(int* p, const T* src, int n) { for (int i = 0; i < n; i++) *p++ = (int)src[i]; return p; }
+static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const int16_t* sig) {
+    if (solo_tap_n >= TAP_MAX) return;
+    const SxEncCtrl* c = &w->ctrl;
+    const int frame = stage >> 4;
+    stage &= 15;
+    int* p0 = solo_tap_buf[solo_tap_n++];
+    int* p = p0;
+    memset(p, 0, sizeof(int) * TAP_REC);
+    *p++ = stage;
+    *p++ = c->sigtype; *p++ = c->QuantOffsetType; *p++ = c->lagIndex; *p++ = c->contourIndex; *p++ = c->PERIndex;
+    p = tput(p, c->LTPIndex, 4); p = tput(p, c->NLSFIndices, 6); *p++ = c->NLSFInterpCoef_Q2;
+    p = tput(p, c->GainsIndices, 4); *p++ = c->DeltaGainsIndices; *p++ = c->Seed; *p++ = c->LTP_scaleIndex;
+    p = tput(p, c->pitchL, 4); p = tput(p, c->Gains_Q16, 4); *p++ = c->DeltaGains_Q16;
+    p = tput(p, c->PredCoef_Q12[0], 10); p = tput(p, c->PredCoef_Q12[1], 10); p = tput(p, c->LTPCoef_Q14, 20);
+    *p++ = c->LTP_scale_Q14;
+    p = tput(p, c->AR1_Q13, 64); p = tput(p, c->AR2_Q13, 64); p = tput(p, c->LF_shp_Q14, 4); p = tput(p, c->GainsPre_Q14, 4);
+    p = tput(p, c->HarmBoost_Q14, 4); p = tput(p, c->Tilt_Q14, 4); p = tput(p, c->HarmShapeGain_Q14, 4);
+    *p++ = c->Lambda_Q10; *p++ = c->input_quality_Q14; *p++ = c->coding_quality_Q14; *p++ = c->current_SNR_dB_Q7;
+    *p++ = c->sparseness_Q8; *p++ = c->predGain_Q16; *p++ = c->LTPredCodGain_Q7;
+    p = tput(p, c->input_quality_bands_Q15, 4); *p++ = c->input_tilt_Q15;
+    p = tput(p, c->ResNrg, 4); p = tput(p, c->ResNrgQ, 4);
+    *p++ = st->speech_activity_Q8; *p++ = st->LTPCorr_Q15;
+    p = p0 + 256;
+    if (sig) tput(p, sig, 160);
+    p += 160;
+    if (stage == 6) {
+        tput(p, &w->q[frame][0][0], 160); p += 160;
+        tput(p, &w->q[frame][1][0], 160); tput(p + 160, &w->q[frame][2][0], 160); p += 320;
+        tput(p, w->r, 160);
+    }
+}
