@@ -62,6 +62,31 @@ __global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, con
     if (status && SX_LANE == 0) status[s] = first_err;
 }
 
+#ifdef SOLO_WITH_ENCODER
+__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncState* states, int n_streams, int silk_rate_bps, int useMDIndex) {
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex);
+}
+
+// Encoder: rows E0-E9.  blockIdx.x = stream; one wavefront encodes the stream's packets in order.
+__global__ void __launch_bounds__(64) solo_encode_kernel(SxEncState* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
+                                                         int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SxEncState* st = &states[s];
+    i32 first_err = 0;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        i32 ret = sx_encode_packet(st, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    if (status && SX_LANE == 0) status[s] = first_err;
+}
+#endif
+
 // ---------------------------------------------------------------------------------------------------
 // host side: handle + C ABI
 // ---------------------------------------------------------------------------------------------------
@@ -84,16 +109,28 @@ static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
 }
 
 #ifdef SOLO_WITH_ENCODER
-int32_t solo_enc_alloc(solo_batch* b);
-int32_t solo_enc_reset(solo_batch* b, hipStream_t s);
-void solo_enc_free(solo_batch* b);
+static int32_t solo_enc_alloc(solo_batch* b) {
+    SOLO_CHECK(hipMalloc(&b->d_enc_state, sizeof(SxEncState) * (size_t)b->n_streams));
+    return 0;
+}
+static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
+    // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the 1600 bps high-band share
+    hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncState*)b->d_enc_state, b->n_streams,
+                       b->enc_ctrl.targetRate_bps - 1600, b->enc_ctrl.useMDIndex);
+    SOLO_CHECK(hipGetLastError());
+    return 0;
+}
+static void solo_enc_free(solo_batch* b) {
+    if (b->d_enc_state) (void)hipFree(b->d_enc_state);
+    b->d_enc_state = NULL;
+}
 #endif
 
 extern "C" {
 
 const char* solo_version(void) { return "solo_mi355x 0.1 (gfx950)"; }
 
-const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : "solo_decode_kernel"; }
+const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_encode_kernel" : "solo_decode_kernel"; }
 
 int32_t solo_batch_n_streams(const solo_batch_t* b) { return b ? b->n_streams : 0; }
 int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
@@ -166,7 +203,16 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     return 0;
 }
 
-#ifndef SOLO_WITH_ENCODER
+#ifdef SOLO_WITH_ENCODER
+int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packets, uint8_t* d_bits, int16_t* d_nbytes,
+                          int32_t* d_status, void* hip_stream) {
+    if (!b || !b->have_enc || !d_pcm || !d_bits || !d_nbytes || n_packets <= 0) return -1;
+    hipLaunchKernelGGL(solo_encode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, (SxEncState*)b->d_enc_state,
+                       d_pcm, b->n_streams, n_packets, b->slot, d_bits, d_nbytes, d_status);
+    SOLO_CHECK(hipGetLastError());
+    return 0;
+}
+#else
 int32_t solo_batch_encode(solo_batch_t*, const int16_t*, int32_t, uint8_t*, int16_t*, int32_t*, void*) { return -1; }
 #endif
 

@@ -1,0 +1,52 @@
+"""CPU checks of the ENCODER kernel source (solo_amd/csrc/solo_enc*.h) compiled for the host (tests/emu):
+bit-exact against the committed golden bitstreams and, where oracle/_ref exists, the compiled reference.
+The GPU parity tests proper are tests/test_gpu_encoder.py."""
+import numpy as np
+import pytest
+
+import refcodec as R
+import solo_testlib as T
+
+
+def test_ch_f1_bitstream_md5():
+    g = T.golden_json()
+    pcm = np.fromfile(T.GOLDEN + "/Ch_f1_raw.pcm", np.int16)
+    e = T.EmuEncoder()
+    recs = [e.encode(pcm[p * 640:(p + 1) * 640]) for p in range(len(pcm) // 640)]
+    assert T.md5(T.write_bit_container(recs)) == g["ch_f1_bit_md5"]
+
+
+def test_synthetic_goldens():
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P, _ = z["pcm"].shape
+    for i in range(N):
+        e = T.EmuEncoder()
+        for p in range(P):
+            pl, n0, n1 = e.encode(z["pcm"][i, p])
+            assert (n0, n1) == tuple(int(v) for v in z["nbytes"][i, p]), (i, p)
+            assert pl == z["bits"][i, p, :n0].tobytes(), (i, p)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not built")
+def test_edge_signals_vs_compiled_reference():
+    rng = np.random.default_rng(11)
+    P = 8
+    t = np.arange(640 * P) / 16000.0
+    sigs = [np.zeros(640 * P), rng.integers(-32768, 32767, 640 * P), 25000 * np.sin(2 * np.pi * 180 * t),
+            30000 * np.sign(np.sin(2 * np.pi * 110 * t)), np.full(640 * P, -20000), (np.arange(640 * P) % 131 == 0) * 32767]
+    for k, s in enumerate(sigs):
+        x = np.asarray(s).astype(np.int16)
+        e, r = T.EmuEncoder(), R.RefEncoder("fix")
+        for p in range(P):
+            assert e.encode(x[p * 640:(p + 1) * 640]) == r.encode(x[p * 640:(p + 1) * 640]), (k, p)
+
+
+def test_round_trip_through_emu_decoder():
+    """encode -> decode with the emulated kernels reproduces the committed reference PCM"""
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    for i in range(2):
+        e, d = T.EmuEncoder(), T.EmuDecoder()
+        for p in range(10):
+            pl, n0, n1 = e.encode(z["pcm"][i, p])
+            x, ret = d.decode(*R.map_loss(pl, n0, n1, False, False))
+            assert ret == 0 and np.array_equal(x, z["dec_clean"][i, p])

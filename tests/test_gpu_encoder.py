@@ -1,0 +1,152 @@
+"""GPU parity of the encoder (rows E0-E9) through the C ABI: HIP kernels vs the committed golden bitstreams
+and, when oracle/_ref travelled with the snapshot, vs the compiled reference itself.  Bit-exact."""
+import numpy as np
+import pytest
+
+import refcodec as R
+import solo_testlib as T
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+def _gpu_encode(torch, pcm, slot=512, batch=None):
+    import solo_amd
+    N, P, _ = pcm.shape
+    b = batch or solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=slot)
+    bits, nb, status = b.encode(torch.from_numpy(np.ascontiguousarray(pcm)).to(b.device))
+    torch.cuda.synchronize()
+    assert int(status.abs().max()) == 0
+    return bits.cpu().numpy(), nb.cpu().numpy()
+
+
+def _assert_streams_equal(bits, nb, ref_bits, ref_nb):
+    assert np.array_equal(nb, ref_nb)
+    N, P, _ = bits.shape
+    for i in range(N):
+        for p in range(P):
+            n = int(nb[i, p, 0])
+            assert np.array_equal(bits[i, p, :n], ref_bits[i, p, :n]), (i, p)
+
+
+def test_ch_f1_bitstream_md5(torch_cuda):
+    """The reference's own sample file -> the byte-exact .bit container its CLI writes (known-answer md5)."""
+    g = T.golden_json()
+    pcm = np.fromfile(T.GOLDEN + "/Ch_f1_raw.pcm", np.int16)
+    P = len(pcm) // 640
+    bits, nb = _gpu_encode(torch_cuda, pcm[:P * 640].reshape(1, P, 640))
+    recs = [(bits[0, p, :nb[0, p, 0]].tobytes(), int(nb[0, p, 0]), int(nb[0, p, 1])) for p in range(P)]
+    assert T.md5(T.write_bit_container(recs)) == g["ch_f1_bit_md5"]
+
+
+def test_synthetic_goldens(torch_cuda):
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    bits, nb = _gpu_encode(torch_cuda, z["pcm"])
+    _assert_streams_equal(bits, nb, z["bits"], z["nbytes"])
+
+
+def test_packetwise_calls_equal_one_call(torch_cuda):
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P, _ = z["pcm"].shape
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
+    for p in range(P):
+        bits, nb = _gpu_encode(torch, z["pcm"][:, p:p + 1], batch=b)
+        _assert_streams_equal(bits, nb, z["bits"][:, p:p + 1], z["nbytes"][:, p:p + 1])
+
+
+def test_round_trip_on_gpu(torch_cuda):
+    """encode -> erase descriptions -> decode, all on the GPU, equals the reference chain's PCM."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P, _ = z["pcm"].shape
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
+    bits, nb, st = b.encode(torch.from_numpy(z["pcm"]).to(b.device))
+    pcm, st2 = b.decode(bits, nb, torch.from_numpy(z["recv"]).to(b.device))
+    torch.cuda.synchronize()
+    assert int(st.abs().max()) == 0 and int(st2.abs().max()) == 0
+    assert np.array_equal(pcm.cpu().numpy(), z["dec_loss"])
+
+
+def _edge_streams(P):
+    rng = np.random.default_rng(7)
+    t = np.arange(640 * P) / 16000.0
+    x = [np.zeros(640 * P), rng.integers(-32768, 32767, 640 * P), rng.integers(-40, 40, 640 * P),
+         20000 * np.sin(2 * np.pi * 200 * t), 28000 * np.sin(2 * np.pi * (100 + 3000 * t) * t),
+         30000 * np.sign(np.sin(2 * np.pi * 130 * t)),
+         np.clip(80000 * np.sin(2 * np.pi * 300 * t) + rng.normal(0, 3000, t.size), -32768, 32767),
+         np.full(640 * P, 12000), (np.arange(640 * P) % 97 == 0) * 30000]
+    return np.stack([np.asarray(v).astype(np.int16).reshape(P, 640) for v in x])
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_edge_signals_vs_compiled_reference(torch_cuda):
+    """silence, full-scale noise, near-silence, tones, sweep, square, clipping, DC, impulse train"""
+    P = 10
+    pcm = _edge_streams(P)
+    bits, nb = _gpu_encode(torch_cuda, pcm)
+    for i in range(pcm.shape[0]):
+        e = R.RefEncoder("fix")
+        for p in range(P):
+            pl, n0, n1 = e.encode(pcm[i, p])
+            assert (int(nb[i, p, 0]), int(nb[i, p, 1])) == (n0, n1), (i, p)
+            assert bits[i, p, :n0].tobytes() == pl, (i, p)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_many_streams_vs_compiled_reference(torch_cuda):
+    """512 independent synthetic streams x 6 packets (config 2/3 shape, reduced count)."""
+    N, P = 512, 6
+    pcm = np.stack([R.synth_stream(5000 + i, P) for i in range(N)])
+    bits, nb = _gpu_encode(torch_cuda, pcm)
+    for i in range(N):
+        e = R.RefEncoder("fix")
+        for p in range(P):
+            pl, n0, n1 = e.encode(pcm[i, p])
+            assert (int(nb[i, p, 0]), int(nb[i, p, 1])) == (n0, n1), (i, p)
+            assert bits[i, p, :n0].tobytes() == pl, (i, p)
+
+
+def test_use_md_index_and_rate(torch_cuda):
+    """useMDIndex = 1 and a second target rate against the host emulation of the same kernel source."""
+    import solo_amd
+    torch = torch_cuda
+    P = 8
+    pcm = np.stack([R.synth_stream(70 + i, P) for i in range(4)])
+    for rate, mdi in ((13600, 1), (24000, 0)):
+        b = solo_amd.SoloBatch(4, rate=rate, encoder=True, decoder=False, slot_bytes=512, use_md_index=mdi)
+        bits, nb = _gpu_encode(torch, pcm, batch=b)
+        for i in range(4):
+            e = T.EmuEncoder(rate, mdi)
+            for p in range(P):
+                pl, n0, n1 = e.encode(pcm[i, p])
+                assert (int(nb[i, p, 0]), int(nb[i, p, 1])) == (n0, n1), (rate, mdi, i, p)
+                assert bits[i, p, :n0].tobytes() == pl, (rate, mdi, i, p)
+
+
+def test_legacy_single_stream_api(torch_cuda):
+    """AGR_Sate_Encoder_Init / _Encode / _Uninit driven exactly like test/enc_main.c does."""
+    import ctypes as C
+    import solo_amd
+    lib = solo_amd.load_library()
+    recs = T.parse_bit_container(open(T.GOLDEN + "/ch_f1.bit", "rb").read())
+    pcm = np.fromfile(T.GOLDEN + "/Ch_f1_raw.pcm", np.int16)
+    ctrl = solo_amd.default_enc_ctrl()
+    h = lib.AGR_Sate_Encoder_Init(C.byref(ctrl))
+    assert h
+    buf = np.zeros(1024, np.uint8)
+    nbv = np.zeros(6, np.int16)
+    for p in range(40):
+        x = np.ascontiguousarray(pcm[p * 640:(p + 1) * 640])
+        n = lib.AGR_Sate_Encoder_Encode(h, x.ctypes.data, buf.ctypes.data, 1024, nbv.ctypes.data)
+        assert (n, int(nbv[0]), int(nbv[1])) == (len(recs[p][0]), recs[p][1], recs[p][2]), p
+        assert buf[:n].tobytes() == recs[p][0], p
+    lib.AGR_Sate_Encoder_Uninit(h)
