@@ -1,0 +1,200 @@
+#!/usr/bin/env python3
+"""Headline benchmark: 40 ms packets/s, encode + decode round trip (BASELINE.json configs[2]).
+
+  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = every stream of the batch encodes `--packets` consecutive 40 ms packets (AGR_Sate_Encoder_Encode
+semantics: QMF split, SILK analysis, 3-track delayed-decision NSQ, range coding of both descriptions, high band)
+and decodes them again (AGR_Sate_Decoder_Decode, both descriptions received, BWE resynthesis + QMF), through the
+C ABI of solo_amd/libsolo_mi355x.so.  Inputs are resident in HBM before the timed region; codec state stays in
+HBM between steps.  Streams shard over ranks with no data-path collective ("weak" scaling: 4096 streams per GPU);
+RCCL is used only for the barrier and the max-over-ranks time.
+
+Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (solo_encode_kernel): algorithmic HBM bytes
+per launch (1280 B PCM in + payload + 4 B lengths per packet) / its average duration measured
+with HIP events on the launch stream.  `cpu_baseline` times the compiled reference (oracle/_ref, fixed-point tree)
+on the host cores for a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def _cpu_gen(args):
+    from solo_amd.synth import synth_stream
+    return synth_stream(args[0], args[1])
+
+
+def _cpu_run(pcm):
+    sys.path.insert(0, os.path.join(HERE, "oracle"))
+    import refcodec as R
+    e, d = R.RefEncoder("fix"), R.RefDecoder("fix")
+    for p in range(pcm.shape[0]):
+        pl, n0, n1 = e.encode(pcm[p])
+        d.decode(*R.map_loss(pl, n0, n1, False, False))
+    e.close()
+    return pcm.shape[0]
+
+
+def cpu_worker(n_packets_total, packets_per_stream):
+    """Runs in a fresh interpreter (no torch / HIP): one process per host CPU, each looping whole streams through the
+    compiled reference encoder + decoder (both descriptions received)."""
+    import multiprocessing as mp
+    sys.path.insert(0, os.path.join(HERE, "oracle"))
+    import refcodec as R
+    if not R.have_ref("fix"):
+        print(json.dumps(None))
+        return
+    cores = os.cpu_count() or 1
+    P = packets_per_stream
+    n_streams = max(cores, n_packets_total // P)
+    n_streams = (n_streams + cores - 1) // cores * cores
+    with mp.get_context("fork").Pool(cores) as pool:
+        pcm = pool.map(_cpu_gen, [(i, P) for i in range(n_streams)])
+        pool.map(_cpu_run, [x[:2] for x in pcm[:cores]])      # warm every worker (library load, page-in)
+        t0 = time.perf_counter()
+        done = sum(pool.map(_cpu_run, pcm, chunksize=1))
+        dt = time.perf_counter() - t0
+    print(json.dumps({"value": round(done / dt, 1), "unit": "40ms packets/s (encode+decode)", "cores": cores, "kind": "reference",
+                      "sample": "%d streams x %d packets of the same synthetic workload through the compiled fixed-point "
+                                "reference (oracle/_ref/libsolo_ref_fix.so, gcc -O2), %d processes, %.1f s wall"
+                                % (n_streams, P, cores, dt)}))
+
+
+def cpu_baseline(n_packets_total, packets_per_stream):
+    import subprocess
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-packets", str(n_packets_total),
+                        "--cpu-packets-per-stream", str(packets_per_stream)], capture_output=True, text=True, timeout=600)
+    for line in reversed(r.stdout.strip().splitlines()):
+        try:
+            return json.loads(line)
+        except Exception:
+            continue
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
+    ap.add_argument("--packets", type=int, default=10, help="40 ms packets per stream per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-packets", type=int, default=0, help="0: 120 packets per host CPU")
+    ap.add_argument("--cpu-packets-per-stream", type=int, default=120)
+    ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_packets <= 0:
+        args.cpu_packets = 120 * (os.cpu_count() or 1)
+    if args.cpu_worker:
+        cpu_worker(args.cpu_packets, args.cpu_packets_per_stream)
+        return
+
+    import torch
+    import solo_amd
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the codec has no CPU path")
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
+    dev = torch.device("cuda", torch.cuda.current_device())
+
+    N, P = args.streams, args.packets
+    from solo_amd.synth import synth_batch
+    pcm = torch.from_numpy(synth_batch(rank * N, N, P, workers=min(16, os.cpu_count() or 1))).to(dev)
+    batch = solo_amd.SoloBatch(N, rate=13600, encoder=True, decoder=True, slot_bytes=512)
+    bits = torch.zeros((N, P, 512), dtype=torch.uint8, device=dev)
+    nb = torch.zeros((N, P, 2), dtype=torch.int16, device=dev)
+    st_e = torch.zeros((N,), dtype=torch.int32, device=dev)
+    st_d = torch.zeros((N,), dtype=torch.int32, device=dev)
+    out = torch.zeros((N, P, 640), dtype=torch.int16, device=dev)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        batch.encode(pcm, bits, nb, st_e)
+        if k is not None:
+            ev[k][1].record()
+        batch.decode(bits, nb, None, out, st_d)
+        if k is not None:
+            ev[k][2].record()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        step(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
+    enc_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
+    dec_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+    mean_payload = float(nb[:, :, 0].float().mean().item())
+    packets_step = N * P
+    value = world * packets_step * args.steps / dt
+
+    if rank == 0:
+        enc_bytes = packets_step * (1280.0 + mean_payload + 4.0)
+        achieved = enc_bytes / (enc_ms * 1e-3) / 1e9
+        res = {
+            "metric": "40 ms frames/sec (encode+decode) per GPU; concurrent real-time WB streams @1/2/4/8 MI355X",
+            "value": round(value, 1), "unit": "40ms packets/s (encode+decode)", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "int32 fixed point (int16 PCM, Q-format arithmetic, bit-exact)", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[2]: %d synthetic 16 kHz WB streams per GPU, full encode -> two-description "
+                                   "bitstream -> decode round trip with BWE resynthesis, 13.6 kbps, %d packets/stream/step" % (N, P),
+                       "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2)},
+            "realtime_streams": round(value / 25.0, 1),
+            "encode_only_packets_per_s": round(packets_step / (enc_ms * 1e-3), 1),
+            "decode_only_packets_per_s": round(packets_step / (dec_ms * 1e-3), 1),
+            "roofline": {"kernel": "solo_encode_kernel", "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
+                         "avg_launch_ms": round(enc_ms, 3), "algorithmic_bytes_per_launch": int(enc_bytes)},
+        }
+        tr = os.path.join(HERE, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, collected separately
+        if os.path.exists(tr):
+            try:
+                res["roofline"]["traffic"] = json.load(open(tr)).get("solo_encode_kernel_bytes_per_packet") * packets_step
+            except Exception:
+                pass
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.cpu_packets, args.cpu_packets_per_stream)
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
