@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Condense the rocprofv3 CSVs that a `gpurun` profiling call left under gpurun_out/prof/ into the small,
+tracked summary under profiles/ (per-kernel trace stats + PMC counters averaged per launch).
+
+  python tools/summarize_profile.py gpurun_out/prof profiles/r01_bench [packets_per_launch]
+"""
+import collections
+import csv
+import json
+import os
+import sys
+
+src, dst = sys.argv[1], sys.argv[2]
+packets = int(sys.argv[3]) if len(sys.argv) > 3 else 40960
+out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
+       "packets_per_launch": packets, "kernels": {}}
+st = os.path.join(src, "trace", "r01_kernel_stats.csv")
+lines = []
+for r in csv.DictReader(open(st)):
+    name = r["Name"].split("(")[0]
+    if name.startswith("solo_"):
+        out["kernels"].setdefault(name, {})["trace"] = {"calls": int(r["Calls"]), "avg_ms": float(r["AverageNs"]) / 1e6,
+                                                        "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
+                                                        "percent": float(r["Percentage"])}
+    lines.append(",".join([name[:60], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
+for d in ("fetch", "write", "sq", "inst"):
+    f = os.path.join(src, d, "r01_counter_collection.csv")
+    if not os.path.exists(f):
+        continue
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    meta = {}
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+        meta[k] = {"vgpr": int(r["VGPR_Count"]), "sgpr": int(r["SGPR_Count"]), "lds_bytes": int(r["LDS_Block_Size"]),
+                   "scratch_bytes_per_lane": int(r["Scratch_Size"]), "grid": int(r["Grid_Size"]), "workgroup": int(r["Workgroup_Size"])}
+    for k, v in agg.items():
+        if k.startswith("solo_") and "init" not in k:
+            e = out["kernels"].setdefault(k, {})
+            e.setdefault("resources", meta[k])
+            e.setdefault("pmc_avg_per_launch", {}).update({c: sum(x) / len(x) for c, x in v.items()})
+for k, e in out["kernels"].items():
+    p = e.get("pmc_avg_per_launch", {})
+    if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
+        # guide (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the
+        # bytes of wide coalesced reads -> doubled here; WRITE_SIZE is taken as is (uncalibrated)
+        e["hbm_bytes_per_launch_corrected"] = (2.0 * p["FETCH_SIZE"] + p["WRITE_SIZE"]) * 1024.0
+        e["hbm_bytes_per_packet_corrected"] = e["hbm_bytes_per_launch_corrected"] / packets
+    if "SQ_INSTS_VALU" in p:
+        e["wave_instructions_per_packet"] = {c[9:]: p[c] / packets for c in p if c.startswith("SQ_INSTS_")}
+    if "SQ_WAVE_CYCLES" in p:
+        wc = p["SQ_WAVE_CYCLES"]
+        e["wave_cycle_split"] = {"active_inst_any": p.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_any(memory/barrier)": p.get("SQ_WAIT_ANY", 0) / wc,
+                                 "wait_inst_any(issue stall)": p.get("SQ_WAIT_INST_ANY", 0) / wc}
+os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
+json.dump(out, open(dst + "_summary.json", "w"), indent=1)
+open(dst + "_kernel_stats.csv", "w").write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n" + "\n".join(lines) + "\n")
+enc = out["kernels"].get("solo_encode_kernel", {})
+if "hbm_bytes_per_packet_corrected" in enc:
+    json.dump({"solo_encode_kernel_bytes_per_packet": enc["hbm_bytes_per_packet_corrected"],
+               "note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per packet; see " + os.path.basename(dst) + "_summary.json"},
+              open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:3000])
