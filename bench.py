@@ -108,11 +108,10 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    from solo_amd import dist as sdist
     if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        dist = sdist.init("nccl", torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
@@ -120,7 +119,8 @@ def main():
 
     N, P = args.streams, args.packets
     from solo_amd.synth import synth_batch
-    pcm = torch.from_numpy(synth_batch(rank * N, N, P, workers=min(16, os.cpu_count() or 1))).to(dev)
+    first = sdist.stream_range(rank, N)[0]
+    pcm = torch.from_numpy(synth_batch(first, N, P, workers=min(16, os.cpu_count() or 1))).to(dev)
     batch = solo_amd.SoloBatch(N, rate=13600, encoder=True, decoder=True, slot_bytes=512)
     bits = torch.zeros((N, P, 512), dtype=torch.uint8, device=dev)
     nb = torch.zeros((N, P, 2), dtype=torch.int16, device=dev)
@@ -154,9 +154,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt = sdist.max_over_ranks(dt, dist, dev)
 
     assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
     enc_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
