@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncState* states, i
 }
 
 // Encoder: rows E0-E9.  blockIdx.x = stream; one wavefront encodes the stream's packets in order.
-__global__ void __launch_bounds__(64) solo_encode_kernel(SxEncState* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
+__global__ void __launch_bounds__(64, 2) solo_encode_kernel(SxEncState* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
                                                          int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
@@ -322,5 +322,17 @@ int32_t AGR_Sate_Decoder_Uninit(void* st) {
     single_free((solo_single*)st);
     return 0;
 }
+
+#if defined(SX_PROF) && defined(SOLO_WITH_ENCODER)
+// debug builds only: read (and clear) the per-section cycle counters of the encoder
+int32_t solo_debug_prof(unsigned long long* out32, int32_t reset) {
+    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sx_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[32] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+#endif
 
 }  // extern "C"

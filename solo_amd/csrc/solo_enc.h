@@ -36,7 +36,7 @@ struct SxEncWork {
     i16 lo[SX_BAND], hi[SX_BAND];
     SxEncCtrl ctrl;
     SxFrameIdx idx[2];
-    i8 q[2][SX_N_TRACKS][SX_FRAME];
+    i8 q[2][2][SX_FRAME];            // pulses of MD1 / MD2 for both frames (the centre stream is never coded)
     i16 xfw[SX_FRAME];
     i32 r[SX_FRAME];
     u8 hb_bytes[8];
@@ -280,30 +280,38 @@ SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int fra
     SxFrontWork* f = &w->u.front;
     c->Seed = st->frameCounter++ & 3;
     i32 SNR_dB_Q7;
+    SX_T_BEGIN
     sx_vad(st, c, pIn, f->Wsig, &SNR_dB_Q7);
     wv_sync();
     sx_hp_variable_cutoff(st, c, f->hp, pIn);
     wv_sync();
     SX_PAR(i, SX_FRAME) st->x_buf[SX_FRAME + SX_LA_SHAPE + i] = f->hp[i];
     wv_sync();
+    SX_T(1)
     sx_find_pitch_lags(st, c, f->res_pitch, f->Wsig, &f->u.pitch);
     wv_sync();
+    SX_T(2)
     SX_ENC_TAP(1, st, w, f->hp);
     sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, st->x_buf + SX_FRAME, f->Wsig);
     wv_sync();
     SX_ENC_TAP(2, st, w, f->res_pitch + SX_FRAME);
+    SX_T(3)
     sx_prefilter(st, c, w->xfw, st->x_buf + SX_FRAME);
     wv_sync();
     SX_ENC_TAP(3, st, w, w->xfw);
+    SX_T(4)
     sx_find_pred_coefs(st, c, f->res_pitch, &f->u.pred);
     wv_sync();
     SX_ENC_TAP(4, st, w, w->xfw);
+    SX_T(5)
     sx_process_gains(st, c);
     wv_sync();
     SX_ENC_TAP(5, st, w, w->xfw);
+    SX_T(6)
     sx_nsq_del_dec(st, c, w->xfw, &w->q[frame][0][0], w->r, &w->u.nsq);
     wv_sync();
     SX_ENC_TAP(6 + 16 * frame, st, w, w->xfw);
+    SX_T(7)
     // VAD / DTX flags (encode_frame_FIX.c:155-171)
     if (st->speech_activity_Q8 < K_SPEECH_ACTIVITY_DTX_THRES_Q8) {
         st->vadFlag = 0;
@@ -332,18 +340,23 @@ SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int fra
     st->first_frame_after_reset = 0;
     st->nFramesInPayloadBuf = frame == 0 ? 1 : 0;
     wv_sync();
+    SX_T(8)
 }
 
 // AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129) for one packet: 640 samples @ 16 kHz -> MD1 || MD2 || HB(8).
 // nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.  Returns the total byte count, or a negative status if the
 // payload does not fit `buf_size`.
 SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+    SX_T_BEGIN
     sx_qmf_decomp(st, pcm, w->u.qmf_tl, w->lo, w->hi);
     wv_sync();
+    SX_T(0)
     for (int frame = 0; frame < 2; frame++) {
         sx_encode_frame(st, w, w->lo + frame * SX_FRAME, frame);
+        SX_T_RESET
         sx_hb_encode_frame(st, w->hi + frame * SX_FRAME, w->r, w->u.hb_lpc_in, w->xfw, &w->hb_bytes[4 * frame]);
         wv_sync();
+        SX_T(9)
     }
     // range coding of the two descriptions: description md on lane md
     i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};
@@ -357,7 +370,7 @@ SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bit
         sx_rc_enc_init(&rc, w->u.code.buf[md]);
         for (int frame = 0; frame < 2; frame++) {
             const int prev = frame == 0 ? 0 : 2 * w->idx[0].sigtype + w->idx[0].QuantOffsetType;
-            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->q[frame][1 + md][0]);
+            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->q[frame][md][0]);
             sx_rc_enc(&rc, frame == 0 ? 1 : 0, T_cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
         }
         i32 nb;
@@ -372,6 +385,7 @@ SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bit
 #endif
     }
     wv_sync();
+    SX_T(10)
     const i32 total = nBytes_md[0] + nBytes_md[1] + 8;
     if (err_md[0] || err_md[1] || total > buf_size || nBytes_md[0] > SX_MAX_ARITHM_BYTES || nBytes_md[1] > SX_MAX_ARITHM_BYTES) {
         nBytesOut[0] = 0;
@@ -388,5 +402,6 @@ SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bit
     nBytesOut[0] = (i16)total;
     nBytesOut[1] = (i16)(nBytes_md[1] + 8);
     wv_sync();
+    SX_T(11)
     return total;
 }

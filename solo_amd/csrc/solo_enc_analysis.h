@@ -947,6 +947,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
     *interpIndex = 4;
     sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order);
     sx_bwexpander_32(a_Q16, order, K_FIND_LPC_CHIRP_Q16);
+    SX_T_BEGIN
     if (useInterp == 1) {
         sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order);
         sx_bwexpander_32(a_tmp_Q16, order, K_FIND_LPC_CHIRP_Q16);
@@ -958,6 +959,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
             res_nrg_Q = res_tmp_nrg_Q;
         }
         sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order);
+        SX_T(21)
         for (int k = 3; k >= 0; k--) {
             for (int i = 0; i < order; i++) NLSF0_Q15[i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
             sx_nlsf2a_stable(a_tmp_Q12, NLSF0_Q15, order);
@@ -989,6 +991,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
             }
         }
     }
+    SX_T(18)
     if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order);
 }
 
@@ -1159,6 +1162,7 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
 SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* res_pitch, SxPredWork* w) {
     i32 invGains_Q16[4], local_gains[4], Wght_Q15[4], NLSF_Q15[SX_MAX_LPC];
+    SX_T_BEGIN
     i32 min_gain_Q16 = SX_I32_MAX >> 6;
     for (int i = 0; i < 4; i++) min_gain_Q16 = sx_min(min_gain_Q16, c->Gains_Q16[i]);
     for (int i = 0; i < 4; i++) {
@@ -1185,10 +1189,14 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* res_pitch
         for (int i = 0; i < 20; i++) c->LTPCoef_Q14[i] = 0;
         c->LTPredCodGain_Q7 = 0;
     }
+    SX_T(16)
     sx_find_LPC(NLSF_Q15, &c->NLSFInterpCoef_Q2, st->prev_NLSFq_Q15, 1 - st->first_frame_after_reset, SX_LPC, w->LPC_in_pre,
                 SX_SUBFR + SX_LPC, w->LPC_res);
+    SX_T(17)
     sx_process_NLSFs(st, c, NLSF_Q15, &w->msvq);
+    SX_T(19)
     sx_residual_energy(c->ResNrg, c->ResNrgQ, w->LPC_in_pre, c->PredCoef_Q12, local_gains, w->LPC_res);
+    SX_T(20)
     for (int i = 0; i < SX_LPC; i++) st->prev_NLSFq_Q15[i] = NLSF_Q15[i];
 }
 

@@ -11,14 +11,15 @@
 
 #define SX_JOINT_LAMBDA 90000        // INTERNAL_JOINT_LAMBDA, SKP_Silk_define.h:48 (LARS_LAMBDA_AGR == 0)
 #define SX_DD_MASK (SX_DD_DELAY - 1)
-#define SX_NSQ_LPC_BUF 32            // NSQ_LPC_BUF_LENGTH
+#define SX_LPC_RING 16
+#define SX_LPC_MASK (SX_LPC_RING - 1)
 
 struct SxDD {                        // NSQ_del_dec_struct, NSQ_del_dec.c:32 (live members only)
-    i32 RandState[SX_DD_DELAY], Q_Q0[SX_DD_DELAY], Xq_Q10[SX_DD_DELAY], Pred_Q16[SX_DD_DELAY], Shape_Q10[SX_DD_DELAY],
-        exc_Q10[SX_DD_DELAY];
+    i32 RandState[SX_DD_DELAY], Xq_Q10[SX_DD_DELAY], Pred_Q16[SX_DD_DELAY], Shape_Q10[SX_DD_DELAY];
     i32 sAR2_Q14[SX_SHAPE_ORDER];
-    i32 sLPC_Q14[SX_NSQ_LPC_BUF + SX_SUBFR];
+    i32 sLPC_Q14[SX_LPC_RING];       // ring of the newest 16 quantised samples (the reference keeps 32 + 40; only 10 are ever read)
     i32 LF_AR_Q12, Seed, Seed2, SeedInit2, RD_Q10;
+    i8 Q_Q0[SX_DD_DELAY];
 };
 #define SX_DD_WORDS ((int)(sizeof(SxDD) / 4))
 
@@ -30,9 +31,9 @@ struct SxSS {                        // NSQ_sample_struct, NSQ_del_dec.c:56 (liv
 struct SxNsqWork {
     SxDD dd[SX_N_TRACKS][SX_DD_STATES];
     SxSS ss[SX_N_TRACKS][SX_DD_STATES][2];
+    i32 exc_Q10[SX_DD_STATES][SX_DD_DELAY];      // excitation ring of the CENTRE states (high-band gain reference)
     i32 Gain_ring[SX_DD_DELAY];
     i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
-    i16 sLTP[SX_N_TRACKS][SX_FRAME];
     i32 x_sc_Q10[SX_SUBFR];
     i32 LTP_pred[12], LPC_pred[12], n_LTP[12], n_AR[12], n_LF[12], rD[12];
 };
@@ -130,15 +131,16 @@ SX_HD void sx_nsq_center_rd(i32 RD_prev, SxSS* sc, SxSS* s1, SxSS* s2, i32 res_Q
 }
 
 // emit the decisionDelay-old sample of state `d` of track t (Agora_Silk_GetWinner{,_Side} / flush loops)
-SX_HD void sx_nsq_emit(SxNSQ* nsq, SxNsqWork* w, int t, const SxDD* d, int ring_idx, int pos, i8* q, i32* r, int sLTP_idx, bool write_pred) {
-    q[pos] = (i8)d->Q_Q0[ring_idx];
-    if (t == 0) r[pos] = d->exc_Q10[ring_idx];
+SX_HD void sx_nsq_emit(SxNSQ* nsq, SxNsqWork* w, int t, int state, int ring_idx, int pos, i8* q, i32* r, int sLTP_idx, bool write_pred) {
+    const SxDD* d = &w->dd[t][state];
+    if (t == 0) r[pos] = w->exc_Q10[state][ring_idx];
+    else q[(t - 1) * SX_FRAME + pos] = d->Q_Q0[ring_idx];
     nsq->xq[SX_FRAME + pos] = (i16)sx_sat16(sx_rshift_round(sx_smulww(d->Xq_Q10[ring_idx], w->Gain_ring[ring_idx]), 10));
     nsq->sLTP_shp_Q10[SX_FRAME + pos] = d->Shape_Q10[ring_idx];
     if (write_pred) w->sLTP_Q16[t][sLTP_idx] = d->Pred_Q16[ring_idx];
 }
 
-// SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  x: prefiltered input (160), q: [3][160] pulses, r: centre excitation Q10 [160]
+// SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  x: prefiltered input (160), q: [2][160] pulses of MD1 / MD2, r: centre excitation Q10 [160]
 SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32* r, SxNsqWork* w) {
     const int voiced = c->sigtype == 0;
     int lag_t[3] = {st->nsq[0].lagPrev, st->nsq[1].lagPrev, st->nsq[2].lagPrev};
@@ -157,6 +159,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
     {
         i32* p = (i32*)&w->dd[0][0];
         SX_PAR(i, 12 * SX_DD_WORDS) p[i] = 0;
+        SX_PAR(i, SX_DD_STATES * SX_DD_DELAY) (&w->exc_Q10[0][0])[i] = 0;
         wv_sync();
         SX_PAR(tk, 12) {
             const int t = tk >> 2, k = tk & 3;
@@ -165,12 +168,13 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
             d->Seed = d->Seed2 = d->SeedInit2 = (k + c->Seed) & 3;
             d->LF_AR_Q12 = n->sLF_AR_shp_Q12;
             d->Shape_Q10[0] = n->sLTP_shp_Q10[SX_FRAME - 1];
-            for (int i = 0; i < SX_MAX_LPC; i++) d->sLPC_Q14[SX_NSQ_LPC_BUF - SX_MAX_LPC + i] = n->sLPC_Q14[i];
+            for (int i = 0; i < SX_LPC_RING; i++) d->sLPC_Q14[i] = n->sLPC_Q14[i];
             for (int i = 0; i < SX_SHAPE_ORDER; i++) d->sAR2_Q14[i] = n->sAR2_Q14[i];
         }
         wv_sync();
     }
     int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
+    int lpc_pos = SX_LPC_RING;                                  // ring write position (identical for all states)
     int subfr = 0;
 
     // MD gain split (md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1401-1417)
@@ -191,6 +195,10 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
         HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[k] >> 1, 16);
         const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k], Gain_Q16 = c->Gains_Q16[k];
         int rewhite = 0;
+        i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
+        inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
+        i32 inv_gain_Q32 = sx_shl(inv_gain_Q16, 16);                    // scale_states, NSQ_del_dec.c:1611-1616
+        if (k == 0) inv_gain_Q32 = sx_shl(sx_smulwb(inv_gain_Q32, c->LTP_scale_Q14), 2);
         if (voiced) {
             lag_t[0] = lag_t[1] = lag_t[2] = c->pitchL[k];
             if ((k & (3 - sx_shl(LSF_interpolation_flag, 1))) == 0) {
@@ -209,7 +217,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                     SX_PAR(ti, 3 * decisionDelay) {
                         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
                         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-                        sx_nsq_emit(&st->nsq[t], w, t, &w->dd[t][Winner_ind], ring, k * SX_SUBFR - decisionDelay + i, q + t * SX_FRAME, r, 0, false);
+                        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, ring, k * SX_SUBFR - decisionDelay + i, q, r, 0, false);
                     }
                     wv_sync();
                 }
@@ -224,7 +232,8 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                     for (int j = 0; j < SX_LPC; j++)
                         if (n - 1 - j >= 0) acc = sx_smlabb(acc, in[n - 1 - j], A_Q12[j]);
                     i32 o = sx_rshift_round(sx_sub(sx_shl((i32)in[n], 12), acc), 12);
-                    w->sLTP[t][start_idx + n] = (i16)sx_sat16(o);
+                    // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[])
+                    w->sLTP_Q16[t][start_idx + n] = sx_smulwb(inv_gain_Q32, sx_sat16(o));
                 }
                 sLTP_buf_idx = SX_FRAME;
                 rewhite = 1;
@@ -232,20 +241,9 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
             }
         }
         // Agora_Silk_DelDecScale + SKP_Silk_nsq_del_dec_scale_states (NSQ_del_dec.c:1593, 1668)
-        i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
-        inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
         SX_PAR(i, SX_SUBFR) w->x_sc_Q10[i] = sx_smulbb(x[k * SX_SUBFR + i], inv_gain_Q16) >> 6;
         {
             const int lag = c->pitchL[k];
-            if (rewhite) {
-                i32 inv_gain_Q32 = sx_shl(inv_gain_Q16, 16);
-                if (k == 0) inv_gain_Q32 = sx_shl(sx_smulwb(inv_gain_Q32, c->LTP_scale_Q14), 2);
-                const int n = lag + SX_LTP_ORDER / 2;
-                SX_PAR(ti, 3 * n) {
-                    const int t = ti / n, i = sLTP_buf_idx - n + (ti - t * n);
-                    w->sLTP_Q16[t][i] = sx_smulwb(inv_gain_Q32, w->sLTP[t][i]);
-                }
-            }
             for (int t = 0; t < SX_N_TRACKS; t++) {
                 SxNSQ* n = &st->nsq[t];
                 if (inv_gain_Q16 != n->prev_inv_gain_Q16) {
@@ -261,12 +259,12 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                             w->sLTP_Q16[t][j] = sx_smulww(gain_adj_Q16, w->sLTP_Q16[t][j]);
                         }
                     }
-                    // per state: LF_AR, sLPC[0..32), sAR2[0..16), Pred_Q16[0..32), Shape_Q10[0..32)
-                    SX_PAR(si, SX_DD_STATES * 113) {
-                        const int s = si / 113, i = si - s * 113;
+                    // per state: LF_AR, sLPC ring, sAR2[0..16), Pred_Q16[0..32), Shape_Q10[0..32)
+                    SX_PAR(si, SX_DD_STATES * 97) {
+                        const int s = si / 97, i = si - s * 97;
                         SxDD* d = &w->dd[t][s];
-                        i32* p = i < 32 ? &d->sLPC_Q14[i] : (i < 48 ? &d->sAR2_Q14[i - 32] : (i < 80 ? &d->Pred_Q16[i - 48] :
-                                 (i < 112 ? &d->Shape_Q10[i - 80] : &d->LF_AR_Q12)));
+                        i32* p = i < 16 ? &d->sLPC_Q14[i] : (i < 32 ? &d->sAR2_Q14[i - 16] : (i < 64 ? &d->Pred_Q16[i - 32] :
+                                 (i < 96 ? &d->Shape_Q10[i - 64] : &d->LF_AR_Q12)));
                         *p = sx_smulww(gain_adj_Q16, *p);
                     }
                 }
@@ -295,12 +293,11 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                     n_LTP_Q14 = sx_smlawt(n_LTP_Q14, ps[-1], HarmShapeFIRPacked_Q14);
                     n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
                 }
-                const i32* psLPC = &d->sLPC_Q14[SX_NSQ_LPC_BUF - 1 + i];
                 i32 LPC_pred_Q10 = 0;
-                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlawb(LPC_pred_Q10, psLPC[-j], A_Q12[j]);
+                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlawb(LPC_pred_Q10, d->sLPC_Q14[(lpc_pos - 1 - j) & SX_LPC_MASK], A_Q12[j]);
                 // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place
                 const i32 warping_Q16 = SX_WARPING_Q16;
-                i32 tmp2 = sx_smlawb(psLPC[0], d->sAR2_Q14[0], warping_Q16);
+                i32 tmp2 = sx_smlawb(d->sLPC_Q14[(lpc_pos - 1) & SX_LPC_MASK], d->sAR2_Q14[0], warping_Q16);
                 i32 tmp1 = sx_smlawb(d->sAR2_Q14[0], d->sAR2_Q14[1] - tmp2, warping_Q16);
                 d->sAR2_Q14[0] = tmp2;
                 i32 n_AR_Q10 = sx_smulwb(tmp2, AR_shp_Q13[0]);
@@ -416,12 +413,13 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                         // SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668) for the three tracks + sample states
                         wv_sync();
                         if (RDmax_ind != RDmin_ind) {
-                            SX_PAR(ti, 3 * SX_DD_WORDS) {
-                                const int t = ti / SX_DD_WORDS, j = ti - t * SX_DD_WORDS;
-                                const int lpc0 = 6 * SX_DD_DELAY + SX_SHAPE_ORDER;
-                                bool live = true;
-                                if (j >= lpc0 && j < lpc0 + SX_NSQ_LPC_BUF + SX_SUBFR) live = (j - lpc0) >= i && (j - lpc0) < i + SX_NSQ_LPC_BUF;
-                                if (live) ((i32*)&w->dd[t][RDmax_ind])[j] = ((const i32*)&w->dd[t][RDmin_ind])[j];
+                            SX_PAR(ti, 3 * SX_DD_WORDS + SX_DD_DELAY) {
+                                if (ti < 3 * SX_DD_WORDS) {
+                                    const int t = ti / SX_DD_WORDS, j = ti - t * SX_DD_WORDS;
+                                    ((i32*)&w->dd[t][RDmax_ind])[j] = ((const i32*)&w->dd[t][RDmin_ind])[j];
+                                } else {
+                                    w->exc_Q10[RDmax_ind][ti - 3 * SX_DD_WORDS] = w->exc_Q10[RDmin_ind][ti - 3 * SX_DD_WORDS];
+                                }
                             }
                         }
                         wv_sync();
@@ -446,7 +444,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                 }
                 if (subfr > 0 || i >= decisionDelay) {
                     SX_PAR(t, SX_N_TRACKS) {
-                        sx_nsq_emit(&st->nsq[t], w, t, &w->dd[t][Winner_ind], last_smple_idx, k * SX_SUBFR + i - decisionDelay, q + t * SX_FRAME, r,
+                        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, last_smple_idx, k * SX_SUBFR + i - decisionDelay, q, r,
                                     pred_base + i - decisionDelay, true);
                     }
                 }
@@ -458,28 +456,22 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                 SxDD* d = &w->dd[t][s];
                 const SxSS* ss = &w->ss[t][s][0];
                 d->LF_AR_Q12 = ss->LF_AR_Q12;
-                d->sLPC_Q14[SX_NSQ_LPC_BUF + i] = ss->xq_Q14;
+                d->sLPC_Q14[lpc_pos & SX_LPC_MASK] = ss->xq_Q14;
                 d->Xq_Q10[smpl_buf_idx] = ss->xq_Q14 >> 4;
-                d->Q_Q0[smpl_buf_idx] = ss->Q_Q0;
+                d->Q_Q0[smpl_buf_idx] = (i8)ss->Q_Q0;
                 d->Pred_Q16[smpl_buf_idx] = ss->LPC_exc_Q16;
                 d->Shape_Q10[smpl_buf_idx] = ss->sLTP_shp_Q10;
                 d->Seed = sx_add(d->Seed, ss->Q_Q0);
                 d->RandState[smpl_buf_idx] = d->Seed;
                 d->RD_Q10 = ss->RD_Q10;
-                d->exc_Q10[smpl_buf_idx] = ss->exc_Q10;
+                if (t == 0) w->exc_Q10[s][smpl_buf_idx] = ss->exc_Q10;
             }
             w->Gain_ring[smpl_buf_idx] = Gain_Q16;
+            lpc_pos++;
             wv_sync();
         }
         sLTP_shp_buf_idx += SX_SUBFR;
         sLTP_buf_idx += SX_SUBFR;
-        // Agora_Silk_Update_DelDecLPCState (NSQ_del_dec.c:904): source [40,72) and destination [0,32) do not overlap
-        SX_PAR(ti, 12 * SX_NSQ_LPC_BUF) {
-            const int tk = ti / SX_NSQ_LPC_BUF, j = ti - tk * SX_NSQ_LPC_BUF;
-            SxDD* d = &w->dd[tk >> 2][tk & 3];
-            d->sLPC_Q14[j] = d->sLPC_Q14[SX_SUBFR + j];
-        }
-        wv_sync();
         subfr++;
     }
 
@@ -494,13 +486,13 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
     SX_PAR(ti, 3 * decisionDelay) {
         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-        sx_nsq_emit(&st->nsq[t], w, t, &w->dd[t][Winner_ind], ring, SX_FRAME - decisionDelay + i, q + t * SX_FRAME, r, 0, false);
+        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, ring, SX_FRAME - decisionDelay + i, q, r, 0, false);
     }
     wv_sync();
     for (int t = 0; t < SX_N_TRACKS; t++) {
         SxNSQ* n = &st->nsq[t];
         const SxDD* d = &w->dd[t][Winner_ind];
-        for (int i = 0; i < SX_MAX_LPC; i++) n->sLPC_Q14[i] = d->sLPC_Q14[SX_NSQ_LPC_BUF - SX_MAX_LPC + i];
+        for (int i = 0; i < SX_LPC_RING; i++) n->sLPC_Q14[i] = d->sLPC_Q14[(lpc_pos + i) & SX_LPC_MASK];
         for (int i = 0; i < SX_SHAPE_ORDER; i++) n->sAR2_Q14[i] = d->sAR2_Q14[i];
         n->sLF_AR_shp_Q12 = d->LF_AR_Q12;
         n->lagPrev = c->pitchL[SX_NB_SUBFR - 1];

@@ -90,8 +90,8 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
     if (sig) tput(p, sig, 160);
     p += 160;
     if (stage == 6) {
-        tput(p, &w->q[frame][0][0], 160); p += 160;
-        tput(p, &w->q[frame][1][0], 160); tput(p + 160, &w->q[frame][2][0], 160); p += 320;
+        p += 160;                                   // centre pulses are not kept by the kernel source
+        tput(p, &w->q[frame][0][0], 160); tput(p + 160, &w->q[frame][1][0], 160); p += 320;
         tput(p, w->r, 160);
     }
 }
