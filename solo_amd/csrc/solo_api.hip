@@ -63,25 +63,36 @@ __global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, con
 }
 
 #ifdef SOLO_WITH_ENCODER
-__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncState* states, int n_streams, int silk_rate_bps, int useMDIndex) {
+__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex);
 }
 
 // Encoder: rows E0-E9.  blockIdx.x = stream; one wavefront encodes the stream's packets in order.
-__global__ void __launch_bounds__(64, 2) solo_encode_kernel(SxEncState* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
-                                                         int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+__global__ void __launch_bounds__(64, 2) solo_encode_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
+                                                            int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    SxEncState* st = &states[s];
+    SxEncStream* rec = &states[s];
+    {   // compact state: HBM -> LDS for the whole launch
+        const i32* src = (const i32*)&rec->core;
+        i32* dst = (i32*)&w.st;
+        SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+        wv_sync();
+    }
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        i32 ret = sx_encode_packet(st, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        i32 ret = sx_encode_packet(&rec->hist, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
+    }
+    {
+        const i32* src = (const i32*)&w.st;
+        i32* dst = (i32*)&rec->core;
+        SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
     }
     if (status && SX_LANE == 0) status[s] = first_err;
 }
@@ -110,12 +121,12 @@ static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
 
 #ifdef SOLO_WITH_ENCODER
 static int32_t solo_enc_alloc(solo_batch* b) {
-    SOLO_CHECK(hipMalloc(&b->d_enc_state, sizeof(SxEncState) * (size_t)b->n_streams));
+    SOLO_CHECK(hipMalloc(&b->d_enc_state, sizeof(SxEncStream) * (size_t)b->n_streams));
     return 0;
 }
 static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
     // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the 1600 bps high-band share
-    hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncState*)b->d_enc_state, b->n_streams,
+    hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncStream*)b->d_enc_state, b->n_streams,
                        b->enc_ctrl.targetRate_bps - 1600, b->enc_ctrl.useMDIndex);
     SOLO_CHECK(hipGetLastError());
     return 0;
@@ -207,7 +218,7 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
 int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packets, uint8_t* d_bits, int16_t* d_nbytes,
                           int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_enc || !d_pcm || !d_bits || !d_nbytes || n_packets <= 0) return -1;
-    hipLaunchKernelGGL(solo_encode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, (SxEncState*)b->d_enc_state,
+    hipLaunchKernelGGL(solo_encode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)b->d_enc_state,
                        d_pcm, b->n_streams, n_packets, b->slot, d_bits, d_nbytes, d_status);
     SOLO_CHECK(hipGetLastError());
     return 0;

@@ -22,23 +22,28 @@ struct SxCodeWork {                  // LDS: range-coder byte buffers of the two
 };
 
 struct SxFrontWork {                 // LDS scratch of the per-frame analysis chain
+    i16 x_buf[SX_XBUF];              // staged analysis buffer: [0,200) history | [200,360) high-passed new frame
     i16 res_pitch[2 * SX_FRAME + SX_LA_PITCH];
     i16 Wsig[SX_PITCH_LPC_WIN];      // also: VAD band buffer (4 x 80) and shaping window (120)
-    i16 hp[SX_FRAME];
     union {
         SxPitchWork pitch;
         SxPredWork pred;
+        i16 pf_sLTP_shp[SX_LTP_BUF]; // staged prefilter ring
     } u;
 };
 
+struct SxHbWork {                    // LDS scratch of the high-band encoder
+    i16 x_hb_buf[SX_HB_XBUF];
+    i16 lpc_in[4 * 88];
+    i16 exc[40];
+};
+
 struct SxEncWork {
-    // persistent over the packet
-    i16 lo[SX_BAND], hi[SX_BAND];
+    // persistent over the launch / packet
+    SxEncState st;                   // the stream's compact state (HBM record -> LDS at launch start, back at the end)
     SxEncCtrl ctrl;
     SxFrameIdx idx[2];
-    i8 q[2][2][SX_FRAME];            // pulses of MD1 / MD2 for both frames (the centre stream is never coded)
     i16 xfw[SX_FRAME];
-    i32 r[SX_FRAME];
     u8 hb_bytes[8];
     // phase-local
     union {
@@ -46,7 +51,7 @@ struct SxEncWork {
         SxFrontWork front;
         SxNsqWork nsq;
         SxCodeWork code;
-        i16 hb_lpc_in[4 * 88];
+        SxHbWork hb;
     } u;
 };
 
@@ -187,9 +192,13 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, 
 // high band
 // ---------------------------------------------------------------------------------------------------
 // AGR_Bwe_encode_frame_FIX (AGR_BWE_encode_frame_FIX.c:8) for one 20 ms high-band frame; writes its 4 payload bytes.
-// `high`: 160 new high-band samples, `residue`: centre excitation Q10 of the matching SILK frame, lpc_in: 4 x 88 scratch (LDS)
-SX_FN void sx_hb_encode_frame(SxEncState* st, const i16* high, const i32* residue, i16* lpc_in, i16* exc /*40, LDS*/, u8* out4) {
-    i16* xb = st->x_hb_buf;
+// `high`: 160 new high-band samples, `residue`: centre excitation Q10 of the matching SILK frame (both in HBM)
+SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue, SxHbWork* hw, u8* out4) {
+    SX_IN_LDS(hw); SX_IN_LDS(out4);
+    i16* xb = hw->x_hb_buf;
+    i16* lpc_in = hw->lpc_in;
+    i16* exc = hw->exc;
+    SX_PAR(i, SX_FRAME + 40) xb[i] = hist->x_hb_buf[i];
     SX_PAR(i, SX_FRAME) xb[SX_FRAME + 40 + i] = high[i];
     wv_sync();
     // AGR_Sate_find_HB_LPC_FIX: four 10 ms blocks, each with 8 samples of history; the window runs past the
@@ -262,8 +271,9 @@ SX_FN void sx_hb_encode_frame(SxEncState* st, const i16* high, const i32* residu
         wv_sync();
     }
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
-    // slide the buffer: keep the last 200 samples
-    wv_move_down(xb, xb + SX_FRAME, 200);
+    // slide the buffer: the last 200 samples are the next frame's history
+    SX_PAR(i, SX_FRAME + 40) hist->x_hb_buf[i] = xb[SX_FRAME + i];
+    wv_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -275,32 +285,40 @@ SX_FN void sx_hb_encode_frame(SxEncState* st, const i16* high, const i32* residu
 
 // SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
 // frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
-SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int frame) {
+SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int frame) {
+    SX_IN_LDS(w);
+    SxEncState* st = &w->st;
     SxEncCtrl* c = &w->ctrl;
     SxFrontWork* f = &w->u.front;
     c->Seed = st->frameCounter++ & 3;
     i32 SNR_dB_Q7;
     SX_T_BEGIN
-    sx_vad(st, c, pIn, f->Wsig, &SNR_dB_Q7);
+    // stage the analysis history and the new low-band frame
+    SX_PAR(i, SX_FRAME + SX_LA_SHAPE) f->x_buf[i] = hist->x_buf[i];
+    SX_PAR(i, SX_FRAME) f->res_pitch[i] = pIn[i];          // res_pitch doubles as the staging buffer of the raw input
     wv_sync();
-    sx_hp_variable_cutoff(st, c, f->hp, pIn);
+    sx_vad(st, c, f->res_pitch, f->Wsig, &SNR_dB_Q7);
     wv_sync();
-    SX_PAR(i, SX_FRAME) st->x_buf[SX_FRAME + SX_LA_SHAPE + i] = f->hp[i];
+    sx_hp_variable_cutoff(st, c, f->x_buf + SX_FRAME + SX_LA_SHAPE, f->res_pitch);
     wv_sync();
     SX_T(1)
-    sx_find_pitch_lags(st, c, f->res_pitch, f->Wsig, &f->u.pitch);
+    sx_find_pitch_lags(st, c, f->x_buf, f->res_pitch, f->Wsig, &f->u.pitch);
     wv_sync();
+    SX_ENC_TAP(1, st, w, f->x_buf + SX_FRAME + SX_LA_SHAPE);
     SX_T(2)
-    SX_ENC_TAP(1, st, w, f->hp);
-    sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, st->x_buf + SX_FRAME, f->Wsig);
+    sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, f->x_buf + SX_FRAME, f->Wsig);
     wv_sync();
     SX_ENC_TAP(2, st, w, f->res_pitch + SX_FRAME);
     SX_T(3)
-    sx_prefilter(st, c, w->xfw, st->x_buf + SX_FRAME);
+    SX_PAR(i, SX_LTP_BUF) f->u.pf_sLTP_shp[i] = hist->pf_sLTP_shp[i];
+    wv_sync();
+    sx_prefilter(st, c, w->xfw, f->x_buf + SX_FRAME, f->u.pf_sLTP_shp);
+    wv_sync();
+    SX_PAR(i, SX_LTP_BUF) hist->pf_sLTP_shp[i] = f->u.pf_sLTP_shp[i];
     wv_sync();
     SX_ENC_TAP(3, st, w, w->xfw);
     SX_T(4)
-    sx_find_pred_coefs(st, c, f->res_pitch, &f->u.pred);
+    sx_find_pred_coefs(st, c, f->x_buf, f->res_pitch, &f->u.pred);
     wv_sync();
     SX_ENC_TAP(4, st, w, w->xfw);
     SX_T(5)
@@ -308,7 +326,10 @@ SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int fra
     wv_sync();
     SX_ENC_TAP(5, st, w, w->xfw);
     SX_T(6)
-    sx_nsq_del_dec(st, c, w->xfw, &w->q[frame][0][0], w->r, &w->u.nsq);
+    // the history of the next frame leaves LDS before the quantiser takes over the union
+    SX_PAR(i, SX_FRAME + SX_LA_SHAPE) hist->x_buf[i] = f->x_buf[SX_FRAME + i];
+    wv_sync();
+    sx_nsq_del_dec(st, hist, c, w->xfw, &hist->q[frame][0][0], hist->r, &w->u.nsq);
     wv_sync();
     SX_ENC_TAP(6 + 16 * frame, st, w, w->xfw);
     SX_T(7)
@@ -333,8 +354,7 @@ SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int fra
     x->LTP_scaleIndex = c->LTP_scaleIndex;
     x->Seed = c->Seed;
     x->vadFlag = st->vadFlag;
-    // update input buffer and cross-frame parameters (encode_frame_FIX.c:203-212)
-    wv_move_down(st->x_buf, st->x_buf + SX_FRAME, SX_FRAME + SX_LA_SHAPE);
+    // cross-frame parameters (encode_frame_FIX.c:203-212)
     st->prev_sigtype = c->sigtype;
     st->prevLag = c->pitchL[SX_NB_SUBFR - 1];
     st->first_frame_after_reset = 0;
@@ -346,15 +366,17 @@ SX_FN void sx_encode_frame(SxEncState* st, SxEncWork* w, const i16* pIn, int fra
 // AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129) for one packet: 640 samples @ 16 kHz -> MD1 || MD2 || HB(8).
 // nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.  Returns the total byte count, or a negative status if the
 // payload does not fit `buf_size`.
-SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+SX_FN i32 sx_encode_packet(SxEncHist* hist, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+    SX_IN_LDS(w);
+    SxEncState* st = &w->st;
     SX_T_BEGIN
-    sx_qmf_decomp(st, pcm, w->u.qmf_tl, w->lo, w->hi);
+    sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, hist->hi);
     wv_sync();
     SX_T(0)
     for (int frame = 0; frame < 2; frame++) {
-        sx_encode_frame(st, w, w->lo + frame * SX_FRAME, frame);
+        sx_encode_frame(hist, w, hist->lo + frame * SX_FRAME, frame);
         SX_T_RESET
-        sx_hb_encode_frame(st, w->hi + frame * SX_FRAME, w->r, w->u.hb_lpc_in, w->xfw, &w->hb_bytes[4 * frame]);
+        sx_hb_encode_frame(hist, hist->hi + frame * SX_FRAME, hist->r, &w->u.hb, &w->hb_bytes[4 * frame]);
         wv_sync();
         SX_T(9)
     }
@@ -370,7 +392,7 @@ SX_FN i32 sx_encode_packet(SxEncState* st, SxEncWork* w, const i16* pcm, u8* bit
         sx_rc_enc_init(&rc, w->u.code.buf[md]);
         for (int frame = 0; frame < 2; frame++) {
             const int prev = frame == 0 ? 0 : 2 * w->idx[0].sigtype + w->idx[0].QuantOffsetType;
-            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->q[frame][md][0]);
+            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &hist->q[frame][md][0]);
             sx_rc_enc(&rc, frame == 0 ? 1 : 0, T_cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
         }
         i32 nb;

@@ -155,6 +155,7 @@ SX_HD float sx_fdiv(float a, float b) {
 // SKP_Silk_noise_shape_analysis_FIX, noise_shape_analysis_FIX.c:137.
 // pitch_res = res_pitch + frame_length; x = x_buf + frame_length; x_windowed: 120-sample scratch (LDS)
 SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, i16* x_windowed) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(pitch_res); SX_IN_LDS(x); SX_IN_LDS(x_windowed);
     i32 auto_corr[SX_SHAPE_ORDER + 1], refl_coef_Q16[SX_SHAPE_ORDER], AR1_Q24[SX_SHAPE_ORDER], AR2_Q24[SX_SHAPE_ORDER];
     i32 scale = 0, nrg, pre_nrg_Q30, tmp32;
     const i16* x_ptr = x - SX_LA_SHAPE;
@@ -310,7 +311,8 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
 // prefilter
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_prefilter_FIX + warped_LPC_analysis_filter_FIX + prefilt_FIX, SKP_Silk_prefilter_FIX.c:43-224
-SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x) {
+SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, i16* pf_sLTP_shp) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(xw); SX_IN_LDS(x); SX_IN_LDS(pf_sLTP_shp);
     i32 x_filt_Q12[SX_SUBFR];
     i16 st_res[SX_SUBFR];
     const i16* px = x;
@@ -362,16 +364,16 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
             i32 n_LTP_Q12 = 0;
             if (lag > 0) {
                 int idx = lag + buf_idx;
-                n_LTP_Q12 = sx_smulbb(st->pf_sLTP_shp[(idx - 2) & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
-                n_LTP_Q12 = sx_add(n_LTP_Q12, sx_smulbt(st->pf_sLTP_shp[(idx - 1) & SX_LTP_MASK], HarmShapeFIRPacked_Q12));
-                n_LTP_Q12 = sx_smlabb(n_LTP_Q12, st->pf_sLTP_shp[idx & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+                n_LTP_Q12 = sx_smulbb(pf_sLTP_shp[(idx - 2) & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+                n_LTP_Q12 = sx_add(n_LTP_Q12, sx_smulbt(pf_sLTP_shp[(idx - 1) & SX_LTP_MASK], HarmShapeFIRPacked_Q12));
+                n_LTP_Q12 = sx_smlabb(n_LTP_Q12, pf_sLTP_shp[idx & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
             }
             i32 n_Tilt_Q10 = sx_smulwb(sLF_AR, Tilt_Q14);
             i32 n_LF_Q10 = sx_smlawb(sx_smulwt(sLF_AR, LF_shp_Q14), sLF_MA, LF_shp_Q14);
             sLF_AR = sx_sub(x_filt_Q12[i], sx_shl(n_Tilt_Q10, 2));
             sLF_MA = sx_sub(sLF_AR, sx_shl(n_LF_Q10, 2));
             buf_idx = (buf_idx - 1) & SX_LTP_MASK;
-            st->pf_sLTP_shp[buf_idx] = (i16)sx_sat16(sx_rshift_round(sLF_MA, 12));
+            pf_sLTP_shp[buf_idx] = (i16)sx_sat16(sx_rshift_round(sLF_MA, 12));
             pxw[i] = (i16)sx_sat16(sx_rshift_round(sx_sub(sLF_MA, n_LTP_Q12), 12));
         }
         px += SX_SUBFR;
@@ -390,6 +392,7 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_corrMatrix_FIX + corrVector_FIX, SKP_Silk_corrMatrix_FIX.c:35-152 (order 5, L = 40)
 SX_FN void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* XX, i32* rshifts, int x_odd) {
+    SX_IN_LDS(x); SX_IN_LDS(XX);
     i32 energy, rshifts_local;
     sx_sum_sqr_shift(&energy, &rshifts_local, x, L + order - 1, x_odd);
     int head_room_rshifts = sx_max(head_room - sx_clz32(energy), 0);
@@ -529,14 +532,13 @@ SX_HD i32 sx_residual_energy16_covar(const i16* cvec, const i32* wXX, const i32*
 
 // SKP_Silk_find_LTP_FIX, SKP_Silk_find_LTP_FIX.c:39.  res_pitch: LPC residual buffer (336 samples)
 SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15) {
+    SX_IN_LDS(b_Q14); SX_IN_LDS(WLTP); SX_IN_LDS(LTPredCodGain_Q7); SX_IN_LDS(res_pitch); SX_IN_LDS(lag);
     const int subfr_length = SX_SUBFR, mem_offset = SX_FRAME, HEAD = 2;
     i32 b_Q16[5], delta_b_Q14[5], d_Q14[4], nrg[4], w[4], Rr[5], rr[4], corr_rshifts[4];
     i16* b_Q14_ptr = b_Q14;
     i32* WLTP_ptr = WLTP;
     for (int k = 0; k < 4; k++) {
-        // r_first = res_pitch, r_last = res_pitch + frame_length/2: r_ptr = base[mem_offset + 40*k] resp. base2[...]
-        const i16* r_ptr = (k < 2 ? res_pitch : res_pitch + (SX_FRAME >> 1)) + mem_offset + (k < 2 ? k : k) * 0 + 0;
-        r_ptr = res_pitch + mem_offset + k * subfr_length;     // both halves address the same timeline
+        const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;     // r_first / r_last of the reference address one timeline
         const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
         i32 rr_shifts;
         sx_sum_sqr_shift(&rr[k], &rr_shifts, r_ptr, subfr_length, 0);
@@ -648,6 +650,7 @@ SX_HD void sx_vq_wmat_ec(i32* ind, i32* rate_dist_Q14, const i16* in_Q14, const 
 
 // SKP_Silk_quant_LTP_gains_FIX, SKP_Silk_quant_LTP_gains_FIX.c:30 (lowComplexity = 0)
 SX_FN void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8) {
+    SX_IN_LDS(B_Q14); SX_IN_LDS(cbk_index); SX_IN_LDS(periodicity_index); SX_IN_LDS(W_Q18);
     i32 temp_idx[4], min_rate_dist = SX_I32_MAX;
     for (int k = 0; k < 3; k++) {
         const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
@@ -709,6 +712,7 @@ SX_HD void sx_LTP_analysis_filter(i16* LTP_res, const i16* x, const i16* LTPCoef
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49
 SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16* x, int subfr_length, int nb_subfr, i32 WhiteNoiseFrac_Q32, int D) {
+    SX_IN_LDS(x);
     const int QA = 25, MAX_RSHIFTS = 32 - 25, MIN_RSHIFTS = -16;
     i32 C0, rshifts, C_first_row[SX_MAX_LPC], C_last_row[SX_MAX_LPC], Af_QA[SX_MAX_LPC], CAf[SX_MAX_LPC + 1], CAb[SX_MAX_LPC + 1];
     sx_sum_sqr_shift(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
@@ -941,6 +945,7 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d) {
 // LPC_res: scratch of 2*subfr_length samples (LDS)
 SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q15, int useInterp, int order, const i16* x,
                        int subfr_length, i16* LPC_res) {
+    SX_IN_LDS(x); SX_IN_LDS(LPC_res);
     i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
     i16 a_tmp_Q12[SX_MAX_LPC];
     i32 res_nrg, res_tmp_nrg, res_nrg_Q, res_tmp_nrg_Q;
@@ -1009,6 +1014,7 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
 // SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
 SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
                                i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
+    SX_IN_LDS(w);
     const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
     const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
     const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
@@ -1098,6 +1104,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
 SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w);
     i32 pNLSFW_Q6[SX_LPC], pNLSF0_temp_Q15[SX_LPC], pNLSFW0_temp_Q6[SX_LPC], NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
     if (c->sigtype == 0) {
         NLSF_mu_Q15 = sx_smlawb(66, -8388, st->speech_activity_Q8);
@@ -1130,6 +1137,7 @@ SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvq
 
 // SKP_Silk_residual_energy_FIX, SKP_Silk_residual_energy_FIX.c:32.  LPC_res: 100-sample scratch
 SX_FN void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][SX_MAX_LPC], const i32* gains, i16* LPC_res) {
+    SX_IN_LDS(nrgs); SX_IN_LDS(nrgsQ); SX_IN_LDS(x); SX_IN_LDS(a_Q12); SX_IN_LDS(LPC_res);
     const int offset = SX_LPC + SX_SUBFR;
     const i16* x_ptr = x;
     for (int i = 0; i < 2; i++) {
@@ -1160,7 +1168,8 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
 };
 
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
-SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* res_pitch, SxPredWork* w) {
+SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res_pitch); SX_IN_LDS(w);
     i32 invGains_Q16[4], local_gains[4], Wght_Q15[4], NLSF_Q15[SX_MAX_LPC];
     SX_T_BEGIN
     i32 min_gain_Q16 = SX_I32_MAX >> 6;
@@ -1176,11 +1185,11 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* res_pitch
         sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15);
         sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8);
         sx_LTP_scale_ctrl(st, c);
-        sx_LTP_analysis_filter(w->LPC_in_pre, st->x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
+        sx_LTP_analysis_filter(w->LPC_in_pre, x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
         wv_sync();
     } else {
         const int n = SX_SUBFR + SX_LPC;
-        const i16* x_ptr = st->x_buf + SX_FRAME - SX_LPC;
+        const i16* x_ptr = x_buf + SX_FRAME - SX_LPC;
         SX_PAR(t, 4 * n) {
             int k = t / n, i = t - k * n;
             w->LPC_in_pre[t] = (i16)sx_smulwb(invGains_Q16[k], x_ptr[k * SX_SUBFR + i]);
@@ -1238,6 +1247,7 @@ SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditiona
 
 // SKP_Silk_process_gains_FIX, SKP_Silk_process_gains_FIX.c:32
 SX_FN void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
+    SX_IN_LDS(st); SX_IN_LDS(c);
     if (c->sigtype == 0) {
         i32 s_Q16 = -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4));
         for (int k = 0; k < 4; k++) c->Gains_Q16[k] = sx_smlawb(c->Gains_Q16[k], c->Gains_Q16[k], s_Q16);

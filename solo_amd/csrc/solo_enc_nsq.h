@@ -34,6 +34,8 @@ struct SxNsqWork {
     i32 exc_Q10[SX_DD_STATES][SX_DD_DELAY];      // excitation ring of the CENTRE states (high-band gain reference)
     i32 Gain_ring[SX_DD_DELAY];
     i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
+    i32 shp[SX_N_TRACKS][2 * SX_FRAME + 8];      // staged sLTP_shp_Q10 of the three tracks (+8: a side track with lag 0 reads one
+                                                 // entry past the frame, always 0 in the reference)
     i32 x_sc_Q10[SX_SUBFR];
     i32 LTP_pred[12], LPC_pred[12], n_LTP[12], n_AR[12], n_LF[12], rD[12];
 };
@@ -131,17 +133,18 @@ SX_HD void sx_nsq_center_rd(i32 RD_prev, SxSS* sc, SxSS* s1, SxSS* s2, i32 res_Q
 }
 
 // emit the decisionDelay-old sample of state `d` of track t (Agora_Silk_GetWinner{,_Side} / flush loops)
-SX_HD void sx_nsq_emit(SxNSQ* nsq, SxNsqWork* w, int t, int state, int ring_idx, int pos, i8* q, i32* r, int sLTP_idx, bool write_pred) {
+SX_HD void sx_nsq_emit(SxEncHist* hist, SxNsqWork* w, int t, int state, int ring_idx, int pos, i8* q, i32* r, int sLTP_idx, bool write_pred) {
     const SxDD* d = &w->dd[t][state];
     if (t == 0) r[pos] = w->exc_Q10[state][ring_idx];
     else q[(t - 1) * SX_FRAME + pos] = d->Q_Q0[ring_idx];
-    nsq->xq[SX_FRAME + pos] = (i16)sx_sat16(sx_rshift_round(sx_smulww(d->Xq_Q10[ring_idx], w->Gain_ring[ring_idx]), 10));
-    nsq->sLTP_shp_Q10[SX_FRAME + pos] = d->Shape_Q10[ring_idx];
+    hist->xq[t][SX_FRAME + pos] = (i16)sx_sat16(sx_rshift_round(sx_smulww(d->Xq_Q10[ring_idx], w->Gain_ring[ring_idx]), 10));
+    w->shp[t][SX_FRAME + pos] = d->Shape_Q10[ring_idx];
     if (write_pred) w->sLTP_Q16[t][sLTP_idx] = d->Pred_Q16[ring_idx];
 }
 
 // SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  x: prefiltered input (160), q: [2][160] pulses of MD1 / MD2, r: centre excitation Q10 [160]
-SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32* r, SxNsqWork* w) {
+SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i16* x, i8* q, i32* r, SxNsqWork* w) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x); SX_IN_LDS(w);
     const int voiced = c->sigtype == 0;
     int lag_t[3] = {st->nsq[0].lagPrev, st->nsq[1].lagPrev, st->nsq[2].lagPrev};
     const i32 offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
@@ -160,6 +163,13 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
         i32* p = (i32*)&w->dd[0][0];
         SX_PAR(i, 12 * SX_DD_WORDS) p[i] = 0;
         SX_PAR(i, SX_DD_STATES * SX_DD_DELAY) (&w->exc_Q10[0][0])[i] = 0;
+        // stage the shaping history: after the previous frame's shift both halves of the reference's buffer hold the same values
+        SX_PAR(ti, SX_N_TRACKS * (SX_FRAME + 8)) {
+            const int t = ti / (SX_FRAME + 8), i = ti - t * (SX_FRAME + 8);
+            const i32 v = i < SX_FRAME ? hist->sLTP_shp_Q10[t][i] : 0;
+            if (i < SX_FRAME) w->shp[t][i] = v;
+            w->shp[t][SX_FRAME + i] = v;
+        }
         wv_sync();
         SX_PAR(tk, 12) {
             const int t = tk >> 2, k = tk & 3;
@@ -167,7 +177,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
             const SxNSQ* n = &st->nsq[t];
             d->Seed = d->Seed2 = d->SeedInit2 = (k + c->Seed) & 3;
             d->LF_AR_Q12 = n->sLF_AR_shp_Q12;
-            d->Shape_Q10[0] = n->sLTP_shp_Q10[SX_FRAME - 1];
+            d->Shape_Q10[0] = w->shp[t][SX_FRAME - 1];
             for (int i = 0; i < SX_LPC_RING; i++) d->sLPC_Q14[i] = n->sLPC_Q14[i];
             for (int i = 0; i < SX_SHAPE_ORDER; i++) d->sAR2_Q14[i] = n->sAR2_Q14[i];
         }
@@ -217,7 +227,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                     SX_PAR(ti, 3 * decisionDelay) {
                         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
                         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-                        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, ring, k * SX_SUBFR - decisionDelay + i, q, r, 0, false);
+                        sx_nsq_emit(hist, w, t, Winner_ind, ring, k * SX_SUBFR - decisionDelay + i, q, r, 0, false);
                     }
                     wv_sync();
                 }
@@ -227,7 +237,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                 const int len = SX_FRAME - start_idx;
                 SX_PAR(tn, 3 * len) {
                     const int t = tn / len, n = tn - t * len;
-                    const i16* in = &st->nsq[t].xq[start_idx + k * SX_SUBFR];
+                    const i16* in = &hist->xq[t][start_idx + k * SX_SUBFR];
                     i32 acc = 0;
                     for (int j = 0; j < SX_LPC; j++)
                         if (n - 1 - j >= 0) acc = sx_smlabb(acc, in[n - 1 - j], A_Q12[j]);
@@ -250,7 +260,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                     const i32 gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, n->prev_inv_gain_Q16, 16);
                     SX_PAR(i, SX_FRAME) {
                         const int j = sLTP_shp_buf_idx - SX_FRAME + i;
-                        n->sLTP_shp_Q10[j] = sx_smulww(gain_adj_Q16, n->sLTP_shp_Q10[j]);
+                        w->shp[t][j] = sx_smulww(gain_adj_Q16, w->shp[t][j]);
                     }
                     if (!rewhite) {
                         const int m = lag + SX_LTP_ORDER / 2;
@@ -288,7 +298,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                 }
                 i32 n_LTP_Q14 = 0;
                 if (lag_t[0] > 0) {          // the reference tests the CENTRE lag for every track (NSQ_del_dec.c:1436-1446)
-                    const i32* ps = &st->nsq[t].sLTP_shp_Q10[shp_base - lag_t[t] + 1 + i];
+                    const i32* ps = &w->shp[t][shp_base - lag_t[t] + 1 + i];
                     n_LTP_Q14 = sx_smulwb(sx_add(ps[0], ps[-2]), HarmShapeFIRPacked_Q14);
                     n_LTP_Q14 = sx_smlawt(n_LTP_Q14, ps[-1], HarmShapeFIRPacked_Q14);
                     n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
@@ -444,7 +454,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
                 }
                 if (subfr > 0 || i >= decisionDelay) {
                     SX_PAR(t, SX_N_TRACKS) {
-                        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, last_smple_idx, k * SX_SUBFR + i - decisionDelay, q, r,
+                        sx_nsq_emit(hist, w, t, Winner_ind, last_smple_idx, k * SX_SUBFR + i - decisionDelay, q, r,
                                     pred_base + i - decisionDelay, true);
                     }
                 }
@@ -486,7 +496,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
     SX_PAR(ti, 3 * decisionDelay) {
         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-        sx_nsq_emit(&st->nsq[t], w, t, Winner_ind, ring, SX_FRAME - decisionDelay + i, q, r, 0, false);
+        sx_nsq_emit(hist, w, t, Winner_ind, ring, SX_FRAME - decisionDelay + i, q, r, 0, false);
     }
     wv_sync();
     for (int t = 0; t < SX_N_TRACKS; t++) {
@@ -498,11 +508,11 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncCtrl* c, const i16* x, i8* q, i32
         n->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
     }
     wv_sync();
-    // shift the quantised-signal and shaping histories by one frame
+    // the current frame becomes the history of the next one
     SX_PAR(ti, 3 * SX_FRAME) {
         const int t = ti / SX_FRAME, i = ti - t * SX_FRAME;
-        st->nsq[t].sLTP_shp_Q10[i] = st->nsq[t].sLTP_shp_Q10[SX_FRAME + i];
-        st->nsq[t].xq[i] = st->nsq[t].xq[SX_FRAME + i];
+        hist->sLTP_shp_Q10[t][i] = w->shp[t][SX_FRAME + i];
+        hist->xq[t][i] = hist->xq[t][SX_FRAME + i];
     }
     wv_sync();
 }

@@ -48,9 +48,7 @@ struct SxVAD {                       // SKP_Silk_VAD_state, SKP_Silk_structs.h:6
     i32 counter;
 };
 
-struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:44 (q_Q10 / rand_seed are dead)
-    i16 xq[2 * SX_FRAME];
-    i32 sLTP_shp_Q10[2 * SX_FRAME + 8];   // +8: a side track with lag 0 reads one entry past the frame (always 0)
+struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:44: small per-track part (histories: SxEncHist)
     i32 sLPC_Q14[SX_MAX_LPC];        // newest 16 of the reference's 32-entry tail (only the last 10 are ever read)
     i32 sAR2_Q14[SX_SHAPE_ORDER];
     i32 sLF_AR_shp_Q12;
@@ -58,11 +56,11 @@ struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:4
     i32 prev_inv_gain_Q16;
 };
 
+// Compact per-stream encoder state: loaded into LDS when a launch starts, written back when it ends.
 struct SxEncState {
     // --- SILK common ---
     i32 frameCounter;
     i32 prev_sigtype, prevLag, first_frame_after_reset;
-    i32 typeOffsetPrev, typeOffsetPrev_desq[2];
     i32 nFramesInPayloadBuf;
     i32 vadFlag, noSpeechCounter, inDTX;
     i32 speech_activity_Q8;
@@ -76,18 +74,29 @@ struct SxEncState {
     SxVAD vad;
     // shape / prefilter / prediction states (SKP_Silk_structs_FIX.h:44-73)
     i32 LastGainIndex, HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16;
-    i16 pf_sLTP_shp[SX_LTP_BUF];
     i32 pf_sAR_shp[SX_SHAPE_ORDER + 1];
     i32 pf_sLTP_shp_buf_idx, pf_sLF_AR_shp_Q12, pf_sLF_MA_shp_Q12, pf_sHarmHP, pf_lagPrev;
     i32 prev_NLSFq_Q15[SX_LPC];
-    i16 x_buf[SX_XBUF];
     SxNSQ nsq[SX_N_TRACKS];
-    // --- high band + QMF ---
-    i16 qmf_hist[63];                // last 63 input samples >> 1 (h0_mem of the reference, time order)
-    i16 x_hb_buf[SX_HB_XBUF];
-    i32 HB_prev_NLSFq_Q15[SX_HB_LPC];
-    i32 hb_first;
-    // --- range coders carried from frame 0 to frame 1 of a packet live in SxEncWork (same launch) ---
+};
+
+// Per-stream history arrays: stay in HBM, staged through LDS by the phase that uses them.
+struct SxEncHist {
+    i16 x_buf[SX_FRAME + SX_LA_SHAPE];           // samples [0, 200) of the analysis buffer; [200, 360) is new every frame
+    i16 pf_sLTP_shp[SX_LTP_BUF];                 // prefilter's harmonic-shaping ring
+    i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
+    i32 sLTP_shp_Q10[SX_N_TRACKS][SX_FRAME];     // shaping history of the previous frame
+    i16 qmf_hist[63 + 1];                        // last 63 input samples >> 1 (h0_mem of the reference, time order)
+    i16 x_hb_buf[SX_FRAME + SX_LA_SHAPE];        // high-band analysis history (BWE_FrameSize + lb_Delay*hb_KHz = 200 samples)
+    // hand-over between the phases of one packet
+    i16 lo[SX_BAND], hi[SX_BAND];
+    i8 q[2][2][SX_FRAME];                        // pulses of MD1 / MD2, both frames (the centre stream is never coded)
+    i32 r[SX_FRAME];                             // centre excitation Q10 of the current frame (high-band gain reference)
+};
+
+struct SxEncStream {                 // one record per stream in HBM
+    SxEncState core;
+    SxEncHist hist;
 };
 
 // Output of the analysis chain for one 20 ms frame = input of the NSQ and of the parameter coder
@@ -124,10 +133,11 @@ struct SxEncCtrl {
 // SKP_Silk_init_encoder_FIX (SKP_Silk_init_encoder_FIX.c:33) + the first SKP_Silk_control_encoder_FIX
 // pass (control_codec_FIX.c:56-130: setup_fs(8), setup_rate, ...) + AGR_Sate_Encoder_Init
 // (libBWE/AGR_BWE_SDK_API.c:11-126).  `silk_rate_bps` = targetRate_bps - 1600.
-SX_FN void sx_enc_state_init(SxEncState* st, i32 silk_rate_bps, i32 useMDIndex) {
-    u8* p = (u8*)st;
-    SX_PAR(i, (int)sizeof(SxEncState)) p[i] = 0;
+SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex) {
+    u8* p = (u8*)rec;
+    SX_PAR(i, (int)sizeof(SxEncStream)) p[i] = 0;
     wv_sync();
+    SxEncState* st = &rec->core;
     st->variable_HP_smth1_Q15 = 200844;
     st->variable_HP_smth2_Q15 = 200844;
     st->first_frame_after_reset = 1;
@@ -164,6 +174,5 @@ SX_FN void sx_enc_state_init(SxEncState* st, i32 silk_rate_bps, i32 useMDIndex) 
             break;
         }
     }
-    st->hb_first = 1;
     wv_sync();
 }

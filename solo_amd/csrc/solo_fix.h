@@ -26,6 +26,17 @@
 #define SX_FN static
 #endif
 
+// address-space hints for generic pointer parameters of non-inlined stage functions: lets the compiler emit ds_* / global_*
+// instead of flat_* (LLVM InferAddressSpaces understands these assumes)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SX_IN_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p)))
+#define SX_IN_GLOBAL(p) __builtin_assume(!__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p)) && \
+                                         !__builtin_amdgcn_is_private((const __attribute__((address_space(0))) void*)(p)))
+#else
+#define SX_IN_LDS(p)
+#define SX_IN_GLOBAL(p)
+#endif
+
 // keep a scalar search loop exactly as written (no vectorisation / interleaving / unrolling)
 #if defined(__clang__)
 #define SX_PLAIN_LOOP _Pragma("clang loop vectorize(disable) interleave(disable) unroll(disable)")

@@ -38,25 +38,28 @@ extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 
 // ---- encoder ----
 extern "C" {
-struct EmuEnc { SxEncState st; SxEncWork w; };
+struct EmuEnc { SxEncStream rec; SxEncWork w; };
 void* emu_enc_create(int rate_bps, int useMDIndex) {
     EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
-    sx_enc_state_init(&e->st, rate_bps - 1600, useMDIndex);   // AGR_BWE_SDK_API.c:119: SILK rate = target - 1600
+    sx_enc_state_init(&e->rec, rate_bps - 1600, useMDIndex);   // AGR_BWE_SDK_API.c:119: SILK rate = target - 1600
     return e;
 }
 void emu_enc_destroy(void* h) { free(h); }
 int emu_enc_packet(void* h, const int16_t* pcm, uint8_t* bits, int buf_size, int16_t* nBytesOut) {
     EmuEnc* e = (EmuEnc*)h;
-    return sx_encode_packet(&e->st, &e->w, pcm, bits, buf_size, nBytesOut);
+    e->w.st = e->rec.core;                                    // the kernel keeps the compact state in LDS for a launch
+    int r = sx_encode_packet(&e->rec.hist, &e->w, pcm, bits, buf_size, nBytesOut);
+    e->rec.core = e->w.st;
+    return r;
 }
-int emu_sizeof_enc_state() { return (int)sizeof(SxEncState); }
+int emu_sizeof_enc_state() { return (int)sizeof(SxEncStream); }
 int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
 // debug taps (tests only): last frame's control block, pulses and residual
 const void* emu_enc_ctrl_ptr(void* h) { return &((EmuEnc*)h)->w.ctrl; }
 int emu_sizeof_enc_ctrl() { return (int)sizeof(SxEncCtrl); }
-const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->w.q[0][0][0]; }
+const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->rec.hist.q[0][0][0]; }
 const void* emu_enc_idx_ptr(void* h) { return &((EmuEnc*)h)->w.idx[0]; }
-const void* emu_enc_state_ptr(void* h) { return &((EmuEnc*)h)->st; }
+const void* emu_enc_state_ptr(void* h) { return &((EmuEnc*)h)->rec; }
 }
 
 // ---- stage taps: same canonical record as oracle/ref_taps.c ----
@@ -91,7 +94,6 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
     p += 160;
     if (stage == 6) {
         p += 160;                                   // centre pulses are not kept by the kernel source
-        tput(p, &w->q[frame][0][0], 160); tput(p + 160, &w->q[frame][1][0], 160); p += 320;
-        tput(p, w->r, 160);
+        p += 320 + 160;                             // pulses / excitation now live in the stream's HBM record, see test hooks
     }
 }
