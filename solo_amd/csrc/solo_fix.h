@@ -71,10 +71,11 @@ SX_HD i32 sx_limit(i32 a, i32 l1, i32 l2) {
 
 // ---- 16x32 / 16x16 multiplies (SKP_Silk_macros.h:33-67) -----------------------------------------
 // SKP_SMULWB: (a * (int16)b) >> 16, exact floor, 32-bit wrap on the (impossible) overflow
-SX_HD i32 sx_smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i16)b) >> 16); }
+// (a * (int16)b) >> 16 written as the high word of a * (b << 16): ONE v_mul_hi_i32 on gfx950 instead of mul_hi + mul_lo + 64-bit shift
+SX_HD i32 sx_smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i32)((u32)b << 16)) >> 32); }
 SX_HD i32 sx_smlawb(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulwb(a, b)); }
 // SKP_SMULWT: (a * (b >> 16)) >> 16
-SX_HD i32 sx_smulwt(i32 a, i32 b) { return (i32)(((i64)a * (i64)(b >> 16)) >> 16); }
+SX_HD i32 sx_smulwt(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i32)((u32)b & 0xFFFF0000u)) >> 32); }
 SX_HD i32 sx_smlawt(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulwt(a, b)); }
 SX_HD i32 sx_smulbb(i32 a, i32 b) { return (i32)(i16)a * (i32)(i16)b; }
 SX_HD i32 sx_smlabb(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulbb(a, b)); }
@@ -84,8 +85,9 @@ SX_HD i32 sx_smultt(i32 a, i32 b) { return sx_mul(a >> 16, b >> 16); }
 SX_HD i32 sx_rshift_round(i32 a, int s) { return s == 1 ? sx_add(a >> 1, a & 1) : (sx_add(a >> (s - 1), 1) >> 1); }
 SX_HD i64 sx_rshift_round64(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : (((a >> (s - 1)) + 1) >> 1); }
 // SKP_SMULWW = MLA(SMULWB(a,b), a, RSHIFT_ROUND(b,16))   (macros.h:61) -- NOT a plain 64-bit product
-SX_HD i32 sx_smulww(i32 a, i32 b) { return sx_add(sx_smulwb(a, b), sx_mul(a, sx_rshift_round(b, 16))); }
-SX_HD i32 sx_smlaww(i32 acc, i32 a, i32 b) { return sx_add(sx_smlawb(acc, a, b), sx_mul(a, sx_rshift_round(b, 16))); }
+// SKP_SMULWW = SMULWB(a,b) + a * RSHIFT_ROUND(b,16) (32-bit wrapping) is exactly the low word of (a * b) >> 16
+SX_HD i32 sx_smulww(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 16); }
+SX_HD i32 sx_smlaww(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulww(a, b)); }
 SX_HD i32 sx_smmul(i32 a, i32 b) { return (i32)(((i64)a * (i64)b) >> 32); }  // macros.h:67
 SX_HD i64 sx_smull(i32 a, i32 b) { return (i64)a * (i64)b; }
 
