@@ -49,6 +49,7 @@ typedef uint32_t u32;
 typedef int16_t i16;
 typedef uint16_t u16;
 typedef int64_t i64;
+typedef uint64_t u64;
 typedef uint8_t u8;
 typedef int8_t i8;
 
