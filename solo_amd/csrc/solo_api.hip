@@ -70,7 +70,7 @@ __global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, 
 }
 
 // Encoder: rows E0-E9.  blockIdx.x = stream; one wavefront encodes the stream's packets in order.
-__global__ void __launch_bounds__(64, 2) solo_encode_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
+__global__ void __launch_bounds__(64, 4) solo_encode_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
                                                             int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;

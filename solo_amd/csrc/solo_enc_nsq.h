@@ -50,10 +50,8 @@ struct SxNsqWork {
     SxRing ring[SX_N_TRACKS];
     i32 exc_Q10[SX_DD_DELAY][SX_DD_STATES];      // excitation cells of the CENTRE track (high-band gain reference)
     i32 Gain_ring[SX_DD_DELAY];
-    i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
-    i32 shp[SX_N_TRACKS][2 * SX_FRAME + 8];      // staged sLTP_shp_Q10 of the three tracks (+8: a side track with lag 0 reads one
-                                                 // entry past the frame, always 0 in the reference)
 };
+
 
 SX_HD u64 sx_sel4u(u64 a0, u64 a1, u64 a2, u64 a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
 SX_HD i32 sx_sel4(i32 a0, i32 a1, i32 a2, i32 a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
@@ -109,6 +107,7 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 // SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  x: prefiltered input (160), q: [2][160] pulses of MD1 / MD2, r: centre excitation Q10 [160]
 SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i16* x, i8* q, i32* r, SxNsqWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x); SX_IN_LDS(w);
+    SxNsqGlobal* g = &hist->nsq;
     SX_T_BEGIN
     const int voiced = c->sigtype == 0;
     int lagC = st->nsq[0].lagPrev, lagP1 = st->nsq[1].lagPrev, lagP2 = st->nsq[2].lagPrev;
@@ -146,13 +145,6 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
         i32* p = (i32*)&w->ring[0];
         SX_PAR(i, (int)(sizeof(w->ring) / 4)) p[i] = 0;
         SX_PAR(i, SX_DD_STATES * SX_DD_DELAY) (&w->exc_Q10[0][0])[i] = 0;
-        // stage the shaping history: after the previous frame's shift both halves of the reference's buffer hold the same values
-        SX_PAR(ti, SX_N_TRACKS * (SX_FRAME + 8)) {
-            const int t = ti / (SX_FRAME + 8), i = ti - t * (SX_FRAME + 8);
-            const i32 v = i < SX_FRAME ? hist->sLTP_shp_Q10[t][i] : 0;
-            if (i < SX_FRAME) w->shp[t][i] = v;
-            w->shp[t][SX_FRAME + i] = v;
-        }
         wv_sync();
         SX_LANES12(tk) {
             const int t = tk >> 2, k = tk & 3, li = SX_LI(tk);
@@ -160,7 +152,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
             Seed[li] = Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
             RD[li] = 0;
             LF_AR[li] = n->sLF_AR_shp_Q12;
-            w->ring[t].Shape_Q10[0][k] = w->shp[t][SX_FRAME - 1];
+            w->ring[t].Shape_Q10[0][k] = g->shp[t][SX_FRAME - 1];
             for (int i = 0; i < SX_LPC; i++) sLPC[li][i] = n->sLPC_Q14[SX_MAX_LPC - 1 - i];
             for (int i = 0; i < SX_SHAPE_ORDER; i++) sAR2[li][i] = n->sAR2_Q14[i];
         }
@@ -188,8 +180,8 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
         else q[((t_)-1) * SX_FRAME + (pos_)] = rg_->Q_Q0[ring_idx_][slot_];                                                  \
         hist->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
             (i16)sx_sat16(sx_rshift_round(sx_smulww(rg_->Xq_Q10[ring_idx_][slot_], w->Gain_ring[ring_idx_]), 10));           \
-        w->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
-        if (write_pred_) w->sLTP_Q16[t_][sLTP_idx_] = rg_->Pred_Q16[ring_idx_][slot_];                                       \
+        g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
+        if (write_pred_) g->sLTP_Q16[t_][sLTP_idx_] = rg_->Pred_Q16[ring_idx_][slot_];                                       \
     }
 
     for (int k = 0; k < SX_NB_SUBFR; k++) {
@@ -238,7 +230,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                         if (n - 1 - j >= 0) acc = sx_smlabb(acc, in[n - 1 - j], A_Q12[j]);
                     i32 o = sx_rshift_round(sx_sub(sx_shl((i32)in[n], 12), acc), 12);
                     // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[])
-                    w->sLTP_Q16[t][start_idx + n] = sx_smulwb(inv_gain_Q32, sx_sat16(o));
+                    g->sLTP_Q16[t][start_idx + n] = sx_smulwb(inv_gain_Q32, sx_sat16(o));
                 }
                 sLTP_buf_idx = SX_FRAME;
                 rewhite = 1;
@@ -256,13 +248,13 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                     const i32 gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, n->prev_inv_gain_Q16, 16);
                     SX_PAR(i, SX_FRAME) {
                         const int j = sLTP_shp_buf_idx - SX_FRAME + i;
-                        w->shp[t][j] = sx_smulww(gain_adj_Q16, w->shp[t][j]);
+                        g->shp[t][j] = sx_smulww(gain_adj_Q16, g->shp[t][j]);
                     }
                     if (!rewhite) {
                         const int m = lag + SX_LTP_ORDER / 2;
                         SX_PAR(i, m) {
                             const int j = sLTP_buf_idx - m + i;
-                            w->sLTP_Q16[t][j] = sx_smulww(gain_adj_Q16, w->sLTP_Q16[t][j]);
+                            g->sLTP_Q16[t][j] = sx_smulww(gain_adj_Q16, g->sLTP_Q16[t][j]);
                         }
                     }
                     // every (position, slot) cell of the Pred / Shape histories is scaled once (the reference scales each
@@ -302,12 +294,12 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                 const int lag_me = t == 0 ? lagC : (t == 1 ? lagP1 : lagP2);
                 i32 LTP_pred_Q14 = 0;
                 if (voiced) {
-                    const i32* pl = &w->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2 + i];
+                    const i32* pl = &g->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2 + i];
                     for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlawb(LTP_pred_Q14, pl[-j], B_Q14[j]);
                 }
                 i32 n_LTP_Q14 = 0;
                 if (lagC > 0) {              // the reference tests the CENTRE lag for every track (NSQ_del_dec.c:1436-1446)
-                    const i32* ps = &w->shp[t][shp_base - lag_me + 1 + i];
+                    const i32* ps = &g->shp[t][shp_base - lag_me + 1 + i];
                     n_LTP_Q14 = sx_smulwb(sx_add(ps[0], ps[-2]), HarmShapeFIRPacked_Q14);
                     n_LTP_Q14 = sx_smlawt(n_LTP_Q14, ps[-1], HarmShapeFIRPacked_Q14);
                     n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
@@ -605,7 +597,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
     // the current frame becomes the history of the next one
     SX_PAR(ti, 3 * SX_FRAME) {
         const int t = ti / SX_FRAME, i = ti - t * SX_FRAME;
-        hist->sLTP_shp_Q10[t][i] = w->shp[t][SX_FRAME + i];
+        g->shp[t][i] = g->shp[t][SX_FRAME + i];      // (the upper half keeps its values: the reference's memcpy does the same)
         hist->xq[t][i] = hist->xq[t][SX_FRAME + i];
     }
     wv_sync();

@@ -80,12 +80,18 @@ struct SxEncState {
     SxNSQ nsq[SX_N_TRACKS];
 };
 
+struct SxNsqGlobal {                 // per-stream NSQ arrays that live in HBM / L2 (predictable addresses, prefetched by the lanes)
+    i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
+    i32 shp[SX_N_TRACKS][2 * SX_FRAME + 8];      // sLTP_shp_Q10 of the three tracks: previous frame | current frame (+8: a side track
+                                                 // with lag 0 reads one entry past the frame, always 0 in the reference)
+};
+
 // Per-stream history arrays: stay in HBM, staged through LDS by the phase that uses them.
 struct SxEncHist {
     i16 x_buf[SX_FRAME + SX_LA_SHAPE];           // samples [0, 200) of the analysis buffer; [200, 360) is new every frame
     i16 pf_sLTP_shp[SX_LTP_BUF];                 // prefilter's harmonic-shaping ring
     i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
-    i32 sLTP_shp_Q10[SX_N_TRACKS][SX_FRAME];     // shaping history of the previous frame
+    SxNsqGlobal nsq;
     i16 qmf_hist[63 + 1];                        // last 63 input samples >> 1 (h0_mem of the reference, time order)
     i16 x_hb_buf[SX_FRAME + SX_LA_SHAPE];        // high-band analysis history (BWE_FrameSize + lb_Delay*hb_KHz = 200 samples)
     // hand-over between the phases of one packet
