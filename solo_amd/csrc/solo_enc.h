@@ -36,6 +36,8 @@ struct SxHbWork {                    // LDS scratch of the high-band encoder
     i16 x_hb_buf[SX_HB_XBUF];
     i16 lpc_in[4 * 88];
     i16 exc[40];
+    i32 NLSF_Q15[SX_MAX_LPC];
+    SxLpcWork lpc;
 };
 
 struct SxEncWork {
@@ -209,10 +211,14 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         lpc_in[t] = src < SX_HB_XBUF ? xb[src] : (i16)0;
     }
     wv_sync();
-    i32 a_Q16[SX_MAX_LPC], NLSF_Q15[SX_MAX_LPC], weight[SX_MAX_LPC], res_nrg, res_nrg_Q;
-    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, 88, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC);
+    i32 weight[SX_MAX_LPC], res_nrg, res_nrg_Q;
+    i32* a_Q16 = hw->lpc.a_Q16;
+    i32* NLSF_Q15 = hw->NLSF_Q15;
+    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, 88, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
     sx_bwexpander_32(a_Q16, SX_HB_LPC, K_FIND_LPC_CHIRP_Q16);
-    sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC);
+    wv_sync();
+    sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q);
+    wv_sync();
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
     sx_nlsf_weights_laroia(weight, NLSF_Q15, SX_HB_LPC);
     i32 best = SX_I32_MAX;

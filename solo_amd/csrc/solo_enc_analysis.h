@@ -710,11 +710,30 @@ SX_HD void sx_LTP_analysis_filter(i16* LTP_res, const i16* x, const i16* LTPCoef
 // ---------------------------------------------------------------------------------------------------
 // LPC analysis: Burg, A2NLSF, interpolation search
 // ---------------------------------------------------------------------------------------------------
-// SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49
-SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16* x, int subfr_length, int nb_subfr, i32 WhiteNoiseFrac_Q32, int D) {
-    SX_IN_LDS(x);
+// LDS scratch of the LPC analysis (Burg, A2NLSF, interpolation search): wave-uniform arrays live here, never in
+// per-lane scratch memory
+struct SxBurgWork {
+    i32 Cf[SX_MAX_LPC], Cl[SX_MAX_LPC], Af[SX_MAX_LPC], CAf[SX_MAX_LPC + 1], CAb[SX_MAX_LPC + 1];
+    i32 T1[4], T2[4];
+    i32 p1[64], p2[64];              // per (subframe, k) partial products / per-k reduction terms
+    i32 q3[SX_MAX_LPC], q4[SX_MAX_LPC];
+};
+struct SxLpcWork {
+    SxBurgWork burg;
+    i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
+    i16 a_tmp_Q12[SX_MAX_LPC];
+    i32 P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1];
+};
+
+// SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49.  The reference's scalar loops over the coefficient index k are
+// spread over lanes (all its accumulations are wrapping int32 sums of independent terms, so lane order is immaterial):
+// lane (s, k) builds the per-subframe prediction terms, lane k owns row / correlation element k.
+SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16* x, int subfr_length, int nb_subfr, i32 WhiteNoiseFrac_Q32,
+                            int D, SxBurgWork* bw) {
+    SX_IN_LDS(x); SX_IN_LDS(bw); SX_IN_LDS(A_Q16);
     const int QA = 25, MAX_RSHIFTS = 32 - 25, MIN_RSHIFTS = -16;
-    i32 C0, rshifts, C_first_row[SX_MAX_LPC], C_last_row[SX_MAX_LPC], Af_QA[SX_MAX_LPC], CAf[SX_MAX_LPC + 1], CAb[SX_MAX_LPC + 1];
+    const int L = subfr_length;
+    i32 C0, rshifts;
     sx_sum_sqr_shift(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
     if (rshifts > MAX_RSHIFTS) {
         C0 = sx_shl(C0, rshifts - MAX_RSHIFTS);
@@ -731,111 +750,172 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         }
         rshifts += rshifts_extra;
     }
-    for (int i = 0; i < SX_MAX_LPC; i++) { C_first_row[i] = 0; Af_QA[i] = 0; }
-    for (int s = 0; s < nb_subfr; s++) {
-        const i16* x_ptr = x + s * subfr_length;
-        for (int n = 1; n < D + 1; n++) {
-            if (rshifts > 0) C_first_row[n - 1] += (i32)(sx_inner_prod64(x_ptr, x_ptr + n, subfr_length - n) >> rshifts);
-            else C_first_row[n - 1] += sx_shl(sx_inner_prod32(x_ptr, x_ptr + n, subfr_length - n), -rshifts);
+    // first row of the correlation matrix: lane (s, n) computes one inner product serially
+    SX_PAR(sn, nb_subfr * 16) {
+        const int s = sn >> 4, n = (sn & 15) + 1;
+        i32 v = 0;
+        if (n <= D) {
+            const i16* xs = x + s * L;
+            if (rshifts > 0) {
+                i64 acc = 0;
+                for (int i = 0; i < L - n; i++) acc += (i64)((i32)xs[i] * (i32)xs[i + n]);
+                v = (i32)(acc >> rshifts);
+            } else {
+                i32 acc = 0;
+                for (int i = 0; i < L - n; i++) acc = sx_smlabb(acc, xs[i], xs[i + n]);
+                v = sx_shl(acc, -rshifts);
+            }
         }
+        bw->p1[sn] = v;
     }
-    for (int i = 0; i < SX_MAX_LPC; i++) C_last_row[i] = C_first_row[i];
-    CAb[0] = CAf[0] = sx_add(sx_add(C0, sx_smmul(WhiteNoiseFrac_Q32, C0)), 1);
-    int n;
-    for (n = 0; n < D; n++) {
-        i32 tmp1, tmp2;
-        if (rshifts > -2) {
-            for (int s = 0; s < nb_subfr; s++) {
-                const i16* x_ptr = x + s * subfr_length;
-                i32 x1 = sx_neg(sx_shl((i32)x_ptr[n], 16 - rshifts));
-                i32 x2 = sx_neg(sx_shl((i32)x_ptr[subfr_length - n - 1], 16 - rshifts));
-                tmp1 = sx_shl((i32)x_ptr[n], QA - 16);
-                tmp2 = sx_shl((i32)x_ptr[subfr_length - n - 1], QA - 16);
-                for (int k = 0; k < n; k++) {
-                    C_first_row[k] = sx_smlawb(C_first_row[k], x1, x_ptr[n - k - 1]);
-                    C_last_row[k] = sx_smlawb(C_last_row[k], x2, x_ptr[subfr_length - n + k]);
-                    i32 Atmp_QA = Af_QA[k];
-                    tmp1 = sx_smlawb(tmp1, Atmp_QA, x_ptr[n - k - 1]);
-                    tmp2 = sx_smlawb(tmp2, Atmp_QA, x_ptr[subfr_length - n + k]);
-                }
-                tmp1 = sx_shl(sx_neg(tmp1), 32 - QA - rshifts);
-                tmp2 = sx_shl(sx_neg(tmp2), 32 - QA - rshifts);
-                for (int k = 0; k <= n; k++) {
-                    CAf[k] = sx_smlawb(CAf[k], tmp1, x_ptr[n - k]);
-                    CAb[k] = sx_smlawb(CAb[k], tmp2, x_ptr[subfr_length - n + k - 1]);
+    wv_sync();
+    SX_PAR(k, SX_MAX_LPC) {
+        i32 v = 0;
+        for (int s = 0; s < nb_subfr; s++) v = sx_add(v, bw->p1[s * 16 + k]);
+        bw->Cf[k] = v;
+        bw->Cl[k] = v;
+        bw->Af[k] = 0;
+    }
+    const i32 CA0 = sx_add(sx_add(C0, sx_smmul(WhiteNoiseFrac_Q32, C0)), 1);
+    bw->CAf[0] = CA0;
+    bw->CAb[0] = CA0;
+    wv_sync();
+    for (int n = 0; n < D; n++) {
+        // (a) per (subframe, k): terms of the forward / backward prediction errors at the two subframe edges
+        SX_PAR(sk, nb_subfr * 16) {
+            const int s = sk >> 4, k = sk & 15;
+            i32 a = 0, b = 0;
+            if (k < n) {
+                const i16* xs = x + s * L;
+                if (rshifts > -2) {
+                    const i32 Atmp_QA = bw->Af[k];
+                    a = sx_smulwb(Atmp_QA, xs[n - k - 1]);
+                    b = sx_smulwb(Atmp_QA, xs[L - n + k]);
+                } else {
+                    const i32 Atmp1 = sx_rshift_round(bw->Af[k], QA - 17);
+                    a = sx_mul(xs[n - k - 1], Atmp1);
+                    b = sx_mul(xs[L - n + k], Atmp1);
                 }
             }
-        } else {
-            for (int s = 0; s < nb_subfr; s++) {
-                const i16* x_ptr = x + s * subfr_length;
-                i32 x1 = sx_neg(sx_shl((i32)x_ptr[n], -rshifts));
-                i32 x2 = sx_neg(sx_shl((i32)x_ptr[subfr_length - n - 1], -rshifts));
-                tmp1 = sx_shl((i32)x_ptr[n], 17);
-                tmp2 = sx_shl((i32)x_ptr[subfr_length - n - 1], 17);
-                for (int k = 0; k < n; k++) {
-                    C_first_row[k] = sx_add(C_first_row[k], sx_mul(x1, x_ptr[n - k - 1]));
-                    C_last_row[k] = sx_add(C_last_row[k], sx_mul(x2, x_ptr[subfr_length - n + k]));
-                    i32 Atmp1 = sx_rshift_round(Af_QA[k], QA - 17);
-                    tmp1 = sx_add(tmp1, sx_mul(x_ptr[n - k - 1], Atmp1));
-                    tmp2 = sx_add(tmp2, sx_mul(x_ptr[subfr_length - n + k], Atmp1));
-                }
-                tmp1 = sx_neg(tmp1);
-                tmp2 = sx_neg(tmp2);
-                for (int k = 0; k <= n; k++) {
-                    CAf[k] = sx_smlaww(CAf[k], tmp1, sx_shl((i32)x_ptr[n - k], -rshifts - 1));
-                    CAb[k] = sx_smlaww(CAb[k], tmp2, sx_shl((i32)x_ptr[subfr_length - n + k - 1], -rshifts - 1));
-                }
+            bw->p1[sk] = a;
+            bw->p2[sk] = b;
+        }
+        wv_sync();
+        SX_PAR(s, nb_subfr) {
+            const i16* xs = x + s * L;
+            i32 tmp1, tmp2;
+            if (rshifts > -2) {
+                tmp1 = sx_shl((i32)xs[n], QA - 16);
+                tmp2 = sx_shl((i32)xs[L - n - 1], QA - 16);
+            } else {
+                tmp1 = sx_shl((i32)xs[n], 17);
+                tmp2 = sx_shl((i32)xs[L - n - 1], 17);
+            }
+            for (int k = 0; k < n; k++) {
+                tmp1 = sx_add(tmp1, bw->p1[s * 16 + k]);
+                tmp2 = sx_add(tmp2, bw->p2[s * 16 + k]);
+            }
+            if (rshifts > -2) {
+                bw->T1[s] = sx_shl(sx_neg(tmp1), 32 - QA - rshifts);
+                bw->T2[s] = sx_shl(sx_neg(tmp2), 32 - QA - rshifts);
+            } else {
+                bw->T1[s] = sx_neg(tmp1);
+                bw->T2[s] = sx_neg(tmp2);
             }
         }
-        tmp1 = C_first_row[n];
-        tmp2 = C_last_row[n];
-        i32 num = 0;
-        i32 nrg = sx_add(CAb[0], CAf[0]);
-        for (int k = 0; k < n; k++) {
-            i32 Atmp_QA = Af_QA[k];
+        wv_sync();
+        // (b) lane k: update correlation rows and the forward / backward correlations with all subframes
+        SX_PAR(k, n + 1) {
+            i32 cf = 0, cl = 0, caf = bw->CAf[k], cab = bw->CAb[k];
+            if (k < n) { cf = bw->Cf[k]; cl = bw->Cl[k]; }
+            for (int s = 0; s < nb_subfr; s++) {
+                const i16* xs = x + s * L;
+                if (rshifts > -2) {
+                    const i32 x1 = sx_neg(sx_shl((i32)xs[n], 16 - rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], 16 - rshifts));
+                    if (k < n) {
+                        cf = sx_smlawb(cf, x1, xs[n - k - 1]);
+                        cl = sx_smlawb(cl, x2, xs[L - n + k]);
+                    }
+                    caf = sx_smlawb(caf, bw->T1[s], xs[n - k]);
+                    cab = sx_smlawb(cab, bw->T2[s], xs[L - n + k - 1]);
+                } else {
+                    const i32 x1 = sx_neg(sx_shl((i32)xs[n], -rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], -rshifts));
+                    if (k < n) {
+                        cf = sx_add(cf, sx_mul(x1, xs[n - k - 1]));
+                        cl = sx_add(cl, sx_mul(x2, xs[L - n + k]));
+                    }
+                    caf = sx_smlaww(caf, bw->T1[s], sx_shl((i32)xs[n - k], -rshifts - 1));
+                    cab = sx_smlaww(cab, bw->T2[s], sx_shl((i32)xs[L - n + k - 1], -rshifts - 1));
+                }
+            }
+            if (k < n) { bw->Cf[k] = cf; bw->Cl[k] = cl; }
+            bw->CAf[k] = caf;
+            bw->CAb[k] = cab;
+        }
+        wv_sync();
+        // (c) lane k: its terms of the reflection-coefficient numerator / denominator
+        SX_PAR(k, n) {
+            const i32 Atmp_QA = bw->Af[k];
             int lz = sx_clz32(sx_abs(Atmp_QA)) - 1;
             lz = sx_min(32 - QA, lz);
-            i32 Atmp1 = sx_shl(Atmp_QA, lz);
-            tmp1 = sx_add(tmp1, sx_shl(sx_smmul(C_last_row[n - k - 1], Atmp1), 32 - QA - lz));
-            tmp2 = sx_add(tmp2, sx_shl(sx_smmul(C_first_row[n - k - 1], Atmp1), 32 - QA - lz));
-            num = sx_add(num, sx_shl(sx_smmul(CAb[n - k], Atmp1), 32 - QA - lz));
-            nrg = sx_add(nrg, sx_shl(sx_smmul(sx_add(CAb[k + 1], CAf[k + 1]), Atmp1), 32 - QA - lz));
+            const i32 Atmp1 = sx_shl(Atmp_QA, lz);
+            const int sh = 32 - QA - lz;
+            bw->p1[k] = sx_shl(sx_smmul(bw->Cl[n - k - 1], Atmp1), sh);
+            bw->p2[k] = sx_shl(sx_smmul(bw->Cf[n - k - 1], Atmp1), sh);
+            bw->q3[k] = sx_shl(sx_smmul(bw->CAb[n - k], Atmp1), sh);
+            bw->q4[k] = sx_shl(sx_smmul(sx_add(bw->CAb[k + 1], bw->CAf[k + 1]), Atmp1), sh);
         }
-        CAf[n + 1] = tmp1;
-        CAb[n + 1] = tmp2;
+        wv_sync();
+        i32 tmp1 = bw->Cf[n], tmp2 = bw->Cl[n];
+        i32 num = 0;
+        i32 nrg = sx_add(bw->CAb[0], bw->CAf[0]);
+        for (int k = 0; k < n; k++) {
+            tmp1 = sx_add(tmp1, bw->p1[k]);
+            tmp2 = sx_add(tmp2, bw->p2[k]);
+            num = sx_add(num, bw->q3[k]);
+            nrg = sx_add(nrg, bw->q4[k]);
+        }
+        wv_sync();
+        bw->CAf[n + 1] = tmp1;
+        bw->CAb[n + 1] = tmp2;
         num = sx_add(num, tmp2);
         num = sx_shl(sx_neg(num), 1);
         i32 rc_Q31;
         if (sx_abs(num) < nrg) {
             rc_Q31 = sx_div32_varQ(num, nrg, 31);
         } else {
-            for (int k = n; k < D; k++) Af_QA[k] = 0;
+            wv_sync();
+            SX_PAR(k, D - n) bw->Af[n + k] = 0;
+            wv_sync();
             break;
         }
-        for (int k = 0; k < (n + 1) >> 1; k++) {
-            tmp1 = Af_QA[k];
-            tmp2 = Af_QA[n - k - 1];
-            Af_QA[k] = sx_add(tmp1, sx_shl(sx_smmul(tmp2, rc_Q31), 1));
-            Af_QA[n - k - 1] = sx_add(tmp2, sx_shl(sx_smmul(tmp1, rc_Q31), 1));
+        wv_sync();
+        // (d) lane k: symmetric coefficient update and correlation update
+        SX_PAR(k, (n + 1) >> 1) {
+            const i32 t1 = bw->Af[k], t2 = bw->Af[n - k - 1];
+            bw->Af[k] = sx_add(t1, sx_shl(sx_smmul(t2, rc_Q31), 1));
+            bw->Af[n - k - 1] = sx_add(t2, sx_shl(sx_smmul(t1, rc_Q31), 1));
         }
-        Af_QA[n] = rc_Q31 >> (31 - QA);
-        for (int k = 0; k <= n + 1; k++) {
-            tmp1 = CAf[k];
-            tmp2 = CAb[n - k + 1];
-            CAf[k] = sx_add(tmp1, sx_shl(sx_smmul(tmp2, rc_Q31), 1));
-            CAb[n - k + 1] = sx_add(tmp2, sx_shl(sx_smmul(tmp1, rc_Q31), 1));
+        SX_PAR(k, n + 2) {
+            const i32 t1 = bw->CAf[k], t2 = bw->CAb[n - k + 1];
+            bw->CAf[k] = sx_add(t1, sx_shl(sx_smmul(t2, rc_Q31), 1));
+            bw->CAb[n - k + 1] = sx_add(t2, sx_shl(sx_smmul(t1, rc_Q31), 1));
         }
+        wv_sync();
+        bw->Af[n] = rc_Q31 >> (31 - QA);
+        wv_sync();
     }
-    i32 nrg = CAf[0];
+    i32 nrg = bw->CAf[0];
     i32 tmp1 = 1 << 16;
     for (int k = 0; k < D; k++) {
-        i32 Atmp1 = sx_rshift_round(Af_QA[k], QA - 16);
-        nrg = sx_smlaww(nrg, CAf[k + 1], Atmp1);
+        const i32 Atmp1 = sx_rshift_round(bw->Af[k], QA - 16);
+        nrg = sx_smlaww(nrg, bw->CAf[k + 1], Atmp1);
         tmp1 = sx_smlaww(tmp1, Atmp1, Atmp1);
-        A_Q16[k] = sx_neg(Atmp1);
     }
+    SX_PAR(k, D) A_Q16[k] = sx_neg(sx_rshift_round(bw->Af[k], QA - 16));
     *res_nrg = sx_smlaww(nrg, sx_smmul(WhiteNoiseFrac_Q32, C0), sx_neg(tmp1));
     *res_nrg_Q = -rshifts;
+    wv_sync();
 }
 
 // A2NLSF helpers, SKP_Silk_A2NLSF.c:46-123
@@ -865,8 +945,8 @@ SX_HD void sx_a2nlsf_init(const i32* a_Q16, i32* P, i32* Q, int dd) {
     sx_a2nlsf_trans_poly(Q, dd);
 }
 // SKP_Silk_A2NLSF, SKP_Silk_A2NLSF.c:127
-SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d) {
-    i32 P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1];
+SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q) {
+    SX_IN_LDS(NLSF); SX_IN_LDS(a_Q16); SX_IN_LDS(P); SX_IN_LDS(Q);
     const int dd = d >> 1;
     sx_a2nlsf_init(a_Q16, P, Q, dd);
     i32* p = P;
@@ -944,18 +1024,22 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d) {
 // SKP_Silk_find_LPC_FIX, SKP_Silk_find_LPC_FIX.c:32.  x: nb_subfr blocks of subfr_length samples (incl. `order` pre-samples)
 // LPC_res: scratch of 2*subfr_length samples (LDS)
 SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q15, int useInterp, int order, const i16* x,
-                       int subfr_length, i16* LPC_res) {
-    SX_IN_LDS(x); SX_IN_LDS(LPC_res);
-    i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
-    i16 a_tmp_Q12[SX_MAX_LPC];
+                       int subfr_length, i16* LPC_res, SxLpcWork* lw) {
+    SX_IN_LDS(NLSF_Q15); SX_IN_LDS(interpIndex); SX_IN_LDS(prev_NLSFq_Q15); SX_IN_LDS(x); SX_IN_LDS(LPC_res); SX_IN_LDS(lw);
+    i32* a_Q16 = lw->a_Q16;
+    i32* a_tmp_Q16 = lw->a_tmp_Q16;
+    i32* NLSF0_Q15 = lw->NLSF0_Q15;
+    i16* a_tmp_Q12 = lw->a_tmp_Q12;
     i32 res_nrg, res_tmp_nrg, res_nrg_Q, res_tmp_nrg_Q;
     *interpIndex = 4;
-    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order);
+    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
     sx_bwexpander_32(a_Q16, order, K_FIND_LPC_CHIRP_Q16);
+    wv_sync();
     SX_T_BEGIN
     if (useInterp == 1) {
-        sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order);
+        sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
         sx_bwexpander_32(a_tmp_Q16, order, K_FIND_LPC_CHIRP_Q16);
+        wv_sync();
         int shift = res_tmp_nrg_Q - res_nrg_Q;
         if (shift >= 0) {
             if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift);
@@ -963,7 +1047,8 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
             res_nrg = (res_nrg >> (-shift)) - res_tmp_nrg;
             res_nrg_Q = res_tmp_nrg_Q;
         }
-        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order);
+        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q);
+        wv_sync();
         SX_T(21)
         for (int k = 3; k >= 0; k--) {
             for (int i = 0; i < order; i++) NLSF0_Q15[i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
@@ -997,7 +1082,8 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
         }
     }
     SX_T(18)
-    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order);
+    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order, lw->P, lw->Q);
+    wv_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1164,13 +1250,18 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
     i32 WLTP[4 * 25];
     i16 LPC_in_pre[4 * (SX_SUBFR + SX_LPC)];
     i16 LPC_res[2 * (SX_SUBFR + SX_LPC)];
-    SxMsvqWork msvq;
+    i32 NLSF_Q15[SX_MAX_LPC];
+    union {
+        SxLpcWork lpc;
+        SxMsvqWork msvq;
+    } u;
 };
 
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
 SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res_pitch); SX_IN_LDS(w);
-    i32 invGains_Q16[4], local_gains[4], Wght_Q15[4], NLSF_Q15[SX_MAX_LPC];
+    i32 invGains_Q16[4], local_gains[4], Wght_Q15[4];
+    i32* NLSF_Q15 = w->NLSF_Q15;
     SX_T_BEGIN
     i32 min_gain_Q16 = SX_I32_MAX >> 6;
     for (int i = 0; i < 4; i++) min_gain_Q16 = sx_min(min_gain_Q16, c->Gains_Q16[i]);
@@ -1200,9 +1291,9 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, co
     }
     SX_T(16)
     sx_find_LPC(NLSF_Q15, &c->NLSFInterpCoef_Q2, st->prev_NLSFq_Q15, 1 - st->first_frame_after_reset, SX_LPC, w->LPC_in_pre,
-                SX_SUBFR + SX_LPC, w->LPC_res);
+                SX_SUBFR + SX_LPC, w->LPC_res, &w->u.lpc);
     SX_T(17)
-    sx_process_NLSFs(st, c, NLSF_Q15, &w->msvq);
+    sx_process_NLSFs(st, c, NLSF_Q15, &w->u.msvq);
     SX_T(19)
     sx_residual_energy(c->ResNrg, c->ResNrgQ, w->LPC_in_pre, c->PredCoef_Q12, local_gains, w->LPC_res);
     SX_T(20)
