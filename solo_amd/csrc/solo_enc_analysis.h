@@ -1091,6 +1091,9 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
 // ---------------------------------------------------------------------------------------------------
 struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 vectors per later stage; 64 in stage 0)
     i32 RateDist_Q18[256];
+    i32 Sorted_Q18[16];
+    u8 taken[256];
+    i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
     i32 Rate_Q5[16], Rate_new_Q5[16];
     i32 TempIndices[16];
     i32 Path[16 * 6], Path_new[16 * 6];
@@ -1100,19 +1103,19 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
 // SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
 SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
                                i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
-    SX_IN_LDS(w);
+    SX_IN_LDS(w); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
     const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
-    const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
     const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
     const i16* rates = sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5;
     const int nStages = 6, S = SX_MSVQ_SURVIVORS;
-    for (int i = 0; i < S; i++) w->Rate_Q5[i] = 0;
-    for (int i = 0; i < SX_LPC; i++) w->Res_Q15[i] = pNLSF_Q15[i];
+    SX_PAR(i, S) w->Rate_Q5[i] = 0;
+    SX_PAR(i, SX_LPC) w->Res_Q15[i] = pNLSF_Q15[i];
+    wv_sync();
     int prev_survivors = 1, cur_survivors = 0;
     const int min_survivors = S / 2;
     int cb_base = 0;
     for (int s = 0; s < nStages; s++) {
-        const int K = nvec[s];
+        const int K = sigtype == 0 ? nvec0[s] : nvec1[s];
         const i16* cbs = cb + cb_base * SX_LPC;
         const i16* rts = rates + cb_base;
         cur_survivors = sx_min(S, sx_smulbb(prev_survivors, K));
@@ -1128,70 +1131,82 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
                 sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
             }
             w->RateDist_Q18[t] = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
+            w->taken[t] = 0;
         }
         wv_sync();
-        // insertion_sort_increasing, K best of `total` (value asc, index asc): rank by counting, wave-parallel
-        SX_PAR(t, total) {
-            i32 v = w->RateDist_Q18[t];
-            int rank = 0;
-            for (int j = 0; j < total; j++) {
-                i32 u = w->RateDist_Q18[j];
-                rank += (u < v || (u == v && j < t)) ? 1 : 0;
+        // SKP_Silk_insertion_sort_increasing (the cur_survivors best of `total`, value ascending, first index wins ties):
+        // repeated wave arg-min over the lanes' remaining candidates
+        for (int r = 0; r < cur_survivors; r++) {
+            i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
+            SX_PAR(t, total) {
+                const i32 v = w->RateDist_Q18[t];
+                if (!w->taken[t] && (v < bv || (v == bv && t < bi))) { bv = v; bi = t; }
             }
-            if (rank < cur_survivors) { w->Path_new[rank] = v; w->TempIndices[rank] = t; }   // Path_new reused as sorted-value scratch
+            wv_argmin(&bv, &bi);
+            w->Sorted_Q18[r] = bv;
+            w->TempIndices[r] = bi;
+            w->taken[bi] = 1;
+            wv_sync();
         }
+        SX_PAR(r, cur_survivors) w->RateDist_Q18[r] = w->Sorted_Q18[r];
         wv_sync();
-        for (int r = 0; r < cur_survivors; r++) w->RateDist_Q18[r] = w->Path_new[r];
         if (w->RateDist_Q18[0] < SX_I32_MAX / 16) {
             i32 thr = sx_smlawb(w->RateDist_Q18[0], sx_mul(S, w->RateDist_Q18[0]), K_NLSF_MSVQ_SURV_MAX_REL_RD_Q16);
             while (w->RateDist_Q18[cur_survivors - 1] > thr && cur_survivors > min_survivors) cur_survivors--;
         }
-        for (int k = 0; k < cur_survivors; k++) {
-            int input_index, cb_index;
+        // new residuals, rates and paths of the survivors: lane (k, i)
+        SX_PAR(ki, cur_survivors * 16) {
+            const int k = ki >> 4, i = ki & 15;
+            int input_index = 0, cb_index = w->TempIndices[k];
             if (s > 0) {
-                input_index = w->TempIndices[k] / K;
-                cb_index = w->TempIndices[k] - input_index * K;
-            } else {
-                input_index = 0;
-                cb_index = w->TempIndices[k];
+                input_index = cb_index / K;
+                cb_index = cb_index - input_index * K;
             }
-            const i32* pin = &w->Res_Q15[input_index * SX_LPC];
-            const i16* pcb = &cbs[cb_index * SX_LPC];
-            for (int i = 0; i < SX_LPC; i++) w->Res_new_Q15[k * SX_LPC + i] = pin[i] - (i32)pcb[i];
-            w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
-            for (int i = 0; i < s; i++) w->Path_new[k * nStages + i] = w->Path[input_index * nStages + i];
-            w->Path_new[k * nStages + s] = cb_index;
+            if (i < SX_LPC) w->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
+            if (i == SX_LPC) w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
+            if (i > SX_LPC && i - SX_LPC - 1 < s) w->Path_new[k * nStages + (i - SX_LPC - 1)] = w->Path[input_index * nStages + (i - SX_LPC - 1)];
+            if (i == 15) w->Path_new[k * nStages + s] = cb_index;
         }
+        wv_sync();
         if (s < nStages - 1) {
-            for (int i = 0; i < cur_survivors * SX_LPC; i++) w->Res_Q15[i] = w->Res_new_Q15[i];
-            for (int i = 0; i < cur_survivors; i++) w->Rate_Q5[i] = w->Rate_new_Q5[i];
-            for (int i = 0; i < cur_survivors * nStages; i++) w->Path[i] = w->Path_new[i];
+            SX_PAR(i, cur_survivors * SX_LPC) w->Res_Q15[i] = w->Res_new_Q15[i];
+            SX_PAR(i, cur_survivors) w->Rate_Q5[i] = w->Rate_new_Q5[i];
+            SX_PAR(i, cur_survivors * nStages) w->Path[i] = w->Path_new[i];
+            wv_sync();
         }
         prev_survivors = cur_survivors;
         cb_base += K;
     }
-    int bestIndex = 0;
+    i32 bestRateDist_Q20 = SX_I32_MAX, bestIndex = 0;
     if (deactivate_fluc_red != 1) {
-        i32 bestRateDist_Q20 = SX_I32_MAX;
-        for (int s = 0; s < cur_survivors; s++) {
-            sx_nlsf_msvq_decode(pNLSF_Q15, sigtype, &w->Path_new[s * nStages]);
+        // every survivor is decoded (and stabilised) by its own lane into its own row of Res_Q15
+        i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
+        SX_PAR(sv, cur_survivors) {
+            i32* out = &w->Res_Q15[sv * SX_LPC];
+            sx_nlsf_msvq_decode(out, sigtype, &w->Path_new[sv * nStages]);
             i32 wsse_Q20 = 0;
             for (int i = 0; i < SX_LPC; i++) {
-                i32 se = pNLSF_Q15[i] - prev_q_Q15[i];
+                i32 se = out[i] - prev_q_Q15[i];
                 wsse_Q20 = sx_smlawb(wsse_Q20, sx_smulbb(se, se), pW_Q6[i]);
             }
-            wsse_Q20 = sx_add_pos_sat32(w->RateDist_Q18[s], sx_smulwb(wsse_Q20, mu_fluc_red_Q16));
-            if (wsse_Q20 < bestRateDist_Q20) { bestRateDist_Q20 = wsse_Q20; bestIndex = s; }
+            wsse_Q20 = sx_add_pos_sat32(w->RateDist_Q18[sv], sx_smulwb(wsse_Q20, mu_fluc_red_Q16));
+            if (wsse_Q20 < bv) { bv = wsse_Q20; bi = sv; }
         }
+        wv_argmin(&bv, &bi);
+        if (bv < bestRateDist_Q20) { bestRateDist_Q20 = bv; bestIndex = bi; }
+        wv_sync();
     }
-    for (int i = 0; i < nStages; i++) NLSFIndices[i] = w->Path_new[bestIndex * nStages + i];
+    SX_PAR(i, nStages) NLSFIndices[i] = w->Path_new[bestIndex * nStages + i];
+    wv_sync();
     sx_nlsf_msvq_decode(pNLSF_Q15, sigtype, NLSFIndices);
+    wv_sync();
 }
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
 SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w);
-    i32 pNLSFW_Q6[SX_LPC], pNLSF0_temp_Q15[SX_LPC], pNLSFW0_temp_Q6[SX_LPC], NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
+    i32 pNLSF0_temp_Q15[SX_LPC], pNLSFW0_temp_Q6[SX_LPC], NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
+    i32* pNLSFW_Q6 = w->W_Q6;
     if (c->sigtype == 0) {
         NLSF_mu_Q15 = sx_smlawb(66, -8388, st->speech_activity_Q8);
         NLSF_mu_fluc_red_Q16 = sx_smlawb(6554, -838848, st->speech_activity_Q8);
@@ -1209,6 +1224,7 @@ SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvq
         i32 i_sqr_Q15 = sx_shl(sx_smulbb(c->NLSFInterpCoef_Q2, c->NLSFInterpCoef_Q2), 11);
         for (int i = 0; i < SX_LPC; i++) pNLSFW_Q6[i] = sx_smlawb(pNLSFW_Q6[i] >> 1, pNLSFW0_temp_Q6[i], i_sqr_Q15);
     }
+    wv_sync();
     sx_nlsf_msvq_encode(c->NLSFIndices, pNLSF_Q15, c->sigtype, st->prev_NLSFq_Q15, pNLSFW_Q6, NLSF_mu_Q15, NLSF_mu_fluc_red_Q16,
                         st->first_frame_after_reset, w);
     sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
