@@ -27,6 +27,7 @@ struct SxFrontWork {                 // LDS scratch of the per-frame analysis ch
     i16 Wsig[SX_PITCH_LPC_WIN];      // also: VAD band buffer (4 x 80) and shaping window (120)
     union {
         SxPitchWork pitch;
+        SxShapeWork shape;
         SxPredWork pred;
         i16 pf_sLTP_shp[SX_LTP_BUF]; // staged prefilter ring
     } u;
@@ -312,7 +313,7 @@ SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int fr
     wv_sync();
     SX_ENC_TAP(1, st, w, f->x_buf + SX_FRAME + SX_LA_SHAPE);
     SX_T(2)
-    sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, f->x_buf + SX_FRAME, f->Wsig);
+    sx_noise_shape_analysis(st, c, f->res_pitch + SX_FRAME, f->x_buf + SX_FRAME, &f->u.shape);
     wv_sync();
     SX_ENC_TAP(2, st, w, f->res_pitch + SX_FRAME);
     SX_T(3)

@@ -45,8 +45,7 @@ SX_FN void sx_warped_autocorr(i32* corr, i32* scale, const i16* input, i32 warpi
 }
 
 // SKP_Silk_schur64, SKP_Silk_schur64.c:42
-SX_HD i32 sx_schur64(i32* rc_Q16, const i32* c, int order) {
-    i32 C[SX_MAX_LPC + 1][2];
+SX_HD i32 sx_schur64(i32* rc_Q16, const i32* c, int order, i32 (*C)[2]) {
     if (c[0] <= 0) {
         for (int k = 0; k < order; k++) rc_Q16[k] = 0;
         return 0;
@@ -65,8 +64,7 @@ SX_HD i32 sx_schur64(i32* rc_Q16, const i32* c, int order) {
 }
 
 // SKP_Silk_k2a_Q16, SKP_Silk_k2a_Q16.c:40
-SX_HD void sx_k2a_Q16(i32* A_Q24, const i32* rc_Q16, int order) {
-    i32 Atmp[SX_MAX_LPC];
+SX_HD void sx_k2a_Q16(i32* A_Q24, const i32* rc_Q16, int order, i32* Atmp) {
     for (int k = 0; k < order; k++) {
         for (int n = 0; n < k; n++) Atmp[n] = A_Q24[n];
         for (int n = 0; n < k; n++) A_Q24[n] = sx_smlaww(A_Q24[n], Atmp[k - n - 1], rc_Q16[k]);
@@ -142,6 +140,75 @@ SX_FN void sx_limit_warped_coefs(i32* syn, i32* ana, i32 lambda_Q16, i32 limit_Q
     }
 }
 
+// LDS scratch of the noise-shape analysis: the four subframes are analysed side by side
+struct SxShapeWork {
+    i16 xw[SX_NB_SUBFR][SX_SHAPE_WIN];                    // windowed input of the four subframes
+    i32 win[2][SX_LA_SHAPE];                              // rising / falling sine-window gains (Q16)
+    i32 o[2][SX_NB_SUBFR][SX_SHAPE_ORDER];                // all-pass section outputs in flight (double buffered)
+    i64 cq[SX_NB_SUBFR][SX_SHAPE_ORDER + 1];
+    i32 corr[SX_NB_SUBFR][SX_SHAPE_ORDER + 1];
+    i32 scale[SX_NB_SUBFR];
+    i32 C[SX_NB_SUBFR][SX_SHAPE_ORDER + 1][2];
+    i32 rc[SX_NB_SUBFR][SX_SHAPE_ORDER];
+    i32 A2[SX_NB_SUBFR][SX_SHAPE_ORDER], A1[SX_NB_SUBFR][SX_SHAPE_ORDER], At[SX_NB_SUBFR][SX_SHAPE_ORDER];
+    i32 inv[SX_NB_SUBFR][2][SX_MAX_LPC];
+};
+
+#if SX_NLANES == 1
+#define SX_NP64 64
+#define SX_PL(l) (l)
+#else
+#define SX_NP64 1
+#define SX_PL(l) 0
+#endif
+
+// SKP_Silk_warped_autocorrelation_FIX (SKP_Silk_warped_autocorrelation_FIX.c:36) for the four subframe windows at once.
+// The reference walks 16 first-order all-pass sections per sample; section j at sample n only needs section j-1 at
+// samples n, n-1 and itself at n-1, so lane (k, j) runs section j of subframe k skewed by j samples: 120 + 15 steps
+// instead of 4 x 120 x 16.  Each lane accumulates correlation j of its subframe in 64 bits; section outputs move to the
+// neighbour lane through a double-buffered LDS row.
+SX_HD void sx_warped_autocorr4(SxShapeWork* sw, i32 warping_Q16) {
+    i32 pin[SX_NP64], pout[SX_NP64];
+    i64 acc[SX_NP64], acc16[SX_NP64];
+    for (int a = 0; a < SX_NP64; a++) { pin[a] = 0; pout[a] = 0; acc[a] = 0; acc16[a] = 0; }
+    for (int t = 0; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) {
+        SX_PAR(l, 64) {
+            const int k = l >> 4, j = l & 15, n = t - j, pl = SX_PL(l);
+            if (n >= 0 && n < SX_SHAPE_WIN) {
+                const i32 x0 = sx_shl((i32)sw->xw[k][n], 14);
+                const i32 in = j == 0 ? x0 : sw->o[(t - 1) & 1][k][j - 1];
+                const i32 out = sx_smlawb(pin[pl], pout[pl] - in, warping_Q16);
+                acc[pl] += sx_smull(in, x0) >> 18;
+                if (j == SX_SHAPE_ORDER - 1) acc16[pl] += sx_smull(out, x0) >> 18;
+                pin[pl] = in;
+                pout[pl] = out;
+                sw->o[t & 1][k][j] = out;
+            }
+        }
+        wv_sync();
+    }
+    SX_PAR(l, 64) {
+        const int k = l >> 4, j = l & 15, pl = SX_PL(l);
+        sw->cq[k][j] = acc[pl];
+        if (j == SX_SHAPE_ORDER - 1) sw->cq[k][SX_SHAPE_ORDER] = acc16[pl];
+    }
+    wv_sync();
+    SX_PAR(l, SX_NB_SUBFR * (SX_SHAPE_ORDER + 1)) {
+        const int k = l / (SX_SHAPE_ORDER + 1), j = l - k * (SX_SHAPE_ORDER + 1);
+        int lsh = sx_clz64(sw->cq[k][0]) - 35;
+        lsh = sx_limit(lsh, -12 - 10, 30 - 10);
+        if (j == 0) sw->scale[k] = -(10 + lsh);
+        sw->corr[k][j] = lsh >= 0 ? (i32)(sw->cq[k][j] << lsh) : (i32)(sw->cq[k][j] >> (-lsh));
+    }
+    wv_sync();
+}
+
+// SKP_Silk_LPC_inverse_pred_gain_Q24 (SKP_Silk_LPC_inv_pred_gain.c:134) with caller-provided step-down rows
+SX_HD int sx_lpc_inv_pred_gain_Q24_ws(i32* invGain_Q30, const i32* A_Q24, int order, i32 (*A)[SX_MAX_LPC]) {
+    for (int k = 0; k < order; k++) A[order & 1][k] = sx_rshift_round(A_Q24[k], 8);
+    return sx_lpc_inv_pred_gain_QA(invGain_Q30, A, order);
+}
+
 // float island of the "fixed point" encoder (noise_shape_analysis_FIX.c:407): IEEE single division
 SX_HD float sx_fdiv(float a, float b) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -154,10 +221,9 @@ SX_HD float sx_fdiv(float a, float b) {
 
 // SKP_Silk_noise_shape_analysis_FIX, noise_shape_analysis_FIX.c:137.
 // pitch_res = res_pitch + frame_length; x = x_buf + frame_length; x_windowed: 120-sample scratch (LDS)
-SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, i16* x_windowed) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(pitch_res); SX_IN_LDS(x); SX_IN_LDS(x_windowed);
-    i32 auto_corr[SX_SHAPE_ORDER + 1], refl_coef_Q16[SX_SHAPE_ORDER], AR1_Q24[SX_SHAPE_ORDER], AR2_Q24[SX_SHAPE_ORDER];
-    i32 scale = 0, nrg, pre_nrg_Q30, tmp32;
+SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, SxShapeWork* sw) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(pitch_res); SX_IN_LDS(x); SX_IN_LDS(sw);
+    i32 tmp32;
     const i16* x_ptr = x - SX_LA_SHAPE;
     c->current_SNR_dB_Q7 = st->SNR_dB_Q7;                 // DISABLE_BUF_RD (SKP_Silk_define.h:53)
     c->current_SNRPerMD_dB_Q7 = st->SNRPerMD_dB_Q7;
@@ -211,41 +277,69 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
     BWExp2_Q16 = sx_add(BWExp2_Q16, delta_Q16);
     BWExp1_Q16 = sx_shl(BWExp1_Q16, 14) / (BWExp2_Q16 >> 2);
     i32 warping_Q16 = sx_smlawb(SX_WARPING_Q16, c->coding_quality_Q14, K_0p01_Q18);
-    // per-subframe shaping filters
-    for (int k = 0; k < SX_NB_SUBFR; k++) {
-        const int flat_part = 40, slope_part = (SX_SHAPE_WIN - flat_part) >> 1;
-        sx_apply_sine_window(x_windowed, x_ptr, 1, slope_part);
-        SX_PAR(i, flat_part) x_windowed[slope_part + i] = x_ptr[slope_part + i];
-        sx_apply_sine_window(x_windowed + slope_part + flat_part, x_ptr + slope_part + flat_part, 2, slope_part);
+    // per-subframe shaping filters: windows and warped autocorrelations of the four subframes side by side
+    {
+        // sine-window gains (SKP_Silk_apply_sine_window.c:39, length 40): a data-independent recursion, evaluated once
+        const int length = SX_LA_SHAPE;
+        const i32 f_Q16 = T_sine_win_freq_Q16[(length >> 2) - 4];
+        const i32 c_Q16 = sx_smulwb(f_Q16, -f_Q16);
+        for (int wt = 0; wt < 2; wt++) {
+            i32 S0 = wt == 0 ? 0 : (1 << 16);
+            i32 S1 = wt == 0 ? f_Q16 + (length >> 3) : (1 << 16) + (c_Q16 >> 1) + (length >> 4);
+            for (int k = 0; k < length; k += 4) {
+                sw->win[wt][k] = (S0 + S1) >> 1;
+                sw->win[wt][k + 1] = S1;
+                S0 = sx_smulwb(S1, c_Q16) + sx_shl(S1, 1) - S0 + 1;
+                S0 = sx_min(S0, 1 << 16);
+                sw->win[wt][k + 2] = (S0 + S1) >> 1;
+                sw->win[wt][k + 3] = S0;
+                S1 = sx_smulwb(S0, c_Q16) + sx_shl(S0, 1) - S1;
+                S1 = sx_min(S1, 1 << 16);
+            }
+        }
         wv_sync();
-        x_ptr += SX_SUBFR;
-        sx_warped_autocorr(auto_corr, &scale, x_windowed, (i16)warping_Q16, SX_SHAPE_WIN);
+        SX_PAR(t, SX_NB_SUBFR * SX_SHAPE_WIN) {
+            const int k = t / SX_SHAPE_WIN, i = t - k * SX_SHAPE_WIN;
+            const i16 v = x_ptr[k * SX_SUBFR + i];
+            sw->xw[k][i] = i < 40 ? (i16)sx_smulwb(sw->win[0][i], v) : (i < 80 ? v : (i16)sx_smulwb(sw->win[1][i - 80], v));
+        }
+        wv_sync();
+        sx_warped_autocorr4(sw, (i16)warping_Q16);
+    }
+    // Schur recursion, warped gain, bandwidth expansion, pre-gains and coefficient limiting: subframe k on lane k
+    SX_PAR(k, SX_NB_SUBFR) {
+        i32* auto_corr = sw->corr[k];
+        i32* AR2_Q24 = sw->A2[k];
+        i32* AR1_Q24 = sw->A1[k];
         auto_corr[0] = sx_add(auto_corr[0], sx_max(sx_smulwb(auto_corr[0] >> 4, K_SHAPE_WHITE_NOISE_FRACTION_Q20), 1));
-        nrg = sx_schur64(refl_coef_Q16, auto_corr, SX_SHAPE_ORDER);
-        sx_k2a_Q16(AR2_Q24, refl_coef_Q16, SX_SHAPE_ORDER);
-        int Qnrg = -scale;
+        i32 nrg = sx_schur64(sw->rc[k], auto_corr, SX_SHAPE_ORDER, sw->C[k]);
+        sx_k2a_Q16(AR2_Q24, sw->rc[k], SX_SHAPE_ORDER, sw->At[k]);
+        int Qnrg = -sw->scale[k];
         if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
-        tmp32 = sx_sqrt_approx(nrg);
+        const i32 sq = sx_sqrt_approx(nrg);
         Qnrg >>= 1;
-        c->Gains_Q16[k] = sx_lshift_sat32(tmp32, 16 - Qnrg);
+        i32 g = sx_lshift_sat32(sq, 16 - Qnrg);
         {
             i32 gain_mult_Q16 = sx_warped_gain(AR2_Q24, warping_Q16, SX_SHAPE_ORDER);
-            c->Gains_Q16[k] = sx_smulww(c->Gains_Q16[k], gain_mult_Q16);
-            if (c->Gains_Q16[k] < 0) c->Gains_Q16[k] = SX_I32_MAX;
+            g = sx_smulww(g, gain_mult_Q16);
+            if (g < 0) g = SX_I32_MAX;
         }
+        c->Gains_Q16[k] = g;
         sx_bwexpander_32(AR2_Q24, SX_SHAPE_ORDER, BWExp2_Q16);
         for (int i = 0; i < SX_SHAPE_ORDER; i++) AR1_Q24[i] = AR2_Q24[i];
         sx_bwexpander_32(AR1_Q24, SX_SHAPE_ORDER, BWExp1_Q16);
-        sx_lpc_inv_pred_gain_Q24(&pre_nrg_Q30, AR2_Q24, SX_SHAPE_ORDER);
-        sx_lpc_inv_pred_gain_Q24(&nrg, AR1_Q24, SX_SHAPE_ORDER);
+        i32 pre_nrg_Q30, nrg1;
+        sx_lpc_inv_pred_gain_Q24_ws(&pre_nrg_Q30, AR2_Q24, SX_SHAPE_ORDER, sw->inv[k]);
+        sx_lpc_inv_pred_gain_Q24_ws(&nrg1, AR1_Q24, SX_SHAPE_ORDER, sw->inv[k]);
         pre_nrg_Q30 = sx_shl(sx_smulwb(pre_nrg_Q30, K_0p7_Q15), 1);
-        c->GainsPre_Q14[k] = K_0p3_Q14 + sx_div32_varQ(pre_nrg_Q30, nrg, 14);
+        c->GainsPre_Q14[k] = K_0p3_Q14 + sx_div32_varQ(pre_nrg_Q30, nrg1, 14);
         sx_limit_warped_coefs(AR2_Q24, AR1_Q24, warping_Q16, K_3p999_Q24, SX_SHAPE_ORDER);
         for (int i = 0; i < SX_SHAPE_ORDER; i++) {
             c->AR1_Q13[k * SX_SHAPE_ORDER + i] = (i16)sx_sat16(sx_rshift_round(AR1_Q24[i], 11));
             c->AR2_Q13[k * SX_SHAPE_ORDER + i] = (i16)sx_sat16(sx_rshift_round(AR2_Q24[i], 11));
         }
     }
+    wv_sync();
     // gain tweaking
     i32 md_gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, md_SNR_adj_dB_Q7, K_0p16_Q16)));
     i32 gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, SNR_adj_dB_Q7, K_0p16_Q16)));
