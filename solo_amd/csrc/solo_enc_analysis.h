@@ -539,8 +539,9 @@ SX_HD void sx_corr_vector(const i16* x, const i16* t, int L, int order, i32* Xt,
 }
 
 // SKP_Silk_solve_LDL_FIX and helpers, SKP_Silk_solve_LS_FIX.c:71-241 (M = 5)
-SX_FN void sx_solve_LDL(i32* A, int M, const i32* b, i32* x_Q16) {
-    i32 L_Q16[25], Y[5], inv_D_Q36[5], inv_D_Q48[5], v_Q0[5], D_Q0[5];
+SX_FN void sx_solve_LDL(i32* A, int M, const i32* b, i32* x_Q16, i32* ws /* 50 words of LDS */) {
+    SX_IN_LDS(A); SX_IN_LDS(b); SX_IN_LDS(x_Q16); SX_IN_LDS(ws);
+    i32 *L_Q16 = ws, *Y = ws + 25, *inv_D_Q36 = ws + 30, *inv_D_Q48 = ws + 35, *v_Q0 = ws + 40, *D_Q0 = ws + 45;
     int status = 1;
     i32 diag_min_value = sx_max(sx_smmul(sx_add_sat32(A[0], A[M * M - 1]), K_FIND_LTP_COND_FAC_Q31), 1 << 9);
     for (int loop_count = 0; loop_count < M && status == 1; loop_count++) {
@@ -624,51 +625,66 @@ SX_HD i32 sx_residual_energy16_covar(const i16* cvec, const i32* wXX, const i32*
     return nrg;
 }
 
+struct SxLtpWork {                   // LDS scratch of the LTP analysis: subframe k is analysed by lane k
+    i32 b_Q16[SX_NB_SUBFR][SX_LTP_ORDER], Rr[SX_NB_SUBFR][SX_LTP_ORDER], delta_b_Q14[SX_NB_SUBFR][SX_LTP_ORDER];
+    i32 rr[SX_NB_SUBFR], nrg[SX_NB_SUBFR], w[SX_NB_SUBFR], corr_rshifts[SX_NB_SUBFR], d_Q14[SX_NB_SUBFR];
+    i32 ldl[SX_NB_SUBFR][50];
+};
+
 // SKP_Silk_find_LTP_FIX, SKP_Silk_find_LTP_FIX.c:39.  res_pitch: LPC residual buffer (336 samples)
-SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15) {
-    SX_IN_LDS(b_Q14); SX_IN_LDS(WLTP); SX_IN_LDS(LTPredCodGain_Q7); SX_IN_LDS(res_pitch); SX_IN_LDS(lag);
+SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15,
+                       SxLtpWork* lw) {
+    SX_IN_LDS(b_Q14); SX_IN_LDS(WLTP); SX_IN_LDS(LTPredCodGain_Q7); SX_IN_LDS(res_pitch); SX_IN_LDS(lag); SX_IN_LDS(Wght_Q15); SX_IN_LDS(lw);
     const int subfr_length = SX_SUBFR, mem_offset = SX_FRAME, HEAD = 2;
-    i32 b_Q16[5], delta_b_Q14[5], d_Q14[4], nrg[4], w[4], Rr[5], rr[4], corr_rshifts[4];
-    i16* b_Q14_ptr = b_Q14;
-    i32* WLTP_ptr = WLTP;
-    for (int k = 0; k < 4; k++) {
+    i32* d_Q14 = lw->d_Q14;
+    i32* nrg = lw->nrg;
+    i32* w = lw->w;
+    i32* rr = lw->rr;
+    i32* corr_rshifts = lw->corr_rshifts;
+    SX_PAR(k, SX_NB_SUBFR) {
+        i16* b_Q14_ptr = b_Q14 + k * SX_LTP_ORDER;
+        i32* WLTP_ptr = WLTP + k * 25;
+        i32* Rr = lw->Rr[k];
+        i32* b_Q16 = lw->b_Q16[k];
         const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;     // r_first / r_last of the reference address one timeline
         const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
-        i32 rr_shifts;
-        sx_sum_sqr_shift(&rr[k], &rr_shifts, r_ptr, subfr_length, 0);
-        int LZs = sx_clz32(rr[k]);
+        i32 rr_shifts, rrk;
+        sx_sum_sqr_shift(&rrk, &rr_shifts, r_ptr, subfr_length, 0);
+        int LZs = sx_clz32(rrk);
         if (LZs < HEAD) {
-            rr[k] = sx_rshift_round(rr[k], HEAD - LZs);
+            rrk = sx_rshift_round(rrk, HEAD - LZs);
             rr_shifts += HEAD - LZs;
         }
-        corr_rshifts[k] = rr_shifts;
-        sx_corr_matrix(lag_ptr, subfr_length, SX_LTP_ORDER, HEAD, WLTP_ptr, &corr_rshifts[k], lag[k] & 1);
-        sx_corr_vector(lag_ptr, r_ptr, subfr_length, SX_LTP_ORDER, Rr, corr_rshifts[k]);
-        if (corr_rshifts[k] > rr_shifts) rr[k] = rr[k] >> (corr_rshifts[k] - rr_shifts);
+        i32 crs = rr_shifts;
+        sx_corr_matrix(lag_ptr, subfr_length, SX_LTP_ORDER, HEAD, WLTP_ptr, &crs, lag[k] & 1);
+        sx_corr_vector(lag_ptr, r_ptr, subfr_length, SX_LTP_ORDER, Rr, crs);
+        if (crs > rr_shifts) rrk = rrk >> (crs - rr_shifts);
         i32 regu = 1;
-        regu = sx_smlawb(regu, rr[k], K_LTP_DAMPING_DIV3_Q16);
+        regu = sx_smlawb(regu, rrk, K_LTP_DAMPING_DIV3_Q16);
         regu = sx_smlawb(regu, WLTP_ptr[0], K_LTP_DAMPING_DIV3_Q16);
         regu = sx_smlawb(regu, WLTP_ptr[24], K_LTP_DAMPING_DIV3_Q16);
         for (int i = 0; i < 5; i++) WLTP_ptr[i * 5 + i] = sx_add(WLTP_ptr[i * 5 + i], regu);
-        rr[k] += regu;
-        sx_solve_LDL(WLTP_ptr, SX_LTP_ORDER, Rr, b_Q16);
+        rrk += regu;
+        sx_solve_LDL(WLTP_ptr, SX_LTP_ORDER, Rr, b_Q16, lw->ldl[k]);
         for (int i = 0; i < 5; i++) b_Q14_ptr[i] = (i16)sx_sat16(sx_rshift_round(b_Q16[i], 2));
-        nrg[k] = sx_residual_energy16_covar(b_Q14_ptr, WLTP_ptr, Rr, rr[k], SX_LTP_ORDER, 14);
-        int extra_shifts = sx_min(corr_rshifts[k], HEAD);
-        i32 denom32 = sx_add(sx_lshift_sat32(sx_smulwb(nrg[k], Wght_Q15[k]), 1 + extra_shifts),
-                             sx_smulwb(subfr_length, 655) >> (corr_rshifts[k] - extra_shifts));
+        const i32 nrgk = sx_residual_energy16_covar(b_Q14_ptr, WLTP_ptr, Rr, rrk, SX_LTP_ORDER, 14);
+        int extra_shifts = sx_min(crs, HEAD);
+        i32 denom32 = sx_add(sx_lshift_sat32(sx_smulwb(nrgk, Wght_Q15[k]), 1 + extra_shifts),
+                             sx_smulwb(subfr_length, 655) >> (crs - extra_shifts));
         denom32 = sx_max(denom32, 1);
         i32 temp32 = sx_shl(Wght_Q15[k], 16) / denom32;
-        temp32 = temp32 >> (31 + corr_rshifts[k] - extra_shifts - 26);
+        temp32 = temp32 >> (31 + crs - extra_shifts - 26);
         i32 WLTP_max = 0;
         for (int i = 0; i < 25; i++) WLTP_max = sx_max(WLTP_ptr[i], WLTP_max);
         int lshift = sx_clz32(WLTP_max) - 1 - 3;
         if (26 - 18 + lshift < 31) temp32 = sx_min(temp32, sx_shl(1, 26 - 18 + lshift));
         for (int i = 0; i < 25; i++) WLTP_ptr[i] = (i32)(sx_smull(WLTP_ptr[i], temp32) >> 8);
         w[k] = WLTP_ptr[2 * 5 + 2];
-        b_Q14_ptr += 5;
-        WLTP_ptr += 25;
+        rr[k] = rrk;
+        nrg[k] = nrgk;
+        corr_rshifts[k] = crs;
     }
+    wv_sync();
     int maxRshifts = 0;
     for (int k = 0; k < 4; k++) maxRshifts = sx_max(corr_rshifts[k], maxRshifts);
     {
@@ -681,12 +697,12 @@ SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* 
         i32 div_Q16 = sx_div32_varQ(LPC_res_nrg, LPC_LTP_res_nrg, 16);
         *LTPredCodGain_Q7 = sx_smulbb(3, sx_lin2log(div_Q16) - (16 << 7));
     }
-    b_Q14_ptr = b_Q14;
-    for (int k = 0; k < 4; k++) {
-        d_Q14[k] = 0;
-        for (int i = 0; i < 5; i++) d_Q14[k] += b_Q14_ptr[i];
-        b_Q14_ptr += 5;
+    SX_PAR(k, SX_NB_SUBFR) {
+        i32 d = 0;
+        for (int i = 0; i < 5; i++) d += b_Q14[k * 5 + i];
+        d_Q14[k] = d;
     }
+    wv_sync();
     i32 max_abs_d_Q14 = 0, max_w_bits = 0;
     for (int k = 0; k < 4; k++) {
         max_abs_d_Q14 = sx_max(max_abs_d_Q14, sx_abs(d_Q14[k]));
@@ -703,22 +719,24 @@ SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* 
         wd = sx_add(wd, sx_shl(sx_smulww(w[k] >> (maxRshifts_wxtra - corr_rshifts[k]), d_Q14[k]), 2));
     }
     i32 m_Q12 = sx_div32_varQ(wd, temp32, 12);
-    b_Q14_ptr = b_Q14;
-    for (int k = 0; k < 4; k++) {
-        if (2 - corr_rshifts[k] > 0) temp32 = w[k] >> (2 - corr_rshifts[k]);
-        else temp32 = sx_lshift_sat32(w[k], corr_rshifts[k] - 2);
-        i32 g_Q26 = sx_mul(K_LTP_SMOOTHING_Q26 / ((K_LTP_SMOOTHING_Q26 >> 10) + temp32),
+    SX_PAR(k, SX_NB_SUBFR) {
+        i16* b_Q14_ptr = b_Q14 + k * 5;
+        i32* delta_b_Q14 = lw->delta_b_Q14[k];
+        i32 t32;
+        if (2 - corr_rshifts[k] > 0) t32 = w[k] >> (2 - corr_rshifts[k]);
+        else t32 = sx_lshift_sat32(w[k], corr_rshifts[k] - 2);
+        i32 g_Q26 = sx_mul(K_LTP_SMOOTHING_Q26 / ((K_LTP_SMOOTHING_Q26 >> 10) + t32),
                            sx_lshift_sat32(sx_sub_sat32(m_Q12, d_Q14[k] >> 2), 4));
-        temp32 = 0;
+        t32 = 0;
         for (int i = 0; i < 5; i++) {
             delta_b_Q14[i] = sx_max(b_Q14_ptr[i], 1638);
-            temp32 += delta_b_Q14[i];
+            t32 += delta_b_Q14[i];
         }
-        temp32 = g_Q26 / temp32;
+        t32 = g_Q26 / t32;
         for (int i = 0; i < 5; i++)
-            b_Q14_ptr[i] = (i16)sx_limit((i32)b_Q14_ptr[i] + sx_smulwb(sx_lshift_sat32(temp32, 4), delta_b_Q14[i]), -16000, 28000);
-        b_Q14_ptr += 5;
+            b_Q14_ptr[i] = (i16)sx_limit((i32)b_Q14_ptr[i] + sx_smulwb(sx_lshift_sat32(t32, 4), delta_b_Q14[i]), -16000, 28000);
     }
+    wv_sync();
 }
 
 // SKP_Silk_VQ_WMat_EC_FIX, SKP_Silk_VQ_nearest_neighbor_FIX.c:31 (generic, non-packed form of the arithmetic)
@@ -1361,7 +1379,9 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
     i16 LPC_in_pre[4 * (SX_SUBFR + SX_LPC)];
     i16 LPC_res[2 * (SX_SUBFR + SX_LPC)];
     i32 NLSF_Q15[SX_MAX_LPC];
+    i32 invGains_Q16[SX_NB_SUBFR], local_gains[SX_NB_SUBFR], Wght_Q15[SX_NB_SUBFR];
     union {
+        SxLtpWork ltp;
         SxLpcWork lpc;
         SxMsvqWork msvq;
     } u;
@@ -1370,7 +1390,7 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
 SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res_pitch); SX_IN_LDS(w);
-    i32 invGains_Q16[4], local_gains[4], Wght_Q15[4];
+    i32 *invGains_Q16 = w->invGains_Q16, *local_gains = w->local_gains, *Wght_Q15 = w->Wght_Q15;
     i32* NLSF_Q15 = w->NLSF_Q15;
     SX_T_BEGIN
     i32 min_gain_Q16 = SX_I32_MAX >> 6;
@@ -1382,8 +1402,9 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, co
         Wght_Q15[i] = tmp >> 1;
         local_gains[i] = (1 << 16) / invGains_Q16[i];
     }
+    wv_sync();
     if (c->sigtype == 0) {
-        sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15);
+        sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15, &w->u.ltp);
         sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8);
         sx_LTP_scale_ctrl(st, c);
         sx_LTP_analysis_filter(w->LPC_in_pre, x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
