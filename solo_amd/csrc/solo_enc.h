@@ -7,6 +7,7 @@
 #pragma once
 #include "solo_enc_analysis.h"
 #include "solo_enc_nsq.h"
+#include "solo_cdf.h"
 
 // what the parameter coder needs of one frame (kept from both frames until the packet is assembled)
 struct SxFrameIdx {
@@ -17,8 +18,11 @@ struct SxFrameIdx {
     i32 Seed, vadFlag;
 };
 
-struct SxCodeWork {                  // LDS: range-coder byte buffers of the two descriptions
+struct SxCodeWork {                  // LDS: range-coder byte buffers of the two descriptions + the coding tables
     u8 buf[2][SX_MAX_ARITHM_BYTES];
+    i16 pulses[2][SX_FRAME + 2 * (SX_FRAME / 16)];   // |pulse| per sample, then sum_pulses / nRshifts per shell block
+    i8 q[2][2][SX_FRAME];                            // staged pulses (frame, description)
+    SxCdf cdf;
 };
 
 struct SxFrontWork {                 // LDS scratch of the per-frame analysis chain
@@ -61,36 +65,37 @@ struct SxEncWork {
 // ---------------------------------------------------------------------------------------------------
 // entropy coding
 // ---------------------------------------------------------------------------------------------------
-SX_HD void sx_enc_split(SxRangeEnc* rc, int p_child1, int p, const u16* shell_table) {
-    if (p > 0) sx_rc_enc(rc, p_child1, &shell_table[T_shell_offsets[p]]);
+SX_HD void sx_enc_split(SxRangeEnc* rc, int p_child1, int p, const u16* shell_table, const SxCdf* cdf) {
+    if (p > 0) sx_rc_enc(rc, p_child1, &shell_table[cdf->shell_offsets[p]]);
 }
 
 // SKP_Silk_shell_encoder, SKP_Silk_shell_coder.c:84
-SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i32* p0) {
+SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i16* p0, const SxCdf* cdf) {
     i32 p1[8], p2[4], p3[2], p4;
     for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
     for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
     for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
     p4 = p3[0] + p3[1];
-    sx_enc_split(rc, p3[0], p4, T_cdf_shell3);
+    sx_enc_split(rc, p3[0], p4, cdf->cdf_shell3, cdf);
     for (int h = 0; h < 2; h++) {
-        sx_enc_split(rc, p2[2 * h], p3[h], T_cdf_shell2);
+        sx_enc_split(rc, p2[2 * h], p3[h], cdf->cdf_shell2, cdf);
         for (int g = 0; g < 2; g++) {
             const int m = 2 * h + g;
-            sx_enc_split(rc, p1[2 * m], p2[m], T_cdf_shell1);
-            sx_enc_split(rc, p0[4 * m], p1[2 * m], T_cdf_shell0);
-            sx_enc_split(rc, p0[4 * m + 2], p1[2 * m + 1], T_cdf_shell0);
+            sx_enc_split(rc, p1[2 * m], p2[m], cdf->cdf_shell1, cdf);
+            sx_enc_split(rc, p0[4 * m], p1[2 * m], cdf->cdf_shell0, cdf);
+            sx_enc_split(rc, p0[4 * m + 2], p1[2 * m + 1], cdf->cdf_shell0, cdf);
         }
     }
 }
 
 // SKP_Silk_encode_pulses + SKP_Silk_encode_signs, SKP_Silk_encode_pulses.c:55, SKP_Silk_code_signs.c:40
-SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q) {
+SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, i16* pw) {
+    SX_IN_LDS(cdf); SX_IN_LDS(pw); SX_IN_LDS(q);
     const int iter = SX_FRAME / 16;
-    i32 abs_pulses[SX_FRAME], sum_pulses[SX_FRAME / 16], nRshifts[SX_FRAME / 16];
+    i16 *abs_pulses = pw, *sum_pulses = pw + SX_FRAME, *nRshifts = pw + SX_FRAME + SX_FRAME / 16;
     for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = q[i] < 0 ? -(i32)q[i] : (i32)q[i];
     for (int i = 0; i < iter; i++) {
-        i32* ap = &abs_pulses[i * 16];
+        i16* ap = &abs_pulses[i * 16];
         nRshifts[i] = 0;
         for (;;) {
             // combine_and_check: 1+1 (max 3), 2+2 (max 6), 4+4 (max 8), 8+8 (max 12); the reference aborts each level at
@@ -117,78 +122,80 @@ SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
     int RateLevelIndex = 0;
     i32 minSumBits_Q6 = SX_I32_MAX;
     for (int k = 0; k < 9; k++) {
-        const i16* nBits = &T_bits_pulses_per_block_Q6[k * 20];
-        i32 sumBits_Q6 = T_bits_rate_levels_Q6[sigtype * 9 + k];
+        const i16* nBits = &cdf->bits_pulses_per_block_Q6[k * 20];
+        i32 sumBits_Q6 = cdf->bits_rate_levels_Q6[sigtype * 9 + k];
         for (int i = 0; i < iter; i++) sumBits_Q6 += nRshifts[i] > 0 ? nBits[18 + 1] : nBits[sum_pulses[i]];
         if (sumBits_Q6 < minSumBits_Q6) { minSumBits_Q6 = sumBits_Q6; RateLevelIndex = k; }
     }
-    sx_rc_enc(rc, RateLevelIndex, &T_cdf_rate_levels[sigtype * 10]);
-    const u16* cdf_ptr = &T_cdf_pulses_per_block[RateLevelIndex * 21];
+    sx_rc_enc(rc, RateLevelIndex, &cdf->cdf_rate_levels[sigtype * 10]);
+    const u16* cdf_ptr = &cdf->cdf_pulses_per_block[RateLevelIndex * 21];
     for (int i = 0; i < iter; i++) {
         if (nRshifts[i] == 0) {
             sx_rc_enc(rc, sum_pulses[i], cdf_ptr);
         } else {
             sx_rc_enc(rc, 18 + 1, cdf_ptr);
-            for (int k = 0; k < nRshifts[i] - 1; k++) sx_rc_enc(rc, 18 + 1, &T_cdf_pulses_per_block[9 * 21]);
-            sx_rc_enc(rc, sum_pulses[i], &T_cdf_pulses_per_block[9 * 21]);
+            for (int k = 0; k < nRshifts[i] - 1; k++) sx_rc_enc(rc, 18 + 1, &cdf->cdf_pulses_per_block[9 * 21]);
+            sx_rc_enc(rc, sum_pulses[i], &cdf->cdf_pulses_per_block[9 * 21]);
         }
     }
     for (int i = 0; i < iter; i++)
-        if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16]);
+        if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16], cdf);
     for (int i = 0; i < iter; i++) {
         if (nRshifts[i] > 0) {
             const i8* pp = &q[i * 16];
             const int nLS = nRshifts[i] - 1;
             for (int k = 0; k < 16; k++) {
                 i32 abs_q = (i8)(pp[k] < 0 ? -pp[k] : pp[k]);
-                for (int j = nLS; j > 0; j--) sx_rc_enc(rc, (abs_q >> j) & 1, T_cdf_lsb);
-                sx_rc_enc(rc, abs_q & 1, T_cdf_lsb);
+                for (int j = nLS; j > 0; j--) sx_rc_enc(rc, (abs_q >> j) & 1, cdf->cdf_lsb);
+                sx_rc_enc(rc, abs_q & 1, cdf->cdf_lsb);
             }
         }
     }
-    u16 cdf[3];
-    cdf[0] = 0;
-    cdf[1] = T_cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
-    cdf[2] = 65535;
+    u16 scdf[3];
+    scdf[0] = 0;
+    scdf[1] = cdf->cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
+    scdf[2] = 65535;
     for (int i = 0; i < SX_FRAME; i++)
-        if (q[i] != 0) sx_rc_enc(rc, ((i32)q[i] >> 15) + 1, cdf);
+        if (q[i] != 0) sx_rc_enc(rc, ((i32)q[i] >> 15) + 1, scdf);
 }
 
 // SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`)
-SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q) {
+SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
+                                const SxCdf* cdf, i16* pw) {
+    SX_IN_LDS(cdf); SX_IN_LDS(x); SX_IN_LDS(q);
     if (frame == 0) {
-        if (writeMDIndex == 1) sx_rc_enc(rc, md, T_cdf_mdindex);
-        sx_rc_enc(rc, 0, T_cdf_fs);                          // SamplingRates_table[0] == 8
+        if (writeMDIndex == 1) sx_rc_enc(rc, md, cdf->cdf_mdindex);
+        sx_rc_enc(rc, 0, cdf->cdf_fs);                          // SamplingRates_table[0] == 8
     }
     const int typeOffset = 2 * x->sigtype + x->QuantOffsetType;
-    if (frame == 0) sx_rc_enc(rc, typeOffset, T_cdf_type_offset);
-    else sx_rc_enc(rc, typeOffset, &T_cdf_type_offset_joint[typeOffsetPrev * 5]);
-    if (frame == 0) sx_rc_enc(rc, x->GainsIndices[0], &T_cdf_gain[x->sigtype * 65]);
-    else sx_rc_enc(rc, x->GainsIndices[0], T_cdf_delta_gain);
-    for (int i = 1; i < SX_NB_SUBFR; i++) sx_rc_enc(rc, x->GainsIndices[i], T_cdf_delta_gain);
-    if (frame == 0) sx_rc_enc(rc, x->DeltaGainsIndices, T_cdf_md_delta_gain);
+    if (frame == 0) sx_rc_enc(rc, typeOffset, cdf->cdf_type_offset);
+    else sx_rc_enc(rc, typeOffset, &cdf->cdf_type_offset_joint[typeOffsetPrev * 5]);
+    if (frame == 0) sx_rc_enc(rc, x->GainsIndices[0], &cdf->cdf_gain[x->sigtype * 65]);
+    else sx_rc_enc(rc, x->GainsIndices[0], cdf->cdf_delta_gain);
+    for (int i = 1; i < SX_NB_SUBFR; i++) sx_rc_enc(rc, x->GainsIndices[i], cdf->cdf_delta_gain);
+    if (frame == 0) sx_rc_enc(rc, x->DeltaGainsIndices, cdf->cdf_md_delta_gain);
     {
         const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
         const i32* nvec = x->sigtype == 0 ? nvec0 : nvec1;
-        const u16* cdf = x->sigtype == 0 ? T_nlsf_cb0_cdf : T_nlsf_cb1_cdf;
+        const u16* ncdf = x->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
         int off = 0;
         for (int s = 0; s < 6; s++) {
-            sx_rc_enc(rc, x->NLSFIndices[s], cdf + off);
+            sx_rc_enc(rc, x->NLSFIndices[s], ncdf + off);
             off += nvec[s] + 1;
         }
     }
-    sx_rc_enc(rc, x->NLSFInterpCoef_Q2, T_cdf_nlsf_interp);
+    sx_rc_enc(rc, x->NLSFInterpCoef_Q2, cdf->cdf_nlsf_interp);
     if (x->sigtype == 0) {
-        sx_rc_enc(rc, x->lagIndex, T_cdf_pitch_lag_nb);
-        sx_rc_enc(rc, x->contourIndex, T_cdf_pitch_contour_nb);
-        sx_rc_enc(rc, x->PERIndex, T_cdf_ltp_per);
-        const u16* gcdf = x->PERIndex == 0 ? T_cdf_ltp_gain0 : (x->PERIndex == 1 ? T_cdf_ltp_gain1 : T_cdf_ltp_gain2);
+        sx_rc_enc(rc, x->lagIndex, cdf->cdf_pitch_lag_nb);
+        sx_rc_enc(rc, x->contourIndex, cdf->cdf_pitch_contour_nb);
+        sx_rc_enc(rc, x->PERIndex, cdf->cdf_ltp_per);
+        const u16* gcdf = x->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (x->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
         for (int k = 0; k < SX_NB_SUBFR; k++) sx_rc_enc(rc, x->LTPIndex[k], gcdf);
-        sx_rc_enc(rc, x->LTP_scaleIndex, T_cdf_ltpscale);
+        sx_rc_enc(rc, x->LTP_scaleIndex, cdf->cdf_ltpscale);
     }
-    sx_rc_enc(rc, x->Seed, T_cdf_seed);
-    sx_encode_pulses(rc, x->sigtype, x->QuantOffsetType, q);
-    sx_rc_enc(rc, x->vadFlag, T_cdf_vadflag);
+    sx_rc_enc(rc, x->Seed, cdf->cdf_seed);
+    sx_encode_pulses(rc, x->sigtype, x->QuantOffsetType, q, cdf, pw);
+    sx_rc_enc(rc, x->vadFlag, cdf->cdf_vadflag);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -387,20 +394,20 @@ SX_FN i32 sx_encode_packet(SxEncHist* hist, SxEncWork* w, const i16* pcm, u8* bi
         wv_sync();
         SX_T(9)
     }
-    // range coding of the two descriptions: description md on lane md
+    // range coding of the two descriptions: description md on lane md, tables served from LDS
+    sx_cdf_load(&w->u.code.cdf);
+    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = (&hist->q[0][0][0])[i];
+    wv_sync();
+    const SxCdf* cdf = &w->u.code.cdf;
     i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};
-#if SX_NLANES == 1
-    for (int md = 0; md < 2; md++)
-#else
-    const int md = SX_LANE & 1;
-#endif
-    {
+    i32 nb_lane = 0, err_lane = 0;
+    SX_PAR(md, 2) {                     // lanes 0 and 1 only: the coder is a serial scalar chain
         SxRangeEnc rc;
         sx_rc_enc_init(&rc, w->u.code.buf[md]);
         for (int frame = 0; frame < 2; frame++) {
             const int prev = frame == 0 ? 0 : 2 * w->idx[0].sigtype + w->idx[0].QuantOffsetType;
-            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &hist->q[frame][md][0]);
-            sx_rc_enc(&rc, frame == 0 ? 1 : 0, T_cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
+            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->u.code.q[frame][md][0], cdf, w->u.code.pulses[md]);
+            sx_rc_enc(&rc, frame == 0 ? 1 : 0, cdf->cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
         }
         i32 nb;
         sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
@@ -409,10 +416,16 @@ SX_FN i32 sx_encode_packet(SxEncHist* hist, SxEncWork* w, const i16* pcm, u8* bi
         nBytes_md[md] = nb;
         err_md[md] = rc.error;
 #else
-        nBytes_md[0] = wv_bcast(nb, 0); nBytes_md[1] = wv_bcast(nb, 1);
-        err_md[0] = wv_bcast(rc.error, 0); err_md[1] = wv_bcast(rc.error, 1);
+        nb_lane = nb;
+        err_lane = rc.error;
 #endif
     }
+#if SX_NLANES != 1
+    nBytes_md[0] = wv_bcast(nb_lane, 0); nBytes_md[1] = wv_bcast(nb_lane, 1);
+    err_md[0] = wv_bcast(err_lane, 0); err_md[1] = wv_bcast(err_lane, 1);
+#else
+    (void)nb_lane; (void)err_lane;
+#endif
     wv_sync();
     SX_T(10)
     const i32 total = nBytes_md[0] + nBytes_md[1] + 8;

@@ -846,7 +846,9 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     const int QA = 25, MAX_RSHIFTS = 32 - 25, MIN_RSHIFTS = -16;
     const int L = subfr_length;
     i32 C0, rshifts;
+    SX_T_BEGIN
     sx_sum_sqr_shift(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
+    SX_T(23)
     if (rshifts > MAX_RSHIFTS) {
         C0 = sx_shl(C0, rshifts - MAX_RSHIFTS);
         rshifts = MAX_RSHIFTS;
@@ -888,6 +890,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         bw->Cl[k] = v;
         bw->Af[k] = 0;
     }
+    SX_T(24)
     const i32 CA0 = sx_add(sx_add(C0, sx_smmul(WhiteNoiseFrac_Q32, C0)), 1);
     bw->CAf[0] = CA0;
     bw->CAb[0] = CA0;
@@ -1017,6 +1020,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         bw->Af[n] = rc_Q31 >> (31 - QA);
         wv_sync();
     }
+    SX_T(25)
     i32 nrg = bw->CAf[0];
     i32 tmp1 = 1 << 16;
     for (int k = 0; k < D; k++) {
@@ -1152,6 +1156,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
         sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
         sx_bwexpander_32(a_tmp_Q16, order, K_FIND_LPC_CHIRP_Q16);
         wv_sync();
+        SX_T(22)
         int shift = res_tmp_nrg_Q - res_nrg_Q;
         if (shift >= 0) {
             if (shift < 32) res_nrg = res_nrg - (res_tmp_nrg >> shift);
