@@ -830,11 +830,16 @@ struct SxBurgWork {
     i32 p1[64], p2[64];              // per (subframe, k) partial products / per-k reduction terms
     i32 q3[SX_MAX_LPC], q4[SX_MAX_LPC];
 };
+struct SxA2nlsfGrid {                // the two polynomials on the 129-point cosine grid (LDS), plus the grid itself
+    i32 x[129 + 1], yP[129 + 1], yQ[129 + 1];
+};
+
 struct SxLpcWork {
     SxBurgWork burg;
     i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
     i16 a_tmp_Q12[SX_MAX_LPC];
     i32 P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1];
+    SxA2nlsfGrid grid;
 };
 
 // SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49.  The reference's scalar loops over the coefficient index k are
@@ -1061,79 +1066,89 @@ SX_HD void sx_a2nlsf_init(const i32* a_Q16, i32* P, i32* Q, int dd) {
     sx_a2nlsf_trans_poly(Q, dd);
 }
 // SKP_Silk_A2NLSF, SKP_Silk_A2NLSF.c:127
-SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q) {
-    SX_IN_LDS(NLSF); SX_IN_LDS(a_Q16); SX_IN_LDS(P); SX_IN_LDS(Q);
+// SKP_Silk_A2NLSF, SKP_Silk_A2NLSF.c:127.  The reference walks the cosine grid evaluating one polynomial per step; here
+// both polynomials are evaluated on the whole grid up front, lane-parallel, and the (inherently serial) root scan reads
+// those values from LDS -- only the three bisection points per root are evaluated on the spot.
+SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid* g) {
+    SX_IN_LDS(NLSF); SX_IN_LDS(a_Q16); SX_IN_LDS(P); SX_IN_LDS(Q); SX_IN_LDS(g);
     const int dd = d >> 1;
-    sx_a2nlsf_init(a_Q16, P, Q, dd);
-    i32* p = P;
-    i32 xlo = T_lsf_cos_Q12[0], ylo = sx_a2nlsf_eval_poly(p, xlo, dd), xhi, yhi;
-    int root_ix;
-    if (ylo < 0) {
-        NLSF[0] = 0;
-        p = Q;
-        ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
-        root_ix = 1;
-    } else {
-        root_ix = 0;
-    }
-    int k = 1, i = 0;
-    for (;;) {
-        xhi = T_lsf_cos_Q12[k];
-        yhi = sx_a2nlsf_eval_poly(p, xhi, dd);
-        if ((ylo <= 0 && yhi >= 0) || (ylo >= 0 && yhi <= 0)) {
-            i32 ffrac = -256;
-            for (int m = 0; m < 3; m++) {
-                i32 xmid = sx_rshift_round(xlo + xhi, 1);
-                i32 ymid = sx_a2nlsf_eval_poly(p, xmid, dd);
-                if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) {
-                    xhi = xmid;
-                    yhi = ymid;
-                } else {
-                    xlo = xmid;
-                    ylo = ymid;
-                    ffrac = ffrac + (128 >> m);
-                }
-            }
-            if (sx_abs(ylo) < 65536) {
-                i32 den = ylo - yhi;
-                i32 nom = sx_shl(ylo, 8 - 3) + (den >> 1);
-                if (den != 0) ffrac += nom / den;
-            } else {
-                ffrac += ylo / ((ylo - yhi) >> (8 - 3));
-            }
-            NLSF[root_ix] = sx_min(sx_shl(k, 8) + ffrac, 32767);
-            root_ix++;
-            if (root_ix >= d) break;
-            p = (root_ix & 1) ? Q : P;
-            xlo = T_lsf_cos_Q12[k - 1];
-            ylo = sx_shl(1 - (root_ix & 2), 12);
+    int i = 0;
+    for (;;) {                               // one pass per bandwidth-expansion retry (A2NLSF.c:259-281)
+        sx_a2nlsf_init(a_Q16, P, Q, dd);
+        wv_sync();
+        SX_PAR(k, 129) {
+            const i32 x = T_lsf_cos_Q12[k];
+            g->x[k] = x;
+            g->yP[k] = sx_a2nlsf_eval_poly(P, x, dd);
+            g->yQ[k] = sx_a2nlsf_eval_poly(Q, x, dd);
+        }
+        wv_sync();
+        const i32* p = P;
+        const i32* yp = g->yP;
+        i32 xlo = g->x[0], ylo = yp[0], xhi, yhi;
+        int root_ix;
+        if (ylo < 0) {
+            NLSF[0] = 0;
+            p = Q;
+            yp = g->yQ;
+            ylo = yp[0];
+            root_ix = 1;
         } else {
-            k++;
-            xlo = xhi;
-            ylo = yhi;
-            if (k > 128) {
-                i++;
-                if (i > 30) {
-                    NLSF[0] = (1 << 15) / (d + 1);
-                    for (k = 1; k < d; k++) NLSF[k] = sx_smulbb(k + 1, NLSF[0]);
-                    return;
+            root_ix = 0;
+        }
+        int k = 1;
+        bool retry = false;
+        for (;;) {
+            xhi = g->x[k];
+            yhi = yp[k];
+            if ((ylo <= 0 && yhi >= 0) || (ylo >= 0 && yhi <= 0)) {
+                i32 ffrac = -256;
+                for (int m = 0; m < 3; m++) {
+                    i32 xmid = sx_rshift_round(xlo + xhi, 1);
+                    i32 ymid = sx_a2nlsf_eval_poly(p, xmid, dd);
+                    if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) {
+                        xhi = xmid;
+                        yhi = ymid;
+                    } else {
+                        xlo = xmid;
+                        ylo = ymid;
+                        ffrac = ffrac + (128 >> m);
+                    }
                 }
-                sx_bwexpander_32(a_Q16, d, 65536 - sx_smulbb(10 + i, i));
-                sx_a2nlsf_init(a_Q16, P, Q, dd);
-                p = P;
-                xlo = T_lsf_cos_Q12[0];
-                ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
-                if (ylo < 0) {
-                    NLSF[0] = 0;
-                    p = Q;
-                    ylo = sx_a2nlsf_eval_poly(p, xlo, dd);
-                    root_ix = 1;
+                if (sx_abs(ylo) < 65536) {
+                    i32 den = ylo - yhi;
+                    i32 nom = sx_shl(ylo, 8 - 3) + (den >> 1);
+                    if (den != 0) ffrac += nom / den;
                 } else {
-                    root_ix = 0;
+                    ffrac += ylo / ((ylo - yhi) >> (8 - 3));
                 }
-                k = 1;
+                NLSF[root_ix] = sx_min(sx_shl(k, 8) + ffrac, 32767);
+                root_ix++;
+                if (root_ix >= d) break;
+                if (root_ix & 1) { p = Q; yp = g->yQ; } else { p = P; yp = g->yP; }
+                xlo = g->x[k - 1];
+                ylo = sx_shl(1 - (root_ix & 2), 12);
+            } else {
+                k++;
+                xlo = xhi;
+                ylo = yhi;
+                if (k > 128) {
+                    i++;
+                    if (i > 30) {
+                        NLSF[0] = (1 << 15) / (d + 1);
+                        for (k = 1; k < d; k++) NLSF[k] = sx_smulbb(k + 1, NLSF[0]);
+                        wv_sync();
+                        return;
+                    }
+                    wv_sync();
+                    sx_bwexpander_32(a_Q16, d, 65536 - sx_smulbb(10 + i, i));
+                    retry = true;
+                    break;
+                }
             }
         }
+        wv_sync();
+        if (!retry) return;
     }
 }
 
@@ -1164,7 +1179,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
             res_nrg = (res_nrg >> (-shift)) - res_tmp_nrg;
             res_nrg_Q = res_tmp_nrg_Q;
         }
-        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q);
+        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q, &lw->grid);
         wv_sync();
         SX_T(21)
         for (int k = 3; k >= 0; k--) {
@@ -1199,7 +1214,7 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
         }
     }
     SX_T(18)
-    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order, lw->P, lw->Q);
+    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order, lw->P, lw->Q, &lw->grid);
     wv_sync();
 }
 
