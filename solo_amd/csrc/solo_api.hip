@@ -32,6 +32,21 @@ __global__ void __launch_bounds__(64) solo_dec_init_kernel(SxDecState* states, i
 }
 
 // Decoder: rows D0-D8.  blockIdx.x = stream.
+// state record HBM <-> LDS (whole launch) and the entropy tables
+__device__ __forceinline__ void solo_dec_enter(SxDecWork* w, const SxDecState* rec) {
+    const i32* src = (const i32*)rec;
+    i32* dst = (i32*)&w->st;
+    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
+    sx_cdf_load(&w->cdf);
+    wv_sync();
+}
+__device__ __forceinline__ void solo_dec_leave(SxDecWork* w, SxDecState* rec) {
+    wv_sync();
+    const i32* src = (const i32*)&w->st;
+    i32* dst = (i32*)rec;
+    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
+}
+
 __global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, const u8* __restrict__ bits,
                                                          const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                          int n_streams, int n_packets, int slot, int useMDIndex,
@@ -39,7 +54,7 @@ __global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, con
     __shared__ SxDecWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    SxDecState* st = &states[s];
+    solo_dec_enter(&w, &states[s]);
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
@@ -55,10 +70,11 @@ __global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, con
         else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
         else { lostflag = 1; a0 = n0; a1 = n1; }
         i16* out = pcm + pk * SX_PACKET;
-        int ret = sx_decode_packet(st, &w, ptr, a0, a1, lostflag, useMDIndex, out);
+        int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
+    solo_dec_leave(&w, &states[s]);
     if (status && SX_LANE == 0) status[s] = first_err;
 }
 
@@ -299,7 +315,9 @@ void* AGR_Sate_Decoder_Init(USER_Ctrl_dec* dec_Ctrl) {
 __global__ void __launch_bounds__(64) solo_decode_raw_kernel(SxDecState* st, const u8* bits, int n0, int n1, int lostflag,
                                                              int useMDIndex, i16* pcm, i32* status) {
     __shared__ SxDecWork w;
-    int ret = sx_decode_packet(st, &w, bits, n0, n1, lostflag, useMDIndex, pcm);
+    solo_dec_enter(&w, st);
+    int ret = sx_decode_packet(&w, bits, n0, n1, lostflag, useMDIndex, pcm);
+    solo_dec_leave(&w, st);
     if (SX_LANE == 0) *status = ret;
 }
 

@@ -16,6 +16,7 @@
 #pragma once
 #include "solo_common.h"
 #include "solo_rc.h"
+#include "solo_cdf.h"
 
 #define SX_PACKET 640            // 40 ms @ 16 kHz
 #define SX_BAND 320              // samples per band per packet
@@ -106,7 +107,11 @@ struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h
     i32 LTP_scale_Q14;
     i32 PERIndex, RateLevelIndex, QuantOffsetType, sigtype, MDIndex, NLSFInterpCoef_Q2;
 };
+#define SX_DEC_PAYLOAD_LDS 1100     // packets up to this size are staged in LDS (the reference harness caps at 1024 + HB)
 struct SxDecWork {
+    SxDecState st;                  // the stream's state: HBM record -> LDS at launch start, back at the end
+    SxCdf cdf;                      // entropy-coding tables (loaded once per launch)
+    u8 payload[SX_DEC_PAYLOAD_LDS + 4];
     SxDecCtrl ctrl;
     i32 pulses[2][SX_FRAME];
     i32 res_Q10[SX_FRAME];          // LPC residual of the current frame
@@ -152,52 +157,53 @@ SX_HD void sx_gains_dequant(i32* gain_Q16, const i32* ind, i32* prev_ind, int co
 }
 
 // decode_split + SKP_Silk_shell_decoder, SKP_Silk_shell_coder.c:59-155 (scalars stay in registers)
-SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* table) {
+SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* table, const SxCdf* cdf) {
     if (p > 0) {
-        *c1 = sx_rc_dec(rc, &table[T_shell_offsets[p]], p >> 1);
+        *c1 = sx_rc_dec(rc, &table[cdf->shell_offsets[p]], p >> 1);
         *c2 = p - *c1;
     } else {
         *c1 = 0;
         *c2 = 0;
     }
 }
-SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4) {
+SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cdf) {
     i32 p3[2], p2[4], p1[8], a, b;
-    sx_shell_split(&p3[0], &p3[1], rc, pulses4, T_cdf_shell3);
-    sx_shell_split(&p2[0], &p2[1], rc, p3[0], T_cdf_shell2);
-    sx_shell_split(&p1[0], &p1[1], rc, p2[0], T_cdf_shell1);
-    sx_shell_split(&a, &b, rc, p1[0], T_cdf_shell0); q[0] = a; q[1] = b;
-    sx_shell_split(&a, &b, rc, p1[1], T_cdf_shell0); q[2] = a; q[3] = b;
-    sx_shell_split(&p1[2], &p1[3], rc, p2[1], T_cdf_shell1);
-    sx_shell_split(&a, &b, rc, p1[2], T_cdf_shell0); q[4] = a; q[5] = b;
-    sx_shell_split(&a, &b, rc, p1[3], T_cdf_shell0); q[6] = a; q[7] = b;
-    sx_shell_split(&p2[2], &p2[3], rc, p3[1], T_cdf_shell2);
-    sx_shell_split(&p1[4], &p1[5], rc, p2[2], T_cdf_shell1);
-    sx_shell_split(&a, &b, rc, p1[4], T_cdf_shell0); q[8] = a; q[9] = b;
-    sx_shell_split(&a, &b, rc, p1[5], T_cdf_shell0); q[10] = a; q[11] = b;
-    sx_shell_split(&p1[6], &p1[7], rc, p2[3], T_cdf_shell1);
-    sx_shell_split(&a, &b, rc, p1[6], T_cdf_shell0); q[12] = a; q[13] = b;
-    sx_shell_split(&a, &b, rc, p1[7], T_cdf_shell0); q[14] = a; q[15] = b;
+    sx_shell_split(&p3[0], &p3[1], rc, pulses4, cdf->cdf_shell3, cdf);
+    sx_shell_split(&p2[0], &p2[1], rc, p3[0], cdf->cdf_shell2, cdf);
+    sx_shell_split(&p1[0], &p1[1], rc, p2[0], cdf->cdf_shell1, cdf);
+    sx_shell_split(&a, &b, rc, p1[0], cdf->cdf_shell0, cdf); q[0] = a; q[1] = b;
+    sx_shell_split(&a, &b, rc, p1[1], cdf->cdf_shell0, cdf); q[2] = a; q[3] = b;
+    sx_shell_split(&p1[2], &p1[3], rc, p2[1], cdf->cdf_shell1, cdf);
+    sx_shell_split(&a, &b, rc, p1[2], cdf->cdf_shell0, cdf); q[4] = a; q[5] = b;
+    sx_shell_split(&a, &b, rc, p1[3], cdf->cdf_shell0, cdf); q[6] = a; q[7] = b;
+    sx_shell_split(&p2[2], &p2[3], rc, p3[1], cdf->cdf_shell2, cdf);
+    sx_shell_split(&p1[4], &p1[5], rc, p2[2], cdf->cdf_shell1, cdf);
+    sx_shell_split(&a, &b, rc, p1[4], cdf->cdf_shell0, cdf); q[8] = a; q[9] = b;
+    sx_shell_split(&a, &b, rc, p1[5], cdf->cdf_shell0, cdf); q[10] = a; q[11] = b;
+    sx_shell_split(&p1[6], &p1[7], rc, p2[3], cdf->cdf_shell1, cdf);
+    sx_shell_split(&a, &b, rc, p1[6], cdf->cdf_shell0, cdf); q[12] = a; q[13] = b;
+    sx_shell_split(&a, &b, rc, p1[7], cdf->cdf_shell0, cdf); q[14] = a; q[15] = b;
 }
 
 // SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64)
-SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q) {
+SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* cdf) {
+    SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf);
     const int iter = SX_FRAME / 16;
     i32 sum_pulses[SX_FRAME / 16], nLshifts[SX_FRAME / 16];
-    c->RateLevelIndex = sx_rc_dec(rc, &T_cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
-    const u16* cdf_ptr = &T_cdf_pulses_per_block[c->RateLevelIndex * 21];
+    c->RateLevelIndex = sx_rc_dec(rc, &cdf->cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
+    const u16* cdf_ptr = &cdf->cdf_pulses_per_block[c->RateLevelIndex * 21];
     for (int i = 0; i < iter; i++) {
         nLshifts[i] = 0;
         sum_pulses[i] = sx_rc_dec(rc, cdf_ptr, T_CDF_MID_PULSES_PER_BLOCK);
         while (sum_pulses[i] == 18 + 1) {
             nLshifts[i]++;
-            sum_pulses[i] = sx_rc_dec(rc, &T_cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
+            sum_pulses[i] = sx_rc_dec(rc, &cdf->cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
             if (rc->error) break;   // (reference would spin on the zero returned after an error only until != 19; 0 != 19)
         }
     }
     for (int i = 0; i < iter; i++) {
         if (sum_pulses[i] > 0) {
-            sx_shell_decoder(&q[i * 16], rc, sum_pulses[i]);
+            sx_shell_decoder(&q[i * 16], rc, sum_pulses[i], cdf);
         } else {
             for (int k = 0; k < 16; k++) q[i * 16 + k] = 0;
         }
@@ -209,20 +215,20 @@ SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q) {
                 i32 abs_q = q[i * 16 + k];
                 for (int j = 0; j < nLS; j++) {
                     abs_q = sx_shl(abs_q, 1);
-                    abs_q += sx_rc_dec(rc, T_cdf_lsb, 1);
+                    abs_q += sx_rc_dec(rc, cdf->cdf_lsb, 1);
                 }
                 q[i * 16 + k] = abs_q;
             }
         }
     }
     // signs
-    u16 cdf[3];
-    cdf[0] = 0;
-    cdf[1] = T_cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
-    cdf[2] = 65535;
+    u16 scdf[3];
+    scdf[0] = 0;
+    scdf[1] = cdf->cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
+    scdf[2] = 65535;
     for (int i = 0; i < SX_FRAME; i++) {
         if (q[i] > 0) {
-            i32 data = sx_rc_dec(rc, cdf, 1);
+            i32 data = sx_rc_dec(rc, scdf, 1);
             q[i] *= (data << 1) - 1;
         }
     }
@@ -245,30 +251,31 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 }
 
 // SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
-SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex) {
+SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf);
     i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], pNLSF_Q15[SX_LPC], pNLSF0_Q15[SX_LPC], DeltaGainIndices;
     SxDecDesc* md = &st->md[kDesp];
     if (st->nFramesDecoded == 0) {
-        if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, T_cdf_mdindex, T_CDF_MID_MDINDEX);
-        Ix = sx_rc_dec(rc, T_cdf_fs, T_CDF_MID_FS);
+        if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, cdf->cdf_mdindex, T_CDF_MID_MDINDEX);
+        Ix = sx_rc_dec(rc, cdf->cdf_fs, T_CDF_MID_FS);
         if (Ix != 0) {  // only the 8 kHz NB mode exists in this build (reference: decoder_set_fs to 12/16/24 kHz)
             if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
             return;
         }
-        Ix = sx_rc_dec(rc, T_cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
+        Ix = sx_rc_dec(rc, cdf->cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
     } else {
-        Ix = sx_rc_dec(rc, &T_cdf_type_offset_joint[md->typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
+        Ix = sx_rc_dec(rc, &cdf->cdf_type_offset_joint[md->typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
     }
     SX_TRACE(1);
     c->sigtype = Ix >> 1;
     c->QuantOffsetType = Ix & 1;
     md->typeOffsetPrev = Ix;
 
-    if (st->nFramesDecoded == 0) GainsIndices[0] = sx_rc_dec(rc, &T_cdf_gain[c->sigtype * 65], T_CDF_MID_GAIN);
-    else GainsIndices[0] = sx_rc_dec(rc, T_cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
-    for (int i = 1; i < SX_NB_SUBFR; i++) GainsIndices[i] = sx_rc_dec(rc, T_cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    if (st->nFramesDecoded == 0) GainsIndices[0] = sx_rc_dec(rc, &cdf->cdf_gain[c->sigtype * 65], T_CDF_MID_GAIN);
+    else GainsIndices[0] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    for (int i = 1; i < SX_NB_SUBFR; i++) GainsIndices[i] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
     if (st->nFramesDecoded == 0) {
-        DeltaGainIndices = sx_rc_dec(rc, T_cdf_md_delta_gain, T_CDF_MID_MD_DELTA_GAIN);
+        DeltaGainIndices = sx_rc_dec(rc, cdf->cdf_md_delta_gain, T_CDF_MID_MD_DELTA_GAIN);
         md->prevDeltaGainIndex = DeltaGainIndices;
     } else {
         DeltaGainIndices = md->prevDeltaGainIndex;
@@ -280,17 +287,17 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     {
         const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
         const i32* nvec = c->sigtype == 0 ? nvec0 : nvec1;
-        const u16* cdf = c->sigtype == 0 ? T_nlsf_cb0_cdf : T_nlsf_cb1_cdf;
+        const u16* ncdf = c->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
         const i32* mid = c->sigtype == 0 ? T_nlsf_cb0_cdf_mid : T_nlsf_cb1_cdf_mid;
         int off = 0;
         for (int s = 0; s < 6; s++) {
-            NLSFIndices[s] = sx_rc_dec(rc, cdf + off, mid[s]);
+            NLSFIndices[s] = sx_rc_dec(rc, ncdf + off, mid[s]);
             off += nvec[s] + 1;
         }
     }
     SX_TRACE(3);
     sx_nlsf_msvq_decode(pNLSF_Q15, c->sigtype, NLSFIndices);
-    c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, T_cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
+    c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, cdf->cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
     if (st->first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
 
     sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
@@ -308,18 +315,18 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     }
 
     if (c->sigtype == 0) {
-        i32 lagIx = sx_rc_dec(rc, T_cdf_pitch_lag_nb, T_CDF_MID_PITCH_LAG_NB);
-        i32 conIx = sx_rc_dec(rc, T_cdf_pitch_contour_nb, T_CDF_MID_PITCH_CONTOUR_NB);
+        i32 lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag_nb, T_CDF_MID_PITCH_LAG_NB);
+        i32 conIx = sx_rc_dec(rc, cdf->cdf_pitch_contour_nb, T_CDF_MID_PITCH_CONTOUR_NB);
         i32 lag = 2 * 8 + lagIx;   // SKP_Silk_decode_pitch.c:43-50
         for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_stage2[i * 11 + conIx];
-        c->PERIndex = sx_rc_dec(rc, T_cdf_ltp_per, T_CDF_MID_LTP_PER);
+        c->PERIndex = sx_rc_dec(rc, cdf->cdf_ltp_per, T_CDF_MID_LTP_PER);
         const i16* cbk = c->PERIndex == 0 ? T_ltp_vq0_Q14 : (c->PERIndex == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
-        const u16* gcdf = c->PERIndex == 0 ? T_cdf_ltp_gain0 : (c->PERIndex == 1 ? T_cdf_ltp_gain1 : T_cdf_ltp_gain2);
+        const u16* gcdf = c->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (c->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
         for (int k = 0; k < SX_NB_SUBFR; k++) {
             Ix = sx_rc_dec(rc, gcdf, T_cdf_mid_ltp_gain[c->PERIndex]);
             for (int i = 0; i < SX_LTP_ORDER; i++) c->LTPCoef_Q14[k * SX_LTP_ORDER + i] = cbk[Ix * SX_LTP_ORDER + i];
         }
-        Ix = sx_rc_dec(rc, T_cdf_ltpscale, T_CDF_MID_LTPSCALE);
+        Ix = sx_rc_dec(rc, cdf->cdf_ltpscale, T_CDF_MID_LTPSCALE);
         c->LTP_scale_Q14 = T_ltp_scales_Q14[Ix];
     } else {
         for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = 0;
@@ -328,12 +335,12 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
         c->LTP_scale_Q14 = 0;
     }
     SX_TRACE(4);
-    c->Seed = sx_rc_dec(rc, T_cdf_seed, T_CDF_MID_SEED);
+    c->Seed = sx_rc_dec(rc, cdf->cdf_seed, T_CDF_MID_SEED);
     SX_TRACE(5);
-    sx_decode_pulses(rc, c, q);
+    sx_decode_pulses(rc, c, q, cdf);
     SX_TRACE(6);
-    st->vadFlag = sx_rc_dec(rc, T_cdf_vadflag, T_CDF_MID_VADFLAG);
-    st->FrameTermination = sx_rc_dec(rc, T_cdf_frame_term, T_CDF_MID_FRAME_TERM);
+    st->vadFlag = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
+    st->FrameTermination = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
 
     i32 nBytesUsed;
     sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytesUsed);
@@ -346,6 +353,7 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
 
 // SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
 SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
+    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(xq);
     SxDecCtrl* c = &w->ctrl;
     const int NLSF_interpolation_flag = c->NLSFInterpCoef_Q2 < 4 ? 1 : 0;
     i32* pexc_Q10 = st->exc_Q10;
@@ -474,6 +482,7 @@ SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
 
 // SKP_Silk_PLC_conceal, SKP_Silk_PLC.c:146
 SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
+    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(signal);
     SxPLC* p = &st->plc;
     SxDecCtrl* c = &w->ctrl;
     i16* exc_buf = w->tmp16;
@@ -588,6 +597,7 @@ SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
 // aligned base, modulo 2 (sum_sqr_shift's alignment branch); the low-band buffer of the reference is
 // a stack array advanced by 160 samples per frame, i.e. always even.
 SX_FN void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
+    SX_IN_LDS(st); SX_IN_LDS(signal);
     SxPLC* p = &st->plc;
     if (st->lossCnt) {
         sx_sum_sqr_shift(&p->conc_energy, &p->conc_energy_shift, signal, length, 0);
@@ -636,6 +646,7 @@ SX_HD void sx_lpc_synthesis_filter(const i16* in, const i16* A_Q12, i32 Gain_Q26
 
 // SKP_Silk_CNG, SKP_Silk_CNG.c:75
 SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
+    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(signal);
     SxCNG* g = &st->cng;
     SxDecCtrl* c = &w->ctrl;
     if (g->fs_kHz != 8) {
@@ -699,6 +710,7 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
 // (SKP_Silk_errors.h) on a corrupt payload.
 SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
                                i32 nB0, i32 nB1, int useMDIndex, i16* pOut) {
+    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(pOut);
     int ret = 0;
     SxDecCtrl* c = &w->ctrl;
     if (st->moreInternalDecoderFrames == 0) st->nFramesDecoded = 0;
@@ -712,8 +724,8 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             sx_rc_dec_init(&rc[0], payload, nB0);
             if (desp_type > 1) sx_rc_dec_init(&rc[1], payload + nB0, nB1);
         }
-        sx_decode_parameters(st, c, &rc[0], w->pulses[0], 0, useMDIndex);
-        if (desp_type > 1) sx_decode_parameters(st, c, &rc[1], w->pulses[1], 1, useMDIndex);
+        sx_decode_parameters(st, c, &rc[0], w->pulses[0], 0, useMDIndex, &w->cdf);
+        if (desp_type > 1) sx_decode_parameters(st, c, &rc[1], w->pulses[1], 1, useMDIndex, &w->cdf);
 
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
         i32 inv_gain_p1_Q16 = inv_gain_Q16;
@@ -803,6 +815,7 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
 
 // AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40.  hb == NULL-equivalent when lost.
 SX_FN void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* OutHigh, const i32* residue_Q10, int lostflag) {
+    SX_IN_LDS(st); SX_IN_LDS(OutHigh); SX_IN_LDS(residue_Q10);
     i32 QHB_LSP[SX_HB_LPC];
     i32 QGain[4];
     i16 lpc[SX_MAX_LPC];
@@ -842,6 +855,7 @@ SX_FN void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* Ou
 //   y[2k+1] = sat( pshr15( sum_m a[2m+1] * s1[k-m] +   a[2m+1] * s2[k-m] ) )      m = 0..31
 // lo/hi hold [32 history | 320 new] samples.  32-bit accumulation wraps, so summation order is free.
 SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
+    SX_IN_LDS(lo); SX_IN_LDS(hi);
     SX_PAR(k, SX_BAND) {
         i32 y0 = 0, y1 = 0;
         const i16* s1 = lo + SX_QMF_HIST + k;
@@ -866,8 +880,9 @@ SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
 //   lostflag 3: bits = MD2|HB,     nBytes0 = len(MD2)+8, nBytes1 = 0
 //   lostflag 1: packet lost (bits ignored)
 // Returns 0 / -1 / negative SILK code like the reference.
-SX_HD int sx_decode_packet(SxDecState* st, SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes1, int lostflag,
+SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes1, int lostflag,
                            int useMDIndex, i16* pcm_out) {
+    SxDecState* st = &w->st;
     if (nBytes0 <= 0) return -1;
     i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - SX_HB_BYTES;
     i32 nB1 = nBytes1 ? nBytes1 - SX_HB_BYTES : 0;
@@ -876,6 +891,11 @@ SX_HD int sx_decode_packet(SxDecState* st, SxDecWork* w, const u8* bits, i32 nBy
     SxRangeDec rc[2];
     rc[0].error = 0; rc[1].error = 0;
     rc[0].bufferLength = 0; rc[1].bufferLength = 0;
+    // the payload is read byte by byte by a serial coder: stage it in LDS
+    if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS) {
+        SX_PAR(i, nBytes0) w->payload[i] = bits[i];
+        bits = w->payload;
+    }
     rc[0].buf = bits; rc[1].buf = bits;
 #ifdef SX_RC_LOG
     rc[0].log = st->rclog; rc[0].nlog = 0; rc[1].log = 0; rc[1].nlog = 0;

@@ -26,7 +26,11 @@ void* emu_dec_create(int useMDIndex) {
 void emu_dec_destroy(void* h) { free(h); }
 int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int lostflag, int16_t* pcm) {
     EmuDec* d = (EmuDec*)h;
-    return sx_decode_packet(&d->st, &d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm);
+    d->w.st = d->st;                                      // the kernel keeps state + tables in LDS for a launch
+    sx_cdf_load(&d->w.cdf);
+    int r = sx_decode_packet(&d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm);
+    d->st = d->w.st;
+    return r;
 }
 int emu_sizeof_dec_state() { return (int)sizeof(SxDecState); }
 int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
