@@ -37,6 +37,11 @@
 #define SX_RL(arr, src) __builtin_amdgcn_readlane((arr)[0], (src))
 #define SX_RL2(arr, j, src) __builtin_amdgcn_readlane((arr)[0][j], (src))
 #endif
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)      // wave-uniform value -> scalar register
+#else
+#define SX_UNIFORM(v) (v)
+#endif
 
 struct SxRing {                      // decision-delay histories of one track: one cell per (ring position, state slot)
     i32 Rand[SX_DD_DELAY][SX_DD_STATES];
@@ -191,6 +196,15 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
         i32 HarmShapeFIRPacked_Q14 = c->HarmShapeGain_Q14[k] >> 2;
         HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[k] >> 1, 16);
         const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k], Gain_Q16 = c->Gains_Q16[k];
+        // filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form and held in
+        // scalar registers for the 40 samples
+        i32 Apre[SX_LPC], ARpre[SX_SHAPE_ORDER], Bpre[SX_LTP_ORDER];
+        for (int j = 0; j < SX_LPC; j++) Apre[j] = SX_UNIFORM(sx_pre16(A_Q12[j]));
+        for (int j = 0; j < SX_SHAPE_ORDER; j++) ARpre[j] = SX_UNIFORM(sx_pre16(AR_shp_Q13[j]));
+        for (int j = 0; j < SX_LTP_ORDER; j++) Bpre[j] = SX_UNIFORM(sx_pre16(B_Q14[j]));
+        const i32 warp_pre = sx_pre16(SX_WARPING_Q16), Tilt_pre = SX_UNIFORM(sx_pre16(Tilt_Q14));
+        const i32 LFb_pre = SX_UNIFORM(sx_pre16(LF_shp_Q14)), LFt_pre = SX_UNIFORM((i32)((u32)LF_shp_Q14 & 0xFFFF0000u));
+        const i32 Hb_pre = SX_UNIFORM(sx_pre16(HarmShapeFIRPacked_Q14)), Ht_pre = SX_UNIFORM((i32)((u32)HarmShapeFIRPacked_Q14 & 0xFFFF0000u));
         int rewhite = 0;
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
         inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
@@ -295,39 +309,39 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                 i32 LTP_pred_Q14 = 0;
                 if (voiced) {
                     const i32* pl = &g->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2 + i];
-                    for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlawb(LTP_pred_Q14, pl[-j], B_Q14[j]);
+                    for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, pl[-j], Bpre[j]);
                 }
                 i32 n_LTP_Q14 = 0;
                 if (lagC > 0) {              // the reference tests the CENTRE lag for every track (NSQ_del_dec.c:1436-1446)
                     const i32* ps = &g->shp[t][shp_base - lag_me + 1 + i];
-                    n_LTP_Q14 = sx_smulwb(sx_add(ps[0], ps[-2]), HarmShapeFIRPacked_Q14);
-                    n_LTP_Q14 = sx_smlawt(n_LTP_Q14, ps[-1], HarmShapeFIRPacked_Q14);
+                    n_LTP_Q14 = sx_smulw_pre(sx_add(ps[0], ps[-2]), Hb_pre);
+                    n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, ps[-1], Ht_pre);
                     n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
                 }
                 i32 LPC_pred_Q10 = 0;
-                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlawb(LPC_pred_Q10, sLPC[li][j], A_Q12[j]);
+                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlaw_pre(LPC_pred_Q10, sLPC[li][j], Apre[j]);
                 // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place
-                const i32 warping_Q16 = SX_WARPING_Q16;
-                i32 tmp2 = sx_smlawb(sLPC[li][0], sAR2[li][0], warping_Q16);
-                i32 tmp1 = sx_smlawb(sAR2[li][0], sAR2[li][1] - tmp2, warping_Q16);
+                i32 tmp2 = sx_smlaw_pre(sLPC[li][0], sAR2[li][0], warp_pre);
+                i32 tmp1 = sx_smlaw_pre(sAR2[li][0], sAR2[li][1] - tmp2, warp_pre);
                 sAR2[li][0] = tmp2;
-                i32 n_AR_Q10 = sx_smulwb(tmp2, AR_shp_Q13[0]);
+                i32 n_AR_Q10 = sx_smulw_pre(tmp2, ARpre[0]);
+#pragma unroll
                 for (int j = 2; j < SX_SHAPE_ORDER; j += 2) {
-                    tmp2 = sx_smlawb(sAR2[li][j - 1], sAR2[li][j] - tmp1, warping_Q16);
+                    tmp2 = sx_smlaw_pre(sAR2[li][j - 1], sAR2[li][j] - tmp1, warp_pre);
                     sAR2[li][j - 1] = tmp1;
-                    n_AR_Q10 = sx_smlawb(n_AR_Q10, tmp1, AR_shp_Q13[j - 1]);
-                    tmp1 = sx_smlawb(sAR2[li][j], sAR2[li][j + 1] - tmp2, warping_Q16);
+                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[j - 1]);
+                    tmp1 = sx_smlaw_pre(sAR2[li][j], sAR2[li][j + 1] - tmp2, warp_pre);
                     sAR2[li][j] = tmp2;
-                    n_AR_Q10 = sx_smlawb(n_AR_Q10, tmp2, AR_shp_Q13[j]);
+                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp2, ARpre[j]);
                 }
                 sAR2[li][SX_SHAPE_ORDER - 1] = tmp1;
-                n_AR_Q10 = sx_smlawb(n_AR_Q10, tmp1, AR_shp_Q13[SX_SHAPE_ORDER - 1]);
+                n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[SX_SHAPE_ORDER - 1]);
                 n_AR_Q10 = n_AR_Q10 >> 1;
-                n_AR_Q10 = sx_smlawb(n_AR_Q10, LF_AR[li], Tilt_Q14);
+                n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, LF_AR[li], Tilt_pre);
                 // newest shaping sample of this state's lineage
                 const int slot = (int)(sx_sel4u(lin0, lin1, lin2, lin3, s) >> (2 * smpl_buf_idx)) & 3;
-                i32 n_LF_Q10 = sx_shl(sx_smulwb(w->ring[t].Shape_Q10[smpl_buf_idx][slot], LF_shp_Q14), 2);
-                n_LF_Q10 = sx_smlawt(n_LF_Q10, LF_AR[li], LF_shp_Q14);
+                i32 n_LF_Q10 = sx_shl(sx_smulw_pre(w->ring[t].Shape_Q10[smpl_buf_idx][slot], LFb_pre), 2);
+                n_LF_Q10 = sx_smlaw_pre(n_LF_Q10, LF_AR[li], LFt_pre);
                 // Agora_Silk_DelDecScale (NSQ_del_dec.c:1668) + Agora_Silk_DoPred_And_Shap (Agora_SILK_func.c:143)
                 const i32 x_sc_Q10 = sx_smulbb(x[k * SX_SUBFR + i], inv_gain_Q16) >> 6;
                 i32 tmp = sx_sub(LTP_pred_Q14, n_LTP_Q14) >> 4;

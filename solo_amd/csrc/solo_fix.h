@@ -75,6 +75,10 @@ SX_HD i32 sx_limit(i32 a, i32 l1, i32 l2) {
 // (a * (int16)b) >> 16 written as the high word of a * (b << 16): ONE v_mul_hi_i32 on gfx950 instead of mul_hi + mul_lo + 64-bit shift
 SX_HD i32 sx_smulwb(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i32)((u32)b << 16)) >> 32); }
 SX_HD i32 sx_smlawb(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulwb(a, b)); }
+// the same with the 16-bit factor already moved to the high half (hoisted out of sample loops): bs = (int16)b << 16
+SX_HD i32 sx_pre16(i32 b) { return (i32)((u32)b << 16); }
+SX_HD i32 sx_smulw_pre(i32 a, i32 bs) { return (i32)(((i64)a * (i64)bs) >> 32); }
+SX_HD i32 sx_smlaw_pre(i32 acc, i32 a, i32 bs) { return sx_add(acc, sx_smulw_pre(a, bs)); }
 // SKP_SMULWT: (a * (b >> 16)) >> 16
 SX_HD i32 sx_smulwt(i32 a, i32 b) { return (i32)(((i64)a * (i64)(i32)((u32)b & 0xFFFF0000u)) >> 32); }
 SX_HD i32 sx_smlawt(i32 acc, i32 a, i32 b) { return sx_add(acc, sx_smulwt(a, b)); }
