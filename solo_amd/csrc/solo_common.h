@@ -68,10 +68,13 @@ SX_HD int sx_lpc_inv_pred_gain_QA(i32* invGain_Q30, i32 A_QA[2][SX_MAX_LPC], int
     return 0;
 }
 // SKP_Silk_LPC_inverse_pred_gain (Q12 input), SKP_Silk_LPC_inv_pred_gain.c:113
-SX_HD int sx_lpc_inv_pred_gain(i32* invGain_Q30, const i16* A_Q12, int order) {
-    i32 A[2][SX_MAX_LPC];
+SX_HD int sx_lpc_inv_pred_gain_ws(i32* invGain_Q30, const i16* A_Q12, int order, i32 (*A)[SX_MAX_LPC]) {
     for (int k = 0; k < order; k++) A[order & 1][k] = sx_shl((i32)A_Q12[k], 4);
     return sx_lpc_inv_pred_gain_QA(invGain_Q30, A, order);
+}
+SX_HD int sx_lpc_inv_pred_gain(i32* invGain_Q30, const i16* A_Q12, int order) {
+    i32 A[2][SX_MAX_LPC];
+    return sx_lpc_inv_pred_gain_ws(invGain_Q30, A_Q12, order, A);
 }
 // SKP_Silk_LPC_inverse_pred_gain_Q24, SKP_Silk_LPC_inv_pred_gain.c:134
 SX_HD int sx_lpc_inv_pred_gain_Q24(i32* invGain_Q30, const i32* A_Q24, int order) {
@@ -94,8 +97,9 @@ SX_HD void sx_nlsf2a_find_poly(i32* out, const i32* cLSF, int dd) {
 }
 
 // SKP_Silk_NLSF2A, SKP_Silk_NLSF2A.c:59   (d even, <= 16)
-SX_HD void sx_nlsf2a(i16* a, const i32* NLSF, int d) {
-    i32 cos_LSF_Q20[SX_MAX_LPC], P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1], a32[SX_MAX_LPC];
+#define SX_NLSF2A_WS (SX_MAX_LPC + 2 * (SX_MAX_LPC / 2 + 1) + SX_MAX_LPC + 2 * SX_MAX_LPC)    // words of workspace
+SX_HD void sx_nlsf2a_ws(i16* a, const i32* NLSF, int d, i32* ws) {
+    i32 *cos_LSF_Q20 = ws, *P = ws + SX_MAX_LPC, *Q = P + SX_MAX_LPC / 2 + 1, *a32 = Q + SX_MAX_LPC / 2 + 1;
     for (int k = 0; k < d; k++) {
         i32 f_int = NLSF[k] >> 8;
         i32 f_frac = NLSF[k] - (f_int << 8);
@@ -131,6 +135,28 @@ SX_HD void sx_nlsf2a(i16* a, const i32* NLSF, int d) {
         for (int k = 0; k < d; k++) a32[k] = sx_sat16(a32[k]);
     }
     for (int k = 0; k < d; k++) a[k] = (i16)a32[k];
+}
+
+SX_HD void sx_nlsf2a(i16* a, const i32* NLSF, int d) {
+    i32 ws[SX_NLSF2A_WS];
+    sx_nlsf2a_ws(a, NLSF, d, ws);
+}
+
+// SKP_Silk_NLSF2A_stable, SKP_Silk_NLSF2A_stable.c:31 with caller-provided workspace (SX_NLSF2A_WS words, e.g. in LDS)
+SX_HD void sx_nlsf2a_stable_ws(i16* pAR_Q12, const i32* pNLSF, int order, i32* ws) {
+    i32 invGain_Q30;
+    sx_nlsf2a_ws(pAR_Q12, pNLSF, order, ws);
+    i32 (*A)[SX_MAX_LPC] = (i32 (*)[SX_MAX_LPC])(ws + SX_NLSF2A_WS - 2 * SX_MAX_LPC);
+    int i;
+    for (i = 0; i < 20; i++) {
+        if (sx_lpc_inv_pred_gain_ws(&invGain_Q30, pAR_Q12, order, A) == 1)
+            sx_bwexpander(pAR_Q12, order, 65536 - sx_smulbb(10 + i, i));
+        else
+            break;
+    }
+    if (i == 20) {
+        for (i = 0; i < order; i++) pAR_Q12[i] = 0;
+    }
 }
 
 // SKP_Silk_NLSF2A_stable, SKP_Silk_NLSF2A_stable.c:31

@@ -839,7 +839,16 @@ struct SxLpcWork {
     i32 a_Q16[SX_MAX_LPC], a_tmp_Q16[SX_MAX_LPC], NLSF0_Q15[SX_MAX_LPC];
     i16 a_tmp_Q12[SX_MAX_LPC];
     i32 P[SX_MAX_LPC / 2 + 1], Q[SX_MAX_LPC / 2 + 1];
-    SxA2nlsfGrid grid;
+    union {
+        SxA2nlsfGrid grid;
+        struct {                     // interpolation search: the four candidates side by side
+            i32 NLSF0[4][SX_MAX_LPC];
+            i16 a_Q12[4][SX_MAX_LPC];
+            i32 ws[4][SX_NLSF2A_WS];
+            i16 res[4][2 * (SX_SUBFR + SX_LPC)];
+            i32 nrg[4][2], rsh[4][2];
+        } it;
+    } u;
 };
 
 // SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49.  The reference's scalar loops over the coefficient index k are
@@ -1159,8 +1168,6 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
     SX_IN_LDS(NLSF_Q15); SX_IN_LDS(interpIndex); SX_IN_LDS(prev_NLSFq_Q15); SX_IN_LDS(x); SX_IN_LDS(LPC_res); SX_IN_LDS(lw);
     i32* a_Q16 = lw->a_Q16;
     i32* a_tmp_Q16 = lw->a_tmp_Q16;
-    i32* NLSF0_Q15 = lw->NLSF0_Q15;
-    i16* a_tmp_Q12 = lw->a_tmp_Q12;
     i32 res_nrg, res_tmp_nrg, res_nrg_Q, res_tmp_nrg_Q;
     *interpIndex = 4;
     sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
@@ -1179,17 +1186,42 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
             res_nrg = (res_nrg >> (-shift)) - res_tmp_nrg;
             res_nrg_Q = res_tmp_nrg_Q;
         }
-        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q, &lw->grid);
+        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q, &lw->u.grid);
         wv_sync();
         SX_T(21)
+        // the four interpolation candidates (SKP_Silk_find_LPC_FIX.c:81-140) are evaluated side by side: candidate k on lane k
+        // for the NLSF -> LPC conversion, lane-strided for the whitening filter, lane (k, half) for the residual energies
+        SX_PAR(k, 4) {
+            for (int i = 0; i < order; i++) lw->u.it.NLSF0[k][i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
+            sx_nlsf2a_stable_ws(lw->u.it.a_Q12[k], lw->u.it.NLSF0[k], order, lw->u.it.ws[k]);
+        }
+        wv_sync();
+        {
+            const int len = 2 * subfr_length;
+            SX_PAR(t, 4 * len) {
+                const int k = t / len, n = t - k * len;
+                const i16* B = lw->u.it.a_Q12[k];
+                i32 acc = 0;
+                for (int j = 0; j < order; j++) {
+                    const int u = n - 1 - j;
+                    if (u >= 0) acc = sx_smlabb(acc, x[u], B[j]);
+                }
+                const i32 o = sx_sub_sat32(sx_shl((i32)x[n], 12), acc);
+                lw->u.it.res[k][n] = (i16)sx_sat16(sx_rshift_round(o, 12));
+            }
+        }
+        wv_sync();
+        SX_PAR(kh, 8) {
+            const int k = kh >> 1, h = kh & 1;
+            i32 e, sh;
+            sx_sum_sqr_shift(&e, &sh, lw->u.it.res[k] + order + h * subfr_length, subfr_length - order, 0);
+            lw->u.it.nrg[k][h] = e;
+            lw->u.it.rsh[k][h] = sh;
+        }
+        wv_sync();
         for (int k = 3; k >= 0; k--) {
-            for (int i = 0; i < order; i++) NLSF0_Q15[i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
-            sx_nlsf2a_stable(a_tmp_Q12, NLSF0_Q15, order);
-            sx_lpc_analysis_filter_zero_state(x, a_tmp_Q12, LPC_res, 2 * subfr_length, order);
-            wv_sync();
-            i32 res_nrg0, res_nrg1, rshift0, rshift1, res_nrg_interp, res_nrg_interp_Q;
-            sx_sum_sqr_shift(&res_nrg0, &rshift0, LPC_res + order, subfr_length - order, 0);
-            sx_sum_sqr_shift(&res_nrg1, &rshift1, LPC_res + order + subfr_length, subfr_length - order, 0);
+            i32 res_nrg0 = lw->u.it.nrg[k][0], res_nrg1 = lw->u.it.nrg[k][1], res_nrg_interp, res_nrg_interp_Q;
+            const i32 rshift0 = lw->u.it.rsh[k][0], rshift1 = lw->u.it.rsh[k][1];
             shift = rshift0 - rshift1;
             if (shift >= 0) {
                 res_nrg1 = res_nrg1 >> shift;
@@ -1212,9 +1244,10 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
                 *interpIndex = k;
             }
         }
+        wv_sync();
     }
     SX_T(18)
-    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order, lw->P, lw->Q, &lw->grid);
+    if (*interpIndex == 4) sx_a2nlsf(NLSF_Q15, a_Q16, order, lw->P, lw->Q, &lw->u.grid);
     wv_sync();
 }
 
