@@ -33,7 +33,7 @@ struct SxFrontWork {                 // LDS scratch of the per-frame analysis ch
         SxPitchWork pitch;
         SxShapeWork shape;
         SxPredWork pred;
-        i16 pf_sLTP_shp[SX_LTP_BUF]; // staged prefilter ring
+        SxPrefWork pref;
     } u;
 };
 
@@ -324,11 +324,11 @@ SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int fr
     wv_sync();
     SX_ENC_TAP(2, st, w, f->res_pitch + SX_FRAME);
     SX_T(3)
-    SX_PAR(i, SX_LTP_BUF) f->u.pf_sLTP_shp[i] = hist->pf_sLTP_shp[i];
+    SX_PAR(i, SX_LTP_BUF) f->u.pref.ring[i] = hist->pf_sLTP_shp[i];
     wv_sync();
-    sx_prefilter(st, c, w->xfw, f->x_buf + SX_FRAME, f->u.pf_sLTP_shp);
+    sx_prefilter(st, c, w->xfw, f->x_buf + SX_FRAME, &f->u.pref);
     wv_sync();
-    SX_PAR(i, SX_LTP_BUF) hist->pf_sLTP_shp[i] = f->u.pf_sLTP_shp[i];
+    SX_PAR(i, SX_LTP_BUF) hist->pf_sLTP_shp[i] = f->u.pref.ring[i];
     wv_sync();
     SX_ENC_TAP(3, st, w, w->xfw);
     SX_T(4)

@@ -405,55 +405,73 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
 // prefilter
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_prefilter_FIX + warped_LPC_analysis_filter_FIX + prefilt_FIX, SKP_Silk_prefilter_FIX.c:43-224
-SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, i16* pf_sLTP_shp) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(xw); SX_IN_LDS(x); SX_IN_LDS(pf_sLTP_shp);
-    i32 x_filt_Q12[SX_SUBFR];
-    i16 st_res[SX_SUBFR];
-    const i16* px = x;
-    i16* pxw = xw;
-    int lag = st->pf_lagPrev;
+struct SxPrefWork {                  // LDS scratch of the prefilter
+    i16 ring[SX_LTP_BUF];            // staged harmonic-shaping ring (pf_sLTP_shp)
+    i32 o[2][SX_SHAPE_ORDER][2];     // (section output, running sum) in flight between neighbouring lanes, double buffered
+    i16 st_res[SX_FRAME + 1];        // short-term residual of the frame; [0] = last sample of the previous frame
+    i32 x_filt_Q12[SX_FRAME];
+    i32 vend[SX_SHAPE_ORDER + 1];
+};
+
+SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, SxPrefWork* pw) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(xw); SX_IN_LDS(x); SX_IN_LDS(pw);
+    i16* pf_sLTP_shp = pw->ring;
     const i32 lambda_Q16 = (i16)SX_WARPING_Q16;
-    i32 state[SX_SHAPE_ORDER + 1];
-    for (int i = 0; i <= SX_SHAPE_ORDER; i++) state[i] = st->pf_sAR_shp[i];
-    i32 sLF_AR = st->pf_sLF_AR_shp_Q12, sLF_MA = st->pf_sLF_MA_shp_Q12;
-    int buf_idx = st->pf_sLTP_shp_buf_idx;
-    i32 sHarmHP = st->pf_sHarmHP;
-    for (int k = 0; k < SX_NB_SUBFR; k++) {
-        if (c->sigtype == 0) lag = c->pitchL[k];
-        i32 HarmShapeGain_Q12 = sx_smulwb(c->HarmShapeGain_Q14[k], 16384 - c->HarmBoost_Q14[k]);
-        i32 HarmShapeFIRPacked_Q12 = HarmShapeGain_Q12 >> 2;
-        HarmShapeFIRPacked_Q12 |= sx_shl(HarmShapeGain_Q12 >> 1, 16);
-        i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k];
-        const i16* coef_Q13 = &c->AR1_Q13[k * SX_SHAPE_ORDER];
-        // warped LPC analysis filter
-        for (int n = 0; n < SX_SUBFR; n++) {
-            i32 tmp2 = sx_smlawb(state[0], state[1], lambda_Q16);
-            state[0] = sx_shl((i32)px[n], 14);
-            i32 tmp1 = sx_smlawb(state[1], state[2] - tmp2, lambda_Q16);
-            state[1] = tmp2;
-            i32 acc_Q11 = sx_smulwb(tmp2, coef_Q13[0]);
-            for (int i = 2; i < SX_SHAPE_ORDER; i += 2) {
-                tmp2 = sx_smlawb(state[i], state[i + 1] - tmp1, lambda_Q16);
-                state[i] = tmp1;
-                acc_Q11 = sx_smlawb(acc_Q11, tmp1, coef_Q13[i - 1]);
-                tmp1 = sx_smlawb(state[i + 1], state[i + 2] - tmp2, lambda_Q16);
-                state[i + 1] = tmp2;
-                acc_Q11 = sx_smlawb(acc_Q11, tmp2, coef_Q13[i]);
-            }
-            state[SX_SHAPE_ORDER] = tmp1;
-            acc_Q11 = sx_smlawb(acc_Q11, tmp1, coef_Q13[SX_SHAPE_ORDER - 1]);
-            st_res[n] = (i16)sx_sat16((i32)px[n] - sx_rshift_round(acc_Q11, 11));
+    // ---- warped_LPC_analysis_filter_FIX (SKP_Silk_prefilter_FIX.c:43) for the whole frame, skewed over 16 lanes ----
+    // v_0(n) = x(n) << 14;  v_1(n) = v_0(n-1) + lambda * v_1(n-1);  v_{j+1}(n) = v_j(n-1) + lambda * (v_{j+1}(n-1) - v_j(n));
+    // acc(n) = sum_j coef_k(n)[j-1] * v_j(n).  Lane l owns section j = l + 1 and works on sample n = t - j at step t, passing
+    // (v_j(n), partial acc) to lane l + 1 through LDS.
+    {
+        i32 pv[SX_NP64], pin[SX_NP64];
+        SX_PAR(l, SX_SHAPE_ORDER) {
+            pv[SX_PL(l)] = st->pf_sAR_shp[l + 1];       // v_j(-1)
+            pin[SX_PL(l)] = st->pf_sAR_shp[l];          // v_{j-1}(-1)
         }
-        i32 B_lo = sx_rshift_round(c->GainsPre_Q14[k], 2);
+        pw->st_res[0] = (i16)st->pf_sHarmHP;
+        for (int t = 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) {
+            SX_PAR(l, SX_SHAPE_ORDER) {
+                const int j = l + 1, n = t - j, pl = SX_PL(l);
+                if (n >= 0 && n < SX_FRAME) {
+                    i32 in, acc;
+                    if (l == 0) { in = sx_shl((i32)x[n], 14); acc = 0; }
+                    else { in = pw->o[(t - 1) & 1][l - 1][0]; acc = pw->o[(t - 1) & 1][l - 1][1]; }
+                    const i32 out = l == 0 ? sx_smlawb(pin[pl], pv[pl], lambda_Q16) : sx_smlawb(pin[pl], pv[pl] - in, lambda_Q16);
+                    acc = sx_smlawb(acc, out, c->AR1_Q13[(n / SX_SUBFR) * SX_SHAPE_ORDER + l]);
+                    pin[pl] = in;
+                    pv[pl] = out;
+                    pw->o[t & 1][l][0] = out;
+                    pw->o[t & 1][l][1] = acc;
+                    if (l == SX_SHAPE_ORDER - 1) pw->st_res[1 + n] = (i16)sx_sat16((i32)x[n] - sx_rshift_round(acc, 11));
+                    if (n == SX_FRAME - 1) { pw->vend[j] = out; if (l == 0) pw->vend[0] = in; }
+                }
+            }
+            wv_sync();
+        }
+        SX_PAR(l, SX_SHAPE_ORDER + 1) st->pf_sAR_shp[l] = pw->vend[l];
+        wv_sync();
+    }
+    // ---- per-subframe FIR on the residual, then prefilt_FIX (SKP_Silk_prefilter_FIX.c:174): serial shaping recursion ----
+    SX_PAR(n, SX_FRAME) {
+        const int k = n / SX_SUBFR;
+        const i32 HarmShapeGain_Q12 = sx_smulwb(c->HarmShapeGain_Q14[k], 16384 - c->HarmBoost_Q14[k]);
+        const i32 B_lo = sx_rshift_round(c->GainsPre_Q14[k], 2);
         i32 tmp_32 = sx_smlabb(K_INPUT_TILT_Q26, c->HarmBoost_Q14[k], HarmShapeGain_Q12);
         tmp_32 = sx_smlabb(tmp_32, c->coding_quality_Q14, K_HIGH_RATE_INPUT_TILT_Q12);
         tmp_32 = sx_smulwb(tmp_32, -c->GainsPre_Q14[k]);
         tmp_32 = sx_rshift_round(tmp_32, 12);
-        i32 B_hi = sx_sat16(tmp_32);
-        x_filt_Q12[0] = sx_add(sx_smulbb(st_res[0], B_lo), sx_smulbb(sHarmHP, B_hi));
-        for (int j = 1; j < SX_SUBFR; j++) x_filt_Q12[j] = sx_add(sx_smulbb(st_res[j], B_lo), sx_smulbb(st_res[j - 1], B_hi));
-        sHarmHP = st_res[SX_SUBFR - 1];
-        // prefilt_FIX
+        const i32 B_hi = sx_sat16(tmp_32);
+        pw->x_filt_Q12[n] = sx_add(sx_smulbb(pw->st_res[1 + n], B_lo), sx_smulbb(pw->st_res[n], B_hi));
+    }
+    wv_sync();
+    int lag = st->pf_lagPrev;
+    i32 sLF_AR = st->pf_sLF_AR_shp_Q12, sLF_MA = st->pf_sLF_MA_shp_Q12;
+    int buf_idx = st->pf_sLTP_shp_buf_idx;
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        if (c->sigtype == 0) lag = c->pitchL[k];
+        const i32 HarmShapeGain_Q12 = sx_smulwb(c->HarmShapeGain_Q14[k], 16384 - c->HarmBoost_Q14[k]);
+        i32 HarmShapeFIRPacked_Q12 = HarmShapeGain_Q12 >> 2;
+        HarmShapeFIRPacked_Q12 |= sx_shl(HarmShapeGain_Q12 >> 1, 16);
+        const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k];
         for (int i = 0; i < SX_SUBFR; i++) {
             i32 n_LTP_Q12 = 0;
             if (lag > 0) {
@@ -464,21 +482,20 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
             }
             i32 n_Tilt_Q10 = sx_smulwb(sLF_AR, Tilt_Q14);
             i32 n_LF_Q10 = sx_smlawb(sx_smulwt(sLF_AR, LF_shp_Q14), sLF_MA, LF_shp_Q14);
-            sLF_AR = sx_sub(x_filt_Q12[i], sx_shl(n_Tilt_Q10, 2));
+            sLF_AR = sx_sub(pw->x_filt_Q12[k * SX_SUBFR + i], sx_shl(n_Tilt_Q10, 2));
             sLF_MA = sx_sub(sLF_AR, sx_shl(n_LF_Q10, 2));
             buf_idx = (buf_idx - 1) & SX_LTP_MASK;
             pf_sLTP_shp[buf_idx] = (i16)sx_sat16(sx_rshift_round(sLF_MA, 12));
-            pxw[i] = (i16)sx_sat16(sx_rshift_round(sx_sub(sLF_MA, n_LTP_Q12), 12));
+            xw[k * SX_SUBFR + i] = (i16)sx_sat16(sx_rshift_round(sx_sub(sLF_MA, n_LTP_Q12), 12));
         }
-        px += SX_SUBFR;
-        pxw += SX_SUBFR;
     }
-    for (int i = 0; i <= SX_SHAPE_ORDER; i++) st->pf_sAR_shp[i] = state[i];
+    wv_sync();
     st->pf_sLF_AR_shp_Q12 = sLF_AR;
     st->pf_sLF_MA_shp_Q12 = sLF_MA;
     st->pf_sLTP_shp_buf_idx = buf_idx;
-    st->pf_sHarmHP = sHarmHP;
+    st->pf_sHarmHP = pw->st_res[SX_FRAME];
     st->pf_lagPrev = c->pitchL[SX_NB_SUBFR - 1];
+    wv_sync();
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -760,30 +777,68 @@ SX_HD void sx_vq_wmat_ec(i32* ind, i32* rate_dist_Q14, const i16* in_Q14, const 
     }
 }
 
-// SKP_Silk_quant_LTP_gains_FIX, SKP_Silk_quant_LTP_gains_FIX.c:30 (lowComplexity = 0)
-SX_FN void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8) {
-    SX_IN_LDS(B_Q14); SX_IN_LDS(cbk_index); SX_IN_LDS(periodicity_index); SX_IN_LDS(W_Q18);
-    i32 temp_idx[4], min_rate_dist = SX_I32_MAX;
-    for (int k = 0; k < 3; k++) {
-        const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
-        const i16* cbk = k == 0 ? T_ltp_vq0_Q14 : (k == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
-        int cbk_size = T_ltp_vq_sizes[k];
-        i32 rate_dist = 0;
-        for (int j = 0; j < 4; j++) {
-            i32 rd;
-            sx_vq_wmat_ec(&temp_idx[j], &rd, &B_Q14[j * 5], &W_Q18[j * 25], cbk, cl, mu_Q8, cbk_size);
-            rate_dist = sx_add_pos_sat32(rate_dist, rd);
-        }
-        rate_dist = sx_min(SX_I32_MAX - 1, rate_dist);
-        if (rate_dist < min_rate_dist) {
-            min_rate_dist = rate_dist;
-            for (int j = 0; j < 4; j++) cbk_index[j] = temp_idx[j];
-            *periodicity_index = k;
+// one codebook entry of SKP_Silk_VQ_WMat_EC_FIX (SKP_Silk_VQ_nearest_neighbor_FIX.c:31)
+SX_HD i32 sx_vq_wmat_ec_one(const i16* in_Q14, const i32* W, const i16* row, i32 cl_Q6, i32 mu_Q8) {
+    const i32 d0 = (i16)(in_Q14[0] - row[0]), d1 = (i16)(in_Q14[1] - row[1]), d2 = (i16)(in_Q14[2] - row[2]),
+              d3 = (i16)(in_Q14[3] - row[3]), d4 = (i16)(in_Q14[4] - row[4]);
+    i32 sum1 = sx_smulbb(mu_Q8, cl_Q6), sum2;
+    sum2 = sx_smulwb(W[1], d1); sum2 = sx_smlawb(sum2, W[2], d2); sum2 = sx_smlawb(sum2, W[3], d3); sum2 = sx_smlawb(sum2, W[4], d4);
+    sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[0], d0); sum1 = sx_smlawb(sum1, sum2, d0);
+    sum2 = sx_smulwb(W[7], d2); sum2 = sx_smlawb(sum2, W[8], d3); sum2 = sx_smlawb(sum2, W[9], d4);
+    sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[6], d1); sum1 = sx_smlawb(sum1, sum2, d1);
+    sum2 = sx_smulwb(W[13], d3); sum2 = sx_smlawb(sum2, W[14], d4);
+    sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[12], d2); sum1 = sx_smlawb(sum1, sum2, d2);
+    sum2 = sx_smulwb(W[19], d4);
+    sum2 = sx_shl(sum2, 1); sum2 = sx_smlawb(sum2, W[18], d3); sum1 = sx_smlawb(sum1, sum2, d3);
+    sum2 = sx_smulwb(W[24], d4); sum1 = sx_smlawb(sum1, sum2, d4);
+    return sum1;
+}
+
+// SKP_Silk_quant_LTP_gains_FIX, SKP_Silk_quant_LTP_gains_FIX.c:30 (lowComplexity = 0): all (codebook, subframe, entry)
+// rate-distortions at once (3 x 4 x up to 40 = 280 lanes' worth), then one lane per (codebook, subframe) picks the first minimum
+SX_FN void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8, i32* rd /* [3][4][40] LDS */,
+                              i32* best /* [3][4][2] LDS */) {
+    SX_IN_LDS(B_Q14); SX_IN_LDS(cbk_index); SX_IN_LDS(periodicity_index); SX_IN_LDS(W_Q18); SX_IN_LDS(rd); SX_IN_LDS(best);
+    SX_PAR(t, 3 * 4 * 40) {
+        const int k = t / 160, j = (t - k * 160) / 40, e = t % 40;
+        const int L = T_ltp_vq_sizes[k];
+        if (e < L) {
+            const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
+            const i16* cbk = k == 0 ? T_ltp_vq0_Q14 : (k == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+            rd[t] = sx_vq_wmat_ec_one(&B_Q14[j * 5], &W_Q18[j * 25], &cbk[e * 5], cl[e], mu_Q8);
         }
     }
-    const i16* cbk = *periodicity_index == 0 ? T_ltp_vq0_Q14 : (*periodicity_index == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
-    for (int j = 0; j < 4; j++)
-        for (int k = 0; k < 5; k++) B_Q14[j * 5 + k] = cbk[cbk_index[j] * 5 + k];
+    wv_sync();
+    SX_PAR(kj, 12) {
+        const int k = kj >> 2;
+        const int L = T_ltp_vq_sizes[k];
+        i32 bv = SX_I32_MAX, bi = 0;
+        for (int e = 0; e < L; e++) {
+            const i32 v = rd[kj * 40 + e];
+            if (v < bv) { bv = v; bi = e; }
+        }
+        best[kj * 2] = bv;
+        best[kj * 2 + 1] = bi;
+    }
+    wv_sync();
+    i32 min_rate_dist = SX_I32_MAX;
+    int per = 0;
+    for (int k = 0; k < 3; k++) {
+        i32 rate_dist = 0;
+        for (int j = 0; j < 4; j++) rate_dist = sx_add_pos_sat32(rate_dist, best[(k * 4 + j) * 2]);
+        rate_dist = sx_min(SX_I32_MAX - 1, rate_dist);
+        if (rate_dist < min_rate_dist) { min_rate_dist = rate_dist; per = k; }
+    }
+    wv_sync();
+    *periodicity_index = per;
+    const i16* cbk = per == 0 ? T_ltp_vq0_Q14 : (per == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+    SX_PAR(t, 20) {
+        const int j = t / 5, i = t - j * 5;
+        const int ix = best[(per * 4 + j) * 2 + 1];
+        if (i == 0) cbk_index[j] = ix;
+        B_Q14[t] = cbk[ix * 5 + i];
+    }
+    wv_sync();
 }
 
 // SKP_Silk_LTP_scale_ctrl_FIX, SKP_Silk_LTP_scale_ctrl_FIX.c:39 (PacketLoss_perc = 0, PacketSize_ms = 40)
@@ -1259,6 +1314,8 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
     i32 Sorted_Q18[16];
     u8 taken[256];
     i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
+    i32 NLSF0[SX_MAX_LPC], W0_Q6[SX_MAX_LPC];
+    i32 ws[2][SX_NLSF2A_WS];
     i32 Rate_Q5[16], Rate_new_Q5[16];
     i32 TempIndices[16];
     i32 Path[16 * 6], Path_new[16 * 6];
@@ -1369,8 +1426,8 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
 SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w);
-    i32 pNLSF0_temp_Q15[SX_LPC], pNLSFW0_temp_Q6[SX_LPC], NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w); SX_IN_LDS(pNLSF_Q15);
+    i32 NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
     i32* pNLSFW_Q6 = w->W_Q6;
     if (c->sigtype == 0) {
         NLSF_mu_Q15 = sx_smlawb(66, -8388, st->speech_activity_Q8);
@@ -1380,25 +1437,40 @@ SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvq
         NLSF_mu_fluc_red_Q16 = sx_smlawb(13107, -1677696, st->speech_activity_Q8 + c->sparseness_Q8);
     }
     NLSF_mu_Q15 = sx_max(NLSF_mu_Q15, 1);
-    sx_nlsf_weights_laroia(pNLSFW_Q6, pNLSF_Q15, SX_LPC);
     const int doInterpolate = c->NLSFInterpCoef_Q2 < 4;     // useInterpolatedNLSFs == 1
+    const i32 interp_Q2 = c->NLSFInterpCoef_Q2;
+    // Laroia weights of the target and (if interpolating) of the interpolated vector: one vector per lane
+    SX_PAR(v, 2) {
+        if (v == 0) {
+            sx_nlsf_weights_laroia(pNLSFW_Q6, pNLSF_Q15, SX_LPC);
+        } else if (doInterpolate) {
+            for (int i = 0; i < SX_LPC; i++)
+                w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
+            sx_nlsf_weights_laroia(w->W0_Q6, w->NLSF0, SX_LPC);
+        }
+    }
+    wv_sync();
     if (doInterpolate) {
-        for (int i = 0; i < SX_LPC; i++)
-            pNLSF0_temp_Q15[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], c->NLSFInterpCoef_Q2) >> 2);
-        sx_nlsf_weights_laroia(pNLSFW0_temp_Q6, pNLSF0_temp_Q15, SX_LPC);
-        i32 i_sqr_Q15 = sx_shl(sx_smulbb(c->NLSFInterpCoef_Q2, c->NLSFInterpCoef_Q2), 11);
-        for (int i = 0; i < SX_LPC; i++) pNLSFW_Q6[i] = sx_smlawb(pNLSFW_Q6[i] >> 1, pNLSFW0_temp_Q6[i], i_sqr_Q15);
+        const i32 i_sqr_Q15 = sx_shl(sx_smulbb(interp_Q2, interp_Q2), 11);
+        SX_PAR(i, SX_LPC) pNLSFW_Q6[i] = sx_smlawb(pNLSFW_Q6[i] >> 1, w->W0_Q6[i], i_sqr_Q15);
     }
     wv_sync();
     sx_nlsf_msvq_encode(c->NLSFIndices, pNLSF_Q15, c->sigtype, st->prev_NLSFq_Q15, pNLSFW_Q6, NLSF_mu_Q15, NLSF_mu_fluc_red_Q16,
                         st->first_frame_after_reset, w);
-    sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
-    if (doInterpolate) {
-        for (int i = 0; i < SX_LPC; i++)
-            pNLSF0_temp_Q15[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], c->NLSFInterpCoef_Q2) >> 2);
-        sx_nlsf2a_stable(c->PredCoef_Q12[0], pNLSF0_temp_Q15, SX_LPC);
-    } else {
-        for (int i = 0; i < SX_LPC; i++) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+    // quantised NLSFs -> LPC for the two frame halves: half v on lane v
+    SX_PAR(v, 2) {
+        if (v == 1) {
+            sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC, w->ws[1]);
+        } else if (doInterpolate) {
+            for (int i = 0; i < SX_LPC; i++)
+                w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
+            sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], w->NLSF0, SX_LPC, w->ws[0]);
+        }
+    }
+    wv_sync();
+    if (!doInterpolate) {
+        SX_PAR(i, SX_LPC) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+        wv_sync();
     }
 }
 
@@ -1435,6 +1507,7 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
     i32 invGains_Q16[SX_NB_SUBFR], local_gains[SX_NB_SUBFR], Wght_Q15[SX_NB_SUBFR];
     union {
         SxLtpWork ltp;
+        struct { i32 rd[3 * 4 * 40]; i32 best[3 * 4 * 2]; } vq;
         SxLpcWork lpc;
         SxMsvqWork msvq;
     } u;
@@ -1458,7 +1531,7 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, co
     wv_sync();
     if (c->sigtype == 0) {
         sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15, &w->u.ltp);
-        sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8);
+        sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8, w->u.vq.rd, w->u.vq.best);
         sx_LTP_scale_ctrl(st, c);
         sx_LTP_analysis_filter(w->LPC_in_pre, x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
         wv_sync();
