@@ -101,7 +101,7 @@ __global__ void __launch_bounds__(64, 4) solo_encode_kernel(SxEncStream* states,
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        i32 ret = sx_encode_packet(&rec->hist, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        i32 ret = sx_encode_packet(rec, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }

@@ -299,8 +299,9 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
 
 // SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
 // frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
-SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int frame) {
+SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame) {
     SX_IN_LDS(w);
+    SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SxEncCtrl* c = &w->ctrl;
     SxFrontWork* f = &w->u.front;
@@ -343,8 +344,24 @@ SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int fr
     // the history of the next frame leaves LDS before the quantiser takes over the union
     SX_PAR(i, SX_FRAME + SX_LA_SHAPE) hist->x_buf[i] = f->x_buf[SX_FRAME + i];
     wv_sync();
-    sx_nsq_del_dec(st, hist, c, w->xfw, &hist->q[frame][0][0], hist->r, &w->u.nsq);
+    // hand-over record for the quantiser
+    {
+        SxNsqIn* in = &rec->nsq_in[frame];
+        in->sigtype = c->sigtype; in->QuantOffsetType = c->QuantOffsetType; in->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
+        in->Seed = c->Seed; in->Lambda_Q10 = c->Lambda_Q10; in->LTP_scale_Q14 = c->LTP_scale_Q14; in->DeltaGains_Q16 = c->DeltaGains_Q16;
+        SX_PAR(i, SX_NB_SUBFR) {
+            in->pitchL[i] = c->pitchL[i]; in->Gains_Q16[i] = c->Gains_Q16[i]; in->LF_shp_Q14[i] = c->LF_shp_Q14[i];
+            in->Tilt_Q14[i] = c->Tilt_Q14[i]; in->HarmShapeGain_Q14[i] = c->HarmShapeGain_Q14[i];
+        }
+        SX_PAR(i, 2 * SX_MAX_LPC) (&in->PredCoef_Q12[0][0])[i] = (&c->PredCoef_Q12[0][0])[i];
+        SX_PAR(i, SX_LTP_ORDER * SX_NB_SUBFR) in->LTPCoef_Q14[i] = c->LTPCoef_Q14[i];
+        SX_PAR(i, SX_NB_SUBFR * SX_SHAPE_ORDER) in->AR2_Q13[i] = c->AR2_Q13[i];
+        SX_PAR(i, SX_FRAME) in->xfw[i] = w->xfw[i];
+        wv_sync();
+    }
+    sx_nsq_del_dec(&rec->nsq, &rec->nsq_in[frame], &rec->nsq_out[frame], &w->u.nsq);
     wv_sync();
+    c->Seed = rec->nsq_out[frame].Seed;
     SX_ENC_TAP(6 + 16 * frame, st, w, w->xfw);
     SX_T(7)
     // VAD / DTX flags (encode_frame_FIX.c:155-171)
@@ -380,23 +397,24 @@ SX_FN void sx_encode_frame(SxEncHist* hist, SxEncWork* w, const i16* pIn, int fr
 // AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129) for one packet: 640 samples @ 16 kHz -> MD1 || MD2 || HB(8).
 // nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.  Returns the total byte count, or a negative status if the
 // payload does not fit `buf_size`.
-SX_FN i32 sx_encode_packet(SxEncHist* hist, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
     SX_IN_LDS(w);
+    SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SX_T_BEGIN
     sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, hist->hi);
     wv_sync();
     SX_T(0)
     for (int frame = 0; frame < 2; frame++) {
-        sx_encode_frame(hist, w, hist->lo + frame * SX_FRAME, frame);
+        sx_encode_frame(rec, w, hist->lo + frame * SX_FRAME, frame);
         SX_T_RESET
-        sx_hb_encode_frame(hist, hist->hi + frame * SX_FRAME, hist->r, &w->u.hb, &w->hb_bytes[4 * frame]);
+        sx_hb_encode_frame(hist, hist->hi + frame * SX_FRAME, rec->nsq_out[frame].r, &w->u.hb, &w->hb_bytes[4 * frame]);
         wv_sync();
         SX_T(9)
     }
     // range coding of the two descriptions: description md on lane md, tables served from LDS
     sx_cdf_load(&w->u.code.cdf);
-    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = (&hist->q[0][0][0])[i];
+    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = rec->nsq_out[i / (2 * SX_FRAME)].q[(i / SX_FRAME) & 1][i % SX_FRAME];
     wv_sync();
     const SxCdf* cdf = &w->u.code.cdf;
     i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};

@@ -110,12 +110,15 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 }
 
 // SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  x: prefiltered input (160), q: [2][160] pulses of MD1 / MD2, r: centre excitation Q10 [160]
-SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i16* x, i8* q, i32* r, SxNsqWork* w) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x); SX_IN_LDS(w);
-    SxNsqGlobal* g = &hist->nsq;
+SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNsqWork* w) {
+    SX_IN_LDS(w);
+    SxNsqGlobal* g = &P->g;
+    const i16* x = c->xfw;
+    i8* q = &out->q[0][0];
+    i32* r = out->r;
     SX_T_BEGIN
     const int voiced = c->sigtype == 0;
-    int lagC = st->nsq[0].lagPrev, lagP1 = st->nsq[1].lagPrev, lagP2 = st->nsq[2].lagPrev;
+    int lagC = P->nsq[0].lagPrev, lagP1 = P->nsq[1].lagPrev, lagP2 = P->nsq[2].lagPrev;
     const i32 offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
     int smpl_buf_idx = 0;
     int decisionDelay = sx_min(SX_DD_DELAY, SX_SUBFR);
@@ -153,7 +156,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
         wv_sync();
         SX_LANES12(tk) {
             const int t = tk >> 2, k = tk & 3, li = SX_LI(tk);
-            const SxNSQ* n = &st->nsq[t];
+            const SxNSQ* n = &P->nsq[t];
             Seed[li] = Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
             RD[li] = 0;
             LF_AR[li] = n->sLF_AR_shp_Q12;
@@ -183,7 +186,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
         const SxRing* rg_ = &w->ring[t_];                                                                                    \
         if ((t_) == 0) r[pos_] = w->exc_Q10[ring_idx_][slot_];                                                               \
         else q[((t_)-1) * SX_FRAME + (pos_)] = rg_->Q_Q0[ring_idx_][slot_];                                                  \
-        hist->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
+        P->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
             (i16)sx_sat16(sx_rshift_round(sx_smulww(rg_->Xq_Q10[ring_idx_][slot_], w->Gain_ring[ring_idx_]), 10));           \
         g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
         if (write_pred_) g->sLTP_Q16[t_][sLTP_idx_] = rg_->Pred_Q16[ring_idx_][slot_];                                       \
@@ -238,7 +241,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                 const int len = SX_FRAME - start_idx;
                 SX_PAR(tn, 3 * len) {
                     const int t = tn / len, n = tn - t * len;
-                    const i16* in = &hist->xq[t][start_idx + k * SX_SUBFR];
+                    const i16* in = &P->xq[t][start_idx + k * SX_SUBFR];
                     i32 acc = 0;
                     for (int j = 0; j < SX_LPC; j++)
                         if (n - 1 - j >= 0) acc = sx_smlabb(acc, in[n - 1 - j], A_Q12[j]);
@@ -256,7 +259,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
             const int lag = c->pitchL[k];
             bool any = false;
             for (int t = 0; t < SX_N_TRACKS; t++) {
-                SxNSQ* n = &st->nsq[t];
+                SxNSQ* n = &P->nsq[t];
                 if (inv_gain_Q16 != n->prev_inv_gain_Q16) {
                     any = true;
                     const i32 gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, n->prev_inv_gain_Q16, 16);
@@ -284,7 +287,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
             if (any) {
                 SX_LANES12(tk) {
                     const int t = tk >> 2, li = SX_LI(tk);
-                    const i32 prev = st->nsq[t].prev_inv_gain_Q16;
+                    const i32 prev = P->nsq[t].prev_inv_gain_Q16;
                     if (inv_gain_Q16 != prev) {
                         const i32 gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, prev, 16);
                         LF_AR[li] = sx_smulww(gain_adj_Q16, LF_AR[li]);
@@ -294,7 +297,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
                 }
             }
             wv_sync();
-            for (int t = 0; t < SX_N_TRACKS; t++) st->nsq[t].prev_inv_gain_Q16 = inv_gain_Q16;
+            for (int t = 0; t < SX_N_TRACKS; t++) P->nsq[t].prev_inv_gain_Q16 = inv_gain_Q16;
             wv_sync();
         }
 
@@ -590,7 +593,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
             if (v < RDmin) { RDmin = v; Winner_ind = s; }
         }
     }
-    c->Seed = SX_RL(SeedInit2, Winner_ind);
+    out->Seed = SX_RL(SeedInit2, Winner_ind);
     SX_PAR(ti, 3 * decisionDelay) {
         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
@@ -600,7 +603,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
     SX_LANES12(tk) {
         const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
         if (s == Winner_ind) {
-            SxNSQ* n = &st->nsq[t];
+            SxNSQ* n = &P->nsq[t];
             for (int i = 0; i < SX_MAX_LPC; i++) n->sLPC_Q14[i] = (SX_MAX_LPC - 1 - i) < SX_LPC ? sLPC[li][SX_MAX_LPC - 1 - i] : 0;
             for (int i = 0; i < SX_SHAPE_ORDER; i++) n->sAR2_Q14[i] = sAR2[li][i];
             n->sLF_AR_shp_Q12 = LF_AR[li];
@@ -612,7 +615,7 @@ SX_FN void sx_nsq_del_dec(SxEncState* st, SxEncHist* hist, SxEncCtrl* c, const i
     SX_PAR(ti, 3 * SX_FRAME) {
         const int t = ti / SX_FRAME, i = ti - t * SX_FRAME;
         g->shp[t][i] = g->shp[t][SX_FRAME + i];      // (the upper half keeps its values: the reference's memcpy does the same)
-        hist->xq[t][i] = hist->xq[t][SX_FRAME + i];
+        P->xq[t][i] = P->xq[t][SX_FRAME + i];
     }
     wv_sync();
 #undef SX_NSQ_EMIT

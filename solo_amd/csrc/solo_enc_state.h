@@ -77,7 +77,6 @@ struct SxEncState {
     i32 pf_sAR_shp[SX_SHAPE_ORDER + 1];
     i32 pf_sLTP_shp_buf_idx, pf_sLF_AR_shp_Q12, pf_sLF_MA_shp_Q12, pf_sHarmHP, pf_lagPrev;
     i32 prev_NLSFq_Q15[SX_LPC];
-    SxNSQ nsq[SX_N_TRACKS];
 };
 
 struct SxNsqGlobal {                 // per-stream NSQ arrays that live in HBM / L2 (predictable addresses, prefetched by the lanes)
@@ -90,19 +89,38 @@ struct SxNsqGlobal {                 // per-stream NSQ arrays that live in HBM /
 struct SxEncHist {
     i16 x_buf[SX_FRAME + SX_LA_SHAPE];           // samples [0, 200) of the analysis buffer; [200, 360) is new every frame
     i16 pf_sLTP_shp[SX_LTP_BUF];                 // prefilter's harmonic-shaping ring
-    i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
-    SxNsqGlobal nsq;
     i16 qmf_hist[63 + 1];                        // last 63 input samples >> 1 (h0_mem of the reference, time order)
     i16 x_hb_buf[SX_FRAME + SX_LA_SHAPE];        // high-band analysis history (BWE_FrameSize + lb_Delay*hb_KHz = 200 samples)
     // hand-over between the phases of one packet
     i16 lo[SX_BAND], hi[SX_BAND];
-    i8 q[2][2][SX_FRAME];                        // pulses of MD1 / MD2, both frames (the centre stream is never coded)
-    i32 r[SX_FRAME];                             // centre excitation Q10 of the current frame (high-band gain reference)
+};
+
+// Hand-over records between the three stages of the encoder (analysis -> quantiser -> coder); they live in HBM.
+struct SxNsqIn {                     // what the quantiser needs of one analysed 20 ms frame
+    i32 sigtype, QuantOffsetType, NLSFInterpCoef_Q2, Seed, Lambda_Q10, LTP_scale_Q14, DeltaGains_Q16;
+    i32 pitchL[SX_NB_SUBFR], Gains_Q16[SX_NB_SUBFR], LF_shp_Q14[SX_NB_SUBFR], Tilt_Q14[SX_NB_SUBFR], HarmShapeGain_Q14[SX_NB_SUBFR];
+    i16 PredCoef_Q12[2][SX_MAX_LPC];
+    i16 LTPCoef_Q14[SX_LTP_ORDER * SX_NB_SUBFR];
+    i16 AR2_Q13[SX_NB_SUBFR * SX_SHAPE_ORDER];
+    i16 xfw[SX_FRAME];               // prefiltered input
+};
+struct SxNsqOut {                    // what the quantiser produces for one frame
+    i32 Seed;                        // dither seed of the winning path (coded)
+    i8 q[2][SX_FRAME];               // pulses of MD1 / MD2 (the centre stream is never coded)
+    i32 r[SX_FRAME];                 // centre excitation Q10 (high-band gain reference)
+};
+struct SxNsqPersist {                // quantiser state of one stream
+    SxNSQ nsq[SX_N_TRACKS];
+    SxNsqGlobal g;
+    i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
 };
 
 struct SxEncStream {                 // one record per stream in HBM
     SxEncState core;
     SxEncHist hist;
+    SxNsqPersist nsq;
+    SxNsqIn nsq_in[2];               // fused single-stream path: hand-over records of the current packet
+    SxNsqOut nsq_out[2];
 };
 
 // Output of the analysis chain for one 20 ms frame = input of the NSQ and of the parameter coder
@@ -156,13 +174,13 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
         st->vad.NrgRatioSmth_Q8[b] = 100 * 256;
     }
     st->vad.counter = 15;
-    for (int t = 0; t < SX_N_TRACKS; t++) st->nsq[t].prev_inv_gain_Q16 = 65536;
+    for (int t = 0; t < SX_N_TRACKS; t++) rec->nsq.nsq[t].prev_inv_gain_Q16 = 65536;
     // setup_fs_FIX (control_codec_FIX.c:232): only the CENTRE nsq state gets lagPrev = 100
     st->prevLag = 100;
     st->prev_sigtype = 1;
     st->pf_lagPrev = 100;
     st->LastGainIndex = 1;
-    st->nsq[0].lagPrev = 100;
+    rec->nsq.nsq[0].lagPrev = 100;
     // setup_rate_FIX (control_codec_FIX.c:319): bitrate -> SNR tables, per description and total
     silk_rate_bps = sx_limit(silk_rate_bps, 5000, 100000);           // enc_API.c:187
     i32 md_rate = silk_rate_bps / 2;

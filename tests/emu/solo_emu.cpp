@@ -52,7 +52,7 @@ void emu_enc_destroy(void* h) { free(h); }
 int emu_enc_packet(void* h, const int16_t* pcm, uint8_t* bits, int buf_size, int16_t* nBytesOut) {
     EmuEnc* e = (EmuEnc*)h;
     e->w.st = e->rec.core;                                    // the kernel keeps the compact state in LDS for a launch
-    int r = sx_encode_packet(&e->rec.hist, &e->w, pcm, bits, buf_size, nBytesOut);
+    int r = sx_encode_packet(&e->rec, &e->w, pcm, bits, buf_size, nBytesOut);
     e->rec.core = e->w.st;
     return r;
 }
@@ -61,7 +61,7 @@ int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
 // debug taps (tests only): last frame's control block, pulses and residual
 const void* emu_enc_ctrl_ptr(void* h) { return &((EmuEnc*)h)->w.ctrl; }
 int emu_sizeof_enc_ctrl() { return (int)sizeof(SxEncCtrl); }
-const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->rec.hist.q[0][0][0]; }
+const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->rec.nsq_out[0].q[0][0]; }
 const void* emu_enc_idx_ptr(void* h) { return &((EmuEnc*)h)->w.idx[0]; }
 const void* emu_enc_state_ptr(void* h) { return &((EmuEnc*)h)->rec; }
 }
