@@ -85,33 +85,57 @@ __global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, 
     sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex);
 }
 
-// Encoder: rows E0-E9.  blockIdx.x = stream; one wavefront encodes the stream's packets in order.
-__global__ void __launch_bounds__(64, 4) solo_encode_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams, int n_packets,
-                                                            int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+// Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
+//   A  solo_enc_analysis_kernel  one wavefront per stream: QMF split + analysis chain of every frame of the launch
+//   B  solo_nsq_kernel           four streams per wavefront (solo_nsq16.hip): the delayed-decision quantiser
+//   C  solo_enc_coding_kernel    one wavefront per stream: high-band encoder, range coding, payload assembly
+__device__ __forceinline__ void solo_enc_enter(SxEncWork* w, const SxEncStream* rec) {
+    const i32* src = (const i32*)&rec->core;
+    i32* dst = (i32*)&w->st;
+    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+    wv_sync();
+}
+__device__ __forceinline__ void solo_enc_leave(SxEncWork* w, SxEncStream* rec) {
+    wv_sync();
+    const i32* src = (const i32*)&w->st;
+    i32* dst = (i32*)&rec->core;
+    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(64, 4) solo_enc_analysis_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
+                                                                  int n_packets, SxNsqIn* __restrict__ nsq_in, SxCodeIn* __restrict__ code_in) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
-    {   // compact state: HBM -> LDS for the whole launch
-        const i32* src = (const i32*)&rec->core;
-        i32* dst = (i32*)&w.st;
-        SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+    solo_enc_enter(&w, rec);
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        sx_enc_stage_a(rec, &w, pcm + pk * SX_PACKET, nsq_in + pk * 2, code_in + pk);
         wv_sync();
     }
+    solo_enc_leave(&w, rec);
+}
+
+__global__ void __launch_bounds__(64, 4) solo_enc_coding_kernel(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
+                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int slot,
+                                                                u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SxEncStream* rec = &states[s];
+    solo_enc_enter(&w, rec);
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        i32 ret = sx_encode_packet(rec, &w, pcm + pk * SX_PACKET, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        i32 ret = sx_enc_stage_c(rec, &w, code_in + pk, nsq_out + pk * 2, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
-    {
-        const i32* src = (const i32*)&w.st;
-        i32* dst = (i32*)&rec->core;
-        SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
-    }
     if (status && SX_LANE == 0) status[s] = first_err;
 }
+
+extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, void* hip_stream);   // solo_nsq16.hip
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -124,7 +148,8 @@ struct solo_batch {
     USER_Ctrl_enc enc_ctrl;
     USER_Ctrl_dec dec_ctrl;
     void* d_enc_state;
-    void* d_enc_work;
+    void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
+    int32_t enc_work_packets;        // P the hand-over area is sized for
     SxDecState* d_dec_state;
 };
 
@@ -149,7 +174,9 @@ static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
 }
 static void solo_enc_free(solo_batch* b) {
     if (b->d_enc_state) (void)hipFree(b->d_enc_state);
+    if (b->d_enc_work) (void)hipFree(b->d_enc_work);
     b->d_enc_state = NULL;
+    b->d_enc_work = NULL;
 }
 #endif
 
@@ -157,7 +184,7 @@ extern "C" {
 
 const char* solo_version(void) { return "solo_mi355x 0.1 (gfx950)"; }
 
-const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_encode_kernel" : "solo_decode_kernel"; }
+const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : (which == 1 ? "solo_decode_kernel" : (which == 2 ? "solo_enc_analysis_kernel" : "solo_enc_coding_kernel")); }
 
 int32_t solo_batch_n_streams(const solo_batch_t* b) { return b ? b->n_streams : 0; }
 int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
@@ -234,8 +261,24 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
 int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packets, uint8_t* d_bits, int16_t* d_nbytes,
                           int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_enc || !d_pcm || !d_bits || !d_nbytes || n_packets <= 0) return -1;
-    hipLaunchKernelGGL(solo_encode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)b->d_enc_state,
-                       d_pcm, b->n_streams, n_packets, b->slot, d_bits, d_nbytes, d_status);
+    hipStream_t st = (hipStream_t)hip_stream;
+    const size_t np = (size_t)b->n_streams * (size_t)n_packets;
+    const size_t sz_in = np * 2 * sizeof(SxNsqIn), sz_out = np * 2 * sizeof(SxNsqOut), sz_code = np * sizeof(SxCodeIn);
+    if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
+        SOLO_CHECK(hipStreamSynchronize(st));
+        if (b->d_enc_work) (void)hipFree(b->d_enc_work);
+        b->d_enc_work = NULL;
+        SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));
+        b->enc_work_packets = n_packets;
+    }
+    SxNsqIn* nin = (SxNsqIn*)b->d_enc_work;
+    SxNsqOut* nout = (SxNsqOut*)((char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63));
+    SxCodeIn* cin = (SxCodeIn*)((char*)nout + ((sz_out + 63) & ~(size_t)63));
+    SxEncStream* states = (SxEncStream*)b->d_enc_state;
+    hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, st, states, d_pcm, b->n_streams, n_packets, nin, cin);
+    if (solo_launch_nsq(states, nin, nout, b->n_streams, n_packets, st) != 0) return -2;
+    hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, st, states, cin, nout, b->n_streams, n_packets, b->slot,
+                       d_bits, d_nbytes, d_status);
     SOLO_CHECK(hipGetLastError());
     return 0;
 }

@@ -56,7 +56,9 @@ struct SxEncWork {
     union {
         i16 qmf_tl[63 + SX_PACKET];
         SxFrontWork front;
-        SxNsqWork nsq;
+#if SX_NLANES == 1
+        SxNsqWork nsq;               // host emulation runs the three stages back to back in one work area
+#endif
         SxCodeWork code;
         SxHbWork hb;
     } u;
@@ -299,7 +301,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
 
 // SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
 // frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
-SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame) {
+SX_FN void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame, SxNsqIn* in, SxFrameIdx* x) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
@@ -346,7 +348,6 @@ SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int f
     wv_sync();
     // hand-over record for the quantiser
     {
-        SxNsqIn* in = &rec->nsq_in[frame];
         in->sigtype = c->sigtype; in->QuantOffsetType = c->QuantOffsetType; in->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
         in->Seed = c->Seed; in->Lambda_Q10 = c->Lambda_Q10; in->LTP_scale_Q14 = c->LTP_scale_Q14; in->DeltaGains_Q16 = c->DeltaGains_Q16;
         SX_PAR(i, SX_NB_SUBFR) {
@@ -359,10 +360,6 @@ SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int f
         SX_PAR(i, SX_FRAME) in->xfw[i] = w->xfw[i];
         wv_sync();
     }
-    sx_nsq_del_dec(&rec->nsq, &rec->nsq_in[frame], &rec->nsq_out[frame], &w->u.nsq);
-    wv_sync();
-    c->Seed = rec->nsq_out[frame].Seed;
-    SX_ENC_TAP(6 + 16 * frame, st, w, w->xfw);
     SX_T(7)
     // VAD / DTX flags (encode_frame_FIX.c:155-171)
     if (st->speech_activity_Q8 < K_SPEECH_ACTIVITY_DTX_THRES_Q8) {
@@ -375,7 +372,6 @@ SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int f
         st->inDTX = 0;
         st->vadFlag = 1;
     }
-    SxFrameIdx* x = &w->idx[frame];
     x->sigtype = c->sigtype; x->QuantOffsetType = c->QuantOffsetType;
     for (int i = 0; i < 4; i++) { x->GainsIndices[i] = c->GainsIndices[i]; x->LTPIndex[i] = c->LTPIndex[i]; }
     x->DeltaGainsIndices = c->DeltaGainsIndices;
@@ -383,7 +379,7 @@ SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int f
     x->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
     x->lagIndex = c->lagIndex; x->contourIndex = c->contourIndex; x->PERIndex = c->PERIndex;
     x->LTP_scaleIndex = c->LTP_scaleIndex;
-    x->Seed = c->Seed;
+    x->Seed = c->Seed;                 // (replaced by the quantiser's winning seed in the coding stage)
     x->vadFlag = st->vadFlag;
     // cross-frame parameters (encode_frame_FIX.c:203-212)
     st->prev_sigtype = c->sigtype;
@@ -394,27 +390,49 @@ SX_FN void sx_encode_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int f
     SX_T(8)
 }
 
-// AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129) for one packet: 640 samples @ 16 kHz -> MD1 || MD2 || HB(8).
-// nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.  Returns the total byte count, or a negative status if the
-// payload does not fit `buf_size`.
-SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+// what the coding stage needs of one analysed packet besides the quantiser's output
+struct SxCodeIn {
+    SxFrameIdx idx[2];
+    i16 hi[SX_BAND];                 // high band of the packet (QMF output) for the BWE encoder
+};
+
+// Stage A of AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129): QMF split and the analysis chain of both 20 ms frames.
+// Nothing here depends on the quantiser's output (DISABLE_BUF_RD, SKP_Silk_define.h:53), so a whole launch of packets
+// can be analysed before any is quantised.
+SX_FN void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsqIn* in2, SxCodeIn* cin) {
+    SX_IN_LDS(w);
+    SxEncHist* hist = &rec->hist;
+    SX_T_BEGIN
+    sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, cin->hi);
+    wv_sync();
+    SX_T(0)
+    for (int frame = 0; frame < 2; frame++) {
+        sx_enc_analyse_frame(rec, w, hist->lo + frame * SX_FRAME, frame, &in2[frame], &cin->idx[frame]);
+        wv_sync();
+    }
+}
+
+// Stage C: high-band encoder (needs the centre excitation of the quantiser), range coding of the two descriptions,
+// payload assembly.  640 samples @ 16 kHz -> MD1 || MD2 || HB(8).  nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.
+// Returns the total byte count, or a negative status if the payload does not fit `buf_size`.
+SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2, u8* bits, i32 buf_size, i16* nBytesOut) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SX_T_BEGIN
-    sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, hist->hi);
-    wv_sync();
-    SX_T(0)
     for (int frame = 0; frame < 2; frame++) {
-        sx_encode_frame(rec, w, hist->lo + frame * SX_FRAME, frame);
-        SX_T_RESET
-        sx_hb_encode_frame(hist, hist->hi + frame * SX_FRAME, rec->nsq_out[frame].r, &w->u.hb, &w->hb_bytes[4 * frame]);
+        sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, &w->u.hb, &w->hb_bytes[4 * frame]);
         wv_sync();
         SX_T(9)
     }
+    SX_PAR(i, (int)(2 * sizeof(SxFrameIdx) / 4)) ((i32*)&w->idx[0])[i] = ((const i32*)&cin->idx[0])[i];
+    wv_sync();
+    w->idx[0].Seed = out2[0].Seed;
+    w->idx[1].Seed = out2[1].Seed;
+    wv_sync();
     // range coding of the two descriptions: description md on lane md, tables served from LDS
     sx_cdf_load(&w->u.code.cdf);
-    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = rec->nsq_out[i / (2 * SX_FRAME)].q[(i / SX_FRAME) & 1][i % SX_FRAME];
+    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = out2[i / (2 * SX_FRAME)].q[(i / SX_FRAME) & 1][i % SX_FRAME];
     wv_sync();
     const SxCdf* cdf = &w->u.code.cdf;
     i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};
@@ -465,3 +483,16 @@ SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, const i16* pcm, u8* b
     SX_T(11)
     return total;
 }
+
+#if SX_NLANES == 1
+// Fused single-stream form (host emulation / debugging): A, quantiser for both frames, C
+SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, SxCodeIn* cin, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
+    sx_enc_stage_a(rec, w, pcm, rec->nsq_in, cin);
+    wv_sync();
+    for (int frame = 0; frame < 2; frame++) {
+        sx_nsq_del_dec(&rec->nsq, &rec->nsq_in[frame], &rec->nsq_out[frame], &w->u.nsq);
+        wv_sync();
+    }
+    return sx_enc_stage_c(rec, w, cin, rec->nsq_out, bits, buf_size, nBytesOut);
+}
+#endif

@@ -32,12 +32,17 @@
 #define SX_NSLOT 1
 #define SX_LANES12(tk) for (int tk = SX_LANE, once_ = 1; once_ && tk < 12; once_ = 0)
 #define SX_LI(tk) 0
-#define SX_XL(arr, src) __shfl((arr)[0], (src), 64)
-#define SX_XL2(arr, j, src) __shfl((arr)[0][j], (src), 64)
+#define SX_XL(arr, src) __shfl((arr)[0], (src), SX_NLANES)
+#define SX_XL2(arr, j, src) __shfl((arr)[0][j], (src), SX_NLANES)
+#if SX_NLANES == 64
 #define SX_RL(arr, src) __builtin_amdgcn_readlane((arr)[0], (src))
 #define SX_RL2(arr, j, src) __builtin_amdgcn_readlane((arr)[0][j], (src))
+#else                                                        // several streams per wave: "uniform" = uniform in the 16-lane group
+#define SX_RL(arr, src) __shfl((arr)[0], (src), SX_NLANES)
+#define SX_RL2(arr, j, src) __shfl((arr)[0][j], (src), SX_NLANES)
 #endif
-#if defined(__HIP_DEVICE_COMPILE__)
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
 #define SX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)      // wave-uniform value -> scalar register
 #else
 #define SX_UNIFORM(v) (v)
@@ -514,7 +519,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                             const int lane = SX_LANE;
                             const bool dst = lane < 12 && (lane & 3) == RDmax_ind;
                             const int src = dst ? ((lane & ~3) | RDmin_ind) : lane;
-#define SX_MV(v) { const i32 t_ = __shfl((v), src, 64); if (dst) (v) = t_; }
+#define SX_MV(v) { const i32 t_ = __shfl((v), src, SX_NLANES); if (dst) (v) = t_; }
                             if (RDmax_ind != RDmin_ind) {
 #pragma unroll
                                 for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MV(sAR2[0][j])
@@ -522,7 +527,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                                 for (int j = 0; j < SX_LPC; j++) SX_MV(sLPC[0][j])
                                 SX_MV(LF_AR[0]) SX_MV(Seed[0]) SX_MV(Seed2[0]) SX_MV(SeedInit2[0]) SX_MV(RD[0])
                             }
-#define SX_MV01(v) { const i32 t_ = __shfl((v)[0][1], src, 64); if (dst) (v)[0][0] = t_; }
+#define SX_MV01(v) { const i32 t_ = __shfl((v)[0][1], src, SX_NLANES); if (dst) (v)[0][0] = t_; }
                             SX_MV01(cRD) SX_MV01(cQ0) SX_MV01(cXq14) SX_MV01(cLFAR) SX_MV01(cShp) SX_MV01(cExc16) SX_MV01(cExc10)
 #undef SX_MV
 #undef SX_MV01

@@ -16,7 +16,14 @@
 #pragma once
 #include "solo_fix.h"
 
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SX_FORCE_SERIAL)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_GROUP16)
+// quantiser kernel: FOUR streams per wavefront, 16 lanes each ("wave-uniform" then means uniform within the 16-lane group;
+// the hardware's exec masking serialises groups that take different branches)
+#define SX_NLANES 16
+#define SX_LANE ((int)(threadIdx.x & 15))
+#define SX_XOR_REDUCE(v, OP)                                              \
+    _Pragma("unroll") for (int o_ = 8; o_ > 0; o_ >>= 1) { auto t_ = __shfl_xor(v, o_, 16); v = OP; }
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SX_FORCE_SERIAL)
 #define SX_NLANES 64
 #define SX_LANE ((int)(threadIdx.x & 63))
 #define SX_XOR_REDUCE(v, OP)                                              \
@@ -40,7 +47,7 @@ SX_HD i32 wv_max(i32 v) { SX_XOR_REDUCE(v, (t_ > v ? t_ : v)) return v; }
 SX_HD i32 wv_min(i32 v) { SX_XOR_REDUCE(v, (t_ < v ? t_ : v)) return v; }
 SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
 #if defined(__HIP_DEVICE_COMPILE__)
-    return __shfl(v, src, 64);
+    return __shfl(v, src, SX_NLANES);
 #else
     (void)src;
     return v;
@@ -50,8 +57,8 @@ SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
 SX_HD void wv_argmin(i32* v, i32* idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
+    for (int o = SX_NLANES / 2; o > 0; o >>= 1) {
+        i32 tv = __shfl_xor(*v, o, SX_NLANES), ti = __shfl_xor(*idx, o, SX_NLANES);
         if (tv < *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
     }
 #else
@@ -62,8 +69,8 @@ SX_HD void wv_argmin(i32* v, i32* idx) {
 SX_HD void wv_argmax(i32* v, i32* idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        i32 tv = __shfl_xor(*v, o, 64), ti = __shfl_xor(*idx, o, 64);
+    for (int o = SX_NLANES / 2; o > 0; o >>= 1) {
+        i32 tv = __shfl_xor(*v, o, SX_NLANES), ti = __shfl_xor(*idx, o, SX_NLANES);
         if (tv > *v || (tv == *v && ti < *idx)) { *v = tv; *idx = ti; }
     }
 #else

@@ -42,7 +42,7 @@ extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 
 // ---- encoder ----
 extern "C" {
-struct EmuEnc { SxEncStream rec; SxEncWork w; };
+struct EmuEnc { SxEncStream rec; SxEncWork w; SxCodeIn cin; };
 void* emu_enc_create(int rate_bps, int useMDIndex) {
     EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
     sx_enc_state_init(&e->rec, rate_bps - 1600, useMDIndex);   // AGR_BWE_SDK_API.c:119: SILK rate = target - 1600
@@ -52,7 +52,7 @@ void emu_enc_destroy(void* h) { free(h); }
 int emu_enc_packet(void* h, const int16_t* pcm, uint8_t* bits, int buf_size, int16_t* nBytesOut) {
     EmuEnc* e = (EmuEnc*)h;
     e->w.st = e->rec.core;                                    // the kernel keeps the compact state in LDS for a launch
-    int r = sx_encode_packet(&e->rec, &e->w, pcm, bits, buf_size, nBytesOut);
+    int r = sx_encode_packet(&e->rec, &e->w, &e->cin, pcm, bits, buf_size, nBytesOut);
     e->rec.core = e->w.st;
     return r;
 }
