@@ -60,6 +60,7 @@ struct SxNsqWork {
     SxRing ring[SX_N_TRACKS];
     i32 exc_Q10[SX_DD_DELAY][SX_DD_STATES];      // excitation cells of the CENTRE track (high-band gain reference)
     i32 Gain_ring[SX_DD_DELAY];
+    i16 x[SX_FRAME];                             // prefiltered input of the frame (staged from the hand-over record)
 };
 
 
@@ -118,7 +119,7 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNsqWork* w) {
     SX_IN_LDS(w);
     SxNsqGlobal* g = &P->g;
-    const i16* x = c->xfw;
+    const i16* x = w->x;
     i8* q = &out->q[0][0];
     i32* r = out->r;
     SX_T_BEGIN
@@ -141,12 +142,15 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     i32 LTP_pred[SX_NSLOT], LPC_pred[SX_NSLOT], n_AR[SX_NSLOT], n_LF[SX_NSLOT], rD[SX_NSLOT];
     i32 cRD[SX_NSLOT][2], cQ0[SX_NSLOT][2], cQ10[SX_NSLOT][2], cRdInd[SX_NSLOT][2];
     i32 cXq14[SX_NSLOT][2], cLFAR[SX_NSLOT][2], cShp[SX_NSLOT][2], cExc16[SX_NSLOT][2], cExc10[SX_NSLOT][2];
-    i32 W1[SX_NSLOT], W2[SX_NSLOT], myRand[SX_NSLOT];
+    i32 W1[SX_NSLOT], W2[SX_NSLOT], myRand[SX_NSLOT], emitPred[SX_NSLOT];
+    i32 curL[SX_NSLOT][SX_LTP_ORDER], nxL[SX_NSLOT][SX_LTP_ORDER], curS[SX_NSLOT][3], nxS[SX_NSLOT][3];   // LTP / shaping taps, prefetched
     for (int a = 0; a < SX_NSLOT; a++) {       // lanes that own no state keep defined values
         for (int j = 0; j < SX_SHAPE_ORDER; j++) sAR2[a][j] = 0;
         for (int j = 0; j < SX_LPC; j++) sLPC[a][j] = 0;
         LF_AR[a] = Seed[a] = Seed2[a] = SeedInit2[a] = RD[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = 0;
-        W1[a] = W2[a] = myRand[a] = 0;
+        W1[a] = W2[a] = myRand[a] = emitPred[a] = 0;
+        for (int j = 0; j < SX_LTP_ORDER; j++) curL[a][j] = nxL[a][j] = 0;
+        for (int j = 0; j < 3; j++) curS[a][j] = nxS[a][j] = 0;
         for (int j = 0; j < 2; j++) cRD[a][j] = cQ0[a][j] = cQ10[a][j] = cRdInd[a][j] = cXq14[a][j] = cLFAR[a][j] = cShp[a][j] = cExc16[a][j] = cExc10[a][j] = 0;
     }
     // lineage words: ring position p of state k lives in slot (lin_k >> 2p) & 3
@@ -158,6 +162,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         i32* p = (i32*)&w->ring[0];
         SX_PAR(i, (int)(sizeof(w->ring) / 4)) p[i] = 0;
         SX_PAR(i, SX_DD_STATES * SX_DD_DELAY) (&w->exc_Q10[0][0])[i] = 0;
+        SX_PAR(i, SX_FRAME) w->x[i] = c->xfw[i];
         wv_sync();
         SX_LANES12(tk) {
             const int t = tk >> 2, k = tk & 3, li = SX_LI(tk);
@@ -194,7 +199,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         P->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
             (i16)sx_sat16(sx_rshift_round(sx_smulww(rg_->Xq_Q10[ring_idx_][slot_], w->Gain_ring[ring_idx_]), 10));           \
         g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
-        if (write_pred_) g->sLTP_Q16[t_][sLTP_idx_] = rg_->Pred_Q16[ring_idx_][slot_];                                       \
+        if (write_pred_) { const i32 pv_ = rg_->Pred_Q16[ring_idx_][slot_]; g->sLTP_Q16[t_][sLTP_idx_] = pv_; emitPred[SX_LI(t_)] = pv_; } \
     }
 
     for (int k = 0; k < SX_NB_SUBFR; k++) {
@@ -309,21 +314,44 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         // ---- the per-sample trellis (SKP_Silk_md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1341) ----
         const int odd = subfr & 1;
         const int shp_base = sLTP_shp_buf_idx, pred_base = sLTP_buf_idx;
+        // the long-term prediction / harmonic-shaping taps live in HBM; their addresses are known a sample ahead, so every
+        // lane keeps the taps of the current sample in registers and fetches the next sample's while it works
+        SX_LANES12(tk) {
+            const int t = tk >> 2, li = SX_LI(tk);
+            const int lag_me = t == 0 ? lagC : (t == 1 ? lagP1 : lagP2);
+            if (voiced) {
+                const i32* pl = &g->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2];
+                for (int j = 0; j < SX_LTP_ORDER; j++) curL[li][j] = pl[-j];
+            }
+            if (lagC > 0) {
+                const i32* ps = &g->shp[t][shp_base - lag_me + 1];
+                curS[li][0] = ps[0]; curS[li][1] = ps[-1]; curS[li][2] = ps[-2];
+            }
+        }
+        SX_T(1)
         for (int i = 0; i < SX_SUBFR; i++) {
             // phase A: predictions, shaping, residual, dither -- one (track, state) per lane
             SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
                 const int lag_me = t == 0 ? lagC : (t == 1 ? lagP1 : lagP2);
+                if (i + 1 < SX_SUBFR) {      // issue the next sample's tap loads now; they land while this sample is processed
+                    if (voiced) {
+                        const i32* pl = &g->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2 + i + 1];
+                        for (int j = 0; j < SX_LTP_ORDER; j++) nxL[li][j] = pl[-j];
+                    }
+                    if (lagC > 0) {
+                        const i32* ps = &g->shp[t][shp_base - lag_me + 1 + i + 1];
+                        nxS[li][0] = ps[0]; nxS[li][1] = ps[-1]; nxS[li][2] = ps[-2];
+                    }
+                }
                 i32 LTP_pred_Q14 = 0;
                 if (voiced) {
-                    const i32* pl = &g->sLTP_Q16[t][pred_base - lag_me + SX_LTP_ORDER / 2 + i];
-                    for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, pl[-j], Bpre[j]);
+                    for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, curL[li][j], Bpre[j]);
                 }
                 i32 n_LTP_Q14 = 0;
                 if (lagC > 0) {              // the reference tests the CENTRE lag for every track (NSQ_del_dec.c:1436-1446)
-                    const i32* ps = &g->shp[t][shp_base - lag_me + 1 + i];
-                    n_LTP_Q14 = sx_smulw_pre(sx_add(ps[0], ps[-2]), Hb_pre);
-                    n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, ps[-1], Ht_pre);
+                    n_LTP_Q14 = sx_smulw_pre(sx_add(curS[li][0], curS[li][2]), Hb_pre);
+                    n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, curS[li][1], Ht_pre);
                     n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
                 }
                 i32 LPC_pred_Q10 = 0;
@@ -368,6 +396,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 n_LF[li] = n_LF_Q10;
                 rD[li] = r_Q10;
             }
+            SX_T(2)
             // phase B: the two candidates of every side state (the centre residual comes over by shuffle)
             SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
@@ -379,6 +408,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                                  first ? offset_p1_Q10 : offset_p2_Q10, cRD[li], cQ0[li], cQ10[li], cRdInd[li]);
                 }
             }
+            SX_T(3)
             // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152): the centre takes the best two of the four combinations of side
             // candidates; the side candidates are then re-ordered so that slot s of every track belongs to combination w_s
             SX_LANES12(tk) {
@@ -458,6 +488,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                     cExc16[li][j] = sx_shl(LPC_exc_Q10, 6);
                 }
             }
+            SX_T(4)
             smpl_buf_idx = (smpl_buf_idx - 1) & SX_DD_MASK;
             const int last_smple_idx = (smpl_buf_idx + decisionDelay) & SX_DD_MASK;
             // phase E: Agora_Silk_JudgeWinner (NSQ_del_dec.c:671) on wave-uniform values
@@ -489,6 +520,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 if (c1 != wr0 || a1 != wr1 || b1 != wr2) { RandSyncCtl++; rd0_1 = sx_add(rd0_1, PEN); rd1_1 = sx_add(rd1_1, PEN); }
                 if (c2 != wr0 || a2 != wr1 || b2 != wr2) { RandSyncCtl++; rd0_2 = sx_add(rd0_2, PEN); rd1_2 = sx_add(rd1_2, PEN); }
                 if (c3 != wr0 || a3 != wr1 || b3 != wr2) { RandSyncCtl++; rd0_3 = sx_add(rd0_3, PEN); rd1_3 = sx_add(rd1_3, PEN); }
+                SX_T(5)
                 do {
                     i32 RDmax = rd0_0, RDmin2 = rd1_0;
                     int RDmax_ind = 0, RDmin_ind = 0;
@@ -537,6 +569,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                         if (RDmax_ind == 0) rd0_0 = nv; else if (RDmax_ind == 1) rd0_1 = nv; else if (RDmax_ind == 2) rd0_2 = nv; else rd0_3 = nv;
                     }
                 } while (--RandSyncCtl > 0);
+                SX_T(6)
                 // the centre lanes take the penalised / replaced cumulative costs back
                 SX_LANES12(tk) {
                     if (tk < 4) cRD[SX_LI(tk)][0] = sx_sel4(rd0_0, rd0_1, rd0_2, rd0_3, tk);
@@ -557,7 +590,9 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                     }
                 }
             }
+            const bool emitted = subfr > 0 || i >= decisionDelay;
             wv_sync();
+            SX_T(7)
             // phase G: Agora_Silk_Update_DelDecState (NSQ_del_dec.c:862): every state pushes candidate [0] into its own cell
             SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
@@ -582,13 +617,25 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 lin3 = (lin3 & m) | (LIN_ID3 & ~m);
             }
             w->Gain_ring[smpl_buf_idx] = Gain_Q16;
+            // next sample's taps become current; its newest LTP tap is the prediction sample emitted just now when the
+            // decision delay is as long as the pitch lag allows (written after the prefetch was issued): forward it
+            SX_LANES12(tk) {
+                const int t = tk >> 2, li = SX_LI(tk);
+                const int lag_me = t == 0 ? lagC : (t == 1 ? lagP1 : lagP2);
+                const i32 fw = SX_XL(emitPred, t);
+                for (int j = 0; j < SX_LTP_ORDER; j++) curL[li][j] = nxL[li][j];
+                if (voiced && emitted && decisionDelay == lag_me - SX_LTP_ORDER / 2 - 1) curL[li][0] = fw;
+                for (int j = 0; j < 3; j++) curS[li][j] = nxS[li][j];
+            }
             wv_sync();
+            SX_T(8)
         }
         sLTP_shp_buf_idx += SX_SUBFR;
         sLTP_buf_idx += SX_SUBFR;
         subfr++;
     }
 
+    SX_T(1)
     // Agora_Silk_DelDec_UpdateState_And_Output{,_Side} (NSQ_del_dec.c:175, 245)
     int Winner_ind = 0;
     {
@@ -623,5 +670,6 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         P->xq[t][i] = P->xq[t][SX_FRAME + i];
     }
     wv_sync();
+    SX_T(9)
 #undef SX_NSQ_EMIT
 }

@@ -10,7 +10,7 @@
 
 // optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
 #if defined(SX_PROF) && defined(__HIPCC__)
-__device__ unsigned long long g_sx_prof[32];
+static __device__ unsigned long long g_sx_prof[32];
 #endif
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();

@@ -16,13 +16,13 @@
 #pragma once
 #include "solo_fix.h"
 
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_GROUP16)
-// quantiser kernel: FOUR streams per wavefront, 16 lanes each ("wave-uniform" then means uniform within the 16-lane group;
-// the hardware's exec masking serialises groups that take different branches)
-#define SX_NLANES 16
-#define SX_LANE ((int)(threadIdx.x & 15))
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_GROUP)
+// quantiser kernel: SEVERAL streams per wavefront, SX_GROUP (16 or 32) lanes each ("wave-uniform" then means uniform within
+// the lane group; the hardware's exec masking serialises groups that take different branches)
+#define SX_NLANES SX_GROUP
+#define SX_LANE ((int)(threadIdx.x & (SX_GROUP - 1)))
 #define SX_XOR_REDUCE(v, OP)                                              \
-    _Pragma("unroll") for (int o_ = 8; o_ > 0; o_ >>= 1) { auto t_ = __shfl_xor(v, o_, 16); v = OP; }
+    _Pragma("unroll") for (int o_ = SX_GROUP / 2; o_ > 0; o_ >>= 1) { auto t_ = __shfl_xor(v, o_, SX_GROUP); v = OP; }
 #elif defined(__HIP_DEVICE_COMPILE__) && !defined(SX_FORCE_SERIAL)
 #define SX_NLANES 64
 #define SX_LANE ((int)(threadIdx.x & 63))
