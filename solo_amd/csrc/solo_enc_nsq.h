@@ -153,9 +153,11 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         for (int j = 0; j < 3; j++) curS[a][j] = nxS[a][j] = 0;
         for (int j = 0; j < 2; j++) cRD[a][j] = cQ0[a][j] = cQ10[a][j] = cRdInd[a][j] = cXq14[a][j] = cLFAR[a][j] = cShp[a][j] = cExc16[a][j] = cExc10[a][j] = 0;
     }
-    // lineage words: ring position p of state k lives in slot (lin_k >> 2p) & 3
-    const u64 LIN_ID0 = 0x0000000000000000ull, LIN_ID1 = 0x5555555555555555ull, LIN_ID2 = 0xAAAAAAAAAAAAAAAAull, LIN_ID3 = 0xFFFFFFFFFFFFFFFFull;
-    u64 lin0 = LIN_ID0, lin1 = LIN_ID1, lin2 = LIN_ID2, lin3 = LIN_ID3;
+    // lineage word of the lane's state (two 32-bit halves): ring position p lives in slot (lin >> 2p) & 3.  The three tracks
+    // of one state index always hold the same word (they are copied together).
+    i32 linLo[SX_NSLOT], linHi[SX_NSLOT];
+    i32 jv[SX_NSLOT], ji[SX_NSLOT], tv[SX_NSLOT], ti[SX_NSLOT], mis[SX_NSLOT];
+    for (int a = 0; a < SX_NSLOT; a++) { linLo[a] = linHi[a] = jv[a] = ji[a] = tv[a] = ti[a] = mis[a] = 0; }
 
     // Agora_Silk_Init_DelDecState (NSQ_del_dec.c:148): every track starts from the same seed
     {
@@ -168,6 +170,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             const int t = tk >> 2, k = tk & 3, li = SX_LI(tk);
             const SxNSQ* n = &P->nsq[t];
             Seed[li] = Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
+            linLo[li] = linHi[li] = k * 0x55555555;                  // slot k at every ring position
             RD[li] = 0;
             LF_AR[li] = n->sLF_AR_shp_Q12;
             w->ring[t].Shape_Q10[0][k] = g->shp[t][SX_FRAME - 1];
@@ -189,10 +192,11 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     const i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);       // _OFFSET_MD_ (SKP_Silk_define.h:41)
     const i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
 
+#define SX_LIN_SLOT(lo_, hi_, pos_) ((int)((((pos_) < 16 ? (u32)(lo_) : (u32)(hi_)) >> (2 * ((pos_) & 15))) & 3u))
     // emit the decisionDelay-old sample of the lineage of state `win` (Agora_Silk_GetWinner{,_Side} / flush loops)
-#define SX_NSQ_EMIT(t_, win_, ring_idx_, pos_, sLTP_idx_, write_pred_)                                                       \
+#define SX_NSQ_EMIT(t_, wlo_, whi_, ring_idx_, pos_, sLTP_idx_, write_pred_)                                                 \
     {                                                                                                                        \
-        const int slot_ = (int)(sx_sel4u(lin0, lin1, lin2, lin3, (win_)) >> (2 * (ring_idx_))) & 3;                         \
+        const int slot_ = SX_LIN_SLOT(wlo_, whi_, ring_idx_);                                                                \
         const SxRing* rg_ = &w->ring[t_];                                                                                    \
         if ((t_) == 0) r[pos_] = w->exc_Q10[ring_idx_][slot_];                                                               \
         else q[((t_)-1) * SX_FRAME + (pos_)] = rg_->Q_Q0[ring_idx_][slot_];                                                  \
@@ -238,10 +242,11 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                     SX_LANES12(tk) {
                         if ((tk & 3) != Winner_ind) RD[SX_LI(tk)] += SX_I32_MAX >> 4;
                     }
+                    const i32 wlo = SX_RL(linLo, Winner_ind), whi = SX_RL(linHi, Winner_ind);
                     SX_PAR(ti, 3 * decisionDelay) {
                         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
                         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-                        SX_NSQ_EMIT(t, Winner_ind, ring, k * SX_SUBFR - decisionDelay + i, 0, false)
+                        SX_NSQ_EMIT(t, wlo, whi, ring, k * SX_SUBFR - decisionDelay + i, 0, false)
                     }
                     wv_sync();
                 }
@@ -375,7 +380,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 n_AR_Q10 = n_AR_Q10 >> 1;
                 n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, LF_AR[li], Tilt_pre);
                 // newest shaping sample of this state's lineage
-                const int slot = (int)(sx_sel4u(lin0, lin1, lin2, lin3, s) >> (2 * smpl_buf_idx)) & 3;
+                const int slot = SX_LIN_SLOT(linLo[li], linHi[li], smpl_buf_idx);
                 i32 n_LF_Q10 = sx_shl(sx_smulw_pre(w->ring[t].Shape_Q10[smpl_buf_idx][slot], LFb_pre), 2);
                 n_LF_Q10 = sx_smlaw_pre(n_LF_Q10, LF_AR[li], LFt_pre);
                 // Agora_Silk_DelDecScale (NSQ_del_dec.c:1668) + Agora_Silk_DoPred_And_Shap (Agora_SILK_func.c:143)
@@ -491,50 +496,52 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             SX_T(4)
             smpl_buf_idx = (smpl_buf_idx - 1) & SX_DD_MASK;
             const int last_smple_idx = (smpl_buf_idx + decisionDelay) & SX_DD_MASK;
-            // phase E: Agora_Silk_JudgeWinner (NSQ_del_dec.c:671) on wave-uniform values
+            // phase E: Agora_Silk_JudgeWinner (NSQ_del_dec.c:671), lane-parallel: the centre lane of state s holds the joint cost
+            // of s; winners / extremes are found by xor-butterflies inside the quad of centre lanes
+#define SX_QUAD_ARG(CMP)                                                                                                     \
+    for (int o_ = 1; o_ <= 2; o_ <<= 1) {                                                                                    \
+        SX_LANES12(tk) { const int li = SX_LI(tk); tv[li] = SX_XL(jv, tk ^ o_); ti[li] = SX_XL(ji, tk ^ o_); }                \
+        SX_LANES12(tk) { const int li = SX_LI(tk); if (tv[li] CMP jv[li] || (tv[li] == jv[li] && ti[li] < ji[li])) { jv[li] = tv[li]; ji[li] = ti[li]; } } \
+    }
             {
-                SX_LANES12(tk) {
-                    const int t = tk >> 2, s = tk & 3;
-                    const int slot = (int)(sx_sel4u(lin0, lin1, lin2, lin3, s) >> (2 * last_smple_idx)) & 3;
-                    myRand[SX_LI(tk)] = w->ring[t].Rand[last_smple_idx][slot];
-                }
-                i32 rd0_0 = SX_RL2(cRD, 0, 0), rd0_1 = SX_RL2(cRD, 0, 1), rd0_2 = SX_RL2(cRD, 0, 2), rd0_3 = SX_RL2(cRD, 0, 3);
-                i32 rd1_0 = SX_RL2(cRD, 1, 0), rd1_1 = SX_RL2(cRD, 1, 1), rd1_2 = SX_RL2(cRD, 1, 2), rd1_3 = SX_RL2(cRD, 1, 3);
-                const i32 j0 = sx_add(sx_add(rd0_0, sx_smulww(SX_RL2(cRD, 0, 4), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 8), SX_JOINT_LAMBDA));
-                const i32 j1 = sx_add(sx_add(rd0_1, sx_smulww(SX_RL2(cRD, 0, 5), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 9), SX_JOINT_LAMBDA));
-                const i32 j2 = sx_add(sx_add(rd0_2, sx_smulww(SX_RL2(cRD, 0, 6), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 10), SX_JOINT_LAMBDA));
-                const i32 j3 = sx_add(sx_add(rd0_3, sx_smulww(SX_RL2(cRD, 0, 7), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 11), SX_JOINT_LAMBDA));
-                int Winner_ind = 0;
-                i32 RDmin = j0;
-                if (j1 < RDmin) { RDmin = j1; Winner_ind = 1; }
-                if (j2 < RDmin) { RDmin = j2; Winner_ind = 2; }
-                if (j3 < RDmin) { RDmin = j3; Winner_ind = 3; }
-                // states whose decisionDelay-old ancestor differs from the winner's, in any track, are expired
-                const i32 c0 = SX_RL(myRand, 0), c1 = SX_RL(myRand, 1), c2 = SX_RL(myRand, 2), c3 = SX_RL(myRand, 3);
-                const i32 a0 = SX_RL(myRand, 4), a1 = SX_RL(myRand, 5), a2 = SX_RL(myRand, 6), a3 = SX_RL(myRand, 7);
-                const i32 b0 = SX_RL(myRand, 8), b1 = SX_RL(myRand, 9), b2 = SX_RL(myRand, 10), b3 = SX_RL(myRand, 11);
-                const i32 wr0 = sx_sel4(c0, c1, c2, c3, Winner_ind), wr1 = sx_sel4(a0, a1, a2, a3, Winner_ind), wr2 = sx_sel4(b0, b1, b2, b3, Winner_ind);
-                int RandSyncCtl = 0;
                 const i32 PEN = SX_I32_MAX >> 4;
-                if (c0 != wr0 || a0 != wr1 || b0 != wr2) { RandSyncCtl++; rd0_0 = sx_add(rd0_0, PEN); rd1_0 = sx_add(rd1_0, PEN); }
-                if (c1 != wr0 || a1 != wr1 || b1 != wr2) { RandSyncCtl++; rd0_1 = sx_add(rd0_1, PEN); rd1_1 = sx_add(rd1_1, PEN); }
-                if (c2 != wr0 || a2 != wr1 || b2 != wr2) { RandSyncCtl++; rd0_2 = sx_add(rd0_2, PEN); rd1_2 = sx_add(rd1_2, PEN); }
-                if (c3 != wr0 || a3 != wr1 || b3 != wr2) { RandSyncCtl++; rd0_3 = sx_add(rd0_3, PEN); rd1_3 = sx_add(rd1_3, PEN); }
+                // joint cost of candidate [0] of every state; the delayed random-state cell of every (track, state)
+                SX_LANES12(tk) {
+                    const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
+                    const i32 a = SX_XL2(cRD, 0, 4 + s), b = SX_XL2(cRD, 0, 8 + s);
+                    jv[li] = sx_add(sx_add(cRD[li][0], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
+                    ji[li] = s;
+                    myRand[li] = w->ring[t].Rand[last_smple_idx][SX_LIN_SLOT(linLo[li], linHi[li], last_smple_idx)];
+                }
+                SX_QUAD_ARG(<)
+                const int Winner_ind = SX_RL(ji, 0);
+                // states whose decisionDelay-old ancestor differs from the winner's, in any track, are expired
+                SX_LANES12(tk) {
+                    const int t = tk >> 2, li = SX_LI(tk);
+                    const i32 wr = SX_XL(myRand, 4 * t + Winner_ind);
+                    mis[li] = myRand[li] != wr ? 1 : 0;
+                }
+                SX_LANES12(tk) {
+                    const int s = tk & 3, li = SX_LI(tk);
+                    const i32 m = mis[li] | SX_XL(mis, 4 + s) | SX_XL(mis, 8 + s);
+                    tv[li] = m;
+                    if (tk < 4 && m) { cRD[li][0] = sx_add(cRD[li][0], PEN); cRD[li][1] = sx_add(cRD[li][1], PEN); }
+                }
+                int RandSyncCtl = SX_RL(tv, 0) + SX_RL(tv, 1) + SX_RL(tv, 2) + SX_RL(tv, 3);
                 SX_T(5)
                 do {
-                    i32 RDmax = rd0_0, RDmin2 = rd1_0;
-                    int RDmax_ind = 0, RDmin_ind = 0;
-                    if (rd0_1 > RDmax) { RDmax = rd0_1; RDmax_ind = 1; }
-                    if (rd0_2 > RDmax) { RDmax = rd0_2; RDmax_ind = 2; }
-                    if (rd0_3 > RDmax) { RDmax = rd0_3; RDmax_ind = 3; }
-                    if (rd1_1 < RDmin2) { RDmin2 = rd1_1; RDmin_ind = 1; }
-                    if (rd1_2 < RDmin2) { RDmin2 = rd1_2; RDmin_ind = 2; }
-                    if (rd1_3 < RDmin2) { RDmin2 = rd1_3; RDmin_ind = 3; }
+                    // worst candidate [0] (first maximum) and best candidate [1] (first minimum) of the centre track
+                    SX_LANES12(tk) { const int li = SX_LI(tk); jv[li] = cRD[li][0]; ji[li] = tk & 3; }
+                    SX_QUAD_ARG(>)
+                    const i32 RDmax = SX_RL(jv, 0);
+                    const int RDmax_ind = SX_RL(ji, 0);
+                    SX_LANES12(tk) { const int li = SX_LI(tk); jv[li] = cRD[li][1]; ji[li] = tk & 3; }
+                    SX_QUAD_ARG(<)
+                    const i32 RDmin2 = SX_RL(jv, 0);
+                    const int RDmin_ind = SX_RL(ji, 0);
                     if (RDmin2 < RDmax) {
                         // SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668) for the three tracks: lineage word + filter memories;
                         // then candidate [RDmax][0] <- candidate [RDmin][1]
-                        const u64 lsrc = sx_sel4u(lin0, lin1, lin2, lin3, RDmin_ind);
-                        if (RDmax_ind == 0) lin0 = lsrc; else if (RDmax_ind == 1) lin1 = lsrc; else if (RDmax_ind == 2) lin2 = lsrc; else lin3 = lsrc;
 #if SX_NLANES == 1
                         for (int t = 0; t < SX_N_TRACKS; t++) {
                             const int d = 4 * t + RDmax_ind, sL = 4 * t + RDmin_ind;
@@ -542,6 +549,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                                 for (int j = 0; j < SX_SHAPE_ORDER; j++) sAR2[d][j] = sAR2[sL][j];
                                 for (int j = 0; j < SX_LPC; j++) sLPC[d][j] = sLPC[sL][j];
                                 LF_AR[d] = LF_AR[sL]; Seed[d] = Seed[sL]; Seed2[d] = Seed2[sL]; SeedInit2[d] = SeedInit2[sL]; RD[d] = RD[sL];
+                                linLo[d] = linLo[sL]; linHi[d] = linHi[sL];
                             }
                             cRD[d][0] = cRD[sL][1]; cQ0[d][0] = cQ0[sL][1]; cXq14[d][0] = cXq14[sL][1]; cLFAR[d][0] = cLFAR[sL][1];
                             cShp[d][0] = cShp[sL][1]; cExc16[d][0] = cExc16[sL][1]; cExc10[d][0] = cExc10[sL][1];
@@ -557,7 +565,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                                 for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MV(sAR2[0][j])
 #pragma unroll
                                 for (int j = 0; j < SX_LPC; j++) SX_MV(sLPC[0][j])
-                                SX_MV(LF_AR[0]) SX_MV(Seed[0]) SX_MV(Seed2[0]) SX_MV(SeedInit2[0]) SX_MV(RD[0])
+                                SX_MV(LF_AR[0]) SX_MV(Seed[0]) SX_MV(Seed2[0]) SX_MV(SeedInit2[0]) SX_MV(RD[0]) SX_MV(linLo[0]) SX_MV(linHi[0])
                             }
 #define SX_MV01(v) { const i32 t_ = __shfl((v)[0][1], src, SX_NLANES); if (dst) (v)[0][0] = t_; }
                             SX_MV01(cRD) SX_MV01(cQ0) SX_MV01(cXq14) SX_MV01(cLFAR) SX_MV01(cShp) SX_MV01(cExc16) SX_MV01(cExc10)
@@ -565,31 +573,26 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
 #undef SX_MV01
                         }
 #endif
-                        const i32 nv = sx_sel4(rd1_0, rd1_1, rd1_2, rd1_3, RDmin_ind);
-                        if (RDmax_ind == 0) rd0_0 = nv; else if (RDmax_ind == 1) rd0_1 = nv; else if (RDmax_ind == 2) rd0_2 = nv; else rd0_3 = nv;
                     }
                 } while (--RandSyncCtl > 0);
                 SX_T(6)
-                // the centre lanes take the penalised / replaced cumulative costs back
-                SX_LANES12(tk) {
-                    if (tk < 4) cRD[SX_LI(tk)][0] = sx_sel4(rd0_0, rd0_1, rd0_2, rd0_3, tk);
-                }
                 // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner
-                const i32 g0 = sx_add(sx_add(rd0_0, sx_smulww(SX_RL2(cRD, 0, 4), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 8), SX_JOINT_LAMBDA));
-                const i32 g1 = sx_add(sx_add(rd0_1, sx_smulww(SX_RL2(cRD, 0, 5), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 9), SX_JOINT_LAMBDA));
-                const i32 g2 = sx_add(sx_add(rd0_2, sx_smulww(SX_RL2(cRD, 0, 6), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 10), SX_JOINT_LAMBDA));
-                const i32 g3 = sx_add(sx_add(rd0_3, sx_smulww(SX_RL2(cRD, 0, 7), SX_JOINT_LAMBDA)), sx_smulww(SX_RL2(cRD, 0, 11), SX_JOINT_LAMBDA));
-                int Win2 = 0;
-                i32 gm = g0;
-                if (g1 < gm) { gm = g1; Win2 = 1; }
-                if (g2 < gm) { gm = g2; Win2 = 2; }
-                if (g3 < gm) { gm = g3; Win2 = 3; }
+                SX_LANES12(tk) {
+                    const int s = tk & 3, li = SX_LI(tk);
+                    const i32 a = SX_XL2(cRD, 0, 4 + s), b = SX_XL2(cRD, 0, 8 + s);
+                    jv[li] = sx_add(sx_add(cRD[li][0], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
+                    ji[li] = s;
+                }
+                SX_QUAD_ARG(<)
+                const int Win2 = SX_RL(ji, 0);
                 if (subfr > 0 || i >= decisionDelay) {
+                    const i32 wlo = SX_RL(linLo, Win2), whi = SX_RL(linHi, Win2);
                     SX_PAR(t, SX_N_TRACKS) {
-                        SX_NSQ_EMIT(t, Win2, last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true)
+                        SX_NSQ_EMIT(t, wlo, whi, last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true)
                     }
                 }
             }
+#undef SX_QUAD_ARG
             const bool emitted = subfr > 0 || i >= decisionDelay;
             wv_sync();
             SX_T(7)
@@ -609,12 +612,11 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 RD[li] = cRD[li][0];
                 if (t == 0) w->exc_Q10[smpl_buf_idx][s] = cExc10[li][0];
             }
-            {
-                const u64 m = ~(3ull << (2 * smpl_buf_idx));
-                lin0 = (lin0 & m) | (LIN_ID0 & ~m);
-                lin1 = (lin1 & m) | (LIN_ID1 & ~m);
-                lin2 = (lin2 & m) | (LIN_ID2 & ~m);
-                lin3 = (lin3 & m) | (LIN_ID3 & ~m);
+            SX_LANES12(tk) {          // the state's own slot now holds its newest ring entry
+                const int s = tk & 3, li = SX_LI(tk);
+                const u32 m = 3u << (2 * (smpl_buf_idx & 15));
+                if (smpl_buf_idx < 16) linLo[li] = (i32)(((u32)linLo[li] & ~m) | (((u32)s * 0x55555555u) & m));
+                else linHi[li] = (i32)(((u32)linHi[li] & ~m) | (((u32)s * 0x55555555u) & m));
             }
             w->Gain_ring[smpl_buf_idx] = Gain_Q16;
             // next sample's taps become current; its newest LTP tap is the prediction sample emitted just now when the
@@ -646,10 +648,13 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         }
     }
     out->Seed = SX_RL(SeedInit2, Winner_ind);
-    SX_PAR(ti, 3 * decisionDelay) {
-        const int t = ti / decisionDelay, i = ti - t * decisionDelay;
-        const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
-        SX_NSQ_EMIT(t, Winner_ind, ring, SX_FRAME - decisionDelay + i, 0, false)
+    {
+        const i32 wlo = SX_RL(linLo, Winner_ind), whi = SX_RL(linHi, Winner_ind);
+        SX_PAR(ti, 3 * decisionDelay) {
+            const int t = ti / decisionDelay, i = ti - t * decisionDelay;
+            const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
+            SX_NSQ_EMIT(t, wlo, whi, ring, SX_FRAME - decisionDelay + i, 0, false)
+        }
     }
     wv_sync();
     SX_LANES12(tk) {
