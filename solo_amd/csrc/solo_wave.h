@@ -41,6 +41,12 @@ SX_HD void wv_sync() {
     __syncthreads();
 #endif
 }
+// same, but only LDS traffic is waited for: for phases that talk through LDS / shuffles while global loads and stores stay in flight
+SX_HD void wv_sync_lds() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#endif
+}
 SX_HD i32 wv_sum(i32 v) { SX_XOR_REDUCE(v, sx_add(v, t_)) return v; }   // sum over the lanes, result in every lane
 SX_HD i64 wv_sum64(i64 v) { SX_XOR_REDUCE(v, v + t_) return v; }
 SX_HD i32 wv_max(i32 v) { SX_XOR_REDUCE(v, (t_ > v ? t_ : v)) return v; }
