@@ -23,6 +23,7 @@
 #if SX_NLANES == 1
 #define SX_NSLOT 12
 #define SX_LANES12(tk) for (int tk = 0; tk < 12; tk++)
+#define SX_LANESALL(tk) for (int tk = 0; tk < 12; tk++)
 #define SX_LI(tk) (tk)
 #define SX_XL(arr, src) ((arr)[src])                       // value of a lane-private variable on lane `src`
 #define SX_XL2(arr, j, src) ((arr)[src][j])
@@ -31,6 +32,7 @@
 #else
 #define SX_NSLOT 1
 #define SX_LANES12(tk) for (int tk = SX_LANE, once_ = 1; once_ && tk < 12; once_ = 0)
+#define SX_LANESALL(tk) for (int tk = SX_LANE, once_ = 1; once_; once_ = 0)
 #define SX_LI(tk) 0
 #define SX_XL(arr, src) __shfl((arr)[0], (src), SX_NLANES)
 #define SX_XL2(arr, j, src) __shfl((arr)[0][j], (src), SX_NLANES)
@@ -42,6 +44,38 @@
 #define SX_RL2(arr, j, src) __shfl((arr)[0][j], (src), SX_NLANES)
 #endif
 #endif
+// Cross-lane moves inside the 12-lane block of one stream.  The lanes of one track form a DPP quad and the three tracks sit
+// 4 lanes apart in one 16-lane row, so on the GPU every exchange is ONE data-parallel-primitive VALU move (quad_perm /
+// row_shl / row_shr) instead of a trip through the LDS crossbar.  Host emulation: plain array indexing.
+//   SX_DN(arr, n, tk)  value of lane tk - n   (side lanes reading their centre lane: n = 4 or 8)
+//   SX_UP(arr, n, tk)  value of lane tk + n   (centre lanes reading their side lanes)
+//   SX_QX(arr, o, tk)  value of lane tk ^ o inside the quad (o = 1, 2)
+//   SX_QB(arr, wv, tk) value of lane `wv` of the own quad (wv uniform in the group)
+#if SX_NLANES == 1
+#define SX_DN(arr, n, tk) ((tk) >= (n) ? (arr)[(tk) - (n)] : 0)
+#define SX_UP(arr, n, tk) ((tk) + (n) < 12 ? (arr)[(tk) + (n)] : 0)
+#define SX_QX(arr, o, tk) ((arr)[(tk) ^ (o)])
+#define SX_QB(arr, wv, tk) ((arr)[((tk) & ~3) | (wv)])
+#else
+#define SX_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
+#define SX_DN(arr, n, tk) SX_DPP((arr)[0], 0x110 | (n))          // row_shr:n
+#define SX_UP(arr, n, tk) SX_DPP((arr)[0], 0x100 | (n))          // row_shl:n
+#define SX_QX(arr, o, tk) ((o) == 1 ? SX_DPP((arr)[0], 0xB1) : SX_DPP((arr)[0], 0x4E))   // quad_perm [1,0,3,2] / [2,3,0,1]
+#define SX_QB(arr, wv, tk) ((wv) == 0 ? SX_DPP((arr)[0], 0x00) : ((wv) == 1 ? SX_DPP((arr)[0], 0x55) : ((wv) == 2 ? SX_DPP((arr)[0], 0xAA) : SX_DPP((arr)[0], 0xFF))))
+#endif
+// a value that all twelve lanes hold identically, as a (group-)uniform scalar for control flow
+#if SX_NLANES == 1
+#define SX_GRP(arr) ((arr)[0])
+#elif SX_NLANES == 64
+#define SX_GRP(arr) __builtin_amdgcn_readfirstlane((arr)[0])
+#else
+#define SX_GRP(arr) ((arr)[0])
+#endif
+// group-uniform copy of a value held by the four centre lanes (after a quad butterfly) to all twelve lanes
+// (lanes 12..15 of a 16-lane group take part, so that values steering the group's control flow are defined in all its lanes)
+#define SX_FROM_CENTRE(dst, arr, tk) { const i32 d4_ = SX_DN(arr, 4, tk), d8_ = SX_DN(arr, 8, tk), d12_ = SX_DN(arr, 12, tk); \
+                                       dst = (tk) < 4 ? (arr)[SX_LI(tk)] : ((tk) < 8 ? d4_ : ((tk) < 12 ? d8_ : d12_)); }
+
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
 #define SX_UNIFORM(v) __builtin_amdgcn_readfirstlane(v)      // wave-uniform value -> scalar register
 #else
@@ -168,8 +202,8 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     // lineage word of the lane's state (two 32-bit halves): ring position p lives in slot (lin >> 2p) & 3.  The three tracks
     // of one state index always hold the same word (they are copied together).
     i32 linLo[SX_NSLOT], linHi[SX_NSLOT];
-    i32 jv[SX_NSLOT], ji[SX_NSLOT], tv[SX_NSLOT], ti[SX_NSLOT], mis[SX_NSLOT];
-    for (int a = 0; a < SX_NSLOT; a++) { linLo[a] = linHi[a] = jv[a] = ji[a] = tv[a] = ti[a] = mis[a] = 0; }
+    i32 jv[SX_NSLOT], ji[SX_NSLOT], tv[SX_NSLOT], ti[SX_NSLOT], mis[SX_NSLOT], xq0[SX_NSLOT], xq1[SX_NSLOT], xr0[SX_NSLOT], xr1[SX_NSLOT];
+    for (int a = 0; a < SX_NSLOT; a++) { linLo[a] = linHi[a] = jv[a] = ji[a] = tv[a] = ti[a] = mis[a] = xq0[a] = xq1[a] = xr0[a] = xr1[a] = 0; }
 
     // Agora_Silk_Init_DelDecState (NSQ_del_dec.c:148): every track starts from the same seed
     {
@@ -215,7 +249,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
         P->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
             (i16)sx_sat16(sx_rshift_round(sx_smulww(rg_->Xq_Q10[ring_idx_][slot_], w->Gain_ring[ring_idx_]), 10));           \
         g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
-        if (write_pred_) { const i32 pv_ = rg_->Pred_Q16[ring_idx_][slot_]; g->sLTP_Q16[t_][sLTP_idx_] = pv_; emitPred[SX_LI(t_)] = pv_;   \
+        if (write_pred_) { const i32 pv_ = rg_->Pred_Q16[ring_idx_][slot_]; g->sLTP_Q16[t_][sLTP_idx_] = pv_; emitPred[SX_LI(4 * (t_))] = pv_;   \
                            w->ebL[t_][i] = pv_; w->ebS[t_][i] = rg_->Shape_Q10[ring_idx_][slot_]; }                          \
     }
 
@@ -429,7 +463,8 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             // phase B: the two candidates of every side state (the centre residual comes over by shuffle)
             SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
-                const i32 rC = SX_XL(rD, s);
+                i32 rC;
+                SX_FROM_CENTRE(rC, rD, tk)
                 if (t != 0) {
                     const bool first = (t == 1) != (odd != 0);      // MD1 takes the p1 share on even subframes, MD2 on odd ones
                     const i32 r_md_Q10 = sx_smulww(first ? inv_gain_p1_Q16 : inv_gain_p2_Q16, rC);
@@ -441,11 +476,13 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152): the centre takes the best two of the four combinations of side
             // candidates; the side candidates are then re-ordered so that slot s of every track belongs to combination w_s
             SX_LANES12(tk) {
+                const int li = SX_LI(tk);
+                xq0[li] = cQ10[li][0]; xq1[li] = cQ10[li][1]; xr0[li] = cRdInd[li][0]; xr1[li] = cRdInd[li][1];
+            }
+            SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
-                const i32 p1q0 = SX_XL2(cQ10, 0, 4 + s), p1q1 = SX_XL2(cQ10, 1, 4 + s);
-                const i32 p2q0 = SX_XL2(cQ10, 0, 8 + s), p2q1 = SX_XL2(cQ10, 1, 8 + s);
-                const i32 p1r0 = SX_XL2(cRdInd, 0, 4 + s), p1r1 = SX_XL2(cRdInd, 1, 4 + s);
-                const i32 p2r0 = SX_XL2(cRdInd, 0, 8 + s), p2r1 = SX_XL2(cRdInd, 1, 8 + s);
+                const i32 p1q0 = SX_UP(xq0, 4, tk), p1q1 = SX_UP(xq1, 4, tk), p2q0 = SX_UP(xq0, 8, tk), p2q1 = SX_UP(xq1, 8, tk);
+                const i32 p1r0 = SX_UP(xr0, 4, tk), p1r1 = SX_UP(xr1, 4, tk), p2r0 = SX_UP(xr0, 8, tk), p2r1 = SX_UP(xr1, 8, tk);
                 if (t == 0) {
                     const i32 off = offset_p1_Q10 + offset_p2_Q10;
                     const i32 qx0 = p1q0 + p2q0, qx1 = p1q1 + p2q1, qx2 = p1q0 + p2q1, qx3 = p1q1 + p2q0;
@@ -489,7 +526,9 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             }
             SX_LANES12(tk) {
                 const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
-                const int w1 = SX_XL(W1, s), w2 = SX_XL(W2, s);
+                int w1, w2;
+                SX_FROM_CENTRE(w1, W1, tk)
+                SX_FROM_CENTRE(w2, W2, tk)
                 if (t != 0) {
                     // the reference's 12-way memcpy case table (NSQ_del_dec.c:1266-1336) is this gather;
                     // member of combination w: MD1 {0,1,0,1}, MD2 {0,1,1,0}
@@ -524,7 +563,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             // of s; winners / extremes are found by xor-butterflies inside the quad of centre lanes
 #define SX_QUAD_ARG(CMP)                                                                                                     \
     for (int o_ = 1; o_ <= 2; o_ <<= 1) {                                                                                    \
-        SX_LANES12(tk) { const int li = SX_LI(tk); tv[li] = SX_XL(jv, tk ^ o_); ti[li] = SX_XL(ji, tk ^ o_); }                \
+        SX_LANES12(tk) { const int li = SX_LI(tk); tv[li] = SX_QX(jv, o_, tk); ti[li] = SX_QX(ji, o_, tk); }                  \
         SX_LANES12(tk) { const int li = SX_LI(tk); if (tv[li] CMP jv[li] || (tv[li] == jv[li] && ti[li] < ji[li])) { jv[li] = tv[li]; ji[li] = ti[li]; } } \
     }
             {
@@ -532,37 +571,51 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 // joint cost of candidate [0] of every state; the delayed random-state cell of every (track, state)
                 SX_LANES12(tk) {
                     const int t = tk >> 2, s = tk & 3, li = SX_LI(tk);
-                    const i32 a = SX_XL2(cRD, 0, 4 + s), b = SX_XL2(cRD, 0, 8 + s);
-                    jv[li] = sx_add(sx_add(cRD[li][0], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
-                    ji[li] = s;
+                    xq0[li] = cRD[li][0];
                     myRand[li] = w->ring[t].Rand[last_smple_idx][SX_LIN_SLOT(linLo[li], linHi[li], last_smple_idx)];
-                }
-                SX_QUAD_ARG(<)
-                const int Winner_ind = SX_RL(ji, 0);
-                // states whose decisionDelay-old ancestor differs from the winner's, in any track, are expired
-                SX_LANES12(tk) {
-                    const int t = tk >> 2, li = SX_LI(tk);
-                    const i32 wr = SX_XL(myRand, 4 * t + Winner_ind);
-                    mis[li] = myRand[li] != wr ? 1 : 0;
                 }
                 SX_LANES12(tk) {
                     const int s = tk & 3, li = SX_LI(tk);
-                    const i32 m = mis[li] | SX_XL(mis, 4 + s) | SX_XL(mis, 8 + s);
-                    tv[li] = m;
+                    const i32 a = SX_UP(xq0, 4, tk), b = SX_UP(xq0, 8, tk);
+                    jv[li] = sx_add(sx_add(xq0[li], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
+                    ji[li] = s;
+                }
+                SX_QUAD_ARG(<)
+                int Winner_ind = 0;
+                SX_LANESALL(tk) { int wl; SX_FROM_CENTRE(wl, ji, tk) xr0[SX_LI(tk)] = wl; }
+                Winner_ind = SX_GRP(xr0);
+                // states whose decisionDelay-old ancestor differs from the winner's, in any track, are expired
+                SX_LANES12(tk) {
+                    const int li = SX_LI(tk);
+                    const i32 wr = SX_QB(myRand, Winner_ind, tk);
+                    mis[li] = myRand[li] != wr ? 1 : 0;
+                }
+                SX_LANES12(tk) {
+                    const int li = SX_LI(tk);
+                    const i32 m = mis[li] | SX_UP(mis, 4, tk) | SX_UP(mis, 8, tk);
+                    jv[li] = m;
                     if (tk < 4 && m) { cRD[li][0] = sx_add(cRD[li][0], PEN); cRD[li][1] = sx_add(cRD[li][1], PEN); }
                 }
-                int RandSyncCtl = SX_RL(tv, 0) + SX_RL(tv, 1) + SX_RL(tv, 2) + SX_RL(tv, 3);
+                // number of expired states: quad sum on the centre lanes
+                for (int o_ = 1; o_ <= 2; o_ <<= 1) {
+                    SX_LANES12(tk) { tv[SX_LI(tk)] = SX_QX(jv, o_, tk); }
+                    SX_LANES12(tk) { jv[SX_LI(tk)] += tv[SX_LI(tk)]; }
+                }
+                SX_LANESALL(tk) { int n_; SX_FROM_CENTRE(n_, jv, tk) xr0[SX_LI(tk)] = n_; }
+                int RandSyncCtl = SX_GRP(xr0);
                 SX_TA(5)
                 do {
                     // worst candidate [0] (first maximum) and best candidate [1] (first minimum) of the centre track
                     SX_LANES12(tk) { const int li = SX_LI(tk); jv[li] = cRD[li][0]; ji[li] = tk & 3; }
                     SX_QUAD_ARG(>)
-                    const i32 RDmax = SX_RL(jv, 0);
-                    const int RDmax_ind = SX_RL(ji, 0);
+                    SX_LANESALL(tk) { i32 a_, b_; SX_FROM_CENTRE(a_, jv, tk) SX_FROM_CENTRE(b_, ji, tk) xq0[SX_LI(tk)] = a_; xq1[SX_LI(tk)] = b_; }
+                    const i32 RDmax = SX_GRP(xq0);
+                    const int RDmax_ind = SX_GRP(xq1);
                     SX_LANES12(tk) { const int li = SX_LI(tk); jv[li] = cRD[li][1]; ji[li] = tk & 3; }
                     SX_QUAD_ARG(<)
-                    const i32 RDmin2 = SX_RL(jv, 0);
-                    const int RDmin_ind = SX_RL(ji, 0);
+                    SX_LANESALL(tk) { i32 a_, b_; SX_FROM_CENTRE(a_, jv, tk) SX_FROM_CENTRE(b_, ji, tk) xr0[SX_LI(tk)] = a_; xr1[SX_LI(tk)] = b_; }
+                    const i32 RDmin2 = SX_GRP(xr0);
+                    const int RDmin_ind = SX_GRP(xr1);
                     if (RDmin2 < RDmax) {
                         // SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668) for the three tracks: lineage word + filter memories;
                         // then candidate [RDmax][0] <- candidate [RDmin][1]
@@ -580,39 +633,56 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                         }
 #else
                         {
-                            const int lane = SX_LANE;
-                            const bool dst = lane < 12 && (lane & 3) == RDmax_ind;
-                            const int src = dst ? ((lane & ~3) | RDmin_ind) : lane;
-#define SX_MV(v) { const i32 t_ = __shfl((v), src, SX_NLANES); if (dst) (v) = t_; }
-                            if (RDmax_ind != RDmin_ind) {
-#pragma unroll
-                                for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MV(sAR2[0][j])
-#pragma unroll
-                                for (int j = 0; j < SX_LPC; j++) SX_MV(sLPC[0][j])
-                                SX_MV(LF_AR[0]) SX_MV(Seed[0]) SX_MV(Seed2[0]) SX_MV(SeedInit2[0]) SX_MV(RD[0]) SX_MV(linLo[0]) SX_MV(linHi[0])
+                            // one DPP quad_perm move per register: lane RDmax of every quad takes lane RDmin's value
+                            const bool dst = (SX_LANE & 3) == RDmax_ind;
+                            const bool full = RDmax_ind != RDmin_ind;
+#define SX_MVD(v, CTRL) { const i32 t_ = SX_DPP((v), CTRL); if (dst) (v) = t_; }
+#define SX_MVD01(v, CTRL) { const i32 t_ = SX_DPP((v)[0][1], CTRL); if (dst) (v)[0][0] = t_; }
+#define SX_COPY_CASE(MX, MN)                                                                                                  \
+    case (MX) * 4 + (MN): {                                                                                                  \
+        constexpr int C_ = ((MX) == 0 ? (MN) : 0) | (((MX) == 1 ? (MN) : 1) << 2) | (((MX) == 2 ? (MN) : 2) << 4) | (((MX) == 3 ? (MN) : 3) << 6); \
+        if (full) {                                                                                                          \
+            _Pragma("unroll") for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MVD(sAR2[0][j], C_)                                \
+            _Pragma("unroll") for (int j = 0; j < SX_LPC; j++) SX_MVD(sLPC[0][j], C_)                                        \
+            SX_MVD(LF_AR[0], C_) SX_MVD(Seed[0], C_) SX_MVD(Seed2[0], C_) SX_MVD(SeedInit2[0], C_) SX_MVD(RD[0], C_)         \
+            SX_MVD(linLo[0], C_) SX_MVD(linHi[0], C_)                                                                        \
+        }                                                                                                                    \
+        SX_MVD01(cRD, C_) SX_MVD01(cQ0, C_) SX_MVD01(cXq14, C_) SX_MVD01(cLFAR, C_) SX_MVD01(cShp, C_) SX_MVD01(cExc16, C_) SX_MVD01(cExc10, C_) \
+    } break;
+                            switch (RDmax_ind * 4 + RDmin_ind) {
+                                SX_COPY_CASE(0, 0) SX_COPY_CASE(0, 1) SX_COPY_CASE(0, 2) SX_COPY_CASE(0, 3)
+                                SX_COPY_CASE(1, 0) SX_COPY_CASE(1, 1) SX_COPY_CASE(1, 2) SX_COPY_CASE(1, 3)
+                                SX_COPY_CASE(2, 0) SX_COPY_CASE(2, 1) SX_COPY_CASE(2, 2) SX_COPY_CASE(2, 3)
+                                SX_COPY_CASE(3, 0) SX_COPY_CASE(3, 1) SX_COPY_CASE(3, 2) SX_COPY_CASE(3, 3)
                             }
-#define SX_MV01(v) { const i32 t_ = __shfl((v)[0][1], src, SX_NLANES); if (dst) (v)[0][0] = t_; }
-                            SX_MV01(cRD) SX_MV01(cQ0) SX_MV01(cXq14) SX_MV01(cLFAR) SX_MV01(cShp) SX_MV01(cExc16) SX_MV01(cExc10)
-#undef SX_MV
-#undef SX_MV01
+#undef SX_COPY_CASE
+#undef SX_MVD
+#undef SX_MVD01
                         }
 #endif
                     }
                 } while (--RandSyncCtl > 0);
                 SX_TA(6)
                 // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner
+                SX_LANES12(tk) { xq0[SX_LI(tk)] = cRD[SX_LI(tk)][0]; }
                 SX_LANES12(tk) {
                     const int s = tk & 3, li = SX_LI(tk);
-                    const i32 a = SX_XL2(cRD, 0, 4 + s), b = SX_XL2(cRD, 0, 8 + s);
-                    jv[li] = sx_add(sx_add(cRD[li][0], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
+                    const i32 a = SX_UP(xq0, 4, tk), b = SX_UP(xq0, 8, tk);
+                    jv[li] = sx_add(sx_add(xq0[li], sx_smulww(a, SX_JOINT_LAMBDA)), sx_smulww(b, SX_JOINT_LAMBDA));
                     ji[li] = s;
                 }
                 SX_QUAD_ARG(<)
-                const int Win2 = SX_RL(ji, 0);
+                SX_LANESALL(tk) { int wl; SX_FROM_CENTRE(wl, ji, tk) xr0[SX_LI(tk)] = wl; }
+                const int Win2 = SX_GRP(xr0);
                 if (subfr > 0 || i >= decisionDelay) {
-                    const i32 wlo = SX_RL(linLo, Win2), whi = SX_RL(linHi, Win2);
-                    SX_PAR(t, SX_N_TRACKS) {
-                        SX_NSQ_EMIT(t, wlo, whi, last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true)
+                    // the first lane of every track's quad emits that track; the lineage word of the winner comes by quad broadcast
+                    SX_LANES12(tk) { const int li = SX_LI(tk); xq0[li] = SX_QB(linLo, Win2, tk); xq1[li] = SX_QB(linHi, Win2, tk); }
+                    SX_LANES12(tk) {
+                        if ((tk & 3) == 0) {
+                            const int t = tk >> 2;
+                            const i32 wlo = xq0[SX_LI(tk)], whi = xq1[SX_LI(tk)];
+                            SX_NSQ_EMIT(t, wlo, whi, last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true)
+                        }
                     }
                 }
             }
@@ -648,7 +718,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
             SX_LANES12(tk) {
                 const int t = tk >> 2, li = SX_LI(tk);
                 const int lag_me = t == 0 ? lagC : (t == 1 ? lagP1 : lagP2);
-                const i32 fw = SX_XL(emitPred, t);
+                const i32 fw = SX_QB(emitPred, 0, tk);
                 for (int j = 0; j < SX_LTP_ORDER; j++) curL[li][j] = nxL[li][j];
                 if (voiced && emitted && decisionDelay == lag_me - SX_LTP_ORDER / 2 - 1) curL[li][0] = fw;
                 for (int j = 0; j < 3; j++) curS[li][j] = nxS[li][j];
