@@ -633,31 +633,23 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                         }
 #else
                         {
-                            // one DPP quad_perm move per register: lane RDmax of every quad takes lane RDmin's value
-                            const bool dst = (SX_LANE & 3) == RDmax_ind;
-                            const bool full = RDmax_ind != RDmin_ind;
-#define SX_MVD(v, CTRL) { const i32 t_ = SX_DPP((v), CTRL); if (dst) (v) = t_; }
-#define SX_MVD01(v, CTRL) { const i32 t_ = SX_DPP((v)[0][1], CTRL); if (dst) (v)[0][0] = t_; }
-#define SX_COPY_CASE(MX, MN)                                                                                                  \
-    case (MX) * 4 + (MN): {                                                                                                  \
-        constexpr int C_ = ((MX) == 0 ? (MN) : 0) | (((MX) == 1 ? (MN) : 1) << 2) | (((MX) == 2 ? (MN) : 2) << 4) | (((MX) == 3 ? (MN) : 3) << 6); \
-        if (full) {                                                                                                          \
-            _Pragma("unroll") for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MVD(sAR2[0][j], C_)                                \
-            _Pragma("unroll") for (int j = 0; j < SX_LPC; j++) SX_MVD(sLPC[0][j], C_)                                        \
-            SX_MVD(LF_AR[0], C_) SX_MVD(Seed[0], C_) SX_MVD(Seed2[0], C_) SX_MVD(SeedInit2[0], C_) SX_MVD(RD[0], C_)         \
-            SX_MVD(linLo[0], C_) SX_MVD(linHi[0], C_)                                                                        \
-        }                                                                                                                    \
-        SX_MVD01(cRD, C_) SX_MVD01(cQ0, C_) SX_MVD01(cXq14, C_) SX_MVD01(cLFAR, C_) SX_MVD01(cShp, C_) SX_MVD01(cExc16, C_) SX_MVD01(cExc10, C_) \
-    } break;
-                            switch (RDmax_ind * 4 + RDmin_ind) {
-                                SX_COPY_CASE(0, 0) SX_COPY_CASE(0, 1) SX_COPY_CASE(0, 2) SX_COPY_CASE(0, 3)
-                                SX_COPY_CASE(1, 0) SX_COPY_CASE(1, 1) SX_COPY_CASE(1, 2) SX_COPY_CASE(1, 3)
-                                SX_COPY_CASE(2, 0) SX_COPY_CASE(2, 1) SX_COPY_CASE(2, 2) SX_COPY_CASE(2, 3)
-                                SX_COPY_CASE(3, 0) SX_COPY_CASE(3, 1) SX_COPY_CASE(3, 2) SX_COPY_CASE(3, 3)
+                            // lane RDmax of every quad takes lane RDmin's registers: a lane-indexed permute, so the four streams
+                            // of a wave (each with its own RDmax / RDmin) move in the same instructions
+                            const int lane = SX_LANE;
+                            const bool dst = lane < 12 && (lane & 3) == RDmax_ind;
+                            const int src = dst ? ((lane & ~3) | RDmin_ind) : lane;
+#define SX_MV(v) { const i32 t_ = __shfl((v), src, SX_NLANES); if (dst) (v) = t_; }
+                            if (RDmax_ind != RDmin_ind) {
+#pragma unroll
+                                for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_MV(sAR2[0][j])
+#pragma unroll
+                                for (int j = 0; j < SX_LPC; j++) SX_MV(sLPC[0][j])
+                                SX_MV(LF_AR[0]) SX_MV(Seed[0]) SX_MV(Seed2[0]) SX_MV(SeedInit2[0]) SX_MV(RD[0]) SX_MV(linLo[0]) SX_MV(linHi[0])
                             }
-#undef SX_COPY_CASE
-#undef SX_MVD
-#undef SX_MVD01
+#define SX_MV01(v) { const i32 t_ = __shfl((v)[0][1], src, SX_NLANES); if (dst) (v)[0][0] = t_; }
+                            SX_MV01(cRD) SX_MV01(cQ0) SX_MV01(cXq14) SX_MV01(cLFAR) SX_MV01(cShp) SX_MV01(cExc16) SX_MV01(cExc10)
+#undef SX_MV
+#undef SX_MV01
                         }
 #endif
                     }
