@@ -10,9 +10,10 @@ C ABI of solo_amd/libsolo_mi355x.so.  Inputs are resident in HBM before the time
 HBM between steps.  Streams shard over ranks with no data-path collective ("weak" scaling: 4096 streams per GPU);
 RCCL is used only for the barrier and the max-over-ranks time.
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (solo_encode_kernel): algorithmic HBM bytes
-per launch (1280 B PCM in + payload + 4 B lengths per packet) / its average duration measured
-with HIP events on the launch stream.  `cpu_baseline` times the compiled reference (oracle/_ref, fixed-point tree)
+Prints ONE JSON line (rank 0).  The encoder is a three-kernel pipeline (analysis -> quantiser -> coding); `roofline`
+is for the longest-running kernel of the step: algorithmic HBM bytes of that kernel per launch /
+its average duration, measured with HIP events recorded by the library on the launch stream around each kernel
+(solo_batch_set_timing).  `kernels` lists all four kernels the same way.  `cpu_baseline` times the compiled reference (oracle/_ref, fixed-point tree)
 on the host cores for a bounded sample of the same workload.
 """
 import argparse
@@ -128,17 +129,12 @@ def main():
     st_d = torch.zeros((N,), dtype=torch.int32, device=dev)
     out = torch.zeros((N, P, 640), dtype=torch.int16, device=dev)
 
-    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+    batch.set_timing(True)
+    kms = {"analysis": [], "quantiser": [], "coding": [], "decode": []}
 
     def step(k=None):
-        if k is not None:
-            ev[k][0].record()
         batch.encode(pcm, bits, nb, st_e)
-        if k is not None:
-            ev[k][1].record()
         batch.decode(bits, nb, None, out, st_d)
-        if k is not None:
-            ev[k][2].record()
 
     def barrier():
         if world > 1:
@@ -153,19 +149,34 @@ def main():
         step(k)
     barrier()
     dt = time.perf_counter() - t0
+    # per-kernel durations: a few extra steps outside the timed region (reading the events synchronises the stream)
+    for _ in range(min(3, args.steps)):
+        step()
+        for name, v in batch.last_kernel_ms().items():
+            kms[name].append(v)
     if world > 1:
         dt = sdist.max_over_ranks(dt, dist, dev)
 
     assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
-    enc_ms = float(np.mean([ev[k][0].elapsed_time(ev[k][1]) for k in range(args.steps)]))
-    dec_ms = float(np.mean([ev[k][1].elapsed_time(ev[k][2]) for k in range(args.steps)]))
+    kavg = {n: float(np.mean(v)) for n, v in kms.items()}
+    enc_ms = kavg["analysis"] + kavg["quantiser"] + kavg["coding"]
+    dec_ms = kavg["decode"]
     mean_payload = float(nb[:, :, 0].float().mean().item())
     packets_step = N * P
     value = world * packets_step * args.steps / dt
 
     if rank == 0:
-        enc_bytes = packets_step * (1280.0 + mean_payload + 4.0)
-        achieved = enc_bytes / (enc_ms * 1e-3) / 1e9
+        # algorithmic HBM bytes per packet of each kernel: stage input + stage output that has to cross HBM
+        rec_in, rec_out, rec_code = 660.0, 964.0, 840.0       # sizeof SxNsqIn / SxNsqOut / SxCodeIn
+        alg = {"analysis": 1280.0 + 2 * rec_in + rec_code, "quantiser": 2 * rec_in + 2 * rec_out,
+               "coding": 2 * rec_out + rec_code + mean_payload + 4.0, "decode": mean_payload + 4.0 + 1280.0}
+        kname = {"analysis": "solo_enc_analysis_kernel", "quantiser": "solo_nsq_kernel", "coding": "solo_enc_coding_kernel",
+                 "decode": "solo_decode_kernel"}
+        kernels = {kname[n]: {"avg_launch_ms": round(kavg[n], 3), "algorithmic_bytes_per_launch": int(alg[n] * packets_step),
+                              "achieved_GBps": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9, 4)} for n in kavg}
+        dom = max(kavg, key=kavg.get)
+        enc_bytes = packets_step * alg[dom]
+        achieved = enc_bytes / (kavg[dom] * 1e-3) / 1e9
         res = {
             "metric": "40 ms frames/sec (encode+decode) per GPU; concurrent real-time WB streams @1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "40ms packets/s (encode+decode)", "n_gpus": world, "steps": args.steps,
@@ -177,14 +188,16 @@ def main():
             "realtime_streams": round(value / 25.0, 1),
             "encode_only_packets_per_s": round(packets_step / (enc_ms * 1e-3), 1),
             "decode_only_packets_per_s": round(packets_step / (dec_ms * 1e-3), 1),
-            "roofline": {"kernel": "solo_encode_kernel", "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
+            "roofline": {"kernel": kname[dom], "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
-                         "avg_launch_ms": round(enc_ms, 3), "algorithmic_bytes_per_launch": int(enc_bytes)},
+                         "avg_launch_ms": round(kavg[dom], 3), "algorithmic_bytes_per_launch": int(enc_bytes),
+                         "note": "serial fixed-point recursions: latency / issue bound, not HBM bound (DESIGN.md section 4)"},
+            "kernels": kernels,
         }
         tr = os.path.join(HERE, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, collected separately
         if os.path.exists(tr):
             try:
-                res["roofline"]["traffic"] = json.load(open(tr)).get("solo_encode_kernel_bytes_per_packet") * packets_step
+                res["roofline"]["traffic"] = int(json.load(open(tr)).get(kname[dom] + "_bytes_per_packet") * packets_step)
             except Exception:
                 pass
         if world == 1 and not args.no_cpu_baseline:

@@ -100,7 +100,12 @@ int32_t solo_batch_decode(solo_batch_t *b, const uint8_t *d_bits, const int16_t 
 int32_t solo_batch_n_streams(const solo_batch_t *b);
 int32_t solo_batch_slot_bytes(const solo_batch_t *b);
 /* Name of the dominant kernel of the last encode / decode launch (for profiling tools). */
-const char *solo_kernel_name(int32_t which /* 0 = encode, 1 = decode */);
+/* Names of the device kernels: 0 = quantiser (dominant encode kernel), 1 = decode, 2 = encoder analysis, 3 = encoder coding. */
+const char *solo_kernel_name(int32_t which);
+/* Benchmark aid: bracket every kernel of this handle with HIP events on its launch stream, and read the durations of
+ * the most recent encode / decode call: ms4 = {analysis, quantiser, coding, decode} (-1 = not run yet). */
+int32_t solo_batch_set_timing(solo_batch_t *b, int32_t on);
+int32_t solo_batch_last_kernel_ms(solo_batch_t *b, float *ms4);
 /* Library version string. */
 const char *solo_version(void);
 

@@ -21,7 +21,8 @@ ABI_SYMBOLS = [
     "AGR_Sate_Encoder_Init", "AGR_Sate_Encoder_Encode", "AGR_Sate_Encoder_Uninit",
     "AGR_Sate_Decoder_Init", "AGR_Sate_Decoder_Decode", "AGR_Sate_Decoder_Uninit",
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
-    "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version",
+    "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
+    "solo_batch_last_kernel_ms",
 ]
 
 
@@ -59,6 +60,10 @@ def load_library():
     lib.solo_batch_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.solo_batch_n_streams.argtypes = [C.c_void_p]
     lib.solo_batch_slot_bytes.argtypes = [C.c_void_p]
+    lib.solo_batch_set_timing.restype = C.c_int32
+    lib.solo_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
+    lib.solo_batch_last_kernel_ms.restype = C.c_int32
+    lib.solo_batch_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
     lib.solo_kernel_name.restype = C.c_char_p
     lib.solo_kernel_name.argtypes = [C.c_int32]
     lib.solo_version.restype = C.c_char_p
@@ -130,6 +135,18 @@ class SoloBatch:
         if r:
             raise RuntimeError("solo_batch_encode -> %d" % r)
         return bits, nbytes, status
+
+    def set_timing(self, on=True):
+        """Bracket every kernel launch with HIP events (benchmarks only)."""
+        if self.lib.solo_batch_set_timing(self.h, 1 if on else 0):
+            raise RuntimeError("solo_batch_set_timing failed")
+
+    def last_kernel_ms(self):
+        """{analysis, quantiser, coding, decode} durations (ms) of the most recent encode / decode call (synchronises)."""
+        ms = (C.c_float * 4)()
+        if self.lib.solo_batch_last_kernel_ms(self.h, ms):
+            raise RuntimeError("solo_batch_last_kernel_ms failed")
+        return dict(zip(("analysis", "quantiser", "coding", "decode"), [float(v) for v in ms]))
 
     def decode(self, bits, nbytes, recv=None, pcm=None, status=None):
         """bits uint8 [N,P,slot], nbytes int16 [N,P,2], recv uint8 [N,P] (bit0 MD1, bit1 MD2) -> pcm int16 [N,P,640]"""

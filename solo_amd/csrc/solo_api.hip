@@ -150,6 +150,9 @@ struct solo_batch {
     void* d_enc_state;
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
     int32_t enc_work_packets;        // P the hand-over area is sized for
+    int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
+    hipEvent_t ev[6];                // encode: 0|A|1|B|2|C|3   decode: 4|D|5
+    int ev_ready, ev_enc, ev_dec;
     SxDecState* d_dec_state;
 };
 
@@ -187,6 +190,32 @@ const char* solo_version(void) { return "solo_mi355x 0.1 (gfx950)"; }
 const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : (which == 1 ? "solo_decode_kernel" : (which == 2 ? "solo_enc_analysis_kernel" : "solo_enc_coding_kernel")); }
 
 int32_t solo_batch_n_streams(const solo_batch_t* b) { return b ? b->n_streams : 0; }
+
+// Kernel timing for benchmarks: when enabled every kernel launch of this handle is bracketed by HIP events on the launch
+// stream; solo_batch_last_kernel_ms() synchronises on them and returns the durations of the most recent encode / decode call:
+// ms[0] analysis, ms[1] quantiser, ms[2] coding, ms[3] decode (a field is -1 if that call has not happened yet).
+int32_t solo_batch_set_timing(solo_batch_t* b, int32_t on) {
+    if (!b) return -1;
+    if (on && !b->ev_ready) {
+        for (int i = 0; i < 6; i++) SOLO_CHECK(hipEventCreate(&b->ev[i]));
+        b->ev_ready = 1;
+    }
+    b->timing = on ? 1 : 0;
+    return 0;
+}
+int32_t solo_batch_last_kernel_ms(solo_batch_t* b, float* ms4) {
+    if (!b || !ms4 || !b->ev_ready) return -1;
+    for (int i = 0; i < 4; i++) ms4[i] = -1.0f;
+    if (b->ev_enc) {
+        SOLO_CHECK(hipEventSynchronize(b->ev[3]));
+        for (int i = 0; i < 3; i++) SOLO_CHECK(hipEventElapsedTime(&ms4[i], b->ev[i], b->ev[i + 1]));
+    }
+    if (b->ev_dec) {
+        SOLO_CHECK(hipEventSynchronize(b->ev[5]));
+        SOLO_CHECK(hipEventElapsedTime(&ms4[3], b->ev[4], b->ev[5]));
+    }
+    return 0;
+}
 int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
 
 int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
@@ -242,6 +271,7 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
 void solo_batch_destroy(solo_batch_t* b) {
     if (!b) return;
     if (b->d_dec_state) (void)hipFree(b->d_dec_state);
+    if (b->ev_ready) for (int i = 0; i < 6; i++) (void)hipEventDestroy(b->ev[i]);
 #ifdef SOLO_WITH_ENCODER
     solo_enc_free(b);
 #endif
@@ -251,8 +281,11 @@ void solo_batch_destroy(solo_batch_t* b) {
 int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
                           int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
+    const bool tm = b->timing && b->ev_ready;
+    if (tm) (void)hipEventRecord(b->ev[4], (hipStream_t)hip_stream);
     hipLaunchKernelGGL(solo_decode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state,
                        d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot, b->dec_ctrl.useMDIndex, d_pcm, d_status);
+    if (tm) { (void)hipEventRecord(b->ev[5], (hipStream_t)hip_stream); b->ev_dec = 1; }
     SOLO_CHECK(hipGetLastError());
     return 0;
 }
@@ -275,10 +308,15 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SxNsqOut* nout = (SxNsqOut*)((char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63));
     SxCodeIn* cin = (SxCodeIn*)((char*)nout + ((sz_out + 63) & ~(size_t)63));
     SxEncStream* states = (SxEncStream*)b->d_enc_state;
+    const bool tm = b->timing && b->ev_ready;
+    if (tm) (void)hipEventRecord(b->ev[0], st);
     hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, st, states, d_pcm, b->n_streams, n_packets, nin, cin);
+    if (tm) (void)hipEventRecord(b->ev[1], st);
     if (solo_launch_nsq(states, nin, nout, b->n_streams, n_packets, st) != 0) return -2;
+    if (tm) (void)hipEventRecord(b->ev[2], st);
     hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, st, states, cin, nout, b->n_streams, n_packets, b->slot,
                        d_bits, d_nbytes, d_status);
+    if (tm) { (void)hipEventRecord(b->ev[3], st); b->ev_enc = 1; }
     SOLO_CHECK(hipGetLastError());
     return 0;
 }
