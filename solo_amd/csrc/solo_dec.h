@@ -113,6 +113,9 @@ struct SxDecWork {
     SxCdf cdf;                      // entropy-coding tables (loaded once per launch)
     u8 payload[SX_DEC_PAYLOAD_LDS + 4];
     SxDecCtrl ctrl;
+    SxDecCtrl ctrl2[2];             // side information as decoded from description 0 / 1 (one description per lane)
+    i32 lane_out[2][4];             // per description: vadFlag, FrameTermination, bytes left, range-coder error
+    i32 lane_len[2];                // per description: range-coder buffer length
     i32 pulses[2][SX_FRAME];
     i32 res_Q10[SX_FRAME];          // LPC residual of the current frame
     i32 sLPC_Q14[SX_MAX_LPC + SX_SUBFR];
@@ -251,8 +254,8 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 }
 
 // SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
-SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf);
+SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf, i32* lane_out) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out);
     i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], pNLSF_Q15[SX_LPC], pNLSF0_Q15[SX_LPC], DeltaGainIndices;
     SxDecDesc* md = &st->md[kDesp];
     if (st->nFramesDecoded == 0) {
@@ -260,6 +263,7 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
         Ix = sx_rc_dec(rc, cdf->cdf_fs, T_CDF_MID_FS);
         if (Ix != 0) {  // only the 8 kHz NB mode exists in this build (reference: decoder_set_fs to 12/16/24 kHz)
             if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
+            lane_out[3] = rc->error;
             return;
         }
         Ix = sx_rc_dec(rc, cdf->cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
@@ -339,15 +343,16 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     SX_TRACE(5);
     sx_decode_pulses(rc, c, q, cdf);
     SX_TRACE(6);
-    st->vadFlag = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
-    st->FrameTermination = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
+    lane_out[0] = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
+    lane_out[1] = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
 
     i32 nBytesUsed;
     sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytesUsed);
     i32 left = rc->bufferLength - nBytesUsed;
-    if (kDesp == 0) st->nBytesLeft0 = left;
+    lane_out[2] = left;
     if (left < 0) rc->error = SX_RC_READ_BEYOND_BUFFER;
     if (left == 0) sx_rc_check_after_decoding(rc);
+    lane_out[3] = rc->error;
     SX_TRACE(7);
 }
 
@@ -720,12 +725,29 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         sx_plc(st, w, pOut, 1);
     } else {
         const int desp_type = action - 2;
-        if (st->nFramesDecoded == 0) {
-            sx_rc_dec_init(&rc[0], payload, nB0);
-            if (desp_type > 1) sx_rc_dec_init(&rc[1], payload + nB0, nB1);
+        const int ndesc = desp_type > 1 ? 2 : 1;
+        // the two descriptions are independent range-coded streams: description md is parsed by lane md
+        SX_PAR(md, ndesc) {
+            SxRangeDec* r = &rc[SX_NLANES == 1 ? md : 0];
+            if (st->nFramesDecoded == 0) {
+                if (md == 0) sx_rc_dec_init(r, payload, nB0);
+                else sx_rc_dec_init(r, payload + nB0, nB1);
+            }
+            sx_decode_parameters(st, &w->ctrl2[md], r, w->pulses[md], md, useMDIndex, &w->cdf, w->lane_out[md]);
+            w->lane_len[md] = r->bufferLength;
         }
-        sx_decode_parameters(st, c, &rc[0], w->pulses[0], 0, useMDIndex, &w->cdf);
-        if (desp_type > 1) sx_decode_parameters(st, c, &rc[1], w->pulses[1], 1, useMDIndex, &w->cdf);
+        wv_sync();
+        {   // the reference parses description 1 after description 0 into the same control block: the last one wins
+            const i32* src = (const i32*)&w->ctrl2[ndesc - 1];
+            i32* dst = (i32*)c;
+            SX_PAR(i, (int)(sizeof(SxDecCtrl) / 4)) dst[i] = src[i];
+            st->vadFlag = w->lane_out[ndesc - 1][0];
+            st->FrameTermination = w->lane_out[ndesc - 1][1];
+            st->nBytesLeft0 = w->lane_out[0][2];
+            wv_sync();
+        }
+        const i32 err0 = w->lane_out[0][3], err1 = ndesc > 1 ? w->lane_out[1][3] : 0;
+        const i32 len0 = w->lane_len[0];
 
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
         i32 inv_gain_p1_Q16 = inv_gain_Q16;
@@ -736,14 +758,14 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);
         i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
 
-        if (rc[0].error || (desp_type > 1 && rc[1].error)) {
+        if (err0 || err1) {
             st->nBytesLeft0 = 0;
-            used = rc[0].bufferLength;
-            ret = rc[0].error == SX_RC_DEC_PAYLOAD_TOO_LONG ? -11 : -12;   // SKP_SILK_DEC_PAYLOAD_TOO_LARGE / _ERROR
+            used = len0;
+            ret = err0 == SX_RC_DEC_PAYLOAD_TOO_LONG ? -11 : -12;   // SKP_SILK_DEC_PAYLOAD_TOO_LARGE / _ERROR
             st->moreInternalDecoderFrames = 0;
         } else {
             st->nFramesDecoded++;
-            used = rc[0].bufferLength - st->nBytesLeft0;
+            used = len0 - st->nBytesLeft0;
             // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
             i32 rand_seed = c->Seed;
             if (desp_type == 2) {
