@@ -237,11 +237,8 @@ SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* c
     }
 }
 
-// SKP_Silk_NLSF_MSVQ_decode, SKP_Silk_NLSF_MSVQ_decode.c:31 (order 10, 6 stages)
-SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
-    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
-    const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
-    const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
+// SKP_Silk_NLSF_MSVQ_decode, SKP_Silk_NLSF_MSVQ_decode.c:31 (order 10, 6 stages); codebook / spacing table wherever the caller keeps them
+SX_HD void sx_nlsf_msvq_decode_cb(i32* pNLSF_Q15, const i32* idx, const i16* cb, const i32* nvec, const i32* ndelta_min_Q15) {
     const i16* e = &cb[idx[0] * SX_LPC];
     for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] = e[i];
     int base = nvec[0];
@@ -250,7 +247,12 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
         for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] += e[i];
         base += nvec[s];
     }
-    sx_nlsf_stabilize(pNLSF_Q15, sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15, SX_LPC);
+    sx_nlsf_stabilize(pNLSF_Q15, ndelta_min_Q15, SX_LPC);
+}
+SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
+    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+    sx_nlsf_msvq_decode_cb(pNLSF_Q15, idx, sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15, sigtype == 0 ? nvec0 : nvec1,
+                           sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15);
 }
 
 // SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)

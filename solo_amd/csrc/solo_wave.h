@@ -47,10 +47,55 @@ SX_HD void wv_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
+#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 16)
+// Reductions without the LDS crossbar: four DPP steps (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) leave the
+// result of each 16-lane row in all of its lanes; the four rows are then combined on the scalar unit (v_readlane), which also
+// makes the result provably wave-uniform.  Wrapping adds / min / max are order-independent, so this equals the serial scan.
+#define SX_DPP_(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define SX_ROW_REDUCE(v, OP)                                                                     \
+    { i32 t_ = SX_DPP_(v, 0xB1); v = OP; } { i32 t_ = SX_DPP_(v, 0x4E); v = OP; }                \
+    { i32 t_ = SX_DPP_(v, 0x141); v = OP; } { i32 t_ = SX_DPP_(v, 0x140); v = OP; }
+#if SX_NLANES == 64
+#define SX_ROWS_COMBINE(v, OP)                                                                   \
+    { i32 a_ = __builtin_amdgcn_readlane(v, 0), b_ = __builtin_amdgcn_readlane(v, 16),           \
+          c_ = __builtin_amdgcn_readlane(v, 32), d_ = __builtin_amdgcn_readlane(v, 48);          \
+      { i32 t_ = b_; v = a_; a_ = OP; } { i32 t_ = d_; v = c_; c_ = OP; } { i32 t_ = c_; v = a_; v = OP; } }
+#else
+#define SX_ROWS_COMBINE(v, OP)
+#endif
+SX_HD i32 wv_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) SX_ROWS_COMBINE(v, sx_add(v, t_)) return v; }
+SX_HD i32 wv_max(i32 v) { SX_ROW_REDUCE(v, (t_ > v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ > v ? t_ : v)) return v; }
+SX_HD i32 wv_min(i32 v) { SX_ROW_REDUCE(v, (t_ < v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ < v ? t_ : v)) return v; }
+SX_HD i64 wv_sum64(i64 v) {
+    u32 lo = (u32)v, hi = (u32)((u64)v >> 32);
+#pragma unroll
+    for (int s_ = 0; s_ < 4; s_++) {
+        u32 tl, th;
+        switch (s_) {           // the DPP control is an immediate
+            case 0: tl = SX_DPP_(lo, 0xB1); th = SX_DPP_(hi, 0xB1); break;
+            case 1: tl = SX_DPP_(lo, 0x4E); th = SX_DPP_(hi, 0x4E); break;
+            case 2: tl = SX_DPP_(lo, 0x141); th = SX_DPP_(hi, 0x141); break;
+            default: tl = SX_DPP_(lo, 0x140); th = SX_DPP_(hi, 0x140); break;
+        }
+        u64 r = (((u64)hi << 32) | lo) + (((u64)th << 32) | tl);
+        lo = (u32)r; hi = (u32)(r >> 32);
+    }
+    u64 r = ((u64)hi << 32) | lo;
+#if SX_NLANES == 64
+    u64 acc = 0;
+#pragma unroll
+    for (int row = 0; row < 4; row++)
+        acc += ((u64)(u32)__builtin_amdgcn_readlane((i32)hi, row * 16) << 32) | (u32)__builtin_amdgcn_readlane((i32)lo, row * 16);
+    r = acc;
+#endif
+    return (i64)r;
+}
+#else
 SX_HD i32 wv_sum(i32 v) { SX_XOR_REDUCE(v, sx_add(v, t_)) return v; }   // sum over the lanes, result in every lane
 SX_HD i64 wv_sum64(i64 v) { SX_XOR_REDUCE(v, v + t_) return v; }
 SX_HD i32 wv_max(i32 v) { SX_XOR_REDUCE(v, (t_ > v ? t_ : v)) return v; }
 SX_HD i32 wv_min(i32 v) { SX_XOR_REDUCE(v, (t_ < v ? t_ : v)) return v; }
+#endif
 SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
 #if defined(__HIP_DEVICE_COMPILE__)
     return __shfl(v, src, SX_NLANES);
@@ -60,6 +105,33 @@ SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
 #endif
 }
 // (value, index) arg-min with "first index wins on ties" (matches a serial `<` scan)
+#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 16)
+#define SX_ARG_STEP(CTRL, CMP)                                                                   \
+    { i32 tv = SX_DPP_(bv, CTRL), ti = SX_DPP_(bi, CTRL);                                        \
+      const bool take_ = (tv CMP bv) | ((tv == bv) & (ti < bi));                                 \
+      bv = take_ ? tv : bv; bi = take_ ? ti : bi; }
+#if SX_NLANES == 64
+#define SX_ARG_ROWS(CMP)                                                                         \
+    { i32 rv = __builtin_amdgcn_readlane(bv, 0), ri = __builtin_amdgcn_readlane(bi, 0);          \
+      _Pragma("unroll") for (int row = 1; row < 4; row++) {                                      \
+          i32 tv = __builtin_amdgcn_readlane(bv, row * 16), ti = __builtin_amdgcn_readlane(bi, row * 16); \
+          const bool take_ = (tv CMP rv) | ((tv == rv) & (ti < ri));                             \
+          rv = take_ ? tv : rv; ri = take_ ? ti : ri; }                                          \
+      bv = rv; bi = ri; }
+#else
+#define SX_ARG_ROWS(CMP)
+#endif
+SX_HD void wv_argmin(i32* v, i32* idx) {
+    i32 bv = *v, bi = *idx;
+    SX_ARG_STEP(0xB1, <) SX_ARG_STEP(0x4E, <) SX_ARG_STEP(0x141, <) SX_ARG_STEP(0x140, <) SX_ARG_ROWS(<)
+    *v = bv; *idx = bi;
+}
+SX_HD void wv_argmax(i32* v, i32* idx) {
+    i32 bv = *v, bi = *idx;
+    SX_ARG_STEP(0xB1, >) SX_ARG_STEP(0x4E, >) SX_ARG_STEP(0x141, >) SX_ARG_STEP(0x140, >) SX_ARG_ROWS(>)
+    *v = bv; *idx = bi;
+}
+#else
 SX_HD void wv_argmin(i32* v, i32* idx) {
 #if defined(__HIP_DEVICE_COMPILE__)
 #pragma unroll
@@ -83,6 +155,8 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
     (void)v; (void)idx;
 #endif
 }
+
+#endif
 
 // lane-strided parallel loop
 #define SX_PAR(i, n) for (int i = SX_LANE; i < (int)(n); i += SX_NLANES)
