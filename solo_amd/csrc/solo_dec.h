@@ -238,7 +238,8 @@ SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* c
 }
 
 // SKP_Silk_NLSF_MSVQ_decode, SKP_Silk_NLSF_MSVQ_decode.c:31 (order 10, 6 stages); codebook / spacing table wherever the caller keeps them
-SX_HD void sx_nlsf_msvq_decode_cb(i32* pNLSF_Q15, const i32* idx, const i16* cb, const i32* nvec, const i32* ndelta_min_Q15) {
+template <typename IDX>
+SX_HD void sx_nlsf_msvq_decode_cb(i32* pNLSF_Q15, const IDX* idx, const i16* cb, const i32* nvec, const i32* ndelta_min_Q15) {
     const i16* e = &cb[idx[0] * SX_LPC];
     for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] = e[i];
     int base = nvec[0];

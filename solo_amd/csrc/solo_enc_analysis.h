@@ -1310,26 +1310,67 @@ SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q1
 // NLSF MSVQ
 // ---------------------------------------------------------------------------------------------------
 struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 vectors per later stage; 64 in stage 0)
+#if SX_NLANES == 1
     i32 RateDist_Q18[256];
-    i32 Sorted_Q18[16];
     u8 taken[256];
+#else
+    i32 RateDist_Q18[16];
+#endif
+    i32 Sorted_Q18[16];
+    i16 cb[1200], rates[120];         // the signal type's codebook and rate table, staged from HBM once per frame
+    i32 ndelta[12], nvec[6];
     i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
     i32 NLSF0[SX_MAX_LPC], W0_Q6[SX_MAX_LPC];
     i32 ws[2][SX_NLSF2A_WS];
     i32 Rate_Q5[16], Rate_new_Q5[16];
     i32 TempIndices[16];
-    i32 Path[16 * 6], Path_new[16 * 6];
+    u8 Path[16 * 6], Path_new[16 * 6];
     i32 Res_Q15[16 * SX_LPC], Res_new_Q15[16 * SX_LPC];
 };
+
+#if SX_NLANES != 1
+// compare-exchange of two (value, index) keys kept as signed 64-bit words (value in the high half): ascending
+#define SX_KEY_CX(a, b) { const i64 lo_ = (a) < (b) ? (a) : (b), hi_ = (a) < (b) ? (b) : (a); (a) = lo_; (b) = hi_; }
+// minimum of a 64-bit key over the wave (same DPP ladder as wv_min), result uniform
+SX_HD i64 wv_min_key(i64 k) {
+    i32 lo = (i32)(u32)k, hi = (i32)((u64)k >> 32);
+#define SX_KEY_STEP(CTRL) { const i32 tl = SX_DPP_(lo, CTRL), th = SX_DPP_(hi, CTRL);                      \
+        const bool take_ = (th < hi) | ((th == hi) & ((u32)tl < (u32)lo)); lo = take_ ? tl : lo; hi = take_ ? th : hi; }
+    SX_KEY_STEP(0xB1) SX_KEY_STEP(0x4E) SX_KEY_STEP(0x141) SX_KEY_STEP(0x140)
+#undef SX_KEY_STEP
+    i32 rl = __builtin_amdgcn_readlane(lo, 0), rh = __builtin_amdgcn_readlane(hi, 0);
+#pragma unroll
+    for (int row = 1; row < 4; row++) {
+        const i32 tl = __builtin_amdgcn_readlane(lo, row * 16), th = __builtin_amdgcn_readlane(hi, row * 16);
+        const bool take_ = (th < rh) | ((th == rh) & ((u32)tl < (u32)rl));
+        rl = take_ ? tl : rl; rh = take_ ? th : rh;
+    }
+    return (i64)(((u64)(u32)rh << 32) | (u32)rl);
+}
+#endif
 
 // SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
 SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
                                i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
     SX_IN_LDS(w); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
     const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
-    const i16* cb = sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15;
-    const i16* rates = sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5;
+    const i32* nvec = w->nvec;
     const int nStages = 6, S = SX_MSVQ_SURVIVORS;
+    {   // stage the codebook of this signal type in LDS (32-bit words, coalesced)
+        const u32* gcb = (const u32*)(sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15);
+        const u32* grt = (const u32*)(sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5);
+        const i32* gnd = sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15;
+        const int nv = sigtype == 0 ? 120 : 72;
+        u32* lcb = (u32*)w->cb;
+        u32* lrt = (u32*)w->rates;
+        SX_PAR(i, nv * SX_LPC / 2) lcb[i] = gcb[i];
+        SX_PAR(i, nv / 2) lrt[i] = grt[i];
+        SX_PAR(i, SX_LPC + 1) w->ndelta[i] = gnd[i];
+        SX_PAR(i, 6) w->nvec[i] = sigtype == 0 ? nvec0[i] : nvec1[i];
+        wv_sync();
+    }
+    const i16* cb = w->cb;
+    const i16* rates = w->rates;
     SX_PAR(i, S) w->Rate_Q5[i] = 0;
     SX_PAR(i, SX_LPC) w->Res_Q15[i] = pNLSF_Q15[i];
     wv_sync();
@@ -1337,12 +1378,13 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
     const int min_survivors = S / 2;
     int cb_base = 0;
     for (int s = 0; s < nStages; s++) {
-        const int K = sigtype == 0 ? nvec0[s] : nvec1[s];
+        const int K = nvec[s];
         const i16* cbs = cb + cb_base * SX_LPC;
         const i16* rts = rates + cb_base;
         cur_survivors = sx_min(S, sx_smulbb(prev_survivors, K));
-        // rate-distortion of every (survivor, codebook vector) pair: wave-parallel
         const int total = prev_survivors * K;
+#if SX_NLANES == 1
+        // rate-distortion of every (survivor, codebook vector) pair
         SX_PAR(t, total) {
             int n = t / K, i = t - n * K;
             const i32* in = &w->Res_Q15[n * SX_LPC];
@@ -1355,22 +1397,54 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
             w->RateDist_Q18[t] = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
             w->taken[t] = 0;
         }
-        wv_sync();
-        // SKP_Silk_insertion_sort_increasing (the cur_survivors best of `total`, value ascending, first index wins ties):
-        // repeated wave arg-min over the lanes' remaining candidates
+        // SKP_Silk_insertion_sort_increasing (the cur_survivors best of `total`, value ascending, first index wins ties)
         for (int r = 0; r < cur_survivors; r++) {
             i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
-            SX_PAR(t, total) {
+            for (int t = 0; t < total; t++) {
                 const i32 v = w->RateDist_Q18[t];
                 if (!w->taken[t] && (v < bv || (v == bv && t < bi))) { bv = v; bi = t; }
             }
-            wv_argmin(&bv, &bi);
             w->Sorted_Q18[r] = bv;
             w->TempIndices[r] = bi;
             w->taken[bi] = 1;
-            wv_sync();
         }
-        SX_PAR(r, cur_survivors) w->RateDist_Q18[r] = w->Sorted_Q18[r];
+        for (int r = 0; r < cur_survivors; r++) w->RateDist_Q18[r] = w->Sorted_Q18[r];
+#else
+        // rate-distortion of every (survivor, codebook vector) pair: a lane owns up to four pairs and keeps them in registers as
+        // sorted (value, pair index) keys; the reference's insertion sort (cur_survivors best, value ascending, first index wins
+        // ties) is then cur_survivors wave minima over the lanes' heads
+        const i64 KEY_MAX = 0x7FFFFFFFFFFFFFFFLL;
+        i64 k0 = KEY_MAX, k1 = KEY_MAX, k2 = KEY_MAX, k3 = KEY_MAX;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int t = SX_LANE + 64 * j;
+            if (j * 64 < total && t < total) {
+                int n = t / K, i = t - n * K;
+                const i32* in = &w->Res_Q15[n * SX_LPC];
+                const i16* cv = &cbs[i * SX_LPC];
+                i32 sum_error = 0;
+#pragma unroll
+                for (int m = 0; m < SX_LPC; m++) {
+                    i32 diff = in[m] - cv[m];
+                    sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
+                }
+                const i32 rd = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
+                const i64 key = (i64)(((u64)(u32)rd << 32) | (u32)t);
+                if (j == 0) k0 = key; else if (j == 1) k1 = key; else if (j == 2) k2 = key; else k3 = key;
+            }
+        }
+        if (total > 64) { SX_KEY_CX(k0, k1) SX_KEY_CX(k2, k3) SX_KEY_CX(k0, k2) SX_KEY_CX(k1, k3) SX_KEY_CX(k1, k2) }
+        i64 mine = KEY_MAX;
+        for (int r = 0; r < cur_survivors; r++) {
+            const i64 m = wv_min_key(k0);
+            if (k0 == m) { k0 = k1; k1 = k2; k2 = k3; k3 = KEY_MAX; }
+            if (SX_LANE == r) mine = m;
+        }
+        if (SX_LANE < cur_survivors) {
+            w->RateDist_Q18[SX_LANE] = (i32)((u64)mine >> 32);
+            w->TempIndices[SX_LANE] = (i32)(u32)mine;
+        }
+#endif
         wv_sync();
         if (w->RateDist_Q18[0] < SX_I32_MAX / 16) {
             i32 thr = sx_smlawb(w->RateDist_Q18[0], sx_mul(S, w->RateDist_Q18[0]), K_NLSF_MSVQ_SURV_MAX_REL_RD_Q16);
@@ -1387,7 +1461,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
             if (i < SX_LPC) w->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
             if (i == SX_LPC) w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
             if (i > SX_LPC && i - SX_LPC - 1 < s) w->Path_new[k * nStages + (i - SX_LPC - 1)] = w->Path[input_index * nStages + (i - SX_LPC - 1)];
-            if (i == 15) w->Path_new[k * nStages + s] = cb_index;
+            if (i == 15) w->Path_new[k * nStages + s] = (u8)cb_index;
         }
         wv_sync();
         if (s < nStages - 1) {
@@ -1405,7 +1479,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
         i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
         SX_PAR(sv, cur_survivors) {
             i32* out = &w->Res_Q15[sv * SX_LPC];
-            sx_nlsf_msvq_decode(out, sigtype, &w->Path_new[sv * nStages]);
+            sx_nlsf_msvq_decode_cb(out, &w->Path_new[sv * nStages], cb, nvec, w->ndelta);
             i32 wsse_Q20 = 0;
             for (int i = 0; i < SX_LPC; i++) {
                 i32 se = out[i] - prev_q_Q15[i];
@@ -1420,7 +1494,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
     }
     SX_PAR(i, nStages) NLSFIndices[i] = w->Path_new[bestIndex * nStages + i];
     wv_sync();
-    sx_nlsf_msvq_decode(pNLSF_Q15, sigtype, NLSFIndices);
+    sx_nlsf_msvq_decode_cb(pNLSF_Q15, NLSFIndices, cb, nvec, w->ndelta);
     wv_sync();
 }
 
