@@ -188,22 +188,26 @@ SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cd
     sx_shell_split(&a, &b, rc, p1[7], cdf->cdf_shell0, cdf); q[14] = a; q[15] = b;
 }
 
-// SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64)
-SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* cdf) {
-    SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf);
+// SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64).
+// tmp: 2 * SX_FRAME/16 words of per-description scratch (LDS)
+SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* cdf, i32* tmp) {
+    SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
     const int iter = SX_FRAME / 16;
-    i32 sum_pulses[SX_FRAME / 16], nLshifts[SX_FRAME / 16];
+    i32 *sum_pulses = tmp, *nLshifts = tmp + SX_FRAME / 16;
     c->RateLevelIndex = sx_rc_dec(rc, &cdf->cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
     const u16* cdf_ptr = &cdf->cdf_pulses_per_block[c->RateLevelIndex * 21];
     for (int i = 0; i < iter; i++) {
-        nLshifts[i] = 0;
-        sum_pulses[i] = sx_rc_dec(rc, cdf_ptr, T_CDF_MID_PULSES_PER_BLOCK);
-        while (sum_pulses[i] == 18 + 1) {
-            nLshifts[i]++;
-            sum_pulses[i] = sx_rc_dec(rc, &cdf->cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
+        i32 nl = 0;
+        i32 sp = sx_rc_dec(rc, cdf_ptr, T_CDF_MID_PULSES_PER_BLOCK);
+        while (sp == 18 + 1) {
+            nl++;
+            sp = sx_rc_dec(rc, &cdf->cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
             if (rc->error) break;   // (reference would spin on the zero returned after an error only until != 19; 0 != 19)
         }
+        nLshifts[i] = nl;
+        sum_pulses[i] = sp;
     }
+    const u32 p_lsb = cdf->cdf_lsb[1];
     for (int i = 0; i < iter; i++) {
         if (sum_pulses[i] > 0) {
             sx_shell_decoder(&q[i * 16], rc, sum_pulses[i], cdf);
@@ -212,27 +216,25 @@ SX_FN void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* c
         }
     }
     for (int i = 0; i < iter; i++) {
-        if (nLshifts[i] > 0) {
-            int nLS = nLshifts[i];
+        const int nLS = nLshifts[i];
+        if (nLS > 0) {
             for (int k = 0; k < 16; k++) {
                 i32 abs_q = q[i * 16 + k];
                 for (int j = 0; j < nLS; j++) {
                     abs_q = sx_shl(abs_q, 1);
-                    abs_q += sx_rc_dec(rc, cdf->cdf_lsb, 1);
+                    abs_q += sx_rc_dec_bin(rc, p_lsb);
                 }
                 q[i * 16 + k] = abs_q;
             }
         }
     }
     // signs
-    u16 scdf[3];
-    scdf[0] = 0;
-    scdf[1] = cdf->cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
-    scdf[2] = 65535;
+    const u32 p_sign = cdf->cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
     for (int i = 0; i < SX_FRAME; i++) {
-        if (q[i] > 0) {
-            i32 data = sx_rc_dec(rc, scdf, 1);
-            q[i] *= (data << 1) - 1;
+        const i32 v = q[i];
+        if (v > 0) {
+            i32 data = sx_rc_dec_bin(rc, p_sign);
+            q[i] = v * ((data << 1) - 1);
         }
     }
 }
@@ -257,9 +259,16 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 }
 
 // SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
-SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf, i32* lane_out) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out);
-    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], pNLSF_Q15[SX_LPC], pNLSF0_Q15[SX_LPC], DeltaGainIndices;
+// The range-coder state is worked on in registers (local copy); the NLSF vectors (interpolated / final) are handed back in
+// nlsf_out[2][SX_LPC] -- their conversion to prediction coefficients only matters for the description that is used and is done
+// by the caller; tmp = per-description scratch of sx_decode_pulses (all LDS).
+SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf,
+                                i32* lane_out, i32* nlsf_out, i32* tmp) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp);
+    SxRangeDec rc_local = *rc_io;
+    SxRangeDec* rc = &rc_local;
+    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], DeltaGainIndices;
+    i32 *pNLSF0_Q15 = nlsf_out, *pNLSF_Q15 = nlsf_out + SX_LPC;
     SxDecDesc* md = &st->md[kDesp];
     if (st->nFramesDecoded == 0) {
         if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, cdf->cdf_mdindex, T_CDF_MID_MDINDEX);
@@ -267,6 +276,7 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
         if (Ix != 0) {  // only the 8 kHz NB mode exists in this build (reference: decoder_set_fs to 12/16/24 kHz)
             if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
             lane_out[3] = rc->error;
+            *rc_io = rc_local;
             return;
         }
         Ix = sx_rc_dec(rc, cdf->cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
@@ -307,19 +317,11 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, cdf->cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
     if (st->first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
 
-    sx_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC);
     if (c->NLSFInterpCoef_Q2 < 4) {
         for (int i = 0; i < SX_LPC; i++)
             pNLSF0_Q15[i] = md->prevNLSF_Q15[i] + (sx_mul(c->NLSFInterpCoef_Q2, pNLSF_Q15[i] - md->prevNLSF_Q15[i]) >> 2);
-        sx_nlsf2a_stable(c->PredCoef_Q12[0], pNLSF0_Q15, SX_LPC);
-    } else {
-        for (int i = 0; i < SX_LPC; i++) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
     }
     for (int i = 0; i < SX_LPC; i++) md->prevNLSF_Q15[i] = pNLSF_Q15[i];
-    if (st->lossCnt) {
-        sx_bwexpander(c->PredCoef_Q12[0], SX_LPC, 63570);
-        sx_bwexpander(c->PredCoef_Q12[1], SX_LPC, 63570);
-    }
 
     if (c->sigtype == 0) {
         i32 lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag_nb, T_CDF_MID_PITCH_LAG_NB);
@@ -344,7 +346,7 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     SX_TRACE(4);
     c->Seed = sx_rc_dec(rc, cdf->cdf_seed, T_CDF_MID_SEED);
     SX_TRACE(5);
-    sx_decode_pulses(rc, c, q, cdf);
+    sx_decode_pulses(rc, c, q, cdf, tmp);
     SX_TRACE(6);
     lane_out[0] = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
     lane_out[1] = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
@@ -357,6 +359,7 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc, i3
     if (left == 0) sx_rc_check_after_decoding(rc);
     lane_out[3] = rc->error;
     SX_TRACE(7);
+    *rc_io = rc_local;
 }
 
 // SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
@@ -721,6 +724,7 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(pOut);
     int ret = 0;
     SxDecCtrl* c = &w->ctrl;
+    SX_T_BEGIN
     if (st->moreInternalDecoderFrames == 0) st->nFramesDecoded = 0;
     c->LTP_scale_Q14 = 0;
     int used = 0;
@@ -736,10 +740,12 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 if (md == 0) sx_rc_dec_init(r, payload, nB0);
                 else sx_rc_dec_init(r, payload + nB0, nB1);
             }
-            sx_decode_parameters(st, &w->ctrl2[md], r, w->pulses[md], md, useMDIndex, &w->cdf, w->lane_out[md]);
+            sx_decode_parameters(st, &w->ctrl2[md], r, w->pulses[md], md, useMDIndex, &w->cdf, w->lane_out[md],
+                                 &w->sig_Q10[md * 2 * SX_LPC], &w->sig_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)]);
             w->lane_len[md] = r->bufferLength;
         }
         wv_sync();
+        SX_T(0)
         {   // the reference parses description 1 after description 0 into the same control block: the last one wins
             const i32* src = (const i32*)&w->ctrl2[ndesc - 1];
             i32* dst = (i32*)c;
@@ -769,6 +775,25 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         } else {
             st->nFramesDecoded++;
             used = len0 - st->nBytesLeft0;
+            {
+                // NLSF -> prediction coefficients of the description in use: the two frame halves on two lanes
+                // (decode_parameters.c:108-131); workspaces in the frame scratch that decode_core only fills later
+                const i32* nl = &w->sig_Q10[(ndesc - 1) * 2 * SX_LPC];
+                const int interp = c->NLSFInterpCoef_Q2 < 4;
+                SX_PAR(v, 2) {
+                    if (v == 1) sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, w->res_Q10);
+                    else if (interp) sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], nl, SX_LPC, &w->sig_Q10[4 * SX_LPC]);
+                }
+                wv_sync();
+                if (!interp) {
+                    SX_PAR(i, SX_LPC) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+                    wv_sync();
+                }
+                if (st->lossCnt) {
+                    SX_PAR(v, 2) sx_bwexpander(c->PredCoef_Q12[v], SX_LPC, 63570);
+                    wv_sync();
+                }
+            }
             // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
             i32 rand_seed = c->Seed;
             if (desp_type == 2) {
@@ -790,18 +815,24 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     st->exc_Q10[i] = sx_smulww(use_p1 ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16, e);
                 }
             }
+            SX_T(1)
             sx_decode_core(st, w, pOut);
+            SX_T(2)
             sx_plc(st, w, pOut, 0);
+            SX_T(3)
             st->lossCnt = 0;
             st->prev_sigtype = c->sigtype;
             st->first_frame_after_reset = 0;
         }
     }
     if (ret < 0) return ret;   // corrupt payload: the reference returns before producing output
+    SX_T_RESET
     SX_PAR(i, SX_FRAME) st->outBuf[i] = pOut[i];
     wv_sync();
     sx_plc_glue_frames(st, pOut, SX_FRAME);
+    SX_T(4)
     sx_cng(st, w, pOut, SX_FRAME);
+    SX_T(5)
     // (output HP filter: guard nFramesDecoded > 2 can never hold with 2 frames per packet, decode_frame.c:381)
     st->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
     // SKP_Silk_SDK_Decode bookkeeping, dec_API.c:125-150
@@ -838,41 +869,60 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
     for (int j = 0; j < SX_HB_LPC; j++) S[SX_HB_LPC - 1 - j] = hist[j];
 }
 
-// AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40.  hb == NULL-equivalent when lost.
-SX_FN void sx_hb_decode_frame(SxDecState* st, const u8* hb, int* bitpos, i16* OutHigh, const i32* residue_Q10, int lostflag) {
-    SX_IN_LDS(st); SX_IN_LDS(OutHigh); SX_IN_LDS(residue_Q10);
-    i32 QHB_LSP[SX_HB_LPC];
-    i32 QGain[4];
-    i16 lpc[SX_MAX_LPC];
+// AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40, for both 20 ms frames of a packet.  The side information of
+// the two frames (LSP -> LPC conversion included) is decoded on two lanes; the synthesis and the state updates then run in
+// frame order.  `hb` = the 8 high-band bytes (ignored when lost); exc0 / exc1 = low-band excitation of frame 0 / 1.
+SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* OutHigh, const i32* exc0, const i32* exc1, int lostflag) {
+    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(OutHigh); SX_IN_LDS(exc0); SX_IN_LDS(exc1);
+    i32* lsp = w->sig_Q10;                       // [2][SX_HB_LPC]
+    i32* gains = &w->sig_Q10[2 * SX_HB_LPC];     // [2][4]
+    i16* lpc = (i16*)&w->sig_Q10[2 * SX_HB_LPC + 8];   // [2][SX_MAX_LPC]
+    i32* zero = &w->res_Q10[SX_NLSF2A_WS];       // [SX_SUBFR]
     const int lost = (lostflag == 1 || lostflag == 2);
-    if (lost) {
-        for (int i = 0; i < SX_HB_LPC; i++) QHB_LSP[i] = st->HB_prev_NLSFq[i];
-        for (int s = 0; s < 4; s++) QGain[s] = st->HB_prev_Gain;
-        st->hb_lossCnt++;
-    } else {
-        u32 idx = sx_hb_unpack(hb, bitpos, 12);
-        u32 idx1 = idx & 0xFF, idx2 = idx >> 8;
-        for (int i = 0; i < SX_HB_LPC; i++) QHB_LSP[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i];
-        for (int s = 0; s < 4; s++) QGain[s] = T_hb_gain_cb[sx_hb_unpack(hb, bitpos, 5)];
-        if (st->hb_first) {
-            for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
-            st->HB_prev_Gain = QGain[3];
+    SX_T_BEGIN
+    SX_PAR(i, SX_SUBFR) zero[i] = 0;
+    SX_PAR(f, 2) {
+        i32* l = &lsp[f * SX_HB_LPC];
+        if (lost) {
+            for (int i = 0; i < SX_HB_LPC; i++) l[i] = st->HB_prev_NLSFq[i];
+            for (int k = 0; k < 4; k++) gains[f * 4 + k] = st->HB_prev_Gain;
+        } else {
+            int bitpos = f * 32;
+            u32 idx = sx_hb_unpack(hb, &bitpos, 12);
+            u32 idx1 = idx & 0xFF, idx2 = idx >> 8;
+            for (int i = 0; i < SX_HB_LPC; i++) l[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i];
+            for (int k = 0; k < 4; k++) gains[f * 4 + k] = T_hb_gain_cb[sx_hb_unpack(hb, &bitpos, 5)];
         }
-        st->hb_lossCnt = 0;
+        sx_nlsf2a_stable_ws(&lpc[f * SX_MAX_LPC], l, SX_HB_LPC, f == 0 ? w->res_Q10 : &w->sig_Q10[2 * SX_HB_LPC + 8 + SX_MAX_LPC]);   // same for all 4 subframes
     }
-    sx_nlsf2a_stable(lpc, QHB_LSP, SX_HB_LPC);     // identical for all 4 subframes (same NLSF vector)
-    for (int s = 0; s < 4; s++) {
-        // excitation = low-band excitation (zero when the high band is lost: decode_frame_FIX.c:65)
-        i32 zero[SX_SUBFR];
-        const i32* ex = &residue_Q10[s * SX_SUBFR];
-        if (lost) { for (int i = 0; i < SX_SUBFR; i++) zero[i] = 0; ex = zero; }
-        sx_hb_lpc_synthesis(ex, lpc, sx_mul(-2867, (i32)(i16)QGain[s]), st->HB_synth_state, &OutHigh[s * SX_SUBFR], SX_SUBFR);
+    wv_sync();
+    SX_T(8)
+    for (int f = 0; f < 2; f++) {
+        const i32* QHB_LSP = &lsp[f * SX_HB_LPC];
+        const i32* QGain = &gains[f * 4];
+        if (lost) {
+            st->hb_lossCnt++;
+        } else {
+            if (st->hb_first) {
+                for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
+                st->HB_prev_Gain = QGain[3];
+            }
+            st->hb_lossCnt = 0;
+        }
+        const i32* exc = f == 0 ? exc0 : exc1;
+        for (int k = 0; k < 4; k++) {
+            // excitation = low-band excitation (zero when the high band is lost: decode_frame_FIX.c:65)
+            const i32* ex = lost ? zero : &exc[k * SX_SUBFR];
+            sx_hb_lpc_synthesis(ex, &lpc[f * SX_MAX_LPC], sx_mul(-2867, (i32)(i16)QGain[k]), st->HB_synth_state,
+                                &OutHigh[f * SX_FRAME + k * SX_SUBFR], SX_SUBFR);
+        }
+        if (lostflag == 0 || lostflag == 4 || lostflag == 3) {
+            st->HB_prev_Gain = QGain[3];
+            for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
+        }
+        st->hb_first = 0;
+        wv_sync();
     }
-    if (lostflag == 0 || lostflag == 4 || lostflag == 3) {
-        st->HB_prev_Gain = QGain[3];
-        for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
-    }
-    st->hb_first = 0;
 }
 
 // AGR_Sate_qmf_synth, libBWE/AGR_BWE_qmf.c:86, as a direct polyphase form (wave-parallel):
@@ -933,11 +983,12 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         SX_PAR(i, SX_FRAME) w->exc_pkt_Q10[f * SX_FRAME + i] = st->exc_Q10[i];
         wv_sync();
     }
-    int bitpos = 0;
-    for (int f = 0; f < 2; f++)
-        sx_hb_decode_frame(st, bits + hb_pos, &bitpos, &w->hi[SX_QMF_HIST + f * SX_FRAME], &w->exc_pkt_Q10[f * SX_FRAME], lostflag);
+    SX_T_BEGIN
+    sx_hb_decode_packet(st, w, bits + hb_pos, &w->hi[SX_QMF_HIST], &w->exc_pkt_Q10[0], &w->exc_pkt_Q10[SX_FRAME], lostflag);
     wv_sync();
+    SX_T(6)
     sx_qmf_synth(w->lo, w->hi, pcm_out);
+    SX_T(7)
     SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->hi[SX_BAND + i]; }
     wv_sync();
     return 0;

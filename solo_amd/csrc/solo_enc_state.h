@@ -8,21 +8,6 @@
 #include "solo_consts.inc"
 #include "solo_dec.h"     // SX_PACKET / SX_BAND, sx_nlsf_msvq_decode (shared with the decoder)
 
-// optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
-#if defined(SX_PROF) && defined(__HIPCC__)
-static __device__ unsigned long long g_sx_prof[32];
-#endif
-#if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();
-#define SX_T_RESET sx_t_last_ = __builtin_readcyclecounter();
-#define SX_T(id) { unsigned long long t_ = __builtin_readcyclecounter(); if (SX_LANE == 0) atomicAdd(&g_sx_prof[id], t_ - sx_t_last_); sx_t_last_ = __builtin_readcyclecounter(); }
-#else
-#define SX_T_BEGIN
-#define SX_T_RESET
-#define SX_T(id)
-#endif
-
-
 #define SX_SHAPE_ORDER 16            // shapingLPCOrder (setup_complexity.h:76)
 #define SX_LA_SHAPE 40               // la_shape = 5 * fs_kHz
 #define SX_LA_PITCH 16               // la_pitch = 2 * fs_kHz

@@ -107,6 +107,45 @@ SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
     return probIx;
 }
 
+// sx_rc_dec for a two-symbol model {0, p, 65535} started at index 1, the threshold kept in a register (the sign / LSB decoders):
+// same arithmetic and the same error exits as the general search above
+SX_HD i32 sx_rc_dec_bin(SxRangeDec* rc, u32 p) {
+    u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16, range_Q32, low_Q16, high_Q16;
+    i32 bufferIx = rc->bufferIx, sym;
+    if (rc->error) return 0;
+    if (range_Q16 * p > base_Q32) {
+        sym = 0; low_Q16 = 0; high_Q16 = p;        // (p == 0 cannot get here: 0 > base is false)
+    } else {
+        if (!(range_Q16 * 0xFFFFu > base_Q32)) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        sym = 1; low_Q16 = p; high_Q16 = 0xFFFFu;
+    }
+    base_Q32 -= range_Q16 * low_Q16;
+    range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+    if (range_Q32 & 0xFF000000) {
+        range_Q16 = range_Q32 >> 16;
+    } else {
+        if (range_Q32 & 0xFFFF0000) {
+            range_Q16 = range_Q32 >> 8;
+            if (base_Q32 >> 24) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }
+        } else {
+            range_Q16 = range_Q32;
+            if (base_Q32 >> 16) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }
+            base_Q32 <<= 8;
+            if (bufferIx < rc->bufferLength) base_Q32 |= sx_rc_byte(rc, 4 + bufferIx++);
+        }
+        base_Q32 <<= 8;
+        if (bufferIx < rc->bufferLength) base_Q32 |= sx_rc_byte(rc, 4 + bufferIx++);
+    }
+    if (range_Q16 == 0) { rc->error = SX_RC_ZERO_INTERVAL_WIDTH; return 0; }
+    rc->base_Q32 = base_Q32;
+    rc->range_Q16 = range_Q16;
+    rc->bufferIx = bufferIx;
+#ifdef SX_RC_LOG
+    if (rc->log && rc->nlog < 500) { rc->log[rc->nlog++] = sym; }
+#endif
+    return sym;
+}
+
 // SKP_Silk_range_coder_get_length, SKP_Silk_range_coder.c:288 (shared by both directions)
 SX_HD i32 sx_rc_length_bits(i32 bufferIx, u32 range_Q16, i32* nBytes) {
     i32 nBits = (bufferIx << 3) + sx_clz32((i32)(range_Q16 - 1)) - 14;

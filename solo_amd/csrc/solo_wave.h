@@ -179,3 +179,17 @@ SX_HD void wv_move_down(T* dst, const T* src, int n) {
         wv_sync();
     }
 }
+
+// optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
+#if defined(SX_PROF) && defined(__HIPCC__)
+static __device__ unsigned long long g_sx_prof[32];
+#endif
+#if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
+#define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();
+#define SX_T_RESET sx_t_last_ = __builtin_readcyclecounter();
+#define SX_T(id) { unsigned long long t_ = __builtin_readcyclecounter(); if (SX_LANE == 0) atomicAdd(&g_sx_prof[id], t_ - sx_t_last_); sx_t_last_ = __builtin_readcyclecounter(); }
+#else
+#define SX_T_BEGIN
+#define SX_T_RESET
+#define SX_T(id)
+#endif
