@@ -419,35 +419,57 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
         st->prev_inv_gain_Q16 = inv_gain_Q16;
 
         if (sigtype == 0) {
-            i32* pred_lag_ptr = &st->sLTP_Q16[sLTP_buf_idx - lag + SX_LTP_ORDER / 2];
-            for (int i = 0; i < SX_SUBFR; i++) {
-                i32 p = sx_smulwb(pred_lag_ptr[0], B_Q14[0]);
-                p = sx_smlawb(p, pred_lag_ptr[-1], B_Q14[1]);
-                p = sx_smlawb(p, pred_lag_ptr[-2], B_Q14[2]);
-                p = sx_smlawb(p, pred_lag_ptr[-3], B_Q14[3]);
-                p = sx_smlawb(p, pred_lag_ptr[-4], B_Q14[4]);
-                pred_lag_ptr++;
-                i32 r = sx_add(pexc_Q10[i], sx_rshift_round(p, 4));
-                pres_Q10[i] = r;
-                st->sLTP_Q16[sLTP_buf_idx] = sx_shl(r, 6);
-                sLTP_buf_idx++;
+            // long-term prediction (decode_core.c:150-186): sample i reads the synthesis buffer at most up to i - lag + 2, so
+            // runs of lag - 2 consecutive samples are independent and go to the lanes
+            const i32 b0 = sx_pre16(B_Q14[0]), b1 = sx_pre16(B_Q14[1]), b2 = sx_pre16(B_Q14[2]), b3 = sx_pre16(B_Q14[3]),
+                      b4 = sx_pre16(B_Q14[4]);
+            const int run = sx_min(sx_max(lag - SX_LTP_ORDER / 2, 1), SX_SUBFR);
+            for (int s0 = 0; s0 < SX_SUBFR; s0 += run) {
+                const int n = sx_min(run, SX_SUBFR - s0);
+                SX_PAR(ii, n) {
+                    const int i = s0 + ii;
+                    const i32* pl = &st->sLTP_Q16[sLTP_buf_idx + i - lag + SX_LTP_ORDER / 2];
+                    i32 p = sx_smulw_pre(pl[0], b0);
+                    p = sx_smlaw_pre(p, pl[-1], b1);
+                    p = sx_smlaw_pre(p, pl[-2], b2);
+                    p = sx_smlaw_pre(p, pl[-3], b3);
+                    p = sx_smlaw_pre(p, pl[-4], b4);
+                    i32 r = sx_add(pexc_Q10[i], sx_rshift_round(p, 4));
+                    pres_Q10[i] = r;
+                    st->sLTP_Q16[sLTP_buf_idx + i] = sx_shl(r, 6);
+                }
+                wv_sync();
             }
+            sLTP_buf_idx += SX_SUBFR;
         } else {
             SX_PAR(i, SX_SUBFR) pres_Q10[i] = pexc_Q10[i];
             wv_sync();
         }
-        // short-term prediction (decode_core.c:188-288), serial recursion
-        for (int i = 0; i < SX_SUBFR; i++) {
-            i32 p = 0;
-            for (int j = 0; j < SX_LPC; j++) p = sx_smlawb(p, w->sLPC_Q14[SX_MAX_LPC + i - j - 1], A_Q12[j]);
-            i32 v = sx_add(pres_Q10[i], p);
-            w->sLPC_Q14[SX_MAX_LPC + i] = sx_shl(v, 4);
-            pxq[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(v, Gain_Q16), 10));
+        // short-term prediction (decode_core.c:188-288), serial recursion: coefficients (pre-shifted for the high-word multiply)
+        // and the last SX_LPC outputs live in registers; slot r of the ring holds the sample of time t = r (mod SX_LPC)
+        {
+            i32 a[SX_LPC], h[SX_LPC];
+#pragma unroll
+            for (int j = 0; j < SX_LPC; j++) { a[j] = sx_pre16(A_Q12[j]); h[j] = w->sLPC_Q14[SX_MAX_LPC - SX_LPC + j]; }
+            for (int i0 = 0; i0 < SX_SUBFR; i0 += SX_LPC) {
+#pragma unroll
+                for (int u = 0; u < SX_LPC; u++) {
+                    i32 p = 0;
+#pragma unroll
+                    for (int j = 0; j < SX_LPC; j++) p = sx_smlaw_pre(p, h[(u - 1 - j + 2 * SX_LPC) % SX_LPC], a[j]);
+                    i32 v = sx_add(pres_Q10[i0 + u], p);
+                    h[u] = sx_shl(v, 4);
+                    w->sLPC_Q14[SX_MAX_LPC + i0 + u] = h[u];
+                    pxq[i0 + u] = (i16)sx_sat16(sx_rshift_round(sx_smulww(v, Gain_Q16), 10));
+                }
+            }
         }
-        for (int i = 0; i < SX_MAX_LPC; i++) {
+        wv_sync();
+        SX_PAR(i, SX_MAX_LPC) {
             i32 t = w->sLPC_Q14[SX_SUBFR + i];
             w->sLPC_Q14[i] = t;
         }
+        wv_sync();
         pexc_Q10 += SX_SUBFR;
         pres_Q10 += SX_SUBFR;
         pxq += SX_SUBFR;
@@ -795,19 +817,17 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 }
             }
             // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
-            i32 rand_seed = c->Seed;
+            const i32 seed0 = c->Seed;
             if (desp_type == 2) {
-                for (int i = 0; i < SX_FRAME; i++) {
-                    rand_seed = sx_rand(rand_seed);
-                    i32 dither = rand_seed >> 31;
+                SX_PAR(i, SX_FRAME) {
+                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
                     i32 q_Q10 = sx_add(sx_shl(w->pulses[0][i], 10), sx_shl(w->pulses[1][i], 10));
                     q_Q10 = sx_add(offset_p1_Q10 + offset_p2_Q10, q_Q10);
                     st->exc_Q10[i] = (q_Q10 ^ dither) - dither;
                 }
             } else {
-                for (int i = 0; i < SX_FRAME; i++) {
-                    rand_seed = sx_rand(rand_seed);
-                    i32 dither = rand_seed >> 31;
+                SX_PAR(i, SX_FRAME) {
+                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
                     int first_half = (i % (SX_SUBFR << 1)) < SX_SUBFR;
                     int use_p1 = desp_type == 0 ? first_half : !first_half;
                     i32 q_Q10 = sx_add(use_p1 ? offset_p1_Q10 : offset_p2_Q10, sx_shl(w->pulses[0][i], 10));
@@ -815,6 +835,7 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     st->exc_Q10[i] = sx_smulww(use_p1 ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16, e);
                 }
             }
+            wv_sync();
             SX_T(1)
             sx_decode_core(st, w, pOut);
             SX_T(2)
@@ -856,17 +877,24 @@ SX_HD u32 sx_hb_unpack(const u8* hb, int* bitpos, int nbBits) {
 
 // AGR_Sate_LPC_synthesis_filter_fix, libBWE/AGR_BWE_LPC_synthesizer.c:56 (order 8, int32 Q10 input)
 SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16, i32* S, i16* out, int len) {
-    i32 hist[SX_HB_LPC];
-    for (int j = 0; j < SX_HB_LPC; j++) hist[j] = S[SX_HB_LPC - 1 - j];
-    for (int k = 0; k < len; k++) {
-        i32 acc = 0;
-        for (int j = 0; j < SX_HB_LPC; j++) acc = sx_smlawb(acc, hist[j], A_Q12[j]);
-        acc = sx_add_sat32(acc, sx_smulww(Gain_Q16, in_Q10[k]));
-        out[k] = (i16)sx_sat16(sx_rshift_round(acc, 10));
-        for (int j = SX_HB_LPC - 1; j > 0; j--) hist[j] = hist[j - 1];
-        hist[0] = sx_lshift_sat32(acc, 4);
+    // coefficients (pre-shifted for the high-word multiply) and the last SX_HB_LPC outputs in registers; slot r of the ring
+    // holds the output of time t = r (mod SX_HB_LPC); len is a multiple of SX_HB_LPC
+    i32 a[SX_HB_LPC], h[SX_HB_LPC];
+#pragma unroll
+    for (int j = 0; j < SX_HB_LPC; j++) { a[j] = sx_pre16(A_Q12[j]); h[j] = S[j]; }
+    for (int k0 = 0; k0 < len; k0 += SX_HB_LPC) {
+#pragma unroll
+        for (int u = 0; u < SX_HB_LPC; u++) {
+            i32 acc = 0;
+#pragma unroll
+            for (int j = 0; j < SX_HB_LPC; j++) acc = sx_smlaw_pre(acc, h[(u - 1 - j + 2 * SX_HB_LPC) % SX_HB_LPC], a[j]);
+            acc = sx_add_sat32(acc, sx_smulww(Gain_Q16, in_Q10[k0 + u]));
+            out[k0 + u] = (i16)sx_sat16(sx_rshift_round(acc, 10));
+            h[u] = sx_lshift_sat32(acc, 4);
+        }
     }
-    for (int j = 0; j < SX_HB_LPC; j++) S[SX_HB_LPC - 1 - j] = hist[j];
+#pragma unroll
+    for (int j = 0; j < SX_HB_LPC; j++) S[j] = h[j];
 }
 
 // AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40, for both 20 ms frames of a packet.  The side information of

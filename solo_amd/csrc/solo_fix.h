@@ -186,6 +186,18 @@ SX_HD i32 sx_inverse32_varQ(i32 b32, int Qres) {
 }
 // SKP_RAND (SigProc_FIX.h:650)
 SX_HD i32 sx_rand(i32 seed) { return (i32)(907633515u + (u32)seed * 196314165u); }
+// n-th iterate of sx_rand (n >= 0) by square-and-multiply on the affine map x -> A x + C (mod 2^32): lets every lane of a
+// data-parallel loop regenerate "its" value of a serial LCG sequence
+SX_HD i32 sx_rand_skip(i32 seed, u32 n) {
+    u32 Ar = 1u, Cr = 0u, Ab = 196314165u, Cb = 907633515u;
+#pragma unroll
+    for (int bit = 0; bit < 8; bit++) {          // n < 256
+        if (n & (1u << bit)) { Ar = Ab * Ar; Cr = Ab * Cr + Cb; }
+        Cb = Ab * Cb + Cb;
+        Ab = Ab * Ab;
+    }
+    return (i32)(Ar * (u32)seed + Cr);
+}
 
 // ---- Speex-derived 16-bit helpers of the QMF (libBWE/AGR_BWE_fixed_generic.h:40-80) ---------------
 SX_HD i32 sx_pshr32(i32 a, int s) { return sx_add(a, (1 << s) >> 1) >> s; }
