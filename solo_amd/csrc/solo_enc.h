@@ -40,8 +40,11 @@ struct SxFrontWork {                 // LDS scratch of the per-frame analysis ch
 struct SxHbWork {                    // LDS scratch of the high-band encoder
     i16 x_hb_buf[SX_HB_XBUF];
     i16 lpc_in[4 * 88];
-    i16 exc[40];
+    i16 exc[SX_FRAME];
     i32 NLSF_Q15[SX_MAX_LPC];
+    i32 weight[SX_MAX_LPC];
+    i16 A_Q12[SX_MAX_LPC];
+    i32 ws[SX_NLSF2A_WS];
     SxLpcWork lpc;
 };
 
@@ -91,10 +94,11 @@ SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i16* p0, const SxCdf* cdf) {
 }
 
 // SKP_Silk_encode_pulses + SKP_Silk_encode_signs, SKP_Silk_encode_pulses.c:55, SKP_Silk_code_signs.c:40
-SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, i16* pw) {
+SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, i16* pw) {
     SX_IN_LDS(cdf); SX_IN_LDS(pw); SX_IN_LDS(q);
     const int iter = SX_FRAME / 16;
     i16 *abs_pulses = pw, *sum_pulses = pw + SX_FRAME, *nRshifts = pw + SX_FRAME + SX_FRAME / 16;
+    const i32 maxp0 = T_max_pulses[0], maxp1 = T_max_pulses[1], maxp2 = T_max_pulses[2], maxp3 = T_max_pulses[3];
     for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = q[i] < 0 ? -(i32)q[i] : (i32)q[i];
     for (int i = 0; i < iter; i++) {
         i16* ap = &abs_pulses[i * 16];
@@ -106,16 +110,16 @@ SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
             i32 c1[8], c2[4], c3[2];
             int scale_down = 0, bad;
             bad = 0;
-            for (int k = 0; k < 8; k++) { c1[k] = ap[2 * k] + ap[2 * k + 1]; bad |= c1[k] > T_max_pulses[0]; }
+            for (int k = 0; k < 8; k++) { c1[k] = ap[2 * k] + ap[2 * k + 1]; bad |= c1[k] > maxp0; }
             scale_down += bad;
             bad = 0;
-            for (int k = 0; k < 4; k++) { c2[k] = c1[2 * k] + c1[2 * k + 1]; bad |= c2[k] > T_max_pulses[1]; }
+            for (int k = 0; k < 4; k++) { c2[k] = c1[2 * k] + c1[2 * k + 1]; bad |= c2[k] > maxp1; }
             scale_down += bad;
             bad = 0;
-            for (int k = 0; k < 2; k++) { c3[k] = c2[2 * k] + c2[2 * k + 1]; bad |= c3[k] > T_max_pulses[2]; }
+            for (int k = 0; k < 2; k++) { c3[k] = c2[2 * k] + c2[2 * k + 1]; bad |= c3[k] > maxp2; }
             scale_down += bad;
             sum_pulses[i] = c3[0] + c3[1];
-            if (sum_pulses[i] > T_max_pulses[3]) scale_down++;
+            if (sum_pulses[i] > maxp3) scale_down++;
             if (!scale_down) break;
             nRshifts[i]++;
             for (int k = 0; k < 16; k++) ap[k] >>= 1;
@@ -142,29 +146,31 @@ SX_FN void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
     }
     for (int i = 0; i < iter; i++)
         if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16], cdf);
+    const u32 p_lsb = cdf->cdf_lsb[1];
     for (int i = 0; i < iter; i++) {
         if (nRshifts[i] > 0) {
             const i8* pp = &q[i * 16];
             const int nLS = nRshifts[i] - 1;
             for (int k = 0; k < 16; k++) {
                 i32 abs_q = (i8)(pp[k] < 0 ? -pp[k] : pp[k]);
-                for (int j = nLS; j > 0; j--) sx_rc_enc(rc, (abs_q >> j) & 1, cdf->cdf_lsb);
-                sx_rc_enc(rc, abs_q & 1, cdf->cdf_lsb);
+                for (int j = nLS; j > 0; j--) sx_rc_enc_bin(rc, (abs_q >> j) & 1, p_lsb);
+                sx_rc_enc_bin(rc, abs_q & 1, p_lsb);
             }
         }
     }
-    u16 scdf[3];
-    scdf[0] = 0;
-    scdf[1] = cdf->cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
-    scdf[2] = 65535;
-    for (int i = 0; i < SX_FRAME; i++)
-        if (q[i] != 0) sx_rc_enc(rc, ((i32)q[i] >> 15) + 1, scdf);
+    const u32 p_sign = cdf->cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
+    for (int i = 0; i < SX_FRAME; i++) {
+        const i32 v = q[i];
+        if (v != 0) sx_rc_enc_bin(rc, (v >> 15) + 1, p_sign);
+    }
 }
 
 // SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`)
-SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
+SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
                                 const SxCdf* cdf, i16* pw) {
     SX_IN_LDS(cdf); SX_IN_LDS(x); SX_IN_LDS(q);
+    SxRangeEnc rc_local = *rc_io;      // coder state in registers for the whole frame
+    SxRangeEnc* rc = &rc_local;
     if (frame == 0) {
         if (writeMDIndex == 1) sx_rc_enc(rc, md, cdf->cdf_mdindex);
         sx_rc_enc(rc, 0, cdf->cdf_fs);                          // SamplingRates_table[0] == 8
@@ -198,6 +204,7 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* x, int frame, 
     sx_rc_enc(rc, x->Seed, cdf->cdf_seed);
     sx_encode_pulses(rc, x->sigtype, x->QuantOffsetType, q, cdf, pw);
     sx_rc_enc(rc, x->vadFlag, cdf->cdf_vadflag);
+    *rc_io = rc_local;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -221,7 +228,8 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         lpc_in[t] = src < SX_HB_XBUF ? xb[src] : (i16)0;
     }
     wv_sync();
-    i32 weight[SX_MAX_LPC], res_nrg, res_nrg_Q;
+    i32 res_nrg, res_nrg_Q;
+    i32* weight = hw->weight;
     i32* a_Q16 = hw->lpc.a_Q16;
     i32* NLSF_Q15 = hw->NLSF_Q15;
     sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, 88, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
@@ -231,7 +239,6 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
     sx_nlsf_weights_laroia(weight, NLSF_Q15, SX_HB_LPC);
-    i32 best = SX_I32_MAX;
     int idx1 = 0;
     {
         i32 my_best = SX_I32_MAX;
@@ -247,44 +254,67 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         wv_argmin(&my_best, &my_idx);
         idx1 = my_idx;
     }
+    wv_sync();
     for (int j = 0; j < SX_HB_LPC; j++) NLSF_Q15[j] -= T_hb_lsp_cb1[idx1 * SX_HB_LPC + j];
+    wv_sync();
     int idx2 = 0;
-    best = SX_I32_MAX;
-    for (int i = 0; i < 16; i++) {
-        i32 dist = 0;
-        for (int j = 0; j < SX_HB_LPC; j++) {
-            i32 tmp = sx_sub(NLSF_Q15[j], T_hb_lsp_cb2[i * SX_HB_LPC + j]);
-            dist = sx_smlawb(dist, sx_smulbb(tmp, tmp), weight[j]);
+    {
+        i32 my_best = SX_I32_MAX;
+        int my_idx = SX_I32_MAX;
+        SX_PAR(i, 16) {
+            i32 dist = 0;
+            for (int j = 0; j < SX_HB_LPC; j++) {
+                i32 tmp = sx_sub(NLSF_Q15[j], T_hb_lsp_cb2[i * SX_HB_LPC + j]);
+                dist = sx_smlawb(dist, sx_smulbb(tmp, tmp), weight[j]);
+            }
+            if (dist < my_best) { my_best = dist; my_idx = i; }
         }
-        if (dist < best) { best = dist; idx2 = i; }
+        wv_argmin(&my_best, &my_idx);
+        idx2 = my_idx;
     }
+    wv_sync();
     for (int j = 0; j < SX_HB_LPC; j++) NLSF_Q15[j] = (i32)T_hb_lsp_cb1[idx1 * SX_HB_LPC + j] + (i32)T_hb_lsp_cb2[idx2 * SX_HB_LPC + j];
+    wv_sync();
     const i32 hb_lsp_idx = (idx2 << 8) + idx1;
-    i16 A_Q12[SX_MAX_LPC];
-    sx_nlsf2a_stable(A_Q12, NLSF_Q15, SX_HB_LPC);
+    i16* A_Q12 = hw->A_Q12;
+    sx_nlsf2a_stable_ws(A_Q12, NLSF_Q15, SX_HB_LPC, hw->ws);
+    wv_sync();
     u32 word = (u32)hb_lsp_idx << 20;
+    // the four 5 ms blocks are filtered from zero state (the reference calls the filter once per block)
+    SX_PAR(t, SX_FRAME) {
+        const int sub = t / 40, k = t - sub * 40;
+        const i16* in = xb + SX_FRAME + sub * 40;
+        i32 acc = 0;
+        for (int j = 0; j < SX_HB_LPC; j++) {
+            int u = k - 1 - j;
+            if (u >= 0) acc = sx_smlabb(acc, in[u], A_Q12[j]);
+        }
+        i32 o = sx_sub_sat32(sx_shl((i32)in[k], 12), acc);
+        exc[t] = (i16)sx_sat16(sx_rshift_round(o, 12));
+    }
+    wv_sync();
     for (int sub = 0; sub < 4; sub++) {
-        const i16* p_hb = xb + SX_FRAME + sub * 40;
-        sx_lpc_analysis_filter_zero_state(p_hb, A_Q12, exc, 40, SX_HB_LPC);
-        wv_sync();
         i32 res_nrg0 = 0, res_nrg1 = 0;
-        for (int i = 0; i < 40; i++) {
-            res_nrg0 = sx_add(res_nrg0, sx_mul((i32)exc[i], (i32)exc[i]));
+        SX_PAR(i, 40) {
+            const i32 e = exc[sub * 40 + i];
+            res_nrg0 = sx_add(res_nrg0, sx_mul(e, e));
             i32 tmp = residue[sub * 40 + i] >> 10;
             res_nrg1 = sx_smlabb(res_nrg1, tmp, tmp);
         }
+        res_nrg0 = wv_sum(res_nrg0);
+        res_nrg1 = wv_sum(res_nrg1);
         res_nrg0 = sx_sqrt_approx(res_nrg0);
         res_nrg1 = sx_sqrt_approx(res_nrg1);
         const i16 gain = (i16)(sx_shl(res_nrg0 + 1, 4) / (res_nrg1 + 1));
         i32 min_dist = SX_I32_MAX;
-        int gidx = 0;
-        for (int i = 0; i < 32; i++) {
+        int gidx = SX_I32_MAX;
+        SX_PAR(i, 32) {
             i16 tmp = (i16)(gain - T_hb_gain_cb[i]);
-            i32 dist = sx_smulbb(tmp, tmp);
+            const i32 dist = sx_smulbb(tmp, tmp);
             if (dist < min_dist) { min_dist = dist; gidx = i; }
         }
+        wv_argmin(&min_dist, &gidx);
         word |= (u32)gidx << (15 - 5 * sub);
-        wv_sync();
     }
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
     // slide the buffer: the last 200 samples are the next frame's history

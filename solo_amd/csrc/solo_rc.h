@@ -221,6 +221,40 @@ SX_HD void sx_rc_enc(SxRangeEnc* rc, i32 data, const u16* prob) {
     rc->bufferIx = bufferIx;
 }
 
+// sx_rc_enc for a two-symbol model {0, p, 65535} with the threshold in a register (signs, LSBs)
+SX_HD void sx_rc_enc_bin(SxRangeEnc* rc, i32 data, u32 p) {
+    if (rc->error) return;
+    u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16;
+    i32 bufferIx = rc->bufferIx;
+    u8* buffer = rc->buf;
+    const u32 low_Q16 = data ? p : 0u, high_Q16 = data ? 0xFFFFu : p;
+    u32 base_tmp = base_Q32;
+    base_Q32 += range_Q16 * low_Q16;
+    u32 range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+    if (base_Q32 < base_tmp) {
+        i32 ix = bufferIx;
+        while ((++buffer[--ix]) == 0) {}
+    }
+    if (range_Q32 & 0xFF000000) {
+        range_Q16 = range_Q32 >> 16;
+    } else {
+        if (range_Q32 & 0xFFFF0000) {
+            range_Q16 = range_Q32 >> 8;
+        } else {
+            range_Q16 = range_Q32;
+            if (bufferIx >= rc->bufferLength) { rc->error = SX_RC_WRITE_BEYOND_BUFFER; return; }
+            buffer[bufferIx++] = (u8)(base_Q32 >> 24);
+            base_Q32 <<= 8;
+        }
+        if (bufferIx >= rc->bufferLength) { rc->error = SX_RC_WRITE_BEYOND_BUFFER; return; }
+        buffer[bufferIx++] = (u8)(base_Q32 >> 24);
+        base_Q32 <<= 8;
+    }
+    rc->base_Q32 = base_Q32;
+    rc->range_Q16 = range_Q16;
+    rc->bufferIx = bufferIx;
+}
+
 // SKP_Silk_range_enc_wrap_up, SKP_Silk_range_coder.c:305
 SX_HD void sx_rc_enc_wrap_up(SxRangeEnc* rc) {
     i32 nBytes;
