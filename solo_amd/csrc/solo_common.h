@@ -266,6 +266,79 @@ SX_FN void sx_sum_sqr_shift(i32* energy, i32* shift, const i16* x, int len, int 
     *energy = nrg;
 }
 
+// The same function for wave-uniform callers: all lanes cooperate.  The reference's loop is a state machine (nrg, shift):
+// add the next pair of squares >> shift; when bit 31 gets set, nrg >>= 2 and shift += 2.  Between two such events the
+// accumulation is a plain sum, so each round takes one saturating prefix scan over the remaining pairs (lane l owns C
+// consecutive pairs), finds the lane where the running total first reaches 2^31, and replays only that lane's pairs.
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+SX_HD u32 sx_uadd_sat(u32 a, u32 b) { const u32 r = a + b; return r < a ? 0xFFFFFFFFu : r; }
+SX_HD u32 wv_scan_sat(u32 v) {      // inclusive saturating prefix sum over the 64 lanes
+    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x111, 0xF, 0xF, true));
+    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x112, 0xF, 0xF, true));
+    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x114, 0xF, 0xF, true));
+    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x118, 0xF, 0xF, true));
+    const u32 r0 = (u32)__builtin_amdgcn_readlane((i32)v, 15), r1 = (u32)__builtin_amdgcn_readlane((i32)v, 31),
+              r2 = (u32)__builtin_amdgcn_readlane((i32)v, 47);
+    const u32 s01 = sx_uadd_sat(r0, r1), s012 = sx_uadd_sat(s01, r2);
+    const int row = SX_LANE >> 4;
+    const u32 off = row == 0 ? 0u : (row == 1 ? r0 : (row == 2 ? s01 : s012));
+    return sx_uadd_sat(v, off);
+}
+SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
+    const int start = odd_start ? 1 : 0;
+    const int npairs = (len - start) >> 1;
+    const int tail = (len - start) & 1;
+    if (npairs > 4 * 64) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); return; }
+    u32 nrg = odd_start ? (u32)sx_smulbb(x[0], x[0]) : 0u;
+    const int C = (npairs + 63) >> 6;
+    u32 P[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+        const int m = SX_LANE * C + j;
+        u32 v = 0;
+        if (j < C && m < npairs) {
+            const i32 a = x[start + 2 * m], b = x[start + 2 * m + 1];
+            v = (u32)(a * a) + (u32)(b * b);
+        }
+        P[j] = v;
+    }
+    int cur = 0, shft = 0;
+    for (;;) {
+        u32 sl = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = SX_LANE * C + j;
+            if (m >= cur) sl = sx_uadd_sat(sl, P[j] >> shft);
+        }
+        const u32 pre = wv_scan_sat(sl);
+        const u32 tot = sx_uadd_sat(nrg, pre);
+        const unsigned long long cross = __builtin_amdgcn_ballot_w64(tot >= 0x80000000u);
+        if (!cross) { nrg = (u32)__builtin_amdgcn_readlane((i32)tot, 63); break; }
+        const int Lc = __builtin_ctzll(cross);
+        u32 base = nrg;
+        if (Lc > 0) base += (u32)__builtin_amdgcn_readlane((i32)pre, Lc - 1);
+        bool found = false;
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+            const int m = Lc * C + j;
+            const u32 pj = (u32)__builtin_amdgcn_readlane((i32)P[j], Lc);
+            if (!found && j < C && m >= cur) {
+                base += pj >> shft;
+                if (base >= 0x80000000u) { found = true; cur = m + 1; }
+            }
+        }
+        nrg = base >> 2;
+        shft += 2;
+    }
+    if (tail) nrg += (u32)sx_smulbb(x[len - 1], x[len - 1]) >> shft;
+    if (nrg & 0xC0000000u) { nrg >>= 2; shft += 2; }
+    *shift = shft;
+    *energy = (i32)nrg;
+}
+#else
+SX_HD void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
+#endif
+
 // SKP_Silk_LPC_analysis_filter, SKP_Silk_MA.c:70 with a ZERO initial state, as a direct-form FIR:
 //   out[k] = sat16( rshift_round( sub_sat32( in[k] << 12, sum_j B[j] * in[k-1-j] ), 12 ) ),  in[<0] = 0
 // (the reference's delay-line update is a plain shift, and its SMLABB accumulation wraps, so the

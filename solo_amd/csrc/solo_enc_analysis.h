@@ -916,7 +916,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     const int L = subfr_length;
     i32 C0, rshifts;
     SX_T_BEGIN
-    sx_sum_sqr_shift(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
+    sx_sum_sqr_shift_wv(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
     SX_T(23)
     if (rshifts > MAX_RSHIFTS) {
         C0 = sx_shl(C0, rshifts - MAX_RSHIFTS);
@@ -1558,7 +1558,7 @@ SX_FN void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][
         wv_sync();
         for (int j = 0; j < 2; j++) {
             i32 rshift;
-            sx_sum_sqr_shift(&nrgs[i * 2 + j], &rshift, LPC_res + SX_LPC + j * offset, SX_SUBFR, 0);
+            sx_sum_sqr_shift_wv(&nrgs[i * 2 + j], &rshift, LPC_res + SX_LPC + j * offset, SX_SUBFR, 0);
             nrgsQ[i * 2 + j] = -rshift;
         }
         x_ptr += 2 * offset;
