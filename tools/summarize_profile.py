@@ -55,9 +55,10 @@ for k, e in out["kernels"].items():
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 json.dump(out, open(dst + "_summary.json", "w"), indent=1)
 open(dst + "_kernel_stats.csv", "w").write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n" + "\n".join(lines) + "\n")
-enc = out["kernels"].get("solo_encode_kernel", {})
-if "hbm_bytes_per_packet_corrected" in enc:
-    json.dump({"solo_encode_kernel_bytes_per_packet": enc["hbm_bytes_per_packet_corrected"],
-               "note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per packet; see " + os.path.basename(dst) + "_summary.json"},
-              open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
-print(json.dumps(out, indent=1)[:3000])
+tr = {"note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per 40 ms packet and kernel; see "
+              + os.path.basename(dst) + "_summary.json"}
+for k, e in out["kernels"].items():
+    if "hbm_bytes_per_packet_corrected" in e:
+        tr[k + "_bytes_per_packet"] = e["hbm_bytes_per_packet_corrected"]
+json.dump(tr, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+print(json.dumps(out, indent=1)[:6000])
