@@ -964,6 +964,119 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     bw->CAf[0] = CA0;
     bw->CAb[0] = CA0;
     wv_sync();
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+    // Register-resident recursion: lane (s, k) = (row, column) of the wave.  Column k of EVERY row holds coefficient / correlation
+    // element k (Af, first / last row correlations Cf / Cl, CAf, CAb: the rows are redundant copies), so the per-subframe terms
+    // reduce inside a row (DPP) and index reversals n-1-k are one lane gather; nothing goes through LDS but the signal.
+    i32 nrg, tmp1;
+    {
+        const int row = SX_LANE >> 4, k = SX_LANE & 15, rowbase = SX_LANE & 48;
+        const int srow = row < nb_subfr ? row : 0;            // rows past nb_subfr compute a copy of subframe 0 and are ignored
+        const i16* xr = x + srow * L;
+        i32 Af_k = 0, Cf_k = bw->Cf[k], Cl_k = Cf_k;
+        i32 CAf_k = k == 0 ? CA0 : 0, CAb_k = CAf_k;
+        const bool hi = rshifts > -2;
+#define SX_GATHER(v, idx) __shfl((v), rowbase | ((idx) & 15), 64)
+        for (int n = 0; n < D; n++) {
+            // (a) forward / backward prediction errors at the two edges of subframe `row`
+            i32 a = 0, b = 0;
+            if (k < n) {
+                if (hi) {
+                    a = sx_smulwb(Af_k, xr[n - k - 1]);
+                    b = sx_smulwb(Af_k, xr[L - n + k]);
+                } else {
+                    const i32 Atmp1 = sx_rshift_round(Af_k, QA - 17);
+                    a = sx_mul(xr[n - k - 1], Atmp1);
+                    b = sx_mul(xr[L - n + k], Atmp1);
+                }
+            }
+            a = wv_row_sum(a);
+            b = wv_row_sum(b);
+            i32 t1 = sx_add(sx_shl((i32)xr[n], hi ? QA - 16 : 17), a), t2 = sx_add(sx_shl((i32)xr[L - n - 1], hi ? QA - 16 : 17), b);
+            t1 = sx_neg(t1); t2 = sx_neg(t2);
+            if (hi) { t1 = sx_shl(t1, 32 - QA - rshifts); t2 = sx_shl(t2, 32 - QA - rshifts); }
+            // (b) column k: correlation rows and forward / backward correlations, all subframes
+            {
+                i32 cf = Cf_k, cl = Cl_k, caf = CAf_k, cab = CAb_k;
+                for (int s = 0; s < nb_subfr; s++) {
+                    const i16* xs = x + s * L;
+                    const i32 T1 = __builtin_amdgcn_readlane(t1, s * 16), T2 = __builtin_amdgcn_readlane(t2, s * 16);
+                    const int kk = sx_min(k, n);                       // columns past n only feed lanes that are never read
+                    if (hi) {
+                        const i32 x1 = sx_neg(sx_shl((i32)xs[n], 16 - rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], 16 - rshifts));
+                        if (k < n) {
+                            cf = sx_smlawb(cf, x1, xs[n - k - 1]);
+                            cl = sx_smlawb(cl, x2, xs[L - n + k]);
+                        }
+                        caf = sx_smlawb(caf, T1, xs[n - kk]);
+                        cab = sx_smlawb(cab, T2, xs[L - n + kk - 1]);
+                    } else {
+                        const i32 x1 = sx_neg(sx_shl((i32)xs[n], -rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], -rshifts));
+                        if (k < n) {
+                            cf = sx_add(cf, sx_mul(x1, xs[n - k - 1]));
+                            cl = sx_add(cl, sx_mul(x2, xs[L - n + k]));
+                        }
+                        caf = sx_smlaww(caf, T1, sx_shl((i32)xs[n - kk], -rshifts - 1));
+                        cab = sx_smlaww(cab, T2, sx_shl((i32)xs[L - n + kk - 1], -rshifts - 1));
+                    }
+                }
+                if (k < n) { Cf_k = cf; Cl_k = cl; }
+                if (k <= n) { CAf_k = caf; CAb_k = cab; }
+            }
+            // (c) reflection coefficient: numerator / denominator terms of column k < n
+            i32 p1 = 0, p2 = 0, q3 = 0, q4 = 0;
+            {
+                const i32 Cl_r = SX_GATHER(Cl_k, n - k - 1), Cf_r = SX_GATHER(Cf_k, n - k - 1), CAb_r = SX_GATHER(CAb_k, n - k);
+                const i32 CA_next = SX_GATHER(sx_add(CAb_k, CAf_k), k + 1);
+                if (k < n) {
+                    int lz = sx_clz32(sx_abs(Af_k)) - 1;
+                    lz = sx_min(32 - QA, lz);
+                    const i32 Atmp1 = sx_shl(Af_k, lz);
+                    const int sh = 32 - QA - lz;
+                    p1 = sx_shl(sx_smmul(Cl_r, Atmp1), sh);
+                    p2 = sx_shl(sx_smmul(Cf_r, Atmp1), sh);
+                    q3 = sx_shl(sx_smmul(CAb_r, Atmp1), sh);
+                    q4 = sx_shl(sx_smmul(CA_next, Atmp1), sh);
+                }
+            }
+            const i32 s1 = sx_add(SX_UNI(wv_row_sum(p1)), __builtin_amdgcn_readlane(Cf_k, n));
+            const i32 s2 = sx_add(SX_UNI(wv_row_sum(p2)), __builtin_amdgcn_readlane(Cl_k, n));
+            i32 num = SX_UNI(wv_row_sum(q3));
+            const i32 den = sx_add(SX_UNI(wv_row_sum(q4)), sx_add(__builtin_amdgcn_readlane(CAb_k, 0), __builtin_amdgcn_readlane(CAf_k, 0)));
+            if (k == n + 1) { CAf_k = s1; CAb_k = s2; }
+            num = sx_add(num, s2);
+            num = sx_shl(sx_neg(num), 1);
+            if (!(sx_abs(num) < den)) {
+                if (k >= n) Af_k = 0;
+                break;
+            }
+            const i32 rc_Q31 = sx_div32_varQ(num, den, 31);
+            // (d) symmetric coefficient update and correlation update
+            {
+                const i32 Af_r = SX_GATHER(Af_k, n - k - 1);
+                const i32 CAb_r = SX_GATHER(CAb_k, n + 1 - k), CAf_r = SX_GATHER(CAf_k, n + 1 - k);
+                if (k < n) Af_k = sx_add(Af_k, sx_shl(sx_smmul(Af_r, rc_Q31), 1));
+                if (k <= n + 1) {
+                    CAf_k = sx_add(CAf_k, sx_shl(sx_smmul(CAb_r, rc_Q31), 1));
+                    CAb_k = sx_add(CAb_k, sx_shl(sx_smmul(CAf_r, rc_Q31), 1));
+                }
+                if (k == n) Af_k = rc_Q31 >> (31 - QA);
+            }
+        }
+#undef SX_GATHER
+        SX_T(25)
+        // residual energy and output
+        const i32 At = k < D ? sx_rshift_round(Af_k, QA - 16) : 0;
+        const i32 CAf_next = __shfl(CAf_k, rowbase | ((k + 1) & 15), 64);
+        nrg = sx_add(__builtin_amdgcn_readlane(CAf_k, 0), SX_UNI(wv_row_sum(k < D ? sx_smulww(CAf_next, At) : 0)));
+        tmp1 = sx_add(1 << 16, SX_UNI(wv_row_sum(sx_smulww(At, At))));
+        if (SX_LANE < D) A_Q16[SX_LANE] = sx_neg(At);
+    }
+    *res_nrg = sx_smlaww(nrg, sx_smmul(WhiteNoiseFrac_Q32, C0), sx_neg(tmp1));
+    *res_nrg_Q = -rshifts;
+    wv_sync();
+}
+#else
     for (int n = 0; n < D; n++) {
         // (a) per (subframe, k): terms of the forward / backward prediction errors at the two subframe edges
         SX_PAR(sk, nb_subfr * 16) {
@@ -1102,6 +1215,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     *res_nrg_Q = -rshifts;
     wv_sync();
 }
+#endif
 
 // A2NLSF helpers, SKP_Silk_A2NLSF.c:46-123
 SX_HD void sx_a2nlsf_trans_poly(i32* p, int dd) {

@@ -39,14 +39,14 @@ SX_FN void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16*
 // SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
 SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
     const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
-    i32 s0 = S[0], s1 = S[1];
+    i32 s0 = SX_UNI(S[0]), s1 = SX_UNI(S[1]);
     for (int k = 0; k < (N >> 1); k++) {
-        i32 in32 = sx_shl((i32)in[2 * k], 10);
+        i32 in32 = sx_shl(SX_UNI(in[2 * k]), 10);
         i32 Y = sx_sub(in32, s0);
         i32 X = sx_smlawb(Y, Y, A21);
         i32 out_1 = sx_add(s0, X);
         s0 = sx_add(in32, X);
-        in32 = sx_shl((i32)in[2 * k + 1], 10);
+        in32 = sx_shl(SX_UNI(in[2 * k + 1]), 10);
         Y = sx_sub(in32, s1);
         X = sx_smulwb(Y, A20);
         i32 out_2 = sx_add(s1, X);
@@ -178,9 +178,11 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
     // biquad_alt (direct form II transposed), serial
     i32 A0_L = sx_neg(A0) & 0x3FFF, A0_U = sx_neg(A0) >> 14;
     i32 A1_L = sx_neg(A1) & 0x3FFF, A1_U = sx_neg(A1) >> 14;
-    i32 S0 = st->In_HP_State[0], S1 = st->In_HP_State[1];
+    A0_L = SX_UNI(A0_L); A0_U = SX_UNI(A0_U); A1_L = SX_UNI(A1_L); A1_U = SX_UNI(A1_U);
+    B0 = SX_UNI(B0); B1 = SX_UNI(B1); B2 = SX_UNI(B2);
+    i32 S0 = SX_UNI(st->In_HP_State[0]), S1 = SX_UNI(st->In_HP_State[1]);
     for (int k = 0; k < SX_FRAME; k++) {
-        i32 inval = in[k];
+        i32 inval = SX_UNI(in[k]);
         i32 out32_Q14 = sx_shl(sx_smlawb(S0, B0, inval), 2);
         S0 = sx_add(S1, sx_rshift_round(sx_smulwb(out32_Q14, A0_L), 14));
         S0 = sx_smlawb(S0, out32_Q14, A0_U);

@@ -63,6 +63,7 @@ SX_HD void wv_sync_lds() {
 #else
 #define SX_ROWS_COMBINE(v, OP)
 #endif
+SX_HD i32 wv_row_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) return v; }    // sum over each 16-lane row, in all of its lanes
 SX_HD i32 wv_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) SX_ROWS_COMBINE(v, sx_add(v, t_)) return v; }
 SX_HD i32 wv_max(i32 v) { SX_ROW_REDUCE(v, (t_ > v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ > v ? t_ : v)) return v; }
 SX_HD i32 wv_min(i32 v) { SX_ROW_REDUCE(v, (t_ < v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ < v ? t_ : v)) return v; }
@@ -156,6 +157,14 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 #endif
 }
 
+#endif
+
+// SX_UNI(x): x is known to be identical in all lanes of a fully active wave (wave-uniform code outside SX_PAR bodies); moving
+// it to an SGPR lets the serial scalar recursions that consume it run on the scalar unit instead of 64 redundant VALU lanes
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+#define SX_UNI(x) ((i32)__builtin_amdgcn_readfirstlane((i32)(x)))
+#else
+#define SX_UNI(x) ((i32)(x))
 #endif
 
 // lane-strided parallel loop
