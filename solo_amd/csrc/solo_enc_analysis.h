@@ -1261,6 +1261,112 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid*
             g->yQ[k] = sx_a2nlsf_eval_poly(Q, x, dd);
         }
         wv_sync();
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+        // The reference walks the grid serially; where it stops depends only on sign patterns, so the stops are found with
+        // bit scans over wave ballots (crossing / sign masks of both polynomials over the 128 intervals), and the refinement of
+        // the d roots (3 bisections + interpolation each) runs one root per lane.
+        bool retry = false;
+        {
+            typedef unsigned long long u64m;
+            // per polynomial (P, Q) and half h: bit (k - 1 - 64 h) <-> grid interval k = 1..128
+            u64m crP0, crP1, crQ0, crQ1, leP0, leP1, leQ0, leQ1, geP0, geP1, geQ0, geQ1;
+            {
+                const int k = SX_LANE + 1;
+                const i32 p0 = g->yP[k - 1], p1 = g->yP[k], q0 = g->yQ[k - 1], q1 = g->yQ[k];
+                crP0 = __builtin_amdgcn_ballot_w64((p0 <= 0 && p1 >= 0) || (p0 >= 0 && p1 <= 0));
+                crQ0 = __builtin_amdgcn_ballot_w64((q0 <= 0 && q1 >= 0) || (q0 >= 0 && q1 <= 0));
+                leP0 = __builtin_amdgcn_ballot_w64(p1 <= 0); geP0 = __builtin_amdgcn_ballot_w64(p1 >= 0);
+                leQ0 = __builtin_amdgcn_ballot_w64(q1 <= 0); geQ0 = __builtin_amdgcn_ballot_w64(q1 >= 0);
+            }
+            {
+                const int k = SX_LANE + 65;
+                const i32 p0 = g->yP[k - 1], p1 = g->yP[k], q0 = g->yQ[k - 1], q1 = g->yQ[k];
+                crP1 = __builtin_amdgcn_ballot_w64((p0 <= 0 && p1 >= 0) || (p0 >= 0 && p1 <= 0));
+                crQ1 = __builtin_amdgcn_ballot_w64((q0 <= 0 && q1 >= 0) || (q0 >= 0 && q1 <= 0));
+                leP1 = __builtin_amdgcn_ballot_w64(p1 <= 0); geP1 = __builtin_amdgcn_ballot_w64(p1 >= 0);
+                leQ1 = __builtin_amdgcn_ballot_w64(q1 <= 0); geQ1 = __builtin_amdgcn_ballot_w64(q1 >= 0);
+            }
+            int root_ix = 0, poly = 0, k = 1;
+            i32 art = 0;                                 // 0: the interval's real left value; else the reference's artificial +-4096
+            const int first_root = SX_UNI(g->yP[0]) < 0 ? 1 : 0;
+            if (first_root) { root_ix = 1; poly = 1; }
+            int my_k = 0;
+            i32 my_art = 0;
+            bool fail = false;
+            while (root_ix < d) {
+                int kk = 129;
+                bool hit = false;
+                if (art != 0) {                          // first test after a switch: only the sign of y[k] matters
+                    const u64m mle = poly ? (k > 64 ? leQ1 : leQ0) : (k > 64 ? leP1 : leP0);
+                    const u64m mge = poly ? (k > 64 ? geQ1 : geQ0) : (k > 64 ? geP1 : geP0);
+                    const u64m m = art > 0 ? mle : mge;
+                    hit = (m >> ((k - 1) & 63)) & 1;
+                }
+                if (hit) {
+                    kk = k;
+                } else {
+                    int k0 = art != 0 ? k + 1 : k;       // real crossings from here on
+                    const u64m c0 = poly ? crQ0 : crP0, c1 = poly ? crQ1 : crP1;
+                    if (k0 <= 64) {
+                        const u64m t = c0 >> (k0 - 1);
+                        if (t) kk = k0 + __builtin_ctzll(t); else k0 = 65;
+                    }
+                    if (kk == 129 && k0 <= 128) {
+                        const u64m t = c1 >> (k0 - 65);
+                        if (t) kk = k0 + __builtin_ctzll(t);
+                    }
+                }
+                if (kk > 128) { fail = true; break; }
+                if (SX_LANE == root_ix) { my_k = kk; my_art = hit ? art : 0; }
+                root_ix++;
+                k = kk;
+                poly = root_ix & 1;
+                art = sx_shl(1 - (root_ix & 2), 12);
+            }
+            if (!fail) {
+                if (first_root && SX_LANE == 0) NLSF[0] = 0;
+                if (SX_LANE >= first_root && SX_LANE < d) {
+                    const int kq = my_k;
+                    const i32* pp = (SX_LANE & 1) ? Q : P;
+                    const i32* yp = (SX_LANE & 1) ? g->yQ : g->yP;
+                    i32 xlo = g->x[kq - 1], ylo = my_art != 0 ? my_art : yp[kq - 1], xhi = g->x[kq], yhi = yp[kq];
+                    i32 ffrac = -256;
+                    for (int m = 0; m < 3; m++) {
+                        i32 xmid = sx_rshift_round(xlo + xhi, 1);
+                        i32 ymid = sx_a2nlsf_eval_poly(pp, xmid, dd);
+                        if ((ylo <= 0 && ymid >= 0) || (ylo >= 0 && ymid <= 0)) {
+                            xhi = xmid;
+                            yhi = ymid;
+                        } else {
+                            xlo = xmid;
+                            ylo = ymid;
+                            ffrac = ffrac + (128 >> m);
+                        }
+                    }
+                    if (sx_abs(ylo) < 65536) {
+                        i32 den = ylo - yhi;
+                        i32 nom = sx_shl(ylo, 8 - 3) + (den >> 1);
+                        if (den != 0) ffrac += nom / den;
+                    } else {
+                        ffrac += ylo / ((ylo - yhi) >> (8 - 3));
+                    }
+                    NLSF[SX_LANE] = sx_min(sx_shl(kq, 8) + ffrac, 32767);
+                }
+            } else {
+                i++;
+                if (i > 30) {
+                    wv_sync();
+                    NLSF[0] = (1 << 15) / (d + 1);
+                    for (int kf = 1; kf < d; kf++) NLSF[kf] = sx_smulbb(kf + 1, (1 << 15) / (d + 1));
+                    wv_sync();
+                    return;
+                }
+                wv_sync();
+                sx_bwexpander_32(a_Q16, d, 65536 - sx_smulbb(10 + i, i));
+                retry = true;
+            }
+        }
+#else
         const i32* p = P;
         const i32* yp = g->yP;
         i32 xlo = g->x[0], ylo = yp[0], xhi, yhi;
@@ -1325,6 +1431,7 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid*
                 }
             }
         }
+#endif
         wv_sync();
         if (!retry) return;
     }
