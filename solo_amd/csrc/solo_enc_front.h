@@ -39,14 +39,47 @@ SX_FN void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16*
 // SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
 SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
     const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
+#ifdef SX_LANE_STREAM
+    // N <= 192 samples in, N/2 <= 96 out per band (in may alias outL: everything is read before anything is stored)
+    i32 r[3], oL[2] = {0, 0}, oH[2] = {0, 0};
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; r[j] = i < N ? (i32)in[i] : 0; }
     i32 s0 = SX_UNI(S[0]), s1 = SX_UNI(S[1]);
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int kend = sx_min(N >> 1, 32 * (c + 1));
+        for (int k = 32 * c; k < kend; k++) {
+            i32 in32 = sx_shl(SX_RDLANE(r[c], (2 * k) & 63), 10);
+            i32 Y = sx_sub(in32, s0);
+            i32 X = sx_smlawb(Y, Y, A21);
+            i32 out_1 = sx_add(s0, X);
+            s0 = sx_add(in32, X);
+            in32 = sx_shl(SX_RDLANE(r[c], (2 * k + 1) & 63), 10);
+            Y = sx_sub(in32, s1);
+            X = sx_smulwb(Y, A20);
+            i32 out_2 = sx_add(s1, X);
+            s1 = sx_add(in32, X);
+            SX_WRLANE(oL[c >> 1], k & 63, sx_sat16(sx_rshift_round(sx_add(out_2, out_1), 11)));
+            SX_WRLANE(oH[c >> 1], k & 63, sx_sat16(sx_rshift_round(sx_sub(out_2, out_1), 11)));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; j++) {
+        const int i = SX_LANE + 64 * j;
+        if (i < (N >> 1)) { outL[i] = (i16)oL[j]; outH[i] = (i16)oH[j]; }
+    }
+    S[0] = s0;
+    S[1] = s1;
+    wv_sync();
+#else
+    i32 s0 = S[0], s1 = S[1];
     for (int k = 0; k < (N >> 1); k++) {
-        i32 in32 = sx_shl(SX_UNI(in[2 * k]), 10);
+        i32 in32 = sx_shl((i32)in[2 * k], 10);
         i32 Y = sx_sub(in32, s0);
         i32 X = sx_smlawb(Y, Y, A21);
         i32 out_1 = sx_add(s0, X);
         s0 = sx_add(in32, X);
-        in32 = sx_shl(SX_UNI(in[2 * k + 1]), 10);
+        in32 = sx_shl((i32)in[2 * k + 1], 10);
         Y = sx_sub(in32, s1);
         X = sx_smulwb(Y, A20);
         i32 out_2 = sx_add(s1, X);
@@ -56,6 +89,7 @@ SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N
     }
     S[0] = s0;
     S[1] = s1;
+#endif
 }
 
 // SKP_Silk_VAD_GetSA_Q8 (+ GetNoiseLevels), SKP_Silk_VAD.c:75-318.  X is a 4 x 80 int16 scratch (LDS).
@@ -181,8 +215,30 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
     A0_L = SX_UNI(A0_L); A0_U = SX_UNI(A0_U); A1_L = SX_UNI(A1_L); A1_U = SX_UNI(A1_U);
     B0 = SX_UNI(B0); B1 = SX_UNI(B1); B2 = SX_UNI(B2);
     i32 S0 = SX_UNI(st->In_HP_State[0]), S1 = SX_UNI(st->In_HP_State[1]);
+#ifdef SX_LANE_STREAM
+    i32 r[3], o[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; r[j] = i < SX_FRAME ? (i32)in[i] : 0; }
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        const int kend = sx_min(SX_FRAME, 64 * (c + 1));
+        for (int k = 64 * c; k < kend; k++) {
+            i32 inval = SX_RDLANE(r[c], k & 63);
+            i32 out32_Q14 = sx_shl(sx_smlawb(S0, B0, inval), 2);
+            S0 = sx_add(S1, sx_rshift_round(sx_smulwb(out32_Q14, A0_L), 14));
+            S0 = sx_smlawb(S0, out32_Q14, A0_U);
+            S0 = sx_smlawb(S0, B1, inval);
+            S1 = sx_rshift_round(sx_smulwb(out32_Q14, A1_L), 14);
+            S1 = sx_smlawb(S1, out32_Q14, A1_U);
+            S1 = sx_smlawb(S1, B2, inval);
+            SX_WRLANE(o[c], k & 63, sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i < SX_FRAME) out[i] = (i16)o[j]; }
+#else
     for (int k = 0; k < SX_FRAME; k++) {
-        i32 inval = SX_UNI(in[k]);
+        i32 inval = in[k];
         i32 out32_Q14 = sx_shl(sx_smlawb(S0, B0, inval), 2);
         S0 = sx_add(S1, sx_rshift_round(sx_smulwb(out32_Q14, A0_L), 14));
         S0 = sx_smlawb(S0, out32_Q14, A0_U);
@@ -192,6 +248,7 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
         S1 = sx_smlawb(S1, B2, inval);
         out[k] = (i16)sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14);
     }
+#endif
     st->In_HP_State[0] = S0;
     st->In_HP_State[1] = S1;
 }
@@ -292,7 +349,33 @@ SX_HD void sx_k2a(i32* A_Q24, const i16* rc_Q15, int order) {
 // SKP_Silk_resampler_down2, SKP_Silk_resampler_down2.c:41 (zero initial state, serial)
 SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
     i32 S0 = 0, S1 = 0;
-    const i32 c0 = T_down2_c0[0], c1 = T_down2_c1[0];
+    const i32 c0 = SX_UNI(T_down2_c0[0]), c1 = SX_UNI(T_down2_c1[0]);
+#ifdef SX_LANE_STREAM
+    // inLen <= 320 samples in (5 lane registers), inLen/2 <= 160 out (3)
+    i32 r[5], o[3] = {0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 5; j++) { const int i = SX_LANE + 64 * j; r[j] = i < inLen ? (i32)in[i] : 0; }
+#pragma unroll
+    for (int c = 0; c < 5; c++) {
+        const int kend = sx_min(inLen >> 1, 32 * (c + 1));
+        for (int k = 32 * c; k < kend; k++) {
+            i32 in32 = sx_shl(SX_RDLANE(r[c], (2 * k) & 63), 10);
+            i32 Y = sx_sub(in32, S0);
+            i32 X = sx_smlawb(Y, Y, c1);
+            i32 out32 = sx_add(S0, X);
+            S0 = sx_add(in32, X);
+            in32 = sx_shl(SX_RDLANE(r[c], (2 * k + 1) & 63), 10);
+            Y = sx_sub(in32, S1);
+            X = sx_smulwb(Y, c0);
+            out32 = sx_add(out32, S1);
+            out32 = sx_add(out32, X);
+            S1 = sx_add(in32, X);
+            SX_WRLANE(o[c >> 1], k & 63, sx_sat16(sx_rshift_round(out32, 11)));
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i < (inLen >> 1)) out[i] = (i16)o[j]; }
+#else
     for (int k = 0; k < (inLen >> 1); k++) {
         i32 in32 = sx_shl((i32)in[2 * k], 10);
         i32 Y = sx_sub(in32, S0);
@@ -307,6 +390,7 @@ SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
         S1 = sx_add(in32, X);
         out[k] = (i16)sx_sat16(sx_rshift_round(out32, 11));
     }
+#endif
 }
 
 // SKP_Silk_int16_array_maxabs (array_maxabs.c:41) -> SKP_FIX_P_Ana_find_scaling (pitch_analysis_core.c:681)

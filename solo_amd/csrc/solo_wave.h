@@ -167,6 +167,15 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 #define SX_UNI(x) ((i32)(x))
 #endif
 
+// Serial recursions over a block of samples (IIR sections that cannot be re-cut over the lanes) read and write their samples
+// through lane registers instead of LDS: sample i lives in lane (i & 63) of register (i >> 6); the scalar loop fetches it with
+// v_readlane and deposits results with a lane-select, so no LDS round trip sits on the recursion's critical path.
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+#define SX_LANE_STREAM 1
+#define SX_RDLANE(v, i) ((i32)__builtin_amdgcn_readlane((i32)(v), (i)))
+#define SX_WRLANE(v, i, val) (v) = (SX_LANE == (i)) ? (i32)(val) : (v)
+#endif
+
 // lane-strided parallel loop
 #define SX_PAR(i, n) for (int i = SX_LANE; i < (int)(n); i += SX_NLANES)
 
