@@ -417,6 +417,48 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(xw); SX_IN_LDS(x); SX_IN_LDS(pw);
     i16* pf_sLTP_shp = pw->ring;
     const i32 lambda_Q16 = (i16)SX_WARPING_Q16;
+#ifdef SX_LANE_STREAM
+    // ---- warped_LPC_analysis_filter_FIX (SKP_Silk_prefilter_FIX.c:43) for the whole frame, skewed over the 16 lanes of a row ----
+    // v_0(n) = x(n) << 14;  v_1(n) = v_0(n-1) + lambda * v_1(n-1);  v_{j+1}(n) = v_j(n-1) + lambda * (v_{j+1}(n-1) - v_j(n));
+    // acc(n) = sum_j coef_k(n)[j-1] * v_j(n).  Lane l owns section j = l + 1 and works on sample n = t - j at step t; (v_j(n),
+    // partial acc) move to lane l + 1 with a DPP row shift, so the recursion never leaves the registers.  (All four rows run
+    // the same computation; their stores coincide.)
+    {
+        const int l = SX_LANE & 15;
+        i32 pv = st->pf_sAR_shp[l + 1], pin = st->pf_sAR_shp[l];
+        const i32 a0 = sx_pre16(c->AR1_Q13[l]), a1 = sx_pre16(c->AR1_Q13[SX_SHAPE_ORDER + l]),
+                  a2 = sx_pre16(c->AR1_Q13[2 * SX_SHAPE_ORDER + l]), a3 = sx_pre16(c->AR1_Q13[3 * SX_SHAPE_ORDER + l]);
+        const i32 lam = sx_pre16(lambda_Q16);
+        pw->st_res[0] = (i16)st->pf_sHarmHP;
+        i32 out = 0, acc = 0, vend = 0, vend0 = 0;
+        i32 xn = (0 - l >= 0) ? (i32)x[0] : 0;                        // x[n] of the coming step (n = t - 1 - l), fetched a step ahead
+        for (int t = 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) {
+            const int n = t - 1 - l;
+            const i32 xcur = xn;
+            {   // prefetch for step t + 1
+                const int nn = n + 1;
+                xn = (nn >= 0 && nn < SX_FRAME) ? (i32)x[nn] : 0;
+            }
+            const i32 in_prev = SX_DPP_(out, 0x111), acc_prev = SX_DPP_(acc, 0x111);     // lane l - 1's results of step t - 1
+            if (n >= 0 && n < SX_FRAME) {
+                const i32 in = l == 0 ? sx_shl(xcur, 14) : in_prev;
+                const i32 o = l == 0 ? sx_smlaw_pre(pin, pv, lam) : sx_smlaw_pre(pin, pv - in, lam);
+                const i32 coef = n < 2 * SX_SUBFR ? (n < SX_SUBFR ? a0 : a1) : (n < 3 * SX_SUBFR ? a2 : a3);
+                acc = sx_smlaw_pre(l == 0 ? 0 : acc_prev, o, coef);
+                pin = in;
+                pv = o;
+                out = o;
+                if (l == SX_SHAPE_ORDER - 1) pw->st_res[1 + n] = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));
+                if (n == SX_FRAME - 1) { vend = o; vend0 = in; }
+            }
+        }
+        if (SX_LANE < SX_SHAPE_ORDER) {
+            st->pf_sAR_shp[l + 1] = vend;
+            if (l == 0) st->pf_sAR_shp[0] = vend0;
+        }
+        wv_sync();
+    }
+#else
     // ---- warped_LPC_analysis_filter_FIX (SKP_Silk_prefilter_FIX.c:43) for the whole frame, skewed over 16 lanes ----
     // v_0(n) = x(n) << 14;  v_1(n) = v_0(n-1) + lambda * v_1(n-1);  v_{j+1}(n) = v_j(n-1) + lambda * (v_{j+1}(n-1) - v_j(n));
     // acc(n) = sum_j coef_k(n)[j-1] * v_j(n).  Lane l owns section j = l + 1 and works on sample n = t - j at step t, passing
@@ -450,6 +492,7 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
         SX_PAR(l, SX_SHAPE_ORDER + 1) st->pf_sAR_shp[l] = pw->vend[l];
         wv_sync();
     }
+#endif
     // ---- per-subframe FIR on the residual, then prefilt_FIX (SKP_Silk_prefilter_FIX.c:174): serial shaping recursion ----
     SX_PAR(n, SX_FRAME) {
         const int k = n / SX_SUBFR;
@@ -463,6 +506,60 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
         pw->x_filt_Q12[n] = sx_add(sx_smulbb(pw->st_res[1 + n], B_lo), sx_smulbb(pw->st_res[n], B_hi));
     }
     wv_sync();
+#ifdef SX_LANE_STREAM
+    // prefilt_FIX's low-frequency recursion (sLF_AR, sLF_MA) only consumes x_filt; the harmonic term is a FIR over the ring of
+    // past sLF_MA values that never feeds back.  So: the scalar recursion streams its 160 samples through lane registers,
+    // then the ring update and the harmonic FIR + output run lane-parallel.  (Sample n reads ring entries written by samples
+    // <= n - lag + 1 < n or by earlier frames; every entry is written once per frame and the 307-entry span cannot wrap.)
+    i32 sLF_AR = SX_UNI(st->pf_sLF_AR_shp_Q12), sLF_MA = SX_UNI(st->pf_sLF_MA_shp_Q12);
+    const int buf_idx0 = SX_UNI(st->pf_sLTP_shp_buf_idx);
+    i32 ma[3] = {0, 0, 0};
+    {
+        i32 xf[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; xf[j] = i < SX_FRAME ? pw->x_filt_Q12[i] : 0; }
+#pragma unroll
+        for (int cc = 0; cc < 3; cc++) {
+            const int nend = sx_min(SX_FRAME, 64 * (cc + 1));
+            for (int n = 64 * cc; n < nend; n++) {
+                const int k = n / SX_SUBFR;
+                const i32 Tilt_Q14 = SX_UNI(c->Tilt_Q14[k]), LF_shp_Q14 = SX_UNI(c->LF_shp_Q14[k]);
+                const i32 xv = SX_RDLANE(xf[cc], n & 63);
+                const i32 n_Tilt_Q10 = sx_smulwb(sLF_AR, Tilt_Q14);
+                const i32 n_LF_Q10 = sx_smlawb(sx_smulwt(sLF_AR, LF_shp_Q14), sLF_MA, LF_shp_Q14);
+                sLF_AR = sx_sub(xv, sx_shl(n_Tilt_Q10, 2));
+                sLF_MA = sx_sub(sLF_AR, sx_shl(n_LF_Q10, 2));
+                SX_WRLANE(ma[cc], n & 63, sLF_MA);
+            }
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = SX_LANE + 64 * j;
+        if (n < SX_FRAME) pf_sLTP_shp[(buf_idx0 - 1 - n) & SX_LTP_MASK] = (i16)sx_sat16(sx_rshift_round(ma[j], 12));
+    }
+    wv_sync();
+    const int buf_idx = (buf_idx0 - SX_FRAME) & SX_LTP_MASK;
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int n = SX_LANE + 64 * j;
+        if (n < SX_FRAME) {
+            const int k = n / SX_SUBFR;
+            const int lag = c->sigtype == 0 ? c->pitchL[k] : st->pf_lagPrev;
+            const i32 HarmShapeGain_Q12 = sx_smulwb(c->HarmShapeGain_Q14[k], 16384 - c->HarmBoost_Q14[k]);
+            i32 HarmShapeFIRPacked_Q12 = HarmShapeGain_Q12 >> 2;
+            HarmShapeFIRPacked_Q12 |= sx_shl(HarmShapeGain_Q12 >> 1, 16);
+            i32 n_LTP_Q12 = 0;
+            if (lag > 0) {
+                const int idx = lag + buf_idx0 - n;
+                n_LTP_Q12 = sx_smulbb(pf_sLTP_shp[(idx - 2) & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+                n_LTP_Q12 = sx_add(n_LTP_Q12, sx_smulbt(pf_sLTP_shp[(idx - 1) & SX_LTP_MASK], HarmShapeFIRPacked_Q12));
+                n_LTP_Q12 = sx_smlabb(n_LTP_Q12, pf_sLTP_shp[idx & SX_LTP_MASK], HarmShapeFIRPacked_Q12);
+            }
+            xw[n] = (i16)sx_sat16(sx_rshift_round(sx_sub(ma[j], n_LTP_Q12), 12));
+        }
+    }
+#else
     int lag = st->pf_lagPrev;
     i32 sLF_AR = st->pf_sLF_AR_shp_Q12, sLF_MA = st->pf_sLF_MA_shp_Q12;
     int buf_idx = st->pf_sLTP_shp_buf_idx;
@@ -489,6 +586,7 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
             xw[k * SX_SUBFR + i] = (i16)sx_sat16(sx_rshift_round(sx_sub(sLF_MA, n_LTP_Q12), 12));
         }
     }
+#endif
     wv_sync();
     st->pf_sLF_AR_shp_Q12 = sLF_AR;
     st->pf_sLF_MA_shp_Q12 = sLF_MA;
