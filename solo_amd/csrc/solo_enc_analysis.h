@@ -168,6 +168,41 @@ struct SxShapeWork {
 // instead of 4 x 120 x 16.  Each lane accumulates correlation j of its subframe in 64 bits; section outputs move to the
 // neighbour lane through a double-buffered LDS row.
 SX_HD void sx_warped_autocorr4(SxShapeWork* sw, i32 warping_Q16) {
+#ifdef SX_LANE_STREAM
+    // row k = subframe, lane j of the row = all-pass section j, skewed by j samples; section outputs move to the next lane with
+    // a DPP row shift (registers only), every lane prefetches its own x(n) a step ahead
+    i64 acc_l = 0, acc16_l = 0;
+    {
+        const int k = SX_LANE >> 4, j = SX_LANE & 15;
+        const i32 lam = sx_pre16(warping_Q16);
+        i32 pin = 0, pout = 0, out = 0;
+        i32 xn = j == 0 ? (i32)sw->xw[k][0] : 0;
+        for (int t = 0; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) {
+            const int n = t - j;
+            const i32 xcur = xn;
+            {
+                const int nn = n + 1;
+                xn = (nn >= 0 && nn < SX_SHAPE_WIN) ? (i32)sw->xw[k][nn] : 0;
+            }
+            const i32 in_prev = SX_DPP_(out, 0x111);
+            if (n >= 0 && n < SX_SHAPE_WIN) {
+                const i32 x0 = sx_shl(xcur, 14);
+                const i32 in = j == 0 ? x0 : in_prev;
+                const i32 o = sx_smlaw_pre(pin, pout - in, lam);
+                acc_l += sx_smull(in, x0) >> 18;
+                if (j == SX_SHAPE_ORDER - 1) acc16_l += sx_smull(o, x0) >> 18;
+                pin = in;
+                pout = o;
+                out = o;
+            }
+        }
+    }
+    {
+        const int k = SX_LANE >> 4, j = SX_LANE & 15;
+        sw->cq[k][j] = acc_l;
+        if (j == SX_SHAPE_ORDER - 1) sw->cq[k][SX_SHAPE_ORDER] = acc16_l;
+    }
+#else
     i32 pin[SX_NP64], pout[SX_NP64];
     i64 acc[SX_NP64], acc16[SX_NP64];
     for (int a = 0; a < SX_NP64; a++) { pin[a] = 0; pout[a] = 0; acc[a] = 0; acc16[a] = 0; }
@@ -192,6 +227,7 @@ SX_HD void sx_warped_autocorr4(SxShapeWork* sw, i32 warping_Q16) {
         sw->cq[k][j] = acc[pl];
         if (j == SX_SHAPE_ORDER - 1) sw->cq[k][SX_SHAPE_ORDER] = acc16[pl];
     }
+#endif
     wv_sync();
     SX_PAR(l, SX_NB_SUBFR * (SX_SHAPE_ORDER + 1)) {
         const int k = l / (SX_SHAPE_ORDER + 1), j = l - k * (SX_SHAPE_ORDER + 1);
