@@ -84,12 +84,14 @@
 
 // phase timer of the quantiser (debug builds with -DSX_PROF): per-lane register accumulators, flushed once per frame
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SX_TA_BEGIN unsigned long long ta_acc_[10] = {0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter();
+#define SX_TA_BEGIN unsigned long long ta_acc_[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter();
 #define SX_TA(id) { const unsigned long long t_ = __builtin_readcyclecounter(); ta_acc_[id] += t_ - ta_last_; ta_last_ = t_; }
-#define SX_TA_END if (SX_LANE == 0) { for (int q_ = 0; q_ < 10; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]); }
+#define SX_TA_END if (SX_LANE == 0) { for (int q_ = 0; q_ < 14; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]); }
+#define SX_TA_COUNT(id, n) ta_acc_[id] += (n);
 #else
 #define SX_TA_BEGIN
 #define SX_TA(id)
+#define SX_TA_COUNT(id, n)
 #define SX_TA_END
 #endif
 
@@ -604,7 +606,9 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 SX_LANESALL(tk) { int n_; SX_FROM_CENTRE(n_, jv, tk) xr0[SX_LI(tk)] = n_; }
                 int RandSyncCtl = SX_GRP(xr0);
                 SX_TA(5)
+                SX_TA_COUNT(10, 1)
                 do {
+                    SX_TA_COUNT(11, 1)
                     // worst candidate [0] (first maximum) and best candidate [1] (first minimum) of the centre track
                     SX_LANES12(tk) { const int li = SX_LI(tk); jv[li] = cRD[li][0]; ji[li] = tk & 3; }
                     SX_QUAD_ARG(>)
@@ -617,6 +621,8 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                     const i32 RDmin2 = SX_GRP(xr0);
                     const int RDmin_ind = SX_GRP(xr1);
                     if (RDmin2 < RDmax) {
+                        SX_TA_COUNT(12, 1)
+                        if (RDmax_ind != RDmin_ind) { SX_TA_COUNT(13, 1) }
                         // SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668) for the three tracks: lineage word + filter memories;
                         // then candidate [RDmax][0] <- candidate [RDmin][1]
 #if SX_NLANES == 1

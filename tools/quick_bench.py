@@ -27,3 +27,9 @@ for _ in range(R):
     te += ev[0].elapsed_time(ev[1]); td += ev[1].elapsed_time(ev[2])
 print("%s parity enc=%s dec=%s | encode %.2f ms (%.0f pkt/s) decode %.2f ms (%.0f pkt/s) round trip %.0f pkt/s" % (
     os.environ.get("SOLO_LIB_OVERRIDE", "default"), ok, ok2, te / R, N * P * R / te * 1e3, td / R, N * P * R / td * 1e3, N * P * R / (te + td) * 1e3))
+try:
+    b.set_timing(True)
+    b.encode(x, bits, nb, st); b.decode(bits, nb, None, out, st2); torch.cuda.synchronize()
+    print("  kernels (ms): " + "  ".join("%s %.2f" % kv for kv in b.last_kernel_ms().items()))
+except Exception as e:      # older builds without the timing entry points
+    print("  (no per-kernel timing: %s)" % e)
