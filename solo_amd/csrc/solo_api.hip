@@ -37,7 +37,7 @@ __device__ __forceinline__ void solo_dec_enter(SxDecWork* w, const SxDecState* r
     const i32* src = (const i32*)rec;
     i32* dst = (i32*)&w->st;
     SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
-    sx_cdf_load(&w->cdf);
+    sx_cdf_load_dec(&w->cdf);
     wv_sync();
 }
 __device__ __forceinline__ void solo_dec_leave(SxDecWork* w, SxDecState* rec) {
@@ -47,7 +47,7 @@ __device__ __forceinline__ void solo_dec_leave(SxDecWork* w, SxDecState* rec) {
     SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(64) solo_decode_kernel(SxDecState* states, const u8* __restrict__ bits,
+__global__ void __launch_bounds__(64, 4) solo_decode_kernel(SxDecState* states, const u8* __restrict__ bits,
                                                          const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                          int n_streams, int n_packets, int slot, int useMDIndex,
                                                          i16* __restrict__ pcm, i32* status) {

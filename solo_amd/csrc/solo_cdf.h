@@ -12,18 +12,16 @@
     X(u16, cdf_ltp_gain2, 41) X(u16, cdf_ltpscale, 4) X(u16, cdf_seed, 5) X(u16, cdf_rate_levels, 20)                   \
     X(u16, cdf_pulses_per_block, 210) X(u16, cdf_shell0, 33) X(u16, cdf_shell1, 52) X(u16, cdf_shell2, 102)             \
     X(u16, cdf_shell3, 207) X(u16, shell_offsets, 19) X(u16, cdf_lsb, 3) X(u16, cdf_sign, 36) X(u16, cdf_vadflag, 3)    \
-    X(u16, cdf_frame_term, 5) X(u16, cdf_mdindex, 3) X(u16, nlsf_cb0_cdf, 126) X(u16, nlsf_cb1_cdf, 78)                 \
-    X(i16, bits_rate_levels_Q6, 18) X(i16, bits_pulses_per_block_Q6, 180)
+    X(u16, cdf_frame_term, 5) X(u16, cdf_mdindex, 3) X(u16, nlsf_cb0_cdf, 126) X(u16, nlsf_cb1_cdf, 78)
+#define SX_CDF_LIST_ENC(X) X(i16, bits_rate_levels_Q6, 18) X(i16, bits_pulses_per_block_Q6, 180)    // rate estimation: encoder only
 
-struct SxCdf {
 #define X(type, name, n) type name[((n) + 1) & ~1];
-    SX_CDF_LIST(X)
+struct SxCdfDec { SX_CDF_LIST(X) };                 // what the decoder mirrors: a layout prefix of SxCdf
+struct SxCdf { SX_CDF_LIST(X) SX_CDF_LIST_ENC(X) };
 #undef X
-};
 
 // lane-strided copy HBM -> LDS; caller must wv_sync() before use
-SX_HD void sx_cdf_load(SxCdf* c) {
 #define X(type, name, n) SX_PAR(i, n) c->name[i] = T_##name[i];
-    SX_CDF_LIST(X)
+SX_HD void sx_cdf_load(SxCdf* c) { SX_CDF_LIST(X) SX_CDF_LIST_ENC(X) }
+SX_HD void sx_cdf_load_dec(SxCdfDec* c) { SX_CDF_LIST(X) }
 #undef X
-}

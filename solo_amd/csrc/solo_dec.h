@@ -107,24 +107,32 @@ struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h
     i32 LTP_scale_Q14;
     i32 PERIndex, RateLevelIndex, QuantOffsetType, sigtype, MDIndex, NLSFInterpCoef_Q2;
 };
-#define SX_DEC_PAYLOAD_LDS 1100     // packets up to this size are staged in LDS (the reference harness caps at 1024 + HB)
+#define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
+// Phases of a packet reuse the same LDS (the decoder's occupancy is LDS-bound): see the lifetimes in the comments
 struct SxDecWork {
     SxDecState st;                  // the stream's state: HBM record -> LDS at launch start, back at the end
-    SxCdf cdf;                      // entropy-coding tables (loaded once per launch)
+    SxCdfDec cdf;                   // entropy-coding tables (loaded once per launch)
     u8 payload[SX_DEC_PAYLOAD_LDS + 4];
     SxDecCtrl ctrl;
-    SxDecCtrl ctrl2[2];             // side information as decoded from description 0 / 1 (one description per lane)
-    i32 lane_out[2][4];             // per description: vadFlag, FrameTermination, bytes left, range-coder error
-    i32 lane_len[2];                // per description: range-coder buffer length
-    i32 pulses[2][SX_FRAME];
-    i32 res_Q10[SX_FRAME];          // LPC residual of the current frame
-    i32 sLPC_Q14[SX_MAX_LPC + SX_SUBFR];
-    i32 sig_Q10[SX_FRAME];          // PLC / scratch
-    i16 sLTP[SX_FRAME];             // re-whitened history
-    i16 tmp16[SX_FRAME];            // exc_buf (PLC) / CNG_sig
-    i32 exc_pkt_Q10[SX_BAND];       // low-band excitation of both frames -> high-band regeneration
+    // frame scratch, in turn: parse (NLSF vectors [0,40) + per-description pulse-decoder scratch [40,80)), NLSF->LPC
+    // workspace [40,122), LPC residual of decode_core / concealment signal of the PLC, high-band side information + workspace
+    i32 res_Q10[SX_FRAME];
+    union {
+        struct {                    // parse .. inverse NSQ
+            i16 pulses[2][SX_FRAME];
+            SxDecCtrl ctrl2[2];     // side information as decoded from description 0 / 1 (one description per lane)
+            i32 lane_out[2][4];     // per description: vadFlag, FrameTermination, bytes left, range-coder error
+            i32 lane_len[2];        // per description: range-coder buffer length
+        } parse;
+        i32 ws1[SX_NLSF2A_WS];      // second NLSF->LPC workspace (after the inverse NSQ / before the high-band synthesis)
+        struct {                    // decode_core, PLC, CNG
+            i32 sLPC_Q14[SX_MAX_LPC + SX_SUBFR];
+            i16 tmp16[SX_FRAME];    // exc_buf (PLC) / CNG_sig
+        } syn;
+        i16 hi[SX_QMF_HIST + SX_BAND];  // [history | packet] high band (high-band synthesis .. QMF)
+    } u;
+    i32 exc0_Q10[SX_FRAME];         // low-band excitation of frame 0 (frame 1's is still in st.exc_Q10) -> high-band regeneration
     i16 lo[SX_QMF_HIST + SX_BAND];  // [history | packet] low band
-    i16 hi[SX_QMF_HIST + SX_BAND];  // [history | packet] high band
 };
 
 // SKP_Silk_init_decoder + first decoder_set_fs(8) folded together (create_init_destroy.c:34,
@@ -169,7 +177,7 @@ SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* ta
         *c2 = 0;
     }
 }
-SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cdf) {
+SX_HD void sx_shell_decoder(i16* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cdf) {
     i32 p3[2], p2[4], p1[8], a, b;
     sx_shell_split(&p3[0], &p3[1], rc, pulses4, cdf->cdf_shell3, cdf);
     sx_shell_split(&p2[0], &p2[1], rc, p3[0], cdf->cdf_shell2, cdf);
@@ -190,7 +198,7 @@ SX_HD void sx_shell_decoder(i32* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cd
 
 // SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64).
 // tmp: 2 * SX_FRAME/16 words of per-description scratch (LDS)
-SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* cdf, i32* tmp) {
+SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i16* q, const SxCdf* cdf, i32* tmp) {
     SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
     const int iter = SX_FRAME / 16;
     i32 *sum_pulses = tmp, *nLshifts = tmp + SX_FRAME / 16;
@@ -224,7 +232,7 @@ SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* c
                     abs_q = sx_shl(abs_q, 1);
                     abs_q += sx_rc_dec_bin(rc, p_lsb);
                 }
-                q[i * 16 + k] = abs_q;
+                q[i * 16 + k] = (i16)abs_q;
             }
         }
     }
@@ -234,7 +242,7 @@ SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i32* q, const SxCdf* c
         const i32 v = q[i];
         if (v > 0) {
             i32 data = sx_rc_dec_bin(rc, p_sign);
-            q[i] = v * ((data << 1) - 1);
+            q[i] = (i16)(v * ((data << 1) - 1));
         }
     }
 }
@@ -262,7 +270,7 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 // The range-coder state is worked on in registers (local copy); the NLSF vectors (interpolated / final) are handed back in
 // nlsf_out[2][SX_LPC] -- their conversion to prediction coefficients only matters for the description that is used and is done
 // by the caller; tmp = per-description scratch of sx_decode_pulses (all LDS).
-SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io, i32* q, int kDesp, int useMDIndex, const SxCdf* cdf,
+SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io, i16* q, int kDesp, int useMDIndex, const SxCdf* cdf,
                                 i32* lane_out, i32* nlsf_out, i32* tmp) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp);
     SxRangeDec rc_local = *rc_io;
@@ -372,7 +380,7 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
     i16* pxq = &st->outBuf[SX_FRAME];
     int sLTP_buf_idx = SX_FRAME;
     int lag = 0;
-    SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = st->sLPC_Q14[i];
+    SX_PAR(i, SX_MAX_LPC) w->u.syn.sLPC_Q14[i] = st->sLPC_Q14[i];
     wv_sync();
     for (int k = 0; k < SX_NB_SUBFR; k++) {
         const i16* A_Q12 = c->PredCoef_Q12[k >> 1];
@@ -414,7 +422,7 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 wv_sync();
             }
         }
-        SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = sx_smulww(gain_adj_Q16, w->sLPC_Q14[i]);
+        SX_PAR(i, SX_MAX_LPC) w->u.syn.sLPC_Q14[i] = sx_smulww(gain_adj_Q16, w->u.syn.sLPC_Q14[i]);
         wv_sync();
         st->prev_inv_gain_Q16 = inv_gain_Q16;
 
@@ -450,7 +458,7 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
         {
             i32 a[SX_LPC], h[SX_LPC];
 #pragma unroll
-            for (int j = 0; j < SX_LPC; j++) { a[j] = sx_pre16(A_Q12[j]); h[j] = w->sLPC_Q14[SX_MAX_LPC - SX_LPC + j]; }
+            for (int j = 0; j < SX_LPC; j++) { a[j] = sx_pre16(A_Q12[j]); h[j] = w->u.syn.sLPC_Q14[SX_MAX_LPC - SX_LPC + j]; }
             for (int i0 = 0; i0 < SX_SUBFR; i0 += SX_LPC) {
 #pragma unroll
                 for (int u = 0; u < SX_LPC; u++) {
@@ -459,22 +467,22 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                     for (int j = 0; j < SX_LPC; j++) p = sx_smlaw_pre(p, h[(u - 1 - j + 2 * SX_LPC) % SX_LPC], a[j]);
                     i32 v = sx_add(pres_Q10[i0 + u], p);
                     h[u] = sx_shl(v, 4);
-                    w->sLPC_Q14[SX_MAX_LPC + i0 + u] = h[u];
+                    w->u.syn.sLPC_Q14[SX_MAX_LPC + i0 + u] = h[u];
                     pxq[i0 + u] = (i16)sx_sat16(sx_rshift_round(sx_smulww(v, Gain_Q16), 10));
                 }
             }
         }
         wv_sync();
         SX_PAR(i, SX_MAX_LPC) {
-            i32 t = w->sLPC_Q14[SX_SUBFR + i];
-            w->sLPC_Q14[i] = t;
+            i32 t = w->u.syn.sLPC_Q14[SX_SUBFR + i];
+            w->u.syn.sLPC_Q14[i] = t;
         }
         wv_sync();
         pexc_Q10 += SX_SUBFR;
         pres_Q10 += SX_SUBFR;
         pxq += SX_SUBFR;
     }
-    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->sLPC_Q14[i];
+    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->u.syn.sLPC_Q14[i];
     SX_PAR(i, SX_FRAME) xq[i] = st->outBuf[SX_FRAME + i];
     wv_sync();
 }
@@ -518,8 +526,8 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(signal);
     SxPLC* p = &st->plc;
     SxDecCtrl* c = &w->ctrl;
-    i16* exc_buf = w->tmp16;
-    i32* sig_Q10 = w->sig_Q10;
+    i16* exc_buf = w->u.syn.tmp16;
+    i32* sig_Q10 = w->res_Q10;
     // shift LTP buffer (source and destination halves do not overlap)
     SX_PAR(i, SX_FRAME) st->sLTP_Q16[i] = st->sLTP_Q16[SX_FRAME + i];
     wv_sync();
@@ -587,24 +595,24 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
         lag = sx_rshift_round(p->pitchL_Q8, 8);
     }
     // LPC synthesis
-    SX_PAR(i, SX_MAX_LPC) w->sLPC_Q14[i] = st->sLPC_Q14[i];
+    SX_PAR(i, SX_MAX_LPC) w->u.syn.sLPC_Q14[i] = st->sLPC_Q14[i];
     wv_sync();
     sig_ptr = sig_Q10;
     for (int k = 0; k < SX_NB_SUBFR; k++) {
         for (int i = 0; i < SX_SUBFR; i++) {
             i32 pr = 0;
-            for (int j = 0; j < SX_LPC; j++) pr = sx_smlawb(pr, w->sLPC_Q14[SX_MAX_LPC + i - j - 1], p->prevLPC_Q12[j]);
+            for (int j = 0; j < SX_LPC; j++) pr = sx_smlawb(pr, w->u.syn.sLPC_Q14[SX_MAX_LPC + i - j - 1], p->prevLPC_Q12[j]);
             i32 v = sx_add(sig_ptr[i], pr);
             sig_ptr[i] = v;
-            w->sLPC_Q14[SX_MAX_LPC + i] = sx_shl(v, 4);
+            w->u.syn.sLPC_Q14[SX_MAX_LPC + i] = sx_shl(v, 4);
         }
         sig_ptr += SX_SUBFR;
         for (int i = 0; i < SX_MAX_LPC; i++) {
-            i32 t = w->sLPC_Q14[SX_SUBFR + i];
-            w->sLPC_Q14[i] = t;
+            i32 t = w->u.syn.sLPC_Q14[SX_SUBFR + i];
+            w->u.syn.sLPC_Q14[i] = t;
         }
     }
-    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->sLPC_Q14[i];
+    SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->u.syn.sLPC_Q14[i];
     SX_PAR(i, SX_FRAME) signal[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(sig_Q10[i], p->prevGain_Q16[SX_NB_SUBFR - 1]), 10));
     wv_sync();
     p->rand_seed = rand_seed;
@@ -717,7 +725,7 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
             g->smth_Gain_Q16 += sx_smulwb(c->Gains_Q16[i] - g->smth_Gain_Q16, 4634);
     }
     if (st->lossCnt) {
-        i16* CNG_sig = w->tmp16;
+        i16* CNG_sig = w->u.syn.tmp16;
         int exc_mask = 255;
         while (exc_mask > length) exc_mask >>= 1;
         // CNG_exc (CNG.c:31): the seed recurrence is a pure LCG, so every lane regenerates it serially
@@ -741,7 +749,7 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
 // One 20 ms low-band frame: SKP_Silk_SDK_Decode + SKP_Silk_decode_frame + AgoraSateDecodeTwoDesps.
 // rc[] persists across the two frames of a packet.  Returns 0, or a negative SILK error code
 // (SKP_Silk_errors.h) on a corrupt payload.
-SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
+SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
                                i32 nB0, i32 nB1, int useMDIndex, i16* pOut) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(pOut);
     int ret = 0;
@@ -762,23 +770,23 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 if (md == 0) sx_rc_dec_init(r, payload, nB0);
                 else sx_rc_dec_init(r, payload + nB0, nB1);
             }
-            sx_decode_parameters(st, &w->ctrl2[md], r, w->pulses[md], md, useMDIndex, &w->cdf, w->lane_out[md],
-                                 &w->sig_Q10[md * 2 * SX_LPC], &w->sig_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)]);
-            w->lane_len[md] = r->bufferLength;
+            sx_decode_parameters(st, &w->u.parse.ctrl2[md], r, w->u.parse.pulses[md], md, useMDIndex, (const SxCdf*)&w->cdf, w->u.parse.lane_out[md],
+                                 &w->res_Q10[md * 2 * SX_LPC], &w->res_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)]);
+            w->u.parse.lane_len[md] = r->bufferLength;
         }
         wv_sync();
         SX_T(0)
         {   // the reference parses description 1 after description 0 into the same control block: the last one wins
-            const i32* src = (const i32*)&w->ctrl2[ndesc - 1];
+            const i32* src = (const i32*)&w->u.parse.ctrl2[ndesc - 1];
             i32* dst = (i32*)c;
             SX_PAR(i, (int)(sizeof(SxDecCtrl) / 4)) dst[i] = src[i];
-            st->vadFlag = w->lane_out[ndesc - 1][0];
-            st->FrameTermination = w->lane_out[ndesc - 1][1];
-            st->nBytesLeft0 = w->lane_out[0][2];
+            st->vadFlag = w->u.parse.lane_out[ndesc - 1][0];
+            st->FrameTermination = w->u.parse.lane_out[ndesc - 1][1];
+            st->nBytesLeft0 = w->u.parse.lane_out[0][2];
             wv_sync();
         }
-        const i32 err0 = w->lane_out[0][3], err1 = ndesc > 1 ? w->lane_out[1][3] : 0;
-        const i32 len0 = w->lane_len[0];
+        const i32 err0 = w->u.parse.lane_out[0][3], err1 = ndesc > 1 ? w->u.parse.lane_out[1][3] : 0;
+        const i32 len0 = w->u.parse.lane_len[0];
 
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
         i32 inv_gain_p1_Q16 = inv_gain_Q16;
@@ -797,14 +805,34 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         } else {
             st->nFramesDecoded++;
             used = len0 - st->nBytesLeft0;
+            // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
+            const i32 seed0 = c->Seed;
+            if (desp_type == 2) {
+                SX_PAR(i, SX_FRAME) {
+                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
+                    i32 q_Q10 = sx_add(sx_shl(w->u.parse.pulses[0][i], 10), sx_shl(w->u.parse.pulses[1][i], 10));
+                    q_Q10 = sx_add(offset_p1_Q10 + offset_p2_Q10, q_Q10);
+                    st->exc_Q10[i] = (q_Q10 ^ dither) - dither;
+                }
+            } else {
+                SX_PAR(i, SX_FRAME) {
+                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
+                    int first_half = (i % (SX_SUBFR << 1)) < SX_SUBFR;
+                    int use_p1 = desp_type == 0 ? first_half : !first_half;
+                    i32 q_Q10 = sx_add(use_p1 ? offset_p1_Q10 : offset_p2_Q10, sx_shl(w->u.parse.pulses[0][i], 10));
+                    i32 e = (q_Q10 ^ dither) - dither;
+                    st->exc_Q10[i] = sx_smulww(use_p1 ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16, e);
+                }
+            }
+            wv_sync();
             {
                 // NLSF -> prediction coefficients of the description in use: the two frame halves on two lanes
-                // (decode_parameters.c:108-131); workspaces in the frame scratch that decode_core only fills later
-                const i32* nl = &w->sig_Q10[(ndesc - 1) * 2 * SX_LPC];
+                // (decode_parameters.c:108-131); runs after the inverse NSQ because its second workspace reuses the pulses' LDS
+                const i32* nl = &w->res_Q10[(ndesc - 1) * 2 * SX_LPC];
                 const int interp = c->NLSFInterpCoef_Q2 < 4;
                 SX_PAR(v, 2) {
-                    if (v == 1) sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, w->res_Q10);
-                    else if (interp) sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], nl, SX_LPC, &w->sig_Q10[4 * SX_LPC]);
+                    if (v == 1) sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, &w->res_Q10[4 * SX_LPC]);
+                    else if (interp) sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1);
                 }
                 wv_sync();
                 if (!interp) {
@@ -816,26 +844,6 @@ SX_FN int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     wv_sync();
                 }
             }
-            // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
-            const i32 seed0 = c->Seed;
-            if (desp_type == 2) {
-                SX_PAR(i, SX_FRAME) {
-                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
-                    i32 q_Q10 = sx_add(sx_shl(w->pulses[0][i], 10), sx_shl(w->pulses[1][i], 10));
-                    q_Q10 = sx_add(offset_p1_Q10 + offset_p2_Q10, q_Q10);
-                    st->exc_Q10[i] = (q_Q10 ^ dither) - dither;
-                }
-            } else {
-                SX_PAR(i, SX_FRAME) {
-                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
-                    int first_half = (i % (SX_SUBFR << 1)) < SX_SUBFR;
-                    int use_p1 = desp_type == 0 ? first_half : !first_half;
-                    i32 q_Q10 = sx_add(use_p1 ? offset_p1_Q10 : offset_p2_Q10, sx_shl(w->pulses[0][i], 10));
-                    i32 e = (q_Q10 ^ dither) - dither;
-                    st->exc_Q10[i] = sx_smulww(use_p1 ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16, e);
-                }
-            }
-            wv_sync();
             SX_T(1)
             sx_decode_core(st, w, pOut);
             SX_T(2)
@@ -902,13 +910,13 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
 // frame order.  `hb` = the 8 high-band bytes (ignored when lost); exc0 / exc1 = low-band excitation of frame 0 / 1.
 SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* OutHigh, const i32* exc0, const i32* exc1, int lostflag) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(OutHigh); SX_IN_LDS(exc0); SX_IN_LDS(exc1);
-    i32* lsp = w->sig_Q10;                       // [2][SX_HB_LPC]
-    i32* gains = &w->sig_Q10[2 * SX_HB_LPC];     // [2][4]
-    i16* lpc = (i16*)&w->sig_Q10[2 * SX_HB_LPC + 8];   // [2][SX_MAX_LPC]
-    i32* zero = &w->res_Q10[SX_NLSF2A_WS];       // [SX_SUBFR]
+    i32* lsp = w->res_Q10;                       // [2][SX_HB_LPC]
+    i32* gains = &w->res_Q10[2 * SX_HB_LPC];     // [2][4]
+    i16* lpc = (i16*)&w->res_Q10[2 * SX_HB_LPC + 8];   // [2][SX_MAX_LPC]
+    i32* zero = w->exc0_Q10;                     // (frame 0's excitation copy is not used when the high band is lost)
     const int lost = (lostflag == 1 || lostflag == 2);
     SX_T_BEGIN
-    SX_PAR(i, SX_SUBFR) zero[i] = 0;
+    if (lost) { SX_PAR(i, SX_SUBFR) zero[i] = 0; }
     SX_PAR(f, 2) {
         i32* l = &lsp[f * SX_HB_LPC];
         if (lost) {
@@ -921,8 +929,10 @@ SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* 
             for (int i = 0; i < SX_HB_LPC; i++) l[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i];
             for (int k = 0; k < 4; k++) gains[f * 4 + k] = T_hb_gain_cb[sx_hb_unpack(hb, &bitpos, 5)];
         }
-        sx_nlsf2a_stable_ws(&lpc[f * SX_MAX_LPC], l, SX_HB_LPC, f == 0 ? w->res_Q10 : &w->sig_Q10[2 * SX_HB_LPC + 8 + SX_MAX_LPC]);   // same for all 4 subframes
+        sx_nlsf2a_stable_ws(&lpc[f * SX_MAX_LPC], l, SX_HB_LPC, f == 0 ? &w->res_Q10[4 * SX_LPC] : w->u.ws1);   // same for all 4 subframes
     }
+    wv_sync();
+    SX_PAR(i, SX_QMF_HIST) w->u.hi[i] = st->qmf_hi_hist[i];      // (the high-band buffer shares its LDS with the workspace above)
     wv_sync();
     SX_T(8)
     for (int f = 0; f < 2; f++) {
@@ -1003,21 +1013,21 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
 #ifdef SX_RC_LOG
     rc[0].log = st->rclog; rc[0].nlog = 0; rc[1].log = 0; rc[1].nlog = 0;
 #endif
-    SX_PAR(i, SX_QMF_HIST) { w->lo[i] = st->qmf_lo_hist[i]; w->hi[i] = st->qmf_hi_hist[i]; }
+    SX_PAR(i, SX_QMF_HIST) w->lo[i] = st->qmf_lo_hist[i];
     wv_sync();
     for (int f = 0; f < 2; f++) {
         int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME]);
         if (ret < 0) { st->last_error = ret; return ret; }
-        SX_PAR(i, SX_FRAME) w->exc_pkt_Q10[f * SX_FRAME + i] = st->exc_Q10[i];
+        if (f == 0) { SX_PAR(i, SX_FRAME) w->exc0_Q10[i] = st->exc_Q10[i]; }
         wv_sync();
     }
     SX_T_BEGIN
-    sx_hb_decode_packet(st, w, bits + hb_pos, &w->hi[SX_QMF_HIST], &w->exc_pkt_Q10[0], &w->exc_pkt_Q10[SX_FRAME], lostflag);
+    sx_hb_decode_packet(st, w, bits + hb_pos, &w->u.hi[SX_QMF_HIST], w->exc0_Q10, st->exc_Q10, lostflag);
     wv_sync();
     SX_T(6)
-    sx_qmf_synth(w->lo, w->hi, pcm_out);
+    sx_qmf_synth(w->lo, w->u.hi, pcm_out);
     SX_T(7)
-    SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->hi[SX_BAND + i]; }
+    SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->u.hi[SX_BAND + i]; }
     wv_sync();
     return 0;
 }

@@ -27,7 +27,7 @@ void emu_dec_destroy(void* h) { free(h); }
 int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int lostflag, int16_t* pcm) {
     EmuDec* d = (EmuDec*)h;
     d->w.st = d->st;                                      // the kernel keeps state + tables in LDS for a launch
-    sx_cdf_load(&d->w.cdf);
+    sx_cdf_load_dec(&d->w.cdf);
     int r = sx_decode_packet(&d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm);
     d->st = d->w.st;
     return r;
