@@ -91,12 +91,12 @@ def main():
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
     ap.add_argument("--packets", type=int, default=10, help="40 ms packets per stream per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-packets", type=int, default=0, help="0: 120 packets per host CPU")
-    ap.add_argument("--cpu-packets-per-stream", type=int, default=120)
+    ap.add_argument("--cpu-packets", type=int, default=0, help="0: 400 packets per host CPU")
+    ap.add_argument("--cpu-packets-per-stream", type=int, default=400)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_packets <= 0:
-        args.cpu_packets = 120 * (os.cpu_count() or 1)
+        args.cpu_packets = 400 * (os.cpu_count() or 1)
     if args.cpu_worker:
         cpu_worker(args.cpu_packets, args.cpu_packets_per_stream)
         return
