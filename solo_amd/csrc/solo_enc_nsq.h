@@ -63,6 +63,12 @@
 #define SX_QX(arr, o, tk) ((o) == 1 ? SX_DPP((arr)[0], 0xB1) : SX_DPP((arr)[0], 0x4E))   // quad_perm [1,0,3,2] / [2,3,0,1]
 #define SX_QB(arr, wv, tk) ((wv) == 0 ? SX_DPP((arr)[0], 0x00) : ((wv) == 1 ? SX_DPP((arr)[0], 0x55) : ((wv) == 2 ? SX_DPP((arr)[0], 0xAA) : SX_DPP((arr)[0], 0xFF))))
 #endif
+//   SX_QG(arr, sl, tk) value of lane `sl` of the own quad, `sl` any per-lane value (lane-indexed gather)
+#if SX_NLANES == 1
+#define SX_QG(arr, sl, tk) ((arr)[((tk) & ~3) | (sl)])
+#else
+#define SX_QG(arr, sl, tk) __shfl((arr)[0], (SX_LANE & ~3) | (sl), SX_NLANES)
+#endif
 // a value that all twelve lanes hold identically, as a (group-)uniform scalar for control flow
 #if SX_NLANES == 1
 #define SX_GRP(arr) ((arr)[0])
@@ -95,17 +101,14 @@
 #define SX_TA_END
 #endif
 
-struct SxRing {                      // decision-delay histories of one track: one cell per (ring position, state slot)
-    i32 Rand[SX_DD_DELAY][SX_DD_STATES];
-    i32 Xq_Q10[SX_DD_DELAY][SX_DD_STATES];
-    i32 Pred_Q16[SX_DD_DELAY][SX_DD_STATES];
+struct SxRing {                      // decision-delay histories of one track: one cell per (ring position, state slot).
+    i32 Rand[SX_DD_DELAY][SX_DD_STATES];         // (the histories that are only read at emission live in HBM: SxNsqRingG)
     i32 Shape_Q10[SX_DD_DELAY][SX_DD_STATES];
     i8 Q_Q0[SX_DD_DELAY][SX_DD_STATES];
 };
 
 struct SxNsqWork {
     SxRing ring[SX_N_TRACKS];
-    i32 exc_Q10[SX_DD_DELAY][SX_DD_STATES];      // excitation cells of the CENTRE track (high-band gain reference)
     i32 Gain_ring[SX_DD_DELAY];
     i16 x[SX_FRAME];                             // prefiltered input of the frame (staged from the hand-over record)
     i32 ebS[SX_N_TRACKS][SX_SUBFR], ebL[SX_N_TRACKS][SX_SUBFR];   // shaping / prediction samples emitted in the current subframe
@@ -167,6 +170,7 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNsqWork* w) {
     SX_IN_LDS(w);
     SxNsqGlobal* g = &P->g;
+    SxNsqRingG* rgG = &P->rg;
     const i16* x = w->x;
     i8* q = &out->q[0][0];
     i32* r = out->r;
@@ -191,12 +195,15 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     i32 cRD[SX_NSLOT][2], cQ0[SX_NSLOT][2], cQ10[SX_NSLOT][2], cRdInd[SX_NSLOT][2];
     i32 cXq14[SX_NSLOT][2], cLFAR[SX_NSLOT][2], cShp[SX_NSLOT][2], cExc16[SX_NSLOT][2], cExc10[SX_NSLOT][2];
     i32 W1[SX_NSLOT], W2[SX_NSLOT], myRand[SX_NSLOT], emitPred[SX_NSLOT];
+    // own-slot cells (HBM rings) of the ring position that is emitted in the current / next sample, fetched a sample ahead
+    i32 pfXq[SX_NSLOT], pfPred[SX_NSLOT], pfExc[SX_NSLOT], nxXq[SX_NSLOT], nxPred[SX_NSLOT], nxExc[SX_NSLOT], gXq[SX_NSLOT], gPred[SX_NSLOT], gExc[SX_NSLOT];
     i32 curL[SX_NSLOT][SX_LTP_ORDER], nxL[SX_NSLOT][SX_LTP_ORDER], curS[SX_NSLOT][3], nxS[SX_NSLOT][3];   // LTP / shaping taps, prefetched
     for (int a = 0; a < SX_NSLOT; a++) {       // lanes that own no state keep defined values
         for (int j = 0; j < SX_SHAPE_ORDER; j++) sAR2[a][j] = 0;
         for (int j = 0; j < SX_LPC; j++) sLPC[a][j] = 0;
         LF_AR[a] = Seed[a] = Seed2[a] = SeedInit2[a] = RD[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = 0;
         W1[a] = W2[a] = myRand[a] = emitPred[a] = 0;
+        pfXq[a] = pfPred[a] = pfExc[a] = nxXq[a] = nxPred[a] = nxExc[a] = gXq[a] = gPred[a] = gExc[a] = 0;
         for (int j = 0; j < SX_LTP_ORDER; j++) curL[a][j] = nxL[a][j] = 0;
         for (int j = 0; j < 3; j++) curS[a][j] = nxS[a][j] = 0;
         for (int j = 0; j < 2; j++) cRD[a][j] = cQ0[a][j] = cQ10[a][j] = cRdInd[a][j] = cXq14[a][j] = cLFAR[a][j] = cShp[a][j] = cExc16[a][j] = cExc10[a][j] = 0;
@@ -211,7 +218,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     {
         i32* p = (i32*)&w->ring[0];
         SX_PAR(i, (int)(sizeof(w->ring) / 4)) p[i] = 0;
-        SX_PAR(i, SX_DD_STATES * SX_DD_DELAY) (&w->exc_Q10[0][0])[i] = 0;
+        SX_PAR(i, (int)(sizeof(SxNsqRingG) / 4)) ((i32*)rgG)[i] = 0;
         SX_PAR(i, SX_FRAME) w->x[i] = c->xfw[i];
         wv_sync();
         SX_LANES12(tk) {
@@ -242,17 +249,22 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
 
 #define SX_LIN_SLOT(lo_, hi_, pos_) ((int)((((pos_) < 16 ? (u32)(lo_) : (u32)(hi_)) >> (2 * ((pos_) & 15))) & 3u))
     // emit the decisionDelay-old sample of the lineage of state `win` (Agora_Silk_GetWinner{,_Side} / flush loops)
+#define SX_NSQ_EMIT_V(t_, slot_, ring_idx_, pos_, sLTP_idx_, write_pred_, xq_v_, pred_v_, exc_v_)                          \
+    {                                                                                                                        \
+        const SxRing* rg_ = &w->ring[t_];                                                                                    \
+        if ((t_) == 0) r[pos_] = (exc_v_);                                                                                   \
+        else q[((t_)-1) * SX_FRAME + (pos_)] = rg_->Q_Q0[ring_idx_][slot_];                                                  \
+        P->xq[t_][SX_FRAME + (pos_)] = (i16)sx_sat16(sx_rshift_round(sx_smulww((xq_v_), w->Gain_ring[ring_idx_]), 10));       \
+        g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
+        if (write_pred_) { const i32 pv_ = (pred_v_); g->sLTP_Q16[t_][sLTP_idx_] = pv_; emitPred[SX_LI(4 * (t_))] = pv_;     \
+                           w->ebL[t_][i] = pv_; w->ebS[t_][i] = rg_->Shape_Q10[ring_idx_][slot_]; }                          \
+    }
+    // flush form (lane-parallel over ring positions, cells read straight from HBM; callers wv_sync() first)
 #define SX_NSQ_EMIT(t_, wlo_, whi_, ring_idx_, pos_, sLTP_idx_, write_pred_)                                                 \
     {                                                                                                                        \
-        const int slot_ = SX_LIN_SLOT(wlo_, whi_, ring_idx_);                                                                \
-        const SxRing* rg_ = &w->ring[t_];                                                                                    \
-        if ((t_) == 0) r[pos_] = w->exc_Q10[ring_idx_][slot_];                                                               \
-        else q[((t_)-1) * SX_FRAME + (pos_)] = rg_->Q_Q0[ring_idx_][slot_];                                                  \
-        P->xq[t_][SX_FRAME + (pos_)] =                                                                                    \
-            (i16)sx_sat16(sx_rshift_round(sx_smulww(rg_->Xq_Q10[ring_idx_][slot_], w->Gain_ring[ring_idx_]), 10));           \
-        g->shp[t_][SX_FRAME + (pos_)] = rg_->Shape_Q10[ring_idx_][slot_];                                                    \
-        if (write_pred_) { const i32 pv_ = rg_->Pred_Q16[ring_idx_][slot_]; g->sLTP_Q16[t_][sLTP_idx_] = pv_; emitPred[SX_LI(4 * (t_))] = pv_;   \
-                           w->ebL[t_][i] = pv_; w->ebS[t_][i] = rg_->Shape_Q10[ring_idx_][slot_]; }                          \
+        const int slotf_ = SX_LIN_SLOT(wlo_, whi_, ring_idx_);                                                               \
+        SX_NSQ_EMIT_V(t_, slotf_, ring_idx_, pos_, sLTP_idx_, write_pred_, rgG->Xq_Q10[t_][ring_idx_][slotf_],               \
+                      rgG->Pred_Q16[t_][ring_idx_][slotf_], rgG->exc_Q10[ring_idx_][slotf_])                                 \
     }
 
     for (int k = 0; k < SX_NB_SUBFR; k++) {
@@ -292,6 +304,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                         if ((tk & 3) != Winner_ind) RD[SX_LI(tk)] += SX_I32_MAX >> 4;
                     }
                     const i32 wlo = SX_RL(linLo, Winner_ind), whi = SX_RL(linHi, Winner_ind);
+                    wv_sync();                      // the HBM ring cells of the last samples must have landed
                     SX_PAR(ti, 3 * decisionDelay) {
                         const int t = ti / decisionDelay, i = ti - t * decisionDelay;
                         const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;
@@ -341,7 +354,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                     // every (position, slot) cell of the Pred / Shape histories is scaled once (the reference scales each
                     // state's private copy once)
                     SX_PAR(i, SX_DD_DELAY * SX_DD_STATES) {
-                        i32* pp = &w->ring[t].Pred_Q16[0][0] + i;
+                        i32* pp = &rgG->Pred_Q16[t][0][0] + i;
                         i32* ps = &w->ring[t].Shape_Q10[0][0] + i;
                         *pp = sx_smulww(gain_adj_Q16, *pp);
                         *ps = sx_smulww(gain_adj_Q16, *ps);
@@ -381,6 +394,12 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 const i32* ps = &g->shp[t][shp_base - lag_me + 1];
                 curS[li][0] = ps[0]; curS[li][1] = ps[-1]; curS[li][2] = ps[-2];
             }
+            {   // ring cells that the first sample of this subframe emits
+                const int s = tk & 3, pos = (smpl_buf_idx - 1 + decisionDelay) & SX_DD_MASK;
+                pfXq[li] = rgG->Xq_Q10[t][pos][s];
+                pfPred[li] = rgG->Pred_Q16[t][pos][s];
+                pfExc[li] = rgG->exc_Q10[pos][s];
+            }
         }
         // Inside the sample loop the lanes talk through LDS and shuffles only, unless the lag is so short that a tap read from
         // HBM can be an entry emitted earlier in this very subframe: only then must the emit stores be waited for.
@@ -407,6 +426,12 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                             const int a = a0 - j, ip = a - (shp_base - decisionDelay);
                             nxS[li][j] = (a >= firstS && ip <= i - 1) ? w->ebS[t][ip] : g->shp[t][a];
                         }
+                    }
+                    {   // own-slot ring cells of the position the NEXT sample emits (written at least 12 samples ago)
+                        const int pos = (smpl_buf_idx - 2 + decisionDelay) & SX_DD_MASK;
+                        nxXq[li] = rgG->Xq_Q10[t][pos][s];
+                        nxPred[li] = rgG->Pred_Q16[t][pos][s];
+                        nxExc[li] = rgG->exc_Q10[pos][s];
                     }
                 }
                 i32 LTP_pred_Q14 = 0;
@@ -675,11 +700,17 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 if (subfr > 0 || i >= decisionDelay) {
                     // the first lane of every track's quad emits that track; the lineage word of the winner comes by quad broadcast
                     SX_LANES12(tk) { const int li = SX_LI(tk); xq0[li] = SX_QB(linLo, Win2, tk); xq1[li] = SX_QB(linHi, Win2, tk); }
+                    // the winner's cell of the emitted position sits in the prefetch registers of the lane that owns its slot
+                    SX_LANES12(tk) { const int li = SX_LI(tk); tv[li] = SX_LIN_SLOT(xq0[li], xq1[li], last_smple_idx); }
+                    SX_LANES12(tk) {
+                        const int li = SX_LI(tk);
+                        gXq[li] = SX_QG(pfXq, tv[li], tk); gPred[li] = SX_QG(pfPred, tv[li], tk); gExc[li] = SX_QG(pfExc, tv[li], tk);
+                    }
                     SX_LANES12(tk) {
                         if ((tk & 3) == 0) {
-                            const int t = tk >> 2;
-                            const i32 wlo = xq0[SX_LI(tk)], whi = xq1[SX_LI(tk)];
-                            SX_NSQ_EMIT(t, wlo, whi, last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true)
+                            const int t = tk >> 2, li = SX_LI(tk);
+                            SX_NSQ_EMIT_V(t, tv[li], last_smple_idx, k * SX_SUBFR + i - decisionDelay, pred_base + i - decisionDelay, true,
+                                          gXq[li], gPred[li], gExc[li])
                         }
                     }
                 }
@@ -695,14 +726,14 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 LF_AR[li] = cLFAR[li][0];
                 for (int j = SX_LPC - 1; j > 0; j--) sLPC[li][j] = sLPC[li][j - 1];
                 sLPC[li][0] = cXq14[li][0];
-                rg->Xq_Q10[smpl_buf_idx][s] = cXq14[li][0] >> 4;
+                rgG->Xq_Q10[t][smpl_buf_idx][s] = cXq14[li][0] >> 4;
                 rg->Q_Q0[smpl_buf_idx][s] = (i8)cQ0[li][0];
-                rg->Pred_Q16[smpl_buf_idx][s] = cExc16[li][0];
+                rgG->Pred_Q16[t][smpl_buf_idx][s] = cExc16[li][0];
                 rg->Shape_Q10[smpl_buf_idx][s] = cShp[li][0];
                 Seed[li] = sx_add(Seed[li], cQ0[li][0]);
                 rg->Rand[smpl_buf_idx][s] = Seed[li];
                 RD[li] = cRD[li][0];
-                if (t == 0) w->exc_Q10[smpl_buf_idx][s] = cExc10[li][0];
+                if (t == 0) rgG->exc_Q10[smpl_buf_idx][s] = cExc10[li][0];
             }
             SX_LANES12(tk) {          // the state's own slot now holds its newest ring entry
                 const int s = tk & 3, li = SX_LI(tk);
@@ -720,6 +751,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
                 for (int j = 0; j < SX_LTP_ORDER; j++) curL[li][j] = nxL[li][j];
                 if (voiced && emitted && decisionDelay == lag_me - SX_LTP_ORDER / 2 - 1) curL[li][0] = fw;
                 for (int j = 0; j < 3; j++) curS[li][j] = nxS[li][j];
+                pfXq[li] = nxXq[li]; pfPred[li] = nxPred[li]; pfExc[li] = nxExc[li];
             }
             wv_sync_lds();
             SX_TA(8)
@@ -742,6 +774,7 @@ SX_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNs
     out->Seed = SX_RL(SeedInit2, Winner_ind);
     {
         const i32 wlo = SX_RL(linLo, Winner_ind), whi = SX_RL(linHi, Winner_ind);
+        wv_sync();                                  // the HBM ring cells of the last samples must have landed
         SX_PAR(ti, 3 * decisionDelay) {
             const int t = ti / decisionDelay, i = ti - t * decisionDelay;
             const int ring = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;

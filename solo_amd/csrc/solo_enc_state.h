@@ -94,9 +94,15 @@ struct SxNsqOut {                    // what the quantiser produces for one fram
     i8 q[2][SX_FRAME];               // pulses of MD1 / MD2 (the centre stream is never coded)
     i32 r[SX_FRAME];                 // centre excitation Q10 (high-band gain reference)
 };
+struct SxNsqRingG {                  // decision-delay histories that are only read when a sample is emitted (HBM, frame-local):
+    i32 Xq_Q10[SX_N_TRACKS][32][4];  // one cell per (track, ring position, state slot); the quantiser prefetches a sample ahead
+    i32 Pred_Q16[SX_N_TRACKS][32][4];
+    i32 exc_Q10[32][4];              // excitation cells of the CENTRE track (high-band gain reference)
+};
 struct SxNsqPersist {                // quantiser state of one stream
     SxNSQ nsq[SX_N_TRACKS];
     SxNsqGlobal g;
+    SxNsqRingG rg;
     i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
 };
 
