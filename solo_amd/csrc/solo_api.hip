@@ -103,13 +103,14 @@ __device__ __forceinline__ void solo_enc_leave(SxEncWork* w, SxEncStream* rec) {
 }
 
 __global__ void __launch_bounds__(64, 4) solo_enc_analysis_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
-                                                                  int n_packets, SxNsqIn* __restrict__ nsq_in, SxCodeIn* __restrict__ code_in) {
+                                                                  int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
+                                                                  SxCodeIn* __restrict__ code_in) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
     solo_enc_enter(&w, rec);
-    for (int p = 0; p < n_packets; p++) {
+    for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
         const size_t pk = (size_t)s * n_packets + p;
         sx_enc_stage_a(rec, &w, pcm + pk * SX_PACKET, nsq_in + pk * 2, code_in + pk);
         wv_sync();
@@ -118,29 +119,35 @@ __global__ void __launch_bounds__(64, 4) solo_enc_analysis_kernel(SxEncStream* s
 }
 
 __global__ void __launch_bounds__(64, 4) solo_enc_coding_kernel(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
-                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int slot,
-                                                                u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
+                                                                int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
     solo_enc_enter(&w, rec);
     i32 first_err = 0;
-    for (int p = 0; p < n_packets; p++) {
+    for (int p = p0; p < p0 + pc; p++) {
         const size_t pk = (size_t)s * n_packets + p;
         i32 ret = sx_enc_stage_c(rec, &w, code_in + pk, nsq_out + pk * 2, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
-    if (status && SX_LANE == 0) status[s] = first_err;
+    if (status && SX_LANE == 0) {                  // first error of the call (the chunks of a call run in order)
+        if (p0 == 0) status[s] = first_err;
+        else if (first_err != 0 && status[s] == 0) status[s] = first_err;
+    }
 }
 
-extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, void* hip_stream);   // solo_nsq16.hip
+extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
+                               void* hip_stream);   // solo_nsq16.hip
+extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);
 #endif
 
 // ---------------------------------------------------------------------------------------------------
 // host side: handle + C ABI
 // ---------------------------------------------------------------------------------------------------
+#define SOLO_MAX_CHUNKS 32
 struct solo_batch {
     int32_t n_streams;
     int32_t slot;
@@ -151,8 +158,17 @@ struct solo_batch {
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
     int32_t enc_work_packets;        // P the hand-over area is sized for
     int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
-    hipEvent_t ev[6];                // encode: 0|A|1|B|2|C|3   decode: 4|D|5
+    hipEvent_t ev[6];                // decode: 4|D|5  (0..3: unused since the encoder is pipelined)
     int ev_ready, ev_enc, ev_dec;
+    // encoder pipeline: the packets of a call go through analysis -> quantiser -> coding in chunks on three streams
+    int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
+    hipStream_t sA, sB, sC;
+    hipEvent_t evFork, evJoinA, evJoinC, evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS];
+    hipEvent_t tev[3][SOLO_MAX_CHUNKS][2];   // timing brackets per kernel type / chunk (created with set_timing)
+    int tev_ready, last_chunks;
+    unsigned int* d_started;         // per chunk slot: workgroups of the quantiser launches that have started (running count)
+    unsigned int started_target[SOLO_MAX_CHUNKS];
+    int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
     SxDecState* d_dec_state;
 };
 
@@ -199,6 +215,8 @@ int32_t solo_batch_set_timing(solo_batch_t* b, int32_t on) {
     if (on && !b->ev_ready) {
         for (int i = 0; i < 6; i++) SOLO_CHECK(hipEventCreate(&b->ev[i]));
         b->ev_ready = 1;
+        for (int k = 0; k < 3; k++) for (int c = 0; c < SOLO_MAX_CHUNKS; c++) for (int e = 0; e < 2; e++) SOLO_CHECK(hipEventCreate(&b->tev[k][c][e]));
+        b->tev_ready = 1;
     }
     b->timing = on ? 1 : 0;
     return 0;
@@ -206,9 +224,17 @@ int32_t solo_batch_set_timing(solo_batch_t* b, int32_t on) {
 int32_t solo_batch_last_kernel_ms(solo_batch_t* b, float* ms4) {
     if (!b || !ms4 || !b->ev_ready) return -1;
     for (int i = 0; i < 4; i++) ms4[i] = -1.0f;
-    if (b->ev_enc) {
-        SOLO_CHECK(hipEventSynchronize(b->ev[3]));
-        for (int i = 0; i < 3; i++) SOLO_CHECK(hipEventElapsedTime(&ms4[i], b->ev[i], b->ev[i + 1]));
+    if (b->ev_enc && b->tev_ready) {               // sum over the chunks (the three kernel types overlap in time)
+        for (int k = 0; k < 3; k++) {
+            float tot = 0.0f;
+            for (int c = 0; c < b->last_chunks; c++) {
+                float t = 0.0f;
+                SOLO_CHECK(hipEventSynchronize(b->tev[k][c][1]));
+                SOLO_CHECK(hipEventElapsedTime(&t, b->tev[k][c][0], b->tev[k][c][1]));
+                tot += t;
+            }
+            ms4[k] = tot;
+        }
     }
     if (b->ev_dec) {
         SOLO_CHECK(hipEventSynchronize(b->ev[5]));
@@ -272,6 +298,14 @@ void solo_batch_destroy(solo_batch_t* b) {
     if (!b) return;
     if (b->d_dec_state) (void)hipFree(b->d_dec_state);
     if (b->ev_ready) for (int i = 0; i < 6; i++) (void)hipEventDestroy(b->ev[i]);
+    if (b->tev_ready) for (int k = 0; k < 3; k++) for (int c = 0; c < SOLO_MAX_CHUNKS; c++) for (int e = 0; e < 2; e++) (void)hipEventDestroy(b->tev[k][c][e]);
+    if (b->pipe_ready) {
+        (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC);
+        (void)hipStreamDestroy(b->sA); (void)hipStreamDestroy(b->sB); (void)hipStreamDestroy(b->sC);
+        if (b->d_started) (void)hipFree(b->d_started);
+        (void)hipEventDestroy(b->evFork); (void)hipEventDestroy(b->evJoinA); (void)hipEventDestroy(b->evJoinC);
+        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) { (void)hipEventDestroy(b->evA[c]); (void)hipEventDestroy(b->evB[c]); }
+    }
 #ifdef SOLO_WITH_ENCODER
     solo_enc_free(b);
 #endif
@@ -308,15 +342,64 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SxNsqOut* nout = (SxNsqOut*)((char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63));
     SxCodeIn* cin = (SxCodeIn*)((char*)nout + ((sz_out + 63) & ~(size_t)63));
     SxEncStream* states = (SxEncStream*)b->d_enc_state;
-    const bool tm = b->timing && b->ev_ready;
-    if (tm) (void)hipEventRecord(b->ev[0], st);
-    hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, st, states, d_pcm, b->n_streams, n_packets, nin, cin);
-    if (tm) (void)hipEventRecord(b->ev[1], st);
-    if (solo_launch_nsq(states, nin, nout, b->n_streams, n_packets, st) != 0) return -2;
-    if (tm) (void)hipEventRecord(b->ev[2], st);
-    hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, st, states, cin, nout, b->n_streams, n_packets, b->slot,
-                       d_bits, d_nbytes, d_status);
-    if (tm) { (void)hipEventRecord(b->ev[3], st); b->ev_enc = 1; }
+    // Pipeline: chunk c of the call's packets goes analysis (stream sA) -> quantiser (sB) -> coding (sC).  A_c follows A_{c-1},
+    // B_c follows A_c and B_{c-1}, C_c follows B_c and C_{c-1}; so the quantiser of chunk c (one wave per SIMD, latency bound)
+    // runs next to the analysis of chunk c + 1 and the coding of chunk c - 1 (instruction bound): they share the SIMDs.  The
+    // kernels of different types touch disjoint parts of the stream records.  The caller's stream is forked / joined by events.
+    if (!b->pipe_ready) {
+        int lo = 0, hi = 0;
+        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);            // hi = numerically lowest = greatest priority
+        SOLO_CHECK(hipStreamCreateWithPriority(&b->sA, hipStreamNonBlocking, lo));
+        SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
+        SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, lo));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA, hipEventDisableTiming));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinC, hipEventDisableTiming));
+        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) {
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evA[c], hipEventDisableTiming));
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evB[c], hipEventDisableTiming));
+        }
+        const char* e = getenv("SOLO_ENC_CHUNK");
+        b->chunk_packets = e ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_GATE");
+        b->gate = e ? atoi(e) : 1;
+        SOLO_CHECK(hipMalloc((void**)&b->d_started, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
+        SOLO_CHECK(hipMemset(b->d_started, 0, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
+        memset(b->started_target, 0, sizeof(b->started_target));
+        b->pipe_ready = 1;
+    }
+    int cp = b->chunk_packets > 0 ? b->chunk_packets : n_packets;
+    int nchunks = (n_packets + cp - 1) / cp;
+    if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
+    const bool tm = b->timing && b->tev_ready;
+    SOLO_CHECK(hipEventRecord(b->evFork, st));
+    SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
+    SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
+    SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
+    for (int c = 0; c < nchunks; c++) {
+        const int p0 = c * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
+        if (c > 0 && b->gate) (void)solo_launch_gate(&b->d_started[c - 1], b->started_target[c - 1], b->sA);
+        if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
+        hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, b->sA, states, d_pcm, b->n_streams, n_packets, p0, pc, nin, cin);
+        if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
+        SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
+        SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
+        if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
+        b->started_target[c] += (unsigned int)((b->n_streams + 3) / 4);          // workgroups of this launch (4 streams each)
+        if (solo_launch_nsq(states, nin, nout, b->n_streams, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
+        if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
+        SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
+        SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
+        if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
+        hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, b->sC, states, cin, nout, b->n_streams, n_packets, p0, pc,
+                           b->slot, d_bits, d_nbytes, d_status);
+        if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
+    }
+    SOLO_CHECK(hipEventRecord(b->evJoinA, b->sA));
+    SOLO_CHECK(hipEventRecord(b->evJoinC, b->sC));
+    SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA, 0));
+    SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC, 0));
+    if (tm) { b->ev_enc = 1; b->last_chunks = nchunks; }
     SOLO_CHECK(hipGetLastError());
     return 0;
 }

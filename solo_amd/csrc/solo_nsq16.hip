@@ -12,16 +12,20 @@
 #include "solo_enc_nsq.h"
 
 #ifndef SX_NSQ_WAVES
-#define SX_NSQ_WAVES 1
+#define SX_NSQ_WAVES 2        // <= 256 VGPRs: leaves half of the SIMD's register file to the kernels that share it
 #endif
 extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) solo_nsq_kernel(SxEncStream* states, const SxNsqIn* __restrict__ in,
-                                                                 SxNsqOut* __restrict__ out, int n_streams, int n_packets) {
+                                                                 SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
+                                                                 unsigned int* started) {
     __shared__ SxNsqWork w[SX_PER_WAVE];
     const int g = threadIdx.x / SX_GROUP;
     const int s = blockIdx.x * SX_PER_WAVE + g;
+    if (started && threadIdx.x == 0) atomicAdd(started, 1u);     // lets the host-side pipeline start the next analysis chunk once this kernel is resident
     if (s >= n_streams) return;
+    // one latency-bound wave per SIMD that shares it with the analysis / coding kernels of neighbouring chunks: issue first
+    __builtin_amdgcn_s_setprio(3);
     SxNsqPersist* P = &states[s].nsq;
-    for (int p = 0; p < n_packets; p++) {
+    for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
         for (int f = 0; f < 2; f++) {
             const size_t r = ((size_t)s * n_packets + p) * 2 + f;
             sx_nsq_del_dec(P, &in[r], &out[r], &w[g]);
@@ -30,10 +34,26 @@ extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) solo_nsq_kernel(S
     }
 }
 
+// gate: holds a stream until `*flag` has reached `target` (modulo 2^32), i.e. until all workgroups of the quantiser launch that
+// counts into it are resident; gives up after ~20 ms so that a runtime that serialises the streams cannot hang
+extern "C" __global__ void __launch_bounds__(64) solo_gate_kernel(const unsigned int* flag, unsigned int target) {
+    if (threadIdx.x == 0) {
+        for (int it = 0; it < 20000; it++) {
+            if (__atomic_load_n(flag, __ATOMIC_RELAXED) - target < 0x80000000u) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream) {
+    hipLaunchKernelGGL(solo_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, flag, target);
+    return (int)hipGetLastError();
+}
+
 // host-side launcher (called from solo_api.hip)
-extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, void* hip_stream) {
+extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
+                               void* hip_stream) {
     hipLaunchKernelGGL(solo_nsq_kernel, dim3((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)states,
-                       (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets);
+                       (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets, p0, pc, started);
     return (int)hipGetLastError();
 }
 
