@@ -103,9 +103,13 @@ int32_t solo_batch_slot_bytes(const solo_batch_t *b);
 /* Names of the device kernels: 0 = quantiser (dominant encode kernel), 1 = decode, 2 = encoder analysis, 3 = encoder coding. */
 const char *solo_kernel_name(int32_t which);
 /* Benchmark aid: bracket every kernel of this handle with HIP events on its launch stream, and read the durations of
- * the most recent encode / decode call: ms4 = {analysis, quantiser, coding, decode} (-1 = not run yet). */
+ * the most recent encode / decode call: ms4 = {analysis, quantiser, coding, decode} (-1 = not run yet).  solo_batch_encode
+ * runs its three kernels as a pipeline over chunks of the call's packets (several launches per kernel, overlapping in
+ * time on internal streams): the encoder entries are the SUM over the launches of that kernel, and
+ * solo_batch_last_encode_chunks() is the number of launches per kernel of that call. */
 int32_t solo_batch_set_timing(solo_batch_t *b, int32_t on);
 int32_t solo_batch_last_kernel_ms(solo_batch_t *b, float *ms4);
+int32_t solo_batch_last_encode_chunks(const solo_batch_t *b);
 /* Library version string. */
 const char *solo_version(void);
 

@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "AGR_Sate_Decoder_Init", "AGR_Sate_Decoder_Decode", "AGR_Sate_Decoder_Uninit",
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
-    "solo_batch_last_kernel_ms",
+    "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks",
 ]
 
 
@@ -64,6 +64,8 @@ def load_library():
     lib.solo_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
     lib.solo_batch_last_kernel_ms.restype = C.c_int32
     lib.solo_batch_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+    lib.solo_batch_last_encode_chunks.restype = C.c_int32
+    lib.solo_batch_last_encode_chunks.argtypes = [C.c_void_p]
     lib.solo_kernel_name.restype = C.c_char_p
     lib.solo_kernel_name.argtypes = [C.c_int32]
     lib.solo_version.restype = C.c_char_p
@@ -147,6 +149,10 @@ class SoloBatch:
         if self.lib.solo_batch_last_kernel_ms(self.h, ms):
             raise RuntimeError("solo_batch_last_kernel_ms failed")
         return dict(zip(("analysis", "quantiser", "coding", "decode"), [float(v) for v in ms]))
+
+    def last_encode_chunks(self):
+        """launches per encoder kernel of the most recent encode call (the call's packets are pipelined in chunks)"""
+        return int(self.lib.solo_batch_last_encode_chunks(self.h))
 
     def decode(self, bits, nbytes, recv=None, pcm=None, status=None):
         """bits uint8 [N,P,slot], nbytes int16 [N,P,2], recv uint8 [N,P] (bit0 MD1, bit1 MD2) -> pcm int16 [N,P,640]"""

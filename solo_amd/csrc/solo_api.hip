@@ -243,6 +243,7 @@ int32_t solo_batch_last_kernel_ms(solo_batch_t* b, float* ms4) {
     return 0;
 }
 int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
+int32_t solo_batch_last_encode_chunks(const solo_batch_t* b) { return b ? b->last_chunks : 0; }
 
 int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
     if (!b) return -1;
@@ -399,7 +400,8 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SOLO_CHECK(hipEventRecord(b->evJoinC, b->sC));
     SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA, 0));
     SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC, 0));
-    if (tm) { b->ev_enc = 1; b->last_chunks = nchunks; }
+    b->last_chunks = nchunks;
+    if (tm) b->ev_enc = 1;
     SOLO_CHECK(hipGetLastError());
     return 0;
 }

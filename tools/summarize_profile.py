@@ -11,9 +11,9 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-packets = int(sys.argv[3]) if len(sys.argv) > 3 else 40960
+packets_step = int(sys.argv[3]) if len(sys.argv) > 3 else 40960
 out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
-       "packets_per_launch": packets, "kernels": {}}
+       "packets_per_step": packets_step, "kernels": {}}
 st = os.path.join(src, "trace", "r01_kernel_stats.csv")
 lines = []
 for r in csv.DictReader(open(st)):
@@ -39,8 +39,13 @@ for d in ("fetch", "write", "sq", "inst"):
             e = out["kernels"].setdefault(k, {})
             e.setdefault("resources", meta[k])
             e.setdefault("pmc_avg_per_launch", {}).update({c: sum(x) / len(x) for c, x in v.items()})
+# the encoder kernels are launched once per chunk of a step's packets, the decoder once per step: packets per LAUNCH differ
+calls = {k: e["trace"]["calls"] for k, e in out["kernels"].items() if "trace" in e and "init" not in k and "gate" not in k}
+steps = min(calls.values()) if calls else 1
 for k, e in out["kernels"].items():
     p = e.get("pmc_avg_per_launch", {})
+    packets = packets_step * steps / calls[k] if k in calls else packets_step
+    e["packets_per_launch"] = packets
     if "FETCH_SIZE" in p and "WRITE_SIZE" in p:
         # guide (MI355X_MICROARCH.md, HBM section): FETCH_SIZE/WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE reports 1/2 of the
         # bytes of wide coalesced reads -> doubled here; WRITE_SIZE is taken as is (uncalibrated)
