@@ -1789,15 +1789,20 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
             }
         }
         if (total > 64) { SX_KEY_CX(k0, k1) SX_KEY_CX(k2, k3) SX_KEY_CX(k0, k2) SX_KEY_CX(k1, k3) SX_KEY_CX(k1, k2) }
-        i64 mine = KEY_MAX;
+        // heads as (value, index) register pairs; one selection round = wave minimum of the values, then wave minimum of the
+        // indices among the lanes that hold that value (two 32-bit DPP ladders instead of one 64-bit compare ladder)
+        i32 v0 = (i32)((u64)k0 >> 32), v1 = (i32)((u64)k1 >> 32), v2 = (i32)((u64)k2 >> 32), v3 = (i32)((u64)k3 >> 32);
+        i32 i0 = (i32)(u32)k0 & 0x7FFFFFFF, i1 = (i32)(u32)k1 & 0x7FFFFFFF, i2 = (i32)(u32)k2 & 0x7FFFFFFF, i3 = (i32)(u32)k3 & 0x7FFFFFFF;
+        i32 mine_v = SX_I32_MAX, mine_i = 0;
         for (int r = 0; r < cur_survivors; r++) {
-            const i64 m = wv_min_key(k0);
-            if (k0 == m) { k0 = k1; k1 = k2; k2 = k3; k3 = KEY_MAX; }
-            if (SX_LANE == r) mine = m;
+            const i32 vmin = wv_min(v0);
+            const i32 imin = wv_min(v0 == vmin ? i0 : SX_I32_MAX);
+            if (v0 == vmin && i0 == imin) { v0 = v1; i0 = i1; v1 = v2; i1 = i2; v2 = v3; i2 = i3; v3 = SX_I32_MAX; i3 = SX_I32_MAX; }
+            if (SX_LANE == r) { mine_v = vmin; mine_i = imin; }
         }
         if (SX_LANE < cur_survivors) {
-            w->RateDist_Q18[SX_LANE] = (i32)((u64)mine >> 32);
-            w->TempIndices[SX_LANE] = (i32)(u32)mine;
+            w->RateDist_Q18[SX_LANE] = mine_v;
+            w->TempIndices[SX_LANE] = mine_i;
         }
 #endif
         wv_sync();
