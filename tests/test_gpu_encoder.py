@@ -62,6 +62,22 @@ def test_packetwise_calls_equal_one_call(torch_cuda):
         _assert_streams_equal(bits, nb, z["bits"][:, p:p + 1], z["nbytes"][:, p:p + 1])
 
 
+@pytest.mark.parametrize("chunk,gate", [("0", "1"), ("3", "1"), ("7", "0"), ("1", "0")])
+def test_pipeline_shapes_give_the_same_bits(torch_cuda, monkeypatch, chunk, gate):
+    """The encoder's chunked three-stream pipeline (SOLO_ENC_CHUNK packets per chunk, 0 = sequential; residency gate on / off)
+    is a schedule, not an algorithm: every shape must reproduce the golden bitstreams, also when a second call follows."""
+    import solo_amd
+    monkeypatch.setenv("SOLO_ENC_CHUNK", chunk)
+    monkeypatch.setenv("SOLO_ENC_GATE", gate)
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P, _ = z["pcm"].shape
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)      # the environment is read at the first encode
+    bits, nb = _gpu_encode(torch_cuda, z["pcm"][:, :10], batch=b)
+    _assert_streams_equal(bits, nb, z["bits"][:, :10], z["nbytes"][:, :10])
+    bits, nb = _gpu_encode(torch_cuda, z["pcm"][:, 10:], batch=b)
+    _assert_streams_equal(bits, nb, z["bits"][:, 10:], z["nbytes"][:, 10:])
+
+
 def test_round_trip_on_gpu(torch_cuda):
     """encode -> erase descriptions -> decode, all on the GPU, equals the reference chain's PCM."""
     import solo_amd
