@@ -426,7 +426,22 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     SX_PAR(i, 320) w->sig8[i] = signal[i];
     wv_sync();
     sx_down2_zero_state(w->sig4, w->sig8, 320);
+#if SX_NLANES == 1
     for (int i = 159; i > 0; i--) w->sig4[i] = (i16)sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]);
+#else
+    {   // y[i] = sat16(x[i] + x[i-1]) of the UNMODIFIED neighbours (the reference walks downwards): read all, then write
+        i32 a[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            a[j] = (i > 0 && i < 160) ? sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]) : 0;
+        }
+        wv_sync();
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i > 0 && i < 160) w->sig4[i] = (i16)a[j]; }
+        wv_sync();
+    }
+#endif
     i32 shift = sx_pitch_find_scaling(w->sig4, 160, sx_max(sf8, 80));
     if (shift > 0) {
         SX_PAR(i, 160) w->sig4[i] = (i16)(w->sig4[i] >> shift);
@@ -440,7 +455,8 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
         i32 E8 = 0;
         {
             const i16* b = target - min_lag_4;
-            for (int n = 0; n < sf8; n++) E8 = sx_smlabb(E8, b[n], b[n]);
+            SX_PAR(n, sf8) E8 = sx_smlabb(E8, b[n], b[n]);
+            E8 = wv_sum(E8);
         }
         i32 N8 = sx_add_sat32(E8, sx_smulbb(sf8, 4000));
         SX_PAR(d, max_lag_4 + 1) {
@@ -478,7 +494,8 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     wv_sync();
     const i16* target = &w->sig4[80];
     i32 energy = 0;
-    for (int n = 0; n < 80; n++) energy = sx_smlabb(energy, target[n], target[n]);
+    SX_PAR(n, 80) energy = sx_smlabb(energy, target[n], target[n]);
+    energy = wv_sum(energy);
     energy = sx_add_pos_sat32(energy, 1000);
     i32 Cmax = w->C[0][min_lag_4];
     i32 threshold = sx_smulbb(Cmax, Cmax);
@@ -492,6 +509,7 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
         if (w->C[0][min_lag_4 + i] > threshold) w->d_srch[i] = (w->d_srch[i] + min_lag_4) << 1;
         else { length_d_srch = i; break; }
     }
+#if SX_NLANES == 1
     for (int i = min_lag_8 - 5; i < max_lag_8 + 5; i++) w->d_comp[i] = 0;
     for (int i = 0; i < length_d_srch; i++) w->d_comp[w->d_srch[i]] = 1;
     for (int i = max_lag_8 + 3; i >= min_lag_8; i--) w->d_comp[i] = (i16)(w->d_comp[i] + w->d_comp[i - 1] + w->d_comp[i - 2]);
@@ -505,6 +523,62 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     for (int i = min_lag_8; i < max_lag_8 + 4; i++) {
         if (w->d_comp[i] > 0) { w->d_comp[length_d_comp] = (i16)(i - 2); length_d_comp++; }
     }
+#else
+    int length_d_comp = 0;
+    {
+        // the reference's downward in-place smears read unmodified lower neighbours: y[i] = x[i] + x[i-1] + x[i-2] (+ x[i-3]);
+        // its ordered scans become ballot compactions.  Lane l covers lags l, l + 64, l + 128 (< 160)
+        const unsigned long long below = (1ull << SX_LANE) - 1ull;
+        i32 m[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            i32 v = 0;
+            for (int q = 0; q < length_d_srch; q++) v |= (w->d_srch[q] == i) ? 1 : 0;
+            m[j] = v;
+        }
+        wv_sync();
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i >= min_lag_8 - 5 && i < max_lag_8 + 5) w->d_comp[i] = (i16)m[j]; }
+        wv_sync();
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            m[j] = (i >= min_lag_8 && i <= max_lag_8 + 3) ? (i32)w->d_comp[i] + w->d_comp[i - 1] + w->d_comp[i - 2] : ((i < 160 && i >= min_lag_8 - 5) ? (i32)w->d_comp[i] : 0);
+        }
+        wv_sync();
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i >= min_lag_8 && i <= max_lag_8 + 3) w->d_comp[i] = (i16)m[j]; }
+        wv_sync();
+        // d_srch = { i in [min_lag_8, max_lag_8] : d_comp[i + 1] > 0 } in ascending order
+        int n_srch = 0;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            const bool pr = i >= min_lag_8 && i <= max_lag_8 && w->d_comp[i + 1] > 0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pr);
+            if (pr) w->d_srch[n_srch + __builtin_popcountll(bal & below)] = i;
+            n_srch += __builtin_popcountll(bal);
+        }
+        length_d_srch = n_srch;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            m[j] = (i >= min_lag_8 && i <= max_lag_8 + 3) ? (i32)w->d_comp[i] + w->d_comp[i - 1] + w->d_comp[i - 2] + w->d_comp[i - 3] : 0;
+        }
+        wv_sync();
+        // d_comp[0 .. n) = { i - 2 : i in [min_lag_8, max_lag_8 + 3], smeared d_comp[i] > 0 } in ascending order
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int i = SX_LANE + 64 * j;
+            const bool pr = i >= min_lag_8 && i <= max_lag_8 + 3 && m[j] > 0;
+            const unsigned long long bal = __builtin_amdgcn_ballot_w64(pr);
+            if (pr) w->d_comp[length_d_comp + __builtin_popcountll(bal & below)] = (i16)(i - 2);
+            length_d_comp += __builtin_popcountll(bal);
+        }
+        wv_sync();
+    }
+#endif
     // ---- second stage (8 kHz) ----
     shift = sx_pitch_find_scaling(w->sig8, 320, sf8);
     if (shift > 0) {
@@ -544,6 +618,7 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     i32 prevLag_log2_Q7 = prevLag > 0 ? sx_lin2log(prevLag) : 0;
     i32 corr_thres_Q15 = sx_smulbb(search_thres2_Q15, search_thres2_Q15) >> 13;
     const int nb_cbks = 11;
+#if SX_NLANES == 1
     for (int k = 0; k < length_d_srch; k++) {
         int d = w->d_srch[k];
         i32 CCmax_new = SX_I32_MIN;
@@ -569,6 +644,42 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
             CBimax = CBimax_new;
         }
     }
+#else
+    {   // one candidate lag per lane; the reference keeps the FIRST lag with the largest biased correlation among those that pass
+        // its tests (strict '>' in lag order) = arg-max with the lower index winning ties
+        i32 best_b = SX_I32_MIN, best_k = SX_I32_MAX, my_cc = 0, my_cb = 0;
+        const int k = SX_LANE;
+        if (k < length_d_srch) {
+            const int d = w->d_srch[k];
+            i32 CCmax_new = SX_I32_MIN;
+            int CBimax_new = 0;
+            for (int j = 0; j < nb_cbks; j++) {
+                i32 cc = 0;
+                for (int i = 0; i < 4; i++) cc += (i32)w->C[i][d + T_pitch_cb_stage2[i * 11 + j]];
+                if (cc > CCmax_new) { CCmax_new = cc; CBimax_new = j; }
+            }
+            i32 lag_log2_Q7 = sx_lin2log(d);
+            i32 CCmax_new_b = CCmax_new - (sx_smulbb(4 * 6554, lag_log2_Q7) >> 7);
+            if (prevLag > 0) {
+                i32 dl = lag_log2_Q7 - prevLag_log2_Q7;
+                dl = sx_smulbb(dl, dl) >> 7;
+                i32 bias = sx_smulbb(4 * 6554, *LTPCorr_Q15) >> 15;
+                bias = sx_mul(bias, dl) / (dl + (1 << 6));
+                CCmax_new_b -= bias;
+            }
+            // (a candidate with CCmax_new_b == INT32_MIN can never be chosen by the reference's strict '>' either)
+            if (CCmax_new_b > SX_I32_MIN && CCmax_new > corr_thres_Q15 && T_pitch_cb_stage2[CBimax_new] <= min_lag_8) {
+                best_b = CCmax_new_b; best_k = k; my_cc = CCmax_new; my_cb = CBimax_new;
+            }
+        }
+        wv_argmax(&best_b, &best_k);
+        if (best_k != SX_I32_MAX && best_b > SX_I32_MIN) {
+            CCmax = wv_bcast(my_cc, best_k);
+            CBimax = wv_bcast(my_cb, best_k);
+            lag = w->d_srch[best_k];
+        }
+    }
+#endif
     if (lag == -1) {
         for (int k = 0; k < 4; k++) pitch_out[k] = 0;
         *LTPCorr_Q15 = 0; *lagIndex = 0; *contourIndex = 0;
