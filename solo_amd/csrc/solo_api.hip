@@ -102,7 +102,8 @@ __device__ __forceinline__ void solo_enc_leave(SxEncWork* w, SxEncStream* rec) {
     SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(64, 4) solo_enc_analysis_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
+// (waves-per-SIMD target 5 = at most 104 VGPRs: two of these waves share a SIMD with one quantiser wave of ~288 VGPRs)
+__global__ void __launch_bounds__(64, 5) solo_enc_analysis_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
     __shared__ SxEncWork w;
@@ -118,7 +119,7 @@ __global__ void __launch_bounds__(64, 4) solo_enc_analysis_kernel(SxEncStream* s
     solo_enc_leave(&w, rec);
 }
 
-__global__ void __launch_bounds__(64, 4) solo_enc_coding_kernel(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
+__global__ void __launch_bounds__(64, 5) solo_enc_coding_kernel(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
                                                                 const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
                                                                 int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
     __shared__ SxEncWork w;
@@ -334,6 +335,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const size_t sz_in = np * 2 * sizeof(SxNsqIn), sz_out = np * 2 * sizeof(SxNsqOut), sz_code = np * sizeof(SxCodeIn);
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
+        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); }
         if (b->d_enc_work) (void)hipFree(b->d_enc_work);
         b->d_enc_work = NULL;
         SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));

@@ -12,7 +12,7 @@
 #include "solo_enc_nsq.h"
 
 #ifndef SX_NSQ_WAVES
-#define SX_NSQ_WAVES 2        // <= 256 VGPRs: leaves half of the SIMD's register file to the kernels that share it
+#define SX_NSQ_WAVES 1        // ~288 VGPRs; the analysis / coding kernels are held to <= 104 so that two of their waves fit beside it
 #endif
 extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) solo_nsq_kernel(SxEncStream* states, const SxNsqIn* __restrict__ in,
                                                                  SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
