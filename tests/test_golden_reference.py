@@ -39,3 +39,28 @@ def test_golden_json_matches_kat():
     assert g["ch_f1_bit_md5"] == KAT["bit"]
     assert g["ch_f1_dec_loss0_md5"] == KAT["dec0"]
     assert g["ch_f1_dec_loss30_md5"] == KAT["dec30"]
+
+
+@pytest.mark.skipif(not (R.have_ref("fix") and R.have_ref("flp")), reason="oracle/_ref not present on this box")
+def test_stated_tolerance_against_the_floating_point_tree():
+    """north_star: bit-exact against the fixed-point tree, 'within a stated PCM tolerance against the FLP path'.  The GPU path
+    equals the fixed-point tree bit for bit (tests/test_gpu_*), so its distance to the FLP tree IS the distance between the
+    two reference builds.  Stated here and checked on the synthetic workload:
+      * same bitstream through the fixed-point decoder vs the FLP tree's decoder (its BWE runs in float): SNR >= 20 dB;
+      * fixed-point encode + decode vs FLP encode + decode of the same input (different analysis decisions, different
+        bitstreams): SNR >= 12 dB between the two decoded signals."""
+    snr_dec, snr_chain = [], []
+    for seed in (77, 78, 79):
+        P = 12
+        pcm = R.synth_stream(seed, P)
+        ef, el = R.RefEncoder("fix"), R.RefEncoder("flp")
+        rf = [ef.encode(pcm[p]) for p in range(P)]
+        rl = [el.encode(pcm[p]) for p in range(P)]
+        d1, d2, d3 = R.RefDecoder("fix"), R.RefDecoder("flp"), R.RefDecoder("flp")
+        a = np.concatenate([d1.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
+        b = np.concatenate([d2.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
+        c = np.concatenate([d3.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rl]).astype(np.float64)
+        snr_dec.append(10 * np.log10((a * a).sum() / max(((a - b) ** 2).sum(), 1e-9)))
+        snr_chain.append(10 * np.log10((a * a).sum() / max(((a - c) ** 2).sum(), 1e-9)))
+    assert min(snr_dec) >= 20.0, snr_dec
+    assert min(snr_chain) >= 12.0, snr_chain
