@@ -96,6 +96,15 @@ int32_t solo_batch_encode(solo_batch_t *b, const int16_t *d_pcm, int32_t n_packe
 int32_t solo_batch_decode(solo_batch_t *b, const uint8_t *d_bits, const int16_t *d_nbytes,
                           const uint8_t *d_recv, int32_t n_packets, int16_t *d_pcm, int32_t *d_status,
                           void *hip_stream);
+/* Receiver front end: the two descriptions of every packet arrive separately (MD1, and MD2 || HB(8)), possibly only one,
+ * possibly in either arrival slot.  d_descA / d_descB: uint8 [N][P][slot_bytes]; d_lenA / d_lenB: int16 [N][P], 0 = nothing
+ * arrived.  With useMDIndex = 1 in the decoder control the kernel identifies the descriptions by the index they carry
+ * (SKP_Silk_decode_parameters.c:55-57) and sorts them itself; with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.
+ * Builds the (ptr, nBytes, lostflag) call of test/dec_main.c:255-378 on the GPU and decodes.  Same outputs as
+ * solo_batch_decode.  Packets above 252 bytes are rejected (status -11). */
+int32_t solo_batch_decode_split(solo_batch_t *b, const uint8_t *d_descA, const int16_t *d_lenA, const uint8_t *d_descB,
+                                const int16_t *d_lenB, int32_t slot_bytes, int32_t n_packets, int16_t *d_pcm,
+                                int32_t *d_status, void *hip_stream);
 /* Geometry / introspection */
 int32_t solo_batch_n_streams(const solo_batch_t *b);
 int32_t solo_batch_slot_bytes(const solo_batch_t *b);

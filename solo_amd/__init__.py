@@ -22,7 +22,7 @@ ABI_SYMBOLS = [
     "AGR_Sate_Decoder_Init", "AGR_Sate_Decoder_Decode", "AGR_Sate_Decoder_Uninit",
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
-    "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks",
+    "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split",
 ]
 
 
@@ -64,6 +64,9 @@ def load_library():
     lib.solo_batch_set_timing.argtypes = [C.c_void_p, C.c_int32]
     lib.solo_batch_last_kernel_ms.restype = C.c_int32
     lib.solo_batch_last_kernel_ms.argtypes = [C.c_void_p, C.c_void_p]
+    lib.solo_batch_decode_split.restype = C.c_int32
+    lib.solo_batch_decode_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
+                                            C.c_void_p, C.c_void_p]
     lib.solo_batch_last_encode_chunks.restype = C.c_int32
     lib.solo_batch_last_encode_chunks.argtypes = [C.c_void_p]
     lib.solo_kernel_name.restype = C.c_char_p
@@ -171,6 +174,24 @@ class SoloBatch:
                                        P, pcm.data_ptr(), status.data_ptr(), self._stream())
         if r:
             raise RuntimeError("solo_batch_decode -> %d" % r)
+        return pcm, status
+
+    def decode_split(self, desc_a, len_a, desc_b, len_b, pcm=None, status=None):
+        """Receiver front end: the two descriptions of every packet in two arrival slots.  desc_a / desc_b uint8 [N,P,S],
+        len_a / len_b int16 [N,P] (0 = nothing arrived) -> pcm int16 [N,P,640] (see solo_batch_decode_split)."""
+        t = self.torch
+        for d, n in ((desc_a, len_a), (desc_b, len_b)):
+            assert d.is_cuda and d.dtype == t.uint8 and d.is_contiguous() and n.dtype == t.int16 and n.is_contiguous()
+        N, P, S = desc_a.shape
+        assert N == self.n_streams and tuple(desc_b.shape) == (N, P, S) and tuple(len_a.shape) == (N, P) == tuple(len_b.shape)
+        if pcm is None:
+            pcm = t.zeros((N, P, PACKET_SAMPLES), dtype=t.int16, device=desc_a.device)
+        if status is None:
+            status = t.zeros((N,), dtype=t.int32, device=desc_a.device)
+        r = self.lib.solo_batch_decode_split(self.h, desc_a.data_ptr(), len_a.data_ptr(), desc_b.data_ptr(), len_b.data_ptr(), S, P,
+                                             pcm.data_ptr(), status.data_ptr(), self._stream())
+        if r:
+            raise RuntimeError("solo_batch_decode_split -> %d" % r)
         return pcm, status
 
     def close(self):

@@ -78,6 +78,63 @@ __global__ void __launch_bounds__(64, 4) solo_decode_kernel(SxDecState* states, 
     if (status && SX_LANE == 0) status[s] = first_err;
 }
 
+// Receiver front end: the two descriptions of a 40 ms packet arrive as separate network packets (MD1, and
+// MD2 || HB), possibly only one of them, possibly swapped.  descA / descB are the two arrival slots of every (stream, packet):
+// uint8 [N][P][slot], lenA / lenB int16 [N][P] (0 = nothing arrived).  With useMDIndex = 1 every description carries its index
+// as its first range-coded symbol (SKP_Silk_decode_parameters.c:55-57): the kernel reads it and sorts the arrivals itself
+// (two copies of the same description count once); with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.  The kernel then
+// builds the (ptr, nBytes, lostflag) triple of test/dec_main.c:255-378 and decodes.  Packets above the LDS staging size
+// (252 B; 13.6 kbps packets are ~80 B) are rejected with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11).
+__global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
+                                                               const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
+                                                               int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    solo_dec_enter(&w, &states[s]);
+    i32 first_err = 0;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const u8* pa = descA + pk * (size_t)slot;
+        const u8* pb = descB + pk * (size_t)slot;
+        i32 la = lenA[pk], lb = lenB[pk];
+        if (la < 0 || la > slot) la = 0;
+        if (lb < 0 || lb > slot) lb = 0;
+        const u8 *p1 = pa, *p2 = pb;
+        i32 l1 = la, l2 = lb;
+        if (useMDIndex == 1) {
+            int ia = -1, ib = -1;
+            if (la > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
+            if (lb > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
+            p1 = pa; l1 = 0; p2 = pb; l2 = 0;
+            if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
+            if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
+        }
+        if (l2 > 0 && l2 <= SX_HB_BYTES) l2 = 0;            // a second description always carries the 8 high-band bytes
+        i16* out = pcm + pk * SX_PACKET;
+        int ret;
+        if (l1 + l2 > SX_DEC_PAYLOAD_LDS) {
+            ret = -11;
+        } else {
+            wv_sync();
+            SX_PAR(i, l1) w.payload[i] = p1[i];
+            SX_PAR(i, l2) w.payload[l1 + i] = p2[i];
+            wv_sync();
+            int lostflag;
+            i32 a0, a1;
+            if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
+            else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
+            else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
+            else { lostflag = 1; a0 = SX_HB_BYTES + 1; a1 = 0; }
+            ret = sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
+        }
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    solo_dec_leave(&w, &states[s]);
+    if (status && SX_LANE == 0) status[s] = first_err;
+}
+
 #ifdef SOLO_WITH_ENCODER
 __global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex) {
     const int s = blockIdx.x;
@@ -322,6 +379,16 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     hipLaunchKernelGGL(solo_decode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state,
                        d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot, b->dec_ctrl.useMDIndex, d_pcm, d_status);
     if (tm) { (void)hipEventRecord(b->ev[5], (hipStream_t)hip_stream); b->ev_dec = 1; }
+    SOLO_CHECK(hipGetLastError());
+    return 0;
+}
+
+int32_t solo_batch_decode_split(solo_batch_t* b, const uint8_t* d_descA, const int16_t* d_lenA, const uint8_t* d_descB,
+                                const int16_t* d_lenB, int32_t slot_bytes, int32_t n_packets, int16_t* d_pcm, int32_t* d_status,
+                                void* hip_stream) {
+    if (!b || !b->have_dec || !d_descA || !d_lenA || !d_descB || !d_lenB || !d_pcm || n_packets <= 0 || slot_bytes <= 0) return -1;
+    hipLaunchKernelGGL(solo_decode_split_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state, d_descA, d_lenA,
+                       d_descB, d_lenB, b->n_streams, n_packets, slot_bytes, b->dec_ctrl.useMDIndex, d_pcm, d_status);
     SOLO_CHECK(hipGetLastError());
     return 0;
 }
