@@ -25,10 +25,10 @@
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) solo_dec_init_kernel(SxDecState* states, int n_streams) {
+__global__ void __launch_bounds__(64) solo_dec_init_kernel(SxDecState* states, int n_streams, int hb_joint) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    sx_dec_state_init(&states[s]);
+    sx_dec_state_init(&states[s], hb_joint);
 }
 
 // Decoder: rows D0-D8.  blockIdx.x = stream.
@@ -110,7 +110,8 @@ __global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* st
             if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
             if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
         }
-        if (l2 > 0 && l2 <= SX_HB_BYTES) l2 = 0;            // a second description always carries the 8 high-band bytes
+        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+        if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
         i16* out = pcm + pk * SX_PACKET;
         int ret;
         if (l1 + l2 > SX_DEC_PAYLOAD_LDS) {
@@ -125,7 +126,7 @@ __global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* st
             if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
             else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
             else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
-            else { lostflag = 1; a0 = SX_HB_BYTES + 1; a1 = 0; }
+            else { lostflag = 1; a0 = hbb + 1; a1 = 0; }
             ret = sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
         }
         if (ret < 0 && first_err == 0) first_err = ret;
@@ -136,10 +137,10 @@ __global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* st
 }
 
 #ifdef SOLO_WITH_ENCODER
-__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex) {
+__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex);
+    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint);
 }
 
 // Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
@@ -230,12 +231,15 @@ struct solo_batch {
     SxDecState* d_dec_state;
 };
 
+// joint_enable = 0, or joint_mode 1 (one 40 ms high-band frame per packet, AGR_BWE_SDK_API.c:64-67); the other joint modes are
+// "reserved" in the reference as well
 static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
-    return c->samplerate == 16000 && c->framesize_ms == 40 && c->joint_enable == 0 && c->dtx_enable == 0;
+    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1) && c->dtx_enable == 0;
 }
 static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
-    return c->samplerate == 16000 && c->framesize_ms == 40 && c->joint_enable == 0;
+    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
 }
+static int ctrl_hb_joint(int joint_enable, int joint_mode) { return joint_enable != 0 && joint_mode == 1; }
 
 #ifdef SOLO_WITH_ENCODER
 static int32_t solo_enc_alloc(solo_batch* b) {
@@ -243,9 +247,10 @@ static int32_t solo_enc_alloc(solo_batch* b) {
     return 0;
 }
 static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
-    // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the 1600 bps high-band share
+    // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the high-band share, 1600 * 20 / bwe_framesize_ms
+    const int joint = ctrl_hb_joint(b->enc_ctrl.joint_enable, b->enc_ctrl.joint_mode);
     hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncStream*)b->d_enc_state, b->n_streams,
-                       b->enc_ctrl.targetRate_bps - 1600, b->enc_ctrl.useMDIndex);
+                       b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint);
     SOLO_CHECK(hipGetLastError());
     return 0;
 }
@@ -307,7 +312,8 @@ int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
     if (!b) return -1;
     hipStream_t s = (hipStream_t)hip_stream;
     if (b->have_dec) {
-        hipLaunchKernelGGL(solo_dec_init_kernel, dim3(b->n_streams), dim3(64), 0, s, b->d_dec_state, b->n_streams);
+        hipLaunchKernelGGL(solo_dec_init_kernel, dim3(b->n_streams), dim3(64), 0, s, b->d_dec_state, b->n_streams,
+                           ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode));
         SOLO_CHECK(hipGetLastError());
     }
 #ifdef SOLO_WITH_ENCODER
@@ -571,8 +577,9 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
     int32_t ret = 0;
     if (hipMemcpy(&ret, h->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     // the reference rewrites the caller's nBytes[] with the low-band lengths (AGR_BWE_decode_frame_FIX.c:150-169)
-    int32_t nb0 = (lostflag == 2) ? n0 : n0 - SX_HB_BYTES;
-    int32_t nb1 = n1 ? n1 - SX_HB_BYTES : 0;
+    const int32_t hbb = ctrl_hb_joint(h->b->dec_ctrl.joint_enable, h->b->dec_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    int32_t nb0 = (lostflag == 2) ? n0 : n0 - hbb;
+    int32_t nb1 = n1 ? n1 - hbb : 0;
     nBytes[0] = (int16_t)(nb0 - nb1);
     nBytes[1] = (int16_t)nb1;
     if (ret < 0) return ret;

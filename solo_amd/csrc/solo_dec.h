@@ -84,6 +84,7 @@ struct SxDecState {
     // high band + QMF (AGR_Sate_decoder_hb_state_FIX / AGR_Sate_HB_decoder_control_FIX)
     i32 hb_lossCnt;
     i32 hb_first;
+    i32 hb_joint;                // joint_mode 1: ONE 40 ms high-band frame per packet (4 HB bytes instead of 8)
     i32 HB_prev_NLSFq[SX_HB_LPC];
     i32 HB_synth_state[SX_HB_LPC];
     i32 HB_prev_Gain;
@@ -140,7 +141,7 @@ struct SxDecWork {
 // payload is parsed; every field touched by that switch has the same value here, so the state after
 // the first received packet is identical.  (A LOST first packet would run the 24 kHz PLC + resampler
 // in the reference; that corner is out of scope -- see DESIGN.md.)
-SX_HD void sx_dec_state_init(SxDecState* st) {
+SX_HD void sx_dec_state_init(SxDecState* st, int hb_joint = 0) {
     u8* p = (u8*)st;
     SX_PAR(i, (int)sizeof(SxDecState)) p[i] = 0;
     wv_sync();
@@ -150,6 +151,7 @@ SX_HD void sx_dec_state_init(SxDecState* st) {
     st->md[0].LastGainIndex = 1;
     st->md[1].LastGainIndex = 1;
     st->hb_first = 1;
+    st->hb_joint = hb_joint;
     // CNG / PLC are (re)initialised on the first call because their fs_kHz field is 0
     wv_sync();
 }
@@ -917,7 +919,9 @@ SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* 
     const int lost = (lostflag == 1 || lostflag == 2);
     SX_T_BEGIN
     if (lost) { SX_PAR(i, SX_SUBFR) zero[i] = 0; }
-    SX_PAR(f, 2) {
+    const int nf = st->hb_joint ? 1 : 2;          // high-band frames per packet
+    const int sub_len = st->hb_joint ? 2 * SX_SUBFR : SX_SUBFR;   // BWE_SubFrameSize
+    SX_PAR(f, nf) {
         i32* l = &lsp[f * SX_HB_LPC];
         if (lost) {
             for (int i = 0; i < SX_HB_LPC; i++) l[i] = st->HB_prev_NLSFq[i];
@@ -935,7 +939,7 @@ SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* 
     SX_PAR(i, SX_QMF_HIST) w->u.hi[i] = st->qmf_hi_hist[i];      // (the high-band buffer shares its LDS with the workspace above)
     wv_sync();
     SX_T(8)
-    for (int f = 0; f < 2; f++) {
+    for (int f = 0; f < nf; f++) {
         const i32* QHB_LSP = &lsp[f * SX_HB_LPC];
         const i32* QGain = &gains[f * 4];
         if (lost) {
@@ -947,12 +951,14 @@ SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* 
             }
             st->hb_lossCnt = 0;
         }
-        const i32* exc = f == 0 ? exc0 : exc1;
         for (int k = 0; k < 4; k++) {
-            // excitation = low-band excitation (zero when the high band is lost: decode_frame_FIX.c:65)
-            const i32* ex = lost ? zero : &exc[k * SX_SUBFR];
-            sx_hb_lpc_synthesis(ex, &lpc[f * SX_MAX_LPC], sx_mul(-2867, (i32)(i16)QGain[k]), st->HB_synth_state,
-                                &OutHigh[f * SX_FRAME + k * SX_SUBFR], SX_SUBFR);
+            // excitation = low-band excitation of the samples under this subframe (zero when the high band is lost:
+            // decode_frame_FIX.c:65); sample n of the packet lives in exc0 for n < 160, in exc1 after
+            const int n0 = f * SX_FRAME + k * sub_len;
+            const i32* ex = lost ? zero : (n0 < SX_FRAME ? &exc0[n0] : &exc1[n0 - SX_FRAME]);
+            for (int h = 0; h < sub_len; h += SX_SUBFR)          // (zero[] is one 40-sample block: feed long subframes in halves)
+                sx_hb_lpc_synthesis(lost ? zero : ex + h, &lpc[f * SX_MAX_LPC], sx_mul(-2867, (i32)(i16)QGain[k]), st->HB_synth_state,
+                                    &OutHigh[n0 + h], SX_SUBFR);
         }
         if (lostflag == 0 || lostflag == 4 || lostflag == 3) {
             st->HB_prev_Gain = QGain[3];
@@ -997,8 +1003,9 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
                            int useMDIndex, i16* pcm_out) {
     SxDecState* st = &w->st;
     if (nBytes0 <= 0) return -1;
-    i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - SX_HB_BYTES;
-    i32 nB1 = nBytes1 ? nBytes1 - SX_HB_BYTES : 0;
+    const i32 hb_bytes = st->hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;     // (QMF_HB_FrameSize / BWE_FrameSize) * HB_BYTE
+    i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - hb_bytes;
+    i32 nB1 = nBytes1 ? nBytes1 - hb_bytes : 0;
     const i32 hb_pos = nB0;
     nB0 -= nB1;
     SxRangeDec rc[2];

@@ -40,7 +40,7 @@ struct SxFrontWork {                 // LDS scratch of the per-frame analysis ch
 struct SxHbWork {                    // LDS scratch of the high-band encoder
     i16 x_hb_buf[SX_HB_XBUF];
     i16 lpc_in[4 * 88];
-    i16 exc[SX_FRAME];
+    i16 exc[2 * SX_FRAME];
     i32 NLSF_Q15[SX_MAX_LPC];
     i32 weight[SX_MAX_LPC];
     i16 A_Q12[SX_MAX_LPC];
@@ -210,22 +210,25 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
 // ---------------------------------------------------------------------------------------------------
 // high band
 // ---------------------------------------------------------------------------------------------------
-// AGR_Bwe_encode_frame_FIX (AGR_BWE_encode_frame_FIX.c:8) for one 20 ms high-band frame; writes its 4 payload bytes.
-// `high`: 160 new high-band samples, `residue`: centre excitation Q10 of the matching SILK frame (both in HBM)
-SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue, SxHbWork* hw, u8* out4) {
+// AGR_Bwe_encode_frame_FIX (AGR_BWE_encode_frame_FIX.c:8) for one high-band frame of N samples (BWE_FrameSize: 160 = 20 ms, or
+// 320 = the 40 ms frame of joint_mode 1, AGR_BWE_SDK_API.c:64-67); writes its 4 payload bytes.
+// `high`: N new high-band samples; residue0 / residue1: centre excitation Q10 of the SILK frame(s) under it (HBM; sample n of the
+// high-band frame takes residue0[n] for n < 160, residue1[n - 160] after)
+SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue0, const i32* residue1, SxHbWork* hw, u8* out4, int N) {
     SX_IN_LDS(hw); SX_IN_LDS(out4);
     i16* xb = hw->x_hb_buf;
     i16* lpc_in = hw->lpc_in;
     i16* exc = hw->exc;
-    SX_PAR(i, SX_FRAME + 40) xb[i] = hist->x_hb_buf[i];
-    SX_PAR(i, SX_FRAME) xb[SX_FRAME + 40 + i] = high[i];
+    const int sub_len = N >> 2;                  // BWE_SubFrameSize
+    SX_PAR(i, N + 40) xb[i] = hist->x_hb_buf[i];
+    SX_PAR(i, N) xb[N + 40 + i] = high[i];
     wv_sync();
     // AGR_Sate_find_HB_LPC_FIX: four 10 ms blocks, each with 8 samples of history; the window runs past the
     // written part of the reference's buffer (zeros)
     SX_PAR(t, 4 * 88) {
         const int k = t / 88, j = t - k * 88;
-        const int src = SX_FRAME - SX_HB_LPC + k * 80 + j;
-        lpc_in[t] = src < SX_HB_XBUF ? xb[src] : (i16)0;
+        const int src = N - SX_HB_LPC + k * 80 + j;
+        lpc_in[t] = src < 2 * N + 40 ? xb[src] : (i16)0;
     }
     wv_sync();
     i32 res_nrg, res_nrg_Q;
@@ -280,10 +283,10 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     sx_nlsf2a_stable_ws(A_Q12, NLSF_Q15, SX_HB_LPC, hw->ws);
     wv_sync();
     u32 word = (u32)hb_lsp_idx << 20;
-    // the four 5 ms blocks are filtered from zero state (the reference calls the filter once per block)
-    SX_PAR(t, SX_FRAME) {
-        const int sub = t / 40, k = t - sub * 40;
-        const i16* in = xb + SX_FRAME + sub * 40;
+    // the four blocks of N / 4 samples are filtered from zero state (the reference calls the filter once per block)
+    SX_PAR(t, N) {
+        const int sub = t / sub_len, k = t - sub * sub_len;
+        const i16* in = xb + N + sub * sub_len;
         i32 acc = 0;
         for (int j = 0; j < SX_HB_LPC; j++) {
             int u = k - 1 - j;
@@ -295,10 +298,11 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     for (int sub = 0; sub < 4; sub++) {
         i32 res_nrg0 = 0, res_nrg1 = 0;
-        SX_PAR(i, 40) {
-            const i32 e = exc[sub * 40 + i];
+        SX_PAR(i, sub_len) {
+            const int n = sub * sub_len + i;
+            const i32 e = exc[n];
             res_nrg0 = sx_add(res_nrg0, sx_mul(e, e));
-            i32 tmp = residue[sub * 40 + i] >> 10;
+            i32 tmp = (n < SX_FRAME ? residue0[n] : residue1[n - SX_FRAME]) >> 10;
             res_nrg1 = sx_smlabb(res_nrg1, tmp, tmp);
         }
         res_nrg0 = wv_sum(res_nrg0);
@@ -318,7 +322,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     }
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
     // slide the buffer: the last 200 samples are the next frame's history
-    SX_PAR(i, SX_FRAME + 40) hist->x_hb_buf[i] = xb[SX_FRAME + i];
+    SX_PAR(i, N + 40) hist->x_hb_buf[i] = xb[N + i];
     wv_sync();
 }
 
@@ -450,10 +454,17 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SX_T_BEGIN
-    for (int frame = 0; frame < 2; frame++) {
-        sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, &w->u.hb, &w->hb_bytes[4 * frame]);
+    const int hb_bytes = st->hb_joint ? 4 : 8;
+    if (st->hb_joint) {
+        sx_hb_encode_frame(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[0], 2 * SX_FRAME);
         wv_sync();
         SX_T(9)
+    } else {
+        for (int frame = 0; frame < 2; frame++) {
+            sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[4 * frame], SX_FRAME);
+            wv_sync();
+            SX_T(9)
+        }
     }
     SX_PAR(i, (int)(2 * sizeof(SxFrameIdx) / 4)) ((i32*)&w->idx[0])[i] = ((const i32*)&cin->idx[0])[i];
     wv_sync();
@@ -494,7 +505,7 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
 #endif
     wv_sync();
     SX_T(10)
-    const i32 total = nBytes_md[0] + nBytes_md[1] + 8;
+    const i32 total = nBytes_md[0] + nBytes_md[1] + hb_bytes;
     if (err_md[0] || err_md[1] || total > buf_size || nBytes_md[0] > SX_MAX_ARITHM_BYTES || nBytes_md[1] > SX_MAX_ARITHM_BYTES) {
         nBytesOut[0] = 0;
         nBytesOut[1] = 0;
@@ -508,7 +519,7 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
         bits[i] = b;
     }
     nBytesOut[0] = (i16)total;
-    nBytesOut[1] = (i16)(nBytes_md[1] + 8);
+    nBytesOut[1] = (i16)(nBytes_md[1] + hb_bytes);
     wv_sync();
     SX_T(11)
     return total;

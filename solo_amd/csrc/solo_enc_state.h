@@ -22,7 +22,7 @@
 #define SX_N_TRACKS 3                // centre, MD1, MD2
 #define SX_WARPING_Q16 (8 * K_WARPING_MULTIPLIER_Q16)    // setup_complexity.h:82
 #define SX_MSVQ_SURVIVORS 16
-#define SX_HB_XBUF 360               // live part of x_hb_buf_fix (BWE_FrameSize*2 + lb_Delay*hb_KHz)
+#define SX_HB_XBUF 680               // x_hb_buf_fix: BWE_FrameSize*2 + lb_Delay*hb_KHz (360 live words with 20 ms high-band frames, 680 with joint_mode 1)
 
 struct SxVAD {                       // SKP_Silk_VAD_state, SKP_Silk_structs.h:69
     i32 AnaState[2], AnaState1[2], AnaState2[2];
@@ -56,6 +56,7 @@ struct SxEncState {
     i32 variable_HP_smth1_Q15, variable_HP_smth2_Q15;
     i32 In_HP_State[2];
     i32 useMDIndex;
+    i32 hb_joint;                    // joint_mode 1: ONE 40 ms high-band frame per packet (4 HB bytes instead of 8)
     SxVAD vad;
     // shape / prefilter / prediction states (SKP_Silk_structs_FIX.h:44-73)
     i32 LastGainIndex, HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16;
@@ -75,7 +76,7 @@ struct SxEncHist {
     i16 x_buf[SX_FRAME + SX_LA_SHAPE];           // samples [0, 200) of the analysis buffer; [200, 360) is new every frame
     i16 pf_sLTP_shp[SX_LTP_BUF];                 // prefilter's harmonic-shaping ring
     i16 qmf_hist[63 + 1];                        // last 63 input samples >> 1 (h0_mem of the reference, time order)
-    i16 x_hb_buf[SX_FRAME + SX_LA_SHAPE];        // high-band analysis history (BWE_FrameSize + lb_Delay*hb_KHz = 200 samples)
+    i16 x_hb_buf[2 * SX_FRAME + SX_LA_SHAPE];    // high-band analysis history (BWE_FrameSize + lb_Delay*hb_KHz = 200 samples; 360 with joint_mode 1)
     // hand-over between the phases of one packet
     i16 lo[SX_BAND], hi[SX_BAND];
 };
@@ -148,7 +149,7 @@ struct SxEncCtrl {
 // SKP_Silk_init_encoder_FIX (SKP_Silk_init_encoder_FIX.c:33) + the first SKP_Silk_control_encoder_FIX
 // pass (control_codec_FIX.c:56-130: setup_fs(8), setup_rate, ...) + AGR_Sate_Encoder_Init
 // (libBWE/AGR_BWE_SDK_API.c:11-126).  `silk_rate_bps` = targetRate_bps - 1600.
-SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex) {
+SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex, i32 hb_joint = 0) {
     u8* p = (u8*)rec;
     SX_PAR(i, (int)sizeof(SxEncStream)) p[i] = 0;
     wv_sync();
@@ -157,6 +158,7 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
     st->variable_HP_smth2_Q15 = 200844;
     st->first_frame_after_reset = 1;
     st->useMDIndex = useMDIndex;
+    st->hb_joint = hb_joint;
     // SKP_Silk_VAD_Init, SKP_Silk_VAD.c:39
     for (int b = 0; b < 4; b++) {
         st->vad.NoiseLevelBias[b] = sx_max(50 / (b + 1), 1);

@@ -17,10 +17,10 @@ extern "C" {
 
 struct EmuDec { SxDecState st; SxDecWork w; int useMDIndex; };
 
-void* emu_dec_create(int useMDIndex) {
+void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argument: joint_mode 1 (40 ms high-band frame)
     EmuDec* d = (EmuDec*)calloc(1, sizeof(EmuDec));
-    sx_dec_state_init(&d->st);
-    d->useMDIndex = useMDIndex;
+    sx_dec_state_init(&d->st, (useMDIndex >> 1) & 1);
+    d->useMDIndex = useMDIndex & 1;
     return d;
 }
 void emu_dec_destroy(void* h) { free(h); }
@@ -43,9 +43,10 @@ extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 // ---- encoder ----
 extern "C" {
 struct EmuEnc { SxEncStream rec; SxEncWork w; SxCodeIn cin; };
-void* emu_enc_create(int rate_bps, int useMDIndex) {
+void* emu_enc_create(int rate_bps, int useMDIndex) {        // bit 1 of the second argument: joint_mode 1
     EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
-    sx_enc_state_init(&e->rec, rate_bps - 1600, useMDIndex);   // AGR_BWE_SDK_API.c:119: SILK rate = target - 1600
+    const int joint = (useMDIndex >> 1) & 1;
+    sx_enc_state_init(&e->rec, rate_bps - (joint ? 800 : 1600), useMDIndex & 1, joint);   // AGR_BWE_SDK_API.c:119
     return e;
 }
 void emu_enc_destroy(void* h) { free(h); }

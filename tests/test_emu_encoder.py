@@ -50,3 +50,26 @@ def test_round_trip_through_emu_decoder():
             pl, n0, n1 = e.encode(z["pcm"][i, p])
             x, ret = d.decode(*R.map_loss(pl, n0, n1, False, False))
             assert ret == 0 and np.array_equal(x, z["dec_clean"][i, p])
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present")
+def test_joint_mode_1_encoder_and_decoder_vs_reference():
+    """`-joint 1` of the reference CLI (one 40 ms high-band frame per packet, 4 high-band bytes, SILK rate = target - 800):
+    kernel source (host emulation) against the compiled reference, encoder and decoder with description loss."""
+    P = 12
+    for seed in (500, 501, 502):
+        pcm = R.synth_stream(seed, P)
+        er, ee = R.RefEncoder("fix", joint=1), T.EmuEncoder(13600, 2)          # bit 1 of the emulation's flag word = joint
+        recs = []
+        for p in range(P):
+            a, b = er.encode(pcm[p]), ee.encode(pcm[p])
+            assert a == b, (seed, p, a[1:], b[1:])
+            recs.append(a)
+        recv = T.bernoulli_recv(1, P, 0.3, seed)[0]
+        dr, de = R.RefDecoder("fix", joint=1), T.EmuDecoder(2)
+        for p, (pl, n0, n1) in enumerate(recs):
+            m = int(recv[p])
+            args = R.map_loss(pl, n0, n1, not (m & 1), not (m & 2))
+            x, r1 = dr.decode(*args)
+            y, r2 = de.decode(*args)
+            assert r1 == r2 == 0 and np.array_equal(x, y), (seed, p, m)

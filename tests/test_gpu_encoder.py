@@ -166,3 +166,29 @@ def test_legacy_single_stream_api(torch_cuda):
         assert (n, int(nbv[0]), int(nbv[1])) == (len(recs[p][0]), recs[p][1], recs[p][2]), p
         assert buf[:n].tobytes() == recs[p][0], p
     lib.AGR_Sate_Encoder_Uninit(h)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_joint_mode_1_round_trip_vs_compiled_reference(torch_cuda):
+    """`-joint 1` (one 40 ms high-band frame per packet, 4 high-band bytes): encoder bitstreams and
+    decoder PCM (with description loss) through the C ABI against the compiled reference."""
+    import solo_amd
+    torch = torch_cuda
+    N, P = 12, 10
+    pcm = np.stack([R.synth_stream(600 + i, P) for i in range(N)])
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512, joint=1)
+    bits, nb, st = b.encode(torch.from_numpy(pcm).to(b.device))
+    recv = T.bernoulli_recv(N, P, 0.3, 5)
+    out, st2 = b.decode(bits, nb, torch.from_numpy(recv).to(b.device))
+    torch.cuda.synchronize()
+    assert int(st.abs().max()) == 0 and int(st2.abs().max()) == 0
+    hb, hn, ho = bits.cpu().numpy(), nb.cpu().numpy(), out.cpu().numpy()
+    for i in range(N):
+        e, d = R.RefEncoder("fix", joint=1), R.RefDecoder("fix", joint=1)
+        for p in range(P):
+            pl, n0, n1 = e.encode(pcm[i, p])
+            assert (int(hn[i, p, 0]), int(hn[i, p, 1])) == (n0, n1), (i, p)
+            assert hb[i, p, :n0].tobytes() == pl, (i, p)
+            m = int(recv[i, p])
+            x, ret = d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0 and np.array_equal(ho[i, p], x), (i, p, m)
