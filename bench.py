@@ -197,7 +197,7 @@ def main():
 
     if rank == 0:
         # algorithmic HBM bytes per packet of each kernel: stage input + stage output that has to cross HBM
-        rec_in, rec_out, rec_code = 660.0, 964.0, 840.0       # sizeof SxNsqIn / SxNsqOut / SxCodeIn
+        rec_in, rec_out, rec_code = 660.0, 964.0, 848.0       # sizeof SxNsqIn / SxNsqOut / SxCodeIn
         alg = {"analysis": 1280.0 + 2 * rec_in + rec_code, "quantiser": 2 * rec_in + 2 * rec_out,
                "coding": 2 * rec_out + rec_code + mean_payload + 4.0, "decode": mean_payload + 4.0 + 1280.0}
         kname = {"analysis": "solo_enc_analysis_kernel", "quantiser": "solo_nsq_kernel", "coding": "solo_enc_coding_kernel",

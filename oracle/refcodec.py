@@ -60,9 +60,9 @@ def load_ref(kind="fix"):
     return _libs[kind]
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0):
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0):
     # defaults of the reference CLI: JC1_SDK_SRC_ARM/test/enc_main.c:92-99; joint=1: `-joint 1` (40 ms high-band frame)
-    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=0,
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=1 if dtx else 0,
                          framesize_ms=40, joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
@@ -72,9 +72,9 @@ def default_dec_ctrl(use_md_index=0, joint=0):
 
 
 class RefEncoder:
-    def __init__(self, kind="fix", rate=13600, joint=0):
+    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0):
         self.lib = load_ref(kind)
-        self.ctrl = default_enc_ctrl(rate, joint=joint)
+        self.ctrl = default_enc_ctrl(rate, joint=joint, dtx=dtx)
         self.h = self.lib.AGR_Sate_Encoder_Init(C.byref(self.ctrl))
         assert self.h
         self._bits = np.zeros(MAX_FRAME_BYTES, np.uint8)

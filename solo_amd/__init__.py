@@ -86,10 +86,10 @@ def load_library():
     return lib
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0):
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0):
     """Defaults of the reference CLI (JC1_SDK_SRC_ARM/test/enc_main.c:92-99); joint=1 is its `-joint 1`: one 40 ms high-band
     frame per packet (4 high-band bytes instead of 8)."""
-    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=0, framesize_ms=40,
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=1 if dtx else 0, framesize_ms=40,
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
@@ -101,7 +101,7 @@ def default_dec_ctrl(use_md_index=0, joint=0):
 class SoloBatch:
     """N independent SOLO streams on the current HIP device (one wavefront per stream)."""
 
-    def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0):
+    def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0, dtx=0):
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("solo_amd needs a HIP device (MI355X); there is no CPU path")
@@ -109,7 +109,7 @@ class SoloBatch:
         self.lib = load_library()
         self.n_streams = int(n_streams)
         self.slot = int(slot_bytes)
-        self._enc = default_enc_ctrl(rate, use_md_index, joint) if encoder else None
+        self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx) if encoder else None
         self._dec = default_dec_ctrl(use_md_index, joint) if decoder else None
         self.h = self.lib.solo_batch_create(self.n_streams, C.byref(self._enc) if encoder else None,
                                             C.byref(self._dec) if decoder else None, self.slot)

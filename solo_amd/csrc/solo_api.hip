@@ -60,7 +60,7 @@ __global__ void __launch_bounds__(64, 4) solo_decode_kernel(SxDecState* states, 
         const size_t pk = (size_t)s * n_packets + p;
         const u8* b = bits + pk * (size_t)slot;
         const i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
-        const int m = recv ? (recv[pk] & 3) : 3;
+        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);      // an empty (DTX) packet is a lost packet, like test/dec_main.c:236-252
         // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
         int lostflag;
         i32 a0, a1;
@@ -68,7 +68,7 @@ __global__ void __launch_bounds__(64, 4) solo_decode_kernel(SxDecState* states, 
         if (m == 3) { lostflag = 4; a0 = n0; a1 = n1; }
         else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
         else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
-        else { lostflag = 1; a0 = n0; a1 = n1; }
+        else { lostflag = 1; a0 = n0 > 0 ? n0 : 16; a1 = n0 > 0 ? n1 : 0; }
         i16* out = pcm + pk * SX_PACKET;
         int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
         if (ret < 0 && first_err == 0) first_err = ret;
@@ -137,10 +137,10 @@ __global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* st
 }
 
 #ifdef SOLO_WITH_ENCODER
-__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint) {
+__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint);
+    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX);
 }
 
 // Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
@@ -234,7 +234,7 @@ struct solo_batch {
 // joint_enable = 0, or joint_mode 1 (one 40 ms high-band frame per packet, AGR_BWE_SDK_API.c:64-67); the other joint modes are
 // "reserved" in the reference as well
 static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
-    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1) && c->dtx_enable == 0;
+    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
 }
 static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
     return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
@@ -250,7 +250,7 @@ static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
     // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the high-band share, 1600 * 20 / bwe_framesize_ms
     const int joint = ctrl_hb_joint(b->enc_ctrl.joint_enable, b->enc_ctrl.joint_mode);
     hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncStream*)b->d_enc_state, b->n_streams,
-                       b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint);
+                       b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint, b->enc_ctrl.dtx_enable ? 1 : 0);
     SOLO_CHECK(hipGetLastError());
     return 0;
 }
@@ -534,6 +534,8 @@ int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int
     int16_t nb[2];
     if (hipMemcpy(nb, h->d_nbytes, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     int32_t n = nb[0];
+    if (n == 0 && h->b->enc_ctrl.dtx_enable)                                 // DTX packet: the reference still returns the high-band bytes
+        n = ctrl_hb_joint(h->b->enc_ctrl.joint_enable, h->b->enc_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     if (n > bufSize) n = bufSize;                                            // AGR_Sate_bits_write truncates to max_nbytes
     if (n > 0 && hipMemcpy(bits, h->d_bits, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     nBytesOut[0] = nb[0];

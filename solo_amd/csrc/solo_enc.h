@@ -16,6 +16,7 @@ struct SxFrameIdx {
     i32 NLSFIndices[6], NLSFInterpCoef_Q2;
     i32 lagIndex, contourIndex, PERIndex, LTPIndex[SX_NB_SUBFR], LTP_scaleIndex;
     i32 Seed, vadFlag;
+    i32 inDTX, pad_;                 // DTX state after this frame (SKP_Silk_encode_frame_FIX.c:155-171); the packet is dropped if set after frame 1
 };
 
 struct SxCodeWork {                  // LDS: range-coder byte buffers of the two descriptions + the coding tables
@@ -415,6 +416,7 @@ SX_FN void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, 
     x->LTP_scaleIndex = c->LTP_scaleIndex;
     x->Seed = c->Seed;                 // (replaced by the quantiser's winning seed in the coding stage)
     x->vadFlag = st->vadFlag;
+    x->inDTX = st->inDTX; x->pad_ = 0;
     // cross-frame parameters (encode_frame_FIX.c:203-212)
     st->prev_sigtype = c->sigtype;
     st->prevLag = c->pitchL[SX_NB_SUBFR - 1];
@@ -468,6 +470,13 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
     }
     SX_PAR(i, (int)(2 * sizeof(SxFrameIdx) / 4)) ((i32*)&w->idx[0])[i] = ((const i32*)&cin->idx[0])[i];
     wv_sync();
+    if (st->useDTX && w->idx[1].inDTX) {         // "DTX simulation" (SKP_Silk_enc_API.c:260-265): the packet is analysed, quantised
+        nBytesOut[0] = 0;                        // and its high band encoded (all states move on), but nothing is sent.
+        nBytesOut[1] = 0;                        // (The reference's bit buffer then holds just the high-band bytes and its Encode
+        SX_PAR(i, hb_bytes) bits[i] = w->hb_bytes[i];   // returns their count; mirrored: they sit at the start of the slot.)
+        wv_sync();
+        return hb_bytes;
+    }
     w->idx[0].Seed = out2[0].Seed;
     w->idx[1].Seed = out2[1].Seed;
     wv_sync();

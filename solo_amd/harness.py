@@ -2,8 +2,8 @@
 test/enc_main.c and read by test/dec_main.c, and the loss simulator of the decoder CLI, so that files produced here
 interoperate with the stock reference binaries and their known-answer md5s can be matched end to end.
 
-  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1]
-  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-MDI 0/1]
+  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1]
+  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-MDI 0/1] [-joint 1]
 
 Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per 40 ms packet  int16 total, int16 len(MD2)+8, `total` payload bytes
 (payload = MD1 || MD2 || HB(8)).  Loss simulator (test/dec_main.c:24,236-252): rand_seed = 1, the LCG
@@ -42,8 +42,9 @@ def write_bit_container(recs):
     return bytes(out)
 
 
-def cli_loss_pattern(n_packets, loss_perc):
-    """[(lost_md1, lost_md2)] per packet, exactly the draws of `dec_main -loss P`"""
+def cli_loss_pattern(n_packets, loss_perc, nbytes=None):
+    """[(lost_md1, lost_md2)] per packet, exactly the draws of `dec_main -loss P`.  nbytes (optional): [(total, len(MD2)+HB)] per
+    packet -- an empty (DTX) packet drawn on an even packet counts as lost, like the CLI's `counter > 0` / `nBytes[j] == 0` tests."""
     seed, lost, out = 1, [0, 0], []
     thr = np.float32(loss_perc) / np.float32(100.0)
     for p in range(n_packets):
@@ -52,7 +53,8 @@ def cli_loss_pattern(n_packets, loss_perc):
                 seed = (907633515 + seed * 196314165) & 0xFFFFFFFF
                 s = seed - (1 << 32) if seed & 0x80000000 else seed
                 v = np.float32((s >> 16) + (1 << 15)) / np.float32(65535.0)
-                lost[j] = 0 if v >= thr else 1
+                empty = nbytes is not None and (nbytes[p][0] <= 0 or nbytes[p][j] == 0)
+                lost[j] = 0 if (v >= thr and not empty) else 1
         out.append(tuple(lost))
     return out
 
@@ -62,7 +64,7 @@ def recv_mask(pattern):
     return np.array([(0 if l1 else 1) | (0 if l2 else 2) for l1, l2 in pattern], np.uint8)
 
 
-def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088):
+def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0):
     """int16 array (16 kHz mono) -> [(payload, total, len(MD2)+8)]; a trailing partial packet is dropped like the CLI does"""
     import torch
     from . import SoloBatch
@@ -70,7 +72,7 @@ def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088):
     P = pcm.size // PACKET_SAMPLES
     if P == 0:
         return []
-    b = SoloBatch(1, rate=rate, encoder=True, decoder=False, slot_bytes=slot_bytes, use_md_index=use_md_index)
+    b = SoloBatch(1, rate=rate, encoder=True, decoder=False, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, dtx=dtx)
     x = torch.from_numpy(np.ascontiguousarray(pcm[:P * PACKET_SAMPLES].reshape(1, P, PACKET_SAMPLES))).to(b.device)
     bits, nb, st = b.encode(x)
     torch.cuda.synchronize()
@@ -80,7 +82,7 @@ def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088):
     return [(hb[p, :hn[p, 0]].tobytes(), int(hn[p, 0]), int(hn[p, 1])) for p in range(P)]
 
 
-def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088):
+def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0):
     """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation"""
     import torch
     from . import SoloBatch
@@ -94,8 +96,8 @@ def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088):
             raise ValueError("packet %d: %d bytes exceed the slot" % (p, n0))
         bits[0, p, :n0] = np.frombuffer(pl[:n0], np.uint8)
         nb[0, p] = (n0, n1)
-    mask = recv_mask(cli_loss_pattern(P, loss_perc))[None, :]
-    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index)
+    mask = recv_mask(cli_loss_pattern(P, loss_perc, [(r[1], r[2]) for r in recs]))[None, :]
+    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint)
     pcm, st = b.decode(torch.from_numpy(bits).to(b.device), torch.from_numpy(nb).to(b.device),
                        torch.from_numpy(np.ascontiguousarray(mask)).to(b.device))
     torch.cuda.synchronize()
@@ -118,11 +120,13 @@ def main(argv=None):
         return 2
     mdi = _opt(argv, "-MDI", 0)
     if argv[0] == "enc":
-        recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi)
+        recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi,
+                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0))
         open(argv[2], "wb").write(write_bit_container(recs))
         print("%d packets, %.3f kbps" % (len(recs), sum(r[1] for r in recs) * 8 / max(len(recs), 1) / 40.0))
     else:
-        pcm = decode_records(parse_bit_container(open(argv[1], "rb").read()), loss_perc=_opt(argv, "-loss", 0), use_md_index=mdi)
+        pcm = decode_records(parse_bit_container(open(argv[1], "rb").read()), loss_perc=_opt(argv, "-loss", 0), use_md_index=mdi,
+                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0)
         pcm.astype(np.int16).tofile(argv[2])
         print("%d packets decoded" % (pcm.size // PACKET_SAMPLES))
     return 0

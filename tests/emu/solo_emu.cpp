@@ -43,10 +43,10 @@ extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 // ---- encoder ----
 extern "C" {
 struct EmuEnc { SxEncStream rec; SxEncWork w; SxCodeIn cin; };
-void* emu_enc_create(int rate_bps, int useMDIndex) {        // bit 1 of the second argument: joint_mode 1
+void* emu_enc_create(int rate_bps, int useMDIndex) {        // bit 1 of the second argument: joint_mode 1, bit 2: DTX
     EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
     const int joint = (useMDIndex >> 1) & 1;
-    sx_enc_state_init(&e->rec, rate_bps - (joint ? 800 : 1600), useMDIndex & 1, joint);   // AGR_BWE_SDK_API.c:119
+    sx_enc_state_init(&e->rec, rate_bps - (joint ? 800 : 1600), useMDIndex & 1, joint, (useMDIndex >> 2) & 1);   // AGR_BWE_SDK_API.c:119
     return e;
 }
 void emu_enc_destroy(void* h) { free(h); }

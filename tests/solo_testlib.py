@@ -122,7 +122,7 @@ class EmuEncoder:
         bits = np.zeros(1100, np.uint8)
         nb = np.zeros(2, np.int16)
         n = self.lib.emu_enc_packet(self.h, pcm.ctypes.data, bits.ctypes.data, 1024, nb.ctypes.data)
-        return bits[:n].tobytes(), int(nb[0]), int(nb[1])
+        return bits[:max(n, 0)].tobytes(), int(nb[0]), int(nb[1])
 
     def __del__(self):
         if getattr(self, "h", None):

@@ -73,3 +73,33 @@ def test_joint_mode_1_encoder_and_decoder_vs_reference():
             x, r1 = dr.decode(*args)
             y, r2 = de.decode(*args)
             assert r1 == r2 == 0 and np.array_equal(x, y), (seed, p, m)
+
+
+def _dtx_signal(seed, P):
+    rng = np.random.default_rng(seed)
+    pcm = R.synth_stream(seed, P).copy()
+    pcm[4:30] = (rng.standard_normal((26, 640)) * 3).astype(np.int16)      # a second of near-silence: DTX engages, and times out once
+    return pcm
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present")
+@pytest.mark.parametrize("joint", [0, 1])
+def test_dtx_vs_reference(joint):
+    """`-DTX 1` (SKP_Silk_encode_frame_FIX.c:155-171, SKP_Silk_enc_API.c:260-265): packets are analysed and quantised but not sent
+    while the encoder is in DTX (nBytesOut = {0, 0}; Encode still returns the high-band bytes); empty packets decode as lost."""
+    P = 40
+    pcm = _dtx_signal(700, P)
+    er, ee = R.RefEncoder("fix", dtx=1, joint=joint), T.EmuEncoder(13600, 4 | (2 if joint else 0))
+    recs = []
+    for p in range(P):
+        a, b = er.encode(pcm[p]), ee.encode(pcm[p])
+        assert a == b, (joint, p, a[1:], b[1:])
+        recs.append(a)
+    sizes = [r[1] for r in recs]
+    assert sizes.count(0) >= 15 and sizes[-1] > 0 and any(s > 0 for s in sizes[8:30])     # DTX engaged, timed out once, ended
+    dr, de = R.RefDecoder("fix", joint=joint), T.EmuDecoder(2 if joint else 0)
+    for p, (pl, n0, n1) in enumerate(recs):
+        args = (b"", 16, 0, 1) if n0 == 0 else (pl, n0, n1, 4)
+        x, r1 = dr.decode(*args)
+        y, r2 = de.decode(*args)
+        assert r1 == r2 == 0 and np.array_equal(x, y), (joint, p)

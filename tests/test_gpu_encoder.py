@@ -192,3 +192,32 @@ def test_joint_mode_1_round_trip_vs_compiled_reference(torch_cuda):
             m = int(recv[i, p])
             x, ret = d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
             assert ret == 0 and np.array_equal(ho[i, p], x), (i, p, m)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_dtx_round_trip_vs_compiled_reference(torch_cuda):
+    """SURVEY 8(f) rank 3 (second half): `-DTX 1` through the C ABI: empty packets where the reference sends none, identical bytes
+    elsewhere, and the decoder treating empty packets as lost (test/dec_main.c:236-252)."""
+    import solo_amd
+    torch = torch_cuda
+    N, P = 6, 40
+    rng = np.random.default_rng(9)
+    pcm = np.stack([R.synth_stream(800 + i, P) for i in range(N)])
+    for i in range(N):
+        a = 3 + i
+        pcm[i, a:a + 24] = (rng.standard_normal((24, 640)) * 3).astype(np.int16)
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512, dtx=1)
+    bits, nb, st = b.encode(torch.from_numpy(pcm).to(b.device))
+    out, st2 = b.decode(bits, nb, None)
+    torch.cuda.synchronize()
+    assert int(st.abs().max()) == 0 and int(st2.abs().max()) == 0
+    hb, hn, ho = bits.cpu().numpy(), nb.cpu().numpy(), out.cpu().numpy()
+    assert int((hn[:, :, 0] == 0).sum()) >= 10 * N
+    for i in range(N):
+        e, d = R.RefEncoder("fix", dtx=1), R.RefDecoder("fix")
+        for p in range(P):
+            pl, n0, n1 = e.encode(pcm[i, p])
+            assert (int(hn[i, p, 0]), int(hn[i, p, 1])) == (n0, n1), (i, p)
+            assert hb[i, p, :n0].tobytes() == pl[:n0], (i, p)
+            x, ret = d.decode(*((b"", 16, 0, 1) if n0 == 0 else (pl, n0, n1, 4)))
+            assert ret == 0 and np.array_equal(ho[i, p], x), (i, p)
