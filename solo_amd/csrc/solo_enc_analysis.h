@@ -342,6 +342,7 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         wv_sync();
         sx_warped_autocorr4(sw, (i16)warping_Q16);
     }
+    SX_T_BEGIN
     // Schur recursion, warped gain, bandwidth expansion, pre-gains and coefficient limiting: subframe k on lane k
     SX_PAR(k, SX_NB_SUBFR) {
         i32* auto_corr = sw->corr[k];
@@ -376,6 +377,7 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         }
     }
     wv_sync();
+    SX_T(26)
     // gain tweaking
     i32 md_gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, md_SNR_adj_dB_Q7, K_0p16_Q16)));
     i32 gain_mult_Q16 = sx_log2lin(sx_neg(sx_smlawb(-K_16p0_Q7, SNR_adj_dB_Q7, K_0p16_Q16)));

@@ -10,7 +10,7 @@ N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 NAMES = {0: "qmf", 1: "vad+hp", 2: "pitch", 3: "noise_shape", 4: "prefilter", 5: "find_pred_coefs", 6: "process_gains", 7: "nsq",
          8: "frame_end", 9: "hb", 10: "range_coding", 11: "output", 15: "(frame call overhead)",
-         16: "  fpc: ltp+filter", 17: "  fpc: find_LPC total(dup)", 18: "  fpc: interp_search", 19: "  fpc: msvq", 20: "  fpc: res_energy", 21: "  fpc: burg2+a2nlsf", 22: "  fpc: burg2 only", 23: "    burg(all 3): sum_sqr", 24: "    burg(all 3): first row", 25: "    burg(all 3): main loop"}
+         16: "  fpc: ltp+filter", 17: "  fpc: find_LPC total(dup)", 18: "  fpc: interp_search", 19: "  fpc: msvq", 20: "  fpc: res_energy", 21: "  fpc: burg2+a2nlsf", 22: "  fpc: burg2 only", 23: "    burg(all 3): sum_sqr", 24: "    burg(all 3): first row", 25: "    burg(all 3): main loop", 26: "  noise_shape: per-subframe lanes (schur .. limit)"}
 b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
 pcm = torch.from_numpy(synth_batch(0, N, P)).cuda()
 b.encode(pcm); torch.cuda.synchronize()
