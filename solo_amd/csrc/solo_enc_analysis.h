@@ -255,6 +255,177 @@ SX_HD float sx_fdiv(float a, float b) {
 #endif
 }
 
+#ifdef SX_LANE_STREAM
+// ---- order-16 recursions of the noise-shape analysis, one subframe per 16-lane row -------------------------------------------
+// Lane j of row s holds element j of subframe s's coefficient vector in a register; the reference's inner loops over the
+// element index disappear (one step per outer iteration), reversals / broadcasts are lane gathers inside the row, neighbour
+// recursions are DPP row shifts.  Values that the reference holds in scalars are computed redundantly by all lanes of the row.
+#define SX_ROWB(v, jj) __shfl((v), (SX_LANE & 48) | (jj), 64)                 // element jj of the own row, in all of its lanes
+#define SX_ROWG(v, idx) __shfl((v), (SX_LANE & 48) | ((idx) & 15), 64)          // element idx (per lane) of the own row
+#define SX_ROW_NEXT(v) SX_DPP_((v), 0x101)                                      // element j + 1 (row_shl:1; 0 beyond the row)
+
+// SKP_Silk_LPC_inverse_pred_gain_Q24 (SKP_Silk_LPC_inv_pred_gain.c:134 -> :43): a = coefficient j in Q16; returns invGain_Q30 as
+// the reference leaves it (also when it bails out on an unstable filter)
+SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
+    const i32 A_LIMIT = 65520;
+    const int j = SX_LANE & 15;
+    i32 inv = 1 << 30;
+    bool done = false;
+    for (int k = SX_SHAPE_ORDER - 1; k > 0; k--) {
+        const i32 ak = SX_ROWB(a, k);
+        done = done || ak > A_LIMIT || ak < -A_LIMIT;
+        const i32 rc_Q31 = sx_neg(sx_shl(ak, 31 - 16));
+        const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+        i32 m2 = sx_inverse32_varQ(m1, 46);
+        const i32 inv_n = sx_shl(sx_smmul(inv, m1), 2);
+        const int headrm = sx_clz32(m2) - 1;
+        m2 = sx_shl(m2, headrm);
+        const i32 ar = SX_ROWG(a, k - 1 - j);
+        const i32 tmp = sx_sub(a, sx_shl(sx_smmul(ar, rc_Q31), 1));
+        const i32 an = sx_shl(sx_smmul(tmp, m2), 16 - headrm);
+        if (!done) {
+            inv = inv_n;
+            if (j < k) a = an;
+        }
+    }
+    const i32 a0 = SX_ROWB(a, 0);
+    if (!done && !(a0 > A_LIMIT || a0 < -A_LIMIT)) {
+        const i32 rc_Q31 = sx_neg(sx_shl(a0, 31 - 16));
+        const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+        inv = sx_shl(sx_smmul(inv, m1), 2);
+    }
+    return inv;
+}
+
+// x[i-1] = smlawb(x[i-1], x[i], lambda) for i = 15 .. 1 (every element sees its already updated upper neighbour), two vectors
+#define SX_ROW_SUFFIX2(xa, xb, lam_)                                                                                    \
+    for (int step_ = 0; step_ < SX_SHAPE_ORDER - 1; step_++) {                                                           \
+        const i32 ta_ = SX_ROW_NEXT(xa), tb_ = SX_ROW_NEXT(xb);                                                          \
+        if (j == SX_SHAPE_ORDER - 2 - step_) { xa = sx_smlawb(xa, ta_, lam_); xb = sx_smlawb(xb, tb_, lam_); }           \
+    }
+// SKP_Silk_bwexpander_32 with chirp (uniform in the row): element i is scaled by the i-th iterate of tmp <- smulww(chirp, tmp)
+#define SX_ROW_BWE2(xa, xb, chirp_)                                                                                     \
+    {                                                                                                                    \
+        i32 t_ = (chirp_), m_ = t_;                                                                                      \
+        for (int i_ = 1; i_ < SX_SHAPE_ORDER; i_++) { t_ = sx_smulww((chirp_), t_); if (j == i_) m_ = t_; }             \
+        xa = sx_smulww(xa, m_); xb = sx_smulww(xb, m_);                                                                  \
+    }
+
+// Schur recursion .. coefficient limiting of noise_shape_analysis_FIX.c:339-399 for the four subframes at once
+SX_FN void sx_shape_rows(SxShapeWork* sw, SxEncCtrl* c, i32 warping_Q16, i32 BWExp1_Q16, i32 BWExp2_Q16) {
+    SX_IN_LDS(sw); SX_IN_LDS(c);
+    const int s = SX_LANE >> 4, j = SX_LANE & 15;
+    const i32* auto_corr = sw->corr[s];
+    i32 c0 = auto_corr[0];
+    c0 = sx_add(c0, sx_max(sx_smulwb(c0 >> 4, K_SHAPE_WHITE_NOISE_FRACTION_Q20), 1));
+    // ---- SKP_Silk_schur64: C1 = C[j][1]; D = C[j + k + 1][0] at step k (the row is shifted down by one element per step)
+    const bool valid = c0 > 0;
+    i32 C1 = j == 0 ? c0 : auto_corr[j];
+    i32 D = auto_corr[j + 1];
+    i32 rcv = 0;                                     // rc_Q16[j]
+    for (int k = 0; k < SX_SHAPE_ORDER; k++) {
+        const i32 b0 = SX_ROWB(D, 0), c01 = SX_ROWB(C1, 0);
+        const i32 rc_Q31 = sx_div32_varQ(sx_neg(b0), c01, 31);
+        if (j == k) rcv = sx_rshift_round(rc_Q31, 15);
+        const i32 t1 = D, t2 = C1;
+        const bool in = j < SX_SHAPE_ORDER - k;
+        const i32 Dn = in ? sx_add(t1, sx_smmul(sx_shl(t2, 1), rc_Q31)) : t1;
+        if (in) C1 = sx_add(t2, sx_smmul(sx_shl(t1, 1), rc_Q31));
+        D = SX_ROW_NEXT(Dn);
+    }
+    i32 nrg = SX_ROWB(C1, 0);
+    if (!valid) { rcv = 0; nrg = 0; }
+    // ---- SKP_Silk_k2a_Q16
+    i32 A2 = 0;
+    for (int k = 0; k < SX_SHAPE_ORDER; k++) {
+        const i32 rck = SX_ROWB(rcv, k);
+        const i32 g = SX_ROWG(A2, k - 1 - j);
+        if (j < k) A2 = sx_smlaww(A2, g, rck);
+        if (j == k) A2 = sx_neg(sx_shl(rck, 8));
+    }
+    // ---- gain
+    int Qnrg = -sw->scale[s];
+    if (Qnrg & 1) { Qnrg -= 1; nrg >>= 1; }
+    const i32 sq = sx_sqrt_approx(nrg);
+    Qnrg >>= 1;
+    i32 g = sx_lshift_sat32(sq, 16 - Qnrg);
+    {   // warped_gain (noise_shape_analysis_FIX.c:33): Horner from the top coefficient down
+        const i32 lam = -warping_Q16;
+        i32 G = A2;
+        for (int step = 0; step < SX_SHAPE_ORDER - 1; step++) {
+            const i32 t = SX_ROW_NEXT(G);
+            if (j == SX_SHAPE_ORDER - 2 - step) G = sx_smlawb(A2, t, lam);
+        }
+        i32 gain_Q24 = SX_ROWB(G, 0);
+        gain_Q24 = sx_smlawb(K_1p0_Q24, gain_Q24, -lam);
+        g = sx_smulww(g, sx_inverse32_varQ(gain_Q24, 40));
+        if (g < 0) g = SX_I32_MAX;
+    }
+    if (j == 0) c->Gains_Q16[s] = g;
+    // ---- bandwidth expansion: AR2 by BWExp2, AR1 = AR2 further by BWExp1
+    i32 A1;
+    {
+        i32 dummy = 0;
+        SX_ROW_BWE2(A2, dummy, BWExp2_Q16)
+        A1 = A2;
+        SX_ROW_BWE2(A1, dummy, BWExp1_Q16)
+    }
+    // ---- pre-gain from the two inverse prediction gains
+    {
+        i32 pre_nrg_Q30 = sx_row_inv_pred_gain_Q16(sx_rshift_round(A2, 8));
+        const i32 nrg1 = sx_row_inv_pred_gain_Q16(sx_rshift_round(A1, 8));
+        pre_nrg_Q30 = sx_shl(sx_smulwb(pre_nrg_Q30, K_0p7_Q15), 1);
+        if (j == 0) c->GainsPre_Q14[s] = K_0p3_Q14 + sx_div32_varQ(pre_nrg_Q30, nrg1, 14);
+    }
+    // ---- limit_warped_coefs (noise_shape_analysis_FIX.c:52): syn = A2, ana = A1
+    {
+        const i32 limit_Q24 = K_3p999_Q24;
+        i32 lam = -warping_Q16;
+        SX_ROW_SUFFIX2(A2, A1, lam)
+        lam = -lam;
+        i32 nom_Q16 = sx_smlawb(K_1p0_Q16, -lam, lam);
+        i32 gs = sx_div32_varQ(nom_Q16, sx_smlawb(K_1p0_Q24, SX_ROWB(A2, 0), lam), 24);
+        i32 ga = sx_div32_varQ(nom_Q16, sx_smlawb(K_1p0_Q24, SX_ROWB(A1, 0), lam), 24);
+        A2 = sx_smulww(gs, A2);
+        A1 = sx_smulww(ga, A1);
+        bool act = true;                             // this row still iterates
+        for (int iter = 0; iter < 10; iter++) {
+            // largest |coefficient| of the row and its first position
+            const i32 aa = (A2 ^ (A2 >> 31)) - (A2 >> 31), ab = (A1 ^ (A1 >> 31)) - (A1 >> 31);
+            i32 bv = sx_max(aa, ab), bi = j;
+            SX_ARG_STEP(0xB1, >) SX_ARG_STEP(0x4E, >) SX_ARG_STEP(0x141, >) SX_ARG_STEP(0x140, >)
+            const i32 maxabs_Q24 = bv;
+            const int ind = bi;
+            act = act && maxabs_Q24 > limit_Q24;
+            if (__builtin_amdgcn_ballot_w64(act) == 0) break;
+            i32 n2 = A2, n1 = A1;
+            {   // x[i-1] = smlawb(x[i-1], x[i], lambda) for i = 1 .. 15: every element sees its OLD upper neighbour
+                const i32 t2 = SX_ROW_NEXT(n2), t1 = SX_ROW_NEXT(n1);
+                if (j < SX_SHAPE_ORDER - 1) { n2 = sx_smlawb(n2, t2, lam); n1 = sx_smlawb(n1, t1, lam); }
+            }
+            gs = sx_inverse32_varQ(gs, 32);
+            ga = sx_inverse32_varQ(ga, 32);
+            n2 = sx_smulww(gs, n2);
+            n1 = sx_smulww(ga, n1);
+            const i32 chirp_Q16 = K_0p99_Q16 - sx_div32_varQ(sx_smulwb(maxabs_Q24 - limit_Q24, sx_smlabb(K_0p8_Q10, K_0p1_Q10, iter)),
+                                                            sx_mul(maxabs_Q24, ind + 1), 22);
+            SX_ROW_BWE2(n2, n1, chirp_Q16)
+            lam = -lam;
+            SX_ROW_SUFFIX2(n2, n1, lam)
+            lam = -lam;
+            nom_Q16 = sx_smlawb(K_1p0_Q16, -lam, lam);
+            const i32 gs_n = sx_div32_varQ(nom_Q16, sx_smlawb(K_1p0_Q24, SX_ROWB(n2, 0), lam), 24);
+            const i32 ga_n = sx_div32_varQ(nom_Q16, sx_smlawb(K_1p0_Q24, SX_ROWB(n1, 0), lam), 24);
+            n2 = sx_smulww(gs_n, n2);
+            n1 = sx_smulww(ga_n, n1);
+            if (act) { A2 = n2; A1 = n1; gs = gs_n; ga = ga_n; }
+        }
+    }
+    c->AR1_Q13[s * SX_SHAPE_ORDER + j] = (i16)sx_sat16(sx_rshift_round(A1, 11));
+    c->AR2_Q13[s * SX_SHAPE_ORDER + j] = (i16)sx_sat16(sx_rshift_round(A2, 11));
+}
+#endif
+
 // SKP_Silk_noise_shape_analysis_FIX, noise_shape_analysis_FIX.c:137.
 // pitch_res = res_pitch + frame_length; x = x_buf + frame_length; x_windowed: 120-sample scratch (LDS)
 SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, SxShapeWork* sw) {
@@ -343,6 +514,9 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         sx_warped_autocorr4(sw, (i16)warping_Q16);
     }
     SX_T_BEGIN
+#ifdef SX_LANE_STREAM
+    sx_shape_rows(sw, c, warping_Q16, BWExp1_Q16, BWExp2_Q16);
+#else
     // Schur recursion, warped gain, bandwidth expansion, pre-gains and coefficient limiting: subframe k on lane k
     SX_PAR(k, SX_NB_SUBFR) {
         i32* auto_corr = sw->corr[k];
@@ -376,6 +550,7 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
             c->AR2_Q13[k * SX_SHAPE_ORDER + i] = (i16)sx_sat16(sx_rshift_round(AR2_Q24[i], 11));
         }
     }
+#endif
     wv_sync();
     SX_T(26)
     // gain tweaking
