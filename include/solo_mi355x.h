@@ -105,6 +105,15 @@ int32_t solo_batch_decode(solo_batch_t *b, const uint8_t *d_bits, const int16_t 
 int32_t solo_batch_decode_split(solo_batch_t *b, const uint8_t *d_descA, const int16_t *d_lenA, const uint8_t *d_descB,
                                 const int16_t *d_lenB, int32_t slot_bytes, int32_t n_packets, int16_t *d_pcm,
                                 int32_t *d_status, void *hip_stream);
+/* Pipelining consecutive encode calls: with on = 1 solo_batch_encode returns without making `hip_stream` wait for the handle's
+ * internal streams, so the next encode call starts while the tail of this one still runs (the caller passes different output
+ * buffers to calls in flight).  Before consuming the outputs of an encode call on some stream, call
+ * solo_batch_wait_encode(b, stream, which): which = 0 the most recent encode call, 1 the one before; the INPUT buffers of a
+ * call must stay valid and unmodified until then as well (a stream-ordered allocator does not know the handle's internal
+ * streams).  Default: off (every
+ * call is complete on its stream when the next operation of that stream runs). */
+int32_t solo_batch_set_async_join(solo_batch_t *b, int32_t on);
+int32_t solo_batch_wait_encode(solo_batch_t *b, void *hip_stream, int32_t which);
 /* Geometry / introspection */
 int32_t solo_batch_n_streams(const solo_batch_t *b);
 int32_t solo_batch_slot_bytes(const solo_batch_t *b);

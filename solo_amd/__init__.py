@@ -22,7 +22,8 @@ ABI_SYMBOLS = [
     "AGR_Sate_Decoder_Init", "AGR_Sate_Decoder_Decode", "AGR_Sate_Decoder_Uninit",
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
-    "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split",
+    "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split", "solo_batch_set_async_join",
+    "solo_batch_wait_encode",
 ]
 
 
@@ -67,6 +68,10 @@ def load_library():
     lib.solo_batch_decode_split.restype = C.c_int32
     lib.solo_batch_decode_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+    lib.solo_batch_set_async_join.restype = C.c_int32
+    lib.solo_batch_set_async_join.argtypes = [C.c_void_p, C.c_int32]
+    lib.solo_batch_wait_encode.restype = C.c_int32
+    lib.solo_batch_wait_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.solo_batch_last_encode_chunks.restype = C.c_int32
     lib.solo_batch_last_encode_chunks.argtypes = [C.c_void_p]
     lib.solo_kernel_name.restype = C.c_char_p
@@ -153,6 +158,16 @@ class SoloBatch:
         if self.lib.solo_batch_last_kernel_ms(self.h, ms):
             raise RuntimeError("solo_batch_last_kernel_ms failed")
         return dict(zip(("analysis", "quantiser", "coding", "decode"), [float(v) for v in ms]))
+
+    def set_async_join(self, on):
+        """encode() returns without joining its internal streams into the caller's stream (see solo_batch_set_async_join)"""
+        if self.lib.solo_batch_set_async_join(self.h, 1 if on else 0):
+            raise RuntimeError("solo_batch_set_async_join failed")
+
+    def wait_encode(self, which=0):
+        """make the current stream wait for an encode call: which = 0 the most recent one, 1 the one before"""
+        if self.lib.solo_batch_wait_encode(self.h, self._stream(), int(which)):
+            raise RuntimeError("solo_batch_wait_encode failed")
 
     def last_encode_chunks(self):
         """launches per encoder kernel of the most recent encode call (the call's packets are pipelined in chunks)"""

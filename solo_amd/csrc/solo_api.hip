@@ -222,7 +222,11 @@ struct solo_batch {
     // encoder pipeline: the packets of a call go through analysis -> quantiser -> coding in chunks on three streams
     int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
     hipStream_t sA, sB, sC;
-    hipEvent_t evFork, evJoinA, evJoinC, evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS];
+    hipEvent_t evFork, evJoinA[2], evJoinC[2], evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS], evC[SOLO_MAX_CHUNKS];
+    int async_join;                  // solo_batch_set_async_join: encode returns without joining its streams into the caller's
+    unsigned int enc_seq;            // encode calls so far (selects the join-event set)
+    int evC_valid;                   // chunks of the previous call whose coding-done events are recorded
+    int last_np, last_cp;            // packets / packets per chunk of the previous call (layout of the hand-over records)
     hipEvent_t tev[3][SOLO_MAX_CHUNKS][2];   // timing brackets per kernel type / chunk (created with set_timing)
     int tev_ready, last_chunks;
     unsigned int* d_started;         // per chunk slot: workgroups of the quantiser launches that have started (running count)
@@ -306,6 +310,22 @@ int32_t solo_batch_last_kernel_ms(solo_batch_t* b, float* ms4) {
     return 0;
 }
 int32_t solo_batch_slot_bytes(const solo_batch_t* b) { return b ? b->slot : 0; }
+// Asynchronous joins: with on = 1 solo_batch_encode returns without making the caller's stream wait for its internal streams, so
+// that the next encode call can start (its first analysis chunk) while the last quantiser / coding chunks of this one still run.
+// Whoever consumes the outputs then calls solo_batch_wait_encode(b, stream, which) first: which = 0 the most recent encode call,
+// 1 the one before.  The hand-over records are guarded inside the library; the OUTPUT buffers of two calls in flight must differ.
+int32_t solo_batch_set_async_join(solo_batch_t* b, int32_t on) {
+    if (!b) return -1;
+    b->async_join = on ? 1 : 0;
+    return 0;
+}
+int32_t solo_batch_wait_encode(solo_batch_t* b, void* hip_stream, int32_t which) {
+    if (!b || !b->pipe_ready || which < 0 || which > 1 || b->enc_seq <= (unsigned int)which) return b ? 0 : -1;
+    const int js = (int)((b->enc_seq - 1u - (unsigned int)which) & 1u);
+    SOLO_CHECK(hipStreamWaitEvent((hipStream_t)hip_stream, b->evJoinA[js], 0));
+    SOLO_CHECK(hipStreamWaitEvent((hipStream_t)hip_stream, b->evJoinC[js], 0));
+    return 0;
+}
 int32_t solo_batch_last_encode_chunks(const solo_batch_t* b) { return b ? b->last_chunks : 0; }
 
 int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
@@ -368,7 +388,9 @@ void solo_batch_destroy(solo_batch_t* b) {
         (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC);
         (void)hipStreamDestroy(b->sA); (void)hipStreamDestroy(b->sB); (void)hipStreamDestroy(b->sC);
         if (b->d_started) (void)hipFree(b->d_started);
-        (void)hipEventDestroy(b->evFork); (void)hipEventDestroy(b->evJoinA); (void)hipEventDestroy(b->evJoinC);
+        (void)hipEventDestroy(b->evFork);
+        for (int i = 0; i < 2; i++) { (void)hipEventDestroy(b->evJoinA[i]); (void)hipEventDestroy(b->evJoinC[i]); }
+        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evC[c]);
         for (int c = 0; c < SOLO_MAX_CHUNKS; c++) { (void)hipEventDestroy(b->evA[c]); (void)hipEventDestroy(b->evB[c]); }
     }
 #ifdef SOLO_WITH_ENCODER
@@ -429,8 +451,11 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, lo));
         SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
-        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA, hipEventDisableTiming));
-        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinC, hipEventDisableTiming));
+        for (int i = 0; i < 2; i++) {
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA[i], hipEventDisableTiming));
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinC[i], hipEventDisableTiming));
+        }
+        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evC[c], hipEventDisableTiming));
         for (int c = 0; c < SOLO_MAX_CHUNKS; c++) {
             SOLO_CHECK(hipEventCreateWithFlags(&b->evA[c], hipEventDisableTiming));
             SOLO_CHECK(hipEventCreateWithFlags(&b->evB[c], hipEventDisableTiming));
@@ -448,12 +473,20 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     int nchunks = (n_packets + cp - 1) / cp;
     if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
     const bool tm = b->timing && b->tev_ready;
+    if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp)) {
+        // the previous call laid its hand-over records out differently: no chunk-wise reuse, wait for all of its coding
+        SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
+        b->evC_valid = 0;
+    }
+    b->last_np = n_packets;
+    b->last_cp = cp;
     SOLO_CHECK(hipEventRecord(b->evFork, st));
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
     for (int c = 0; c < nchunks; c++) {
         const int p0 = c * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
+        if (c < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
         if (c > 0 && b->gate) (void)solo_launch_gate(&b->d_started[c - 1], b->started_target[c - 1], b->sA);
         if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
         hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, b->sA, states, d_pcm, b->n_streams, n_packets, p0, pc, nin, cin);
@@ -470,11 +503,17 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, b->sC, states, cin, nout, b->n_streams, n_packets, p0, pc,
                            b->slot, d_bits, d_nbytes, d_status);
         if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
+        SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
     }
-    SOLO_CHECK(hipEventRecord(b->evJoinA, b->sA));
-    SOLO_CHECK(hipEventRecord(b->evJoinC, b->sC));
-    SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA, 0));
-    SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC, 0));
+    b->evC_valid = nchunks;
+    const int js = (int)(b->enc_seq & 1u);
+    b->enc_seq++;
+    SOLO_CHECK(hipEventRecord(b->evJoinA[js], b->sA));
+    SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->sC));
+    if (!b->async_join) {
+        SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA[js], 0));
+        SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC[js], 0));
+    }
     b->last_chunks = nchunks;
     if (tm) b->ev_enc = 1;
     SOLO_CHECK(hipGetLastError());

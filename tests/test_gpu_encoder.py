@@ -221,3 +221,34 @@ def test_dtx_round_trip_vs_compiled_reference(torch_cuda):
             assert hb[i, p, :n0].tobytes() == pl[:n0], (i, p)
             x, ret = d.decode(*((b"", 16, 0, 1) if n0 == 0 else (pl, n0, n1, 4)))
             assert ret == 0 and np.array_equal(ho[i, p], x), (i, p)
+
+
+def test_async_join_pipelines_consecutive_calls(torch_cuda):
+    """solo_batch_set_async_join: encode calls return without joining; two calls in flight write different output buffers and
+    the consumer waits with solo_batch_wait_encode.  Same bits as the golden vectors, same PCM after decoding."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P, S = z["bits"].shape
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=S)
+    b.set_async_join(True)
+    pcm = torch.from_numpy(z["pcm"]).to(b.device)
+    cuts = [(0, 9), (9, 17), (17, 25)]
+    outs, pcms = [], []
+    prev = None
+    ins = [pcm[:, a:e].contiguous() for a, e in cuts]              # inputs (and outputs) stay alive and untouched until wait_encode
+    torch.cuda.synchronize()
+    for x in ins:
+        cur = b.encode(x)                                          # fresh output tensors per call
+        if prev is not None:
+            b.wait_encode(1)
+            pcms.append(b.decode(prev[0], prev[1], None)[0])
+        outs.append(cur)
+        prev = cur
+    b.wait_encode(0)
+    pcms.append(b.decode(prev[0], prev[1], None)[0])
+    torch.cuda.synchronize()
+    bits = np.concatenate([o[0].cpu().numpy() for o in outs], axis=1)
+    nb = np.concatenate([o[1].cpu().numpy() for o in outs], axis=1)
+    _assert_streams_equal(bits, nb, z["bits"], z["nbytes"])
+    assert np.array_equal(np.concatenate([p.cpu().numpy() for p in pcms], axis=1), z["dec_clean"])
