@@ -139,8 +139,8 @@ struct SxDecWork {
 // SKP_Silk_init_decoder + first decoder_set_fs(8) folded together (create_init_destroy.c:34,
 // decoder_set_fs.c:31).  The reference starts at 24 kHz and switches to 8 kHz when the first
 // payload is parsed; every field touched by that switch has the same value here, so the state after
-// the first received packet is identical.  (A LOST first packet would run the 24 kHz PLC + resampler
-// in the reference; that corner is out of scope -- see DESIGN.md.)
+// the first received packet is identical.  Packets LOST before that run the reference's 24 kHz concealment +
+// resampler: sx_silk_decode_frame models exactly what survives of it (first_frame_after_reset doubles as "still at 24 kHz").
 SX_HD void sx_dec_state_init(SxDecState* st, int hb_joint = 0) {
     u8* p = (u8*)st;
     SX_PAR(i, (int)sizeof(SxDecState)) p[i] = 0;
@@ -638,8 +638,11 @@ SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
 
 // SKP_Silk_PLC_glue_frames, SKP_Silk_PLC.c:363.  `odd` = int16 offset of `signal` from a 4-byte
 // aligned base, modulo 2 (sum_sqr_shift's alignment branch); the low-band buffer of the reference is
-// a stack array advanced by 160 samples per frame, i.e. always even.
-SX_FN void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
+// a stack array advanced by 160 samples per frame, i.e. always even.  `ramp_len` = the reference's `length` argument: 160,
+// except for the first frame ever decoded, where decode_frame.c:303 latched L = 480 before the payload switched the decoder
+// to 8 kHz -- after lost leading packets that frame is faded in with the 480-sample slope (the 320 samples past the frame
+// only enter the energy, which the zero concealed energy makes irrelevant: any non-zero frame gets gain 0, slope 4096/480).
+SX_FN void sx_plc_glue_frames(SxDecState* st, i16* signal, int length, int ramp_len) {
     SX_IN_LDS(st); SX_IN_LDS(signal);
     SxPLC* p = &st->plc;
     if (st->lossCnt) {
@@ -657,7 +660,7 @@ SX_FN void sx_plc_glue_frames(SxDecState* st, i16* signal, int length) {
                 energy = energy >> sx_max(24 - LZ, 0);
                 i32 frac_Q24 = p->conc_energy / sx_max(energy, 1);
                 i32 gain_Q12 = sx_sqrt_approx(frac_Q24);
-                i32 slope_Q12 = ((1 << 12) - gain_Q12) / length;
+                i32 slope_Q12 = ((1 << 12) - gain_Q12) / ramp_len;
                 // serial ramp (rare path: first good frame after a loss); uniform code, all lanes identical
                 for (int i = 0; i < length; i++) {
                     signal[i] = (i16)(sx_mul(gain_Q12, signal[i]) >> 12);
@@ -760,6 +763,27 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
     if (st->moreInternalDecoderFrames == 0) st->nFramesDecoded = 0;
     c->LTP_scale_Q14 = 0;
     int used = 0;
+    if (action == 1 && st->first_frame_after_reset) {
+        // Lost frame before any frame has been decoded: the reference decoder is still at its initial 24 kHz
+        // (create_init_destroy.c:41), so SKP_Silk_PLC_conceal / glue_frames / CNG run on 480-sample all-zero state and
+        // the 24 -> 8 kHz resampler (dec_API.c:158-176) turns 480 zeros into 160 zeros.  What survives the switch to 8 kHz
+        // at the first decoded frame (decoder_set_fs.c:36-64 resets the rest): the concealment LCG advanced once per 24 kHz
+        // sample (PLC.c:243), the loss counter, the zero concealed energy that makes glue_frames fade the first good frame
+        // in (PLC.c:375-413), and the 24 kHz tags that force PLC_Reset / CNG_Reset on the first decoded frame.
+        {   // (wave-uniform: every lane stores the same values)
+            st->plc.fs_kHz = 24;
+            st->plc.rand_seed = sx_rand_skip(sx_rand_skip(st->plc.rand_seed, 240), 240);    // 480 steps (sx_rand_skip takes n < 256)
+            st->plc.randScale_Q14 = 0;           // (1 << 14) * prevLTP_scale_Q14 (= 0) >> 14, PLC.c:213
+            st->plc.conc_energy = 0;
+            st->plc.conc_energy_shift = 0;
+            st->plc.last_frame_lost = 1;
+            st->lossCnt++;
+            st->cng.fs_kHz = 24;
+        }
+        SX_PAR(i, SX_FRAME) pOut[i] = 0;
+        wv_sync();
+        return 0;
+    }
     if (action == 1) {
         sx_plc(st, w, pOut, 1);
     } else {
@@ -853,14 +877,14 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             SX_T(3)
             st->lossCnt = 0;
             st->prev_sigtype = c->sigtype;
-            st->first_frame_after_reset = 0;
         }
     }
     if (ret < 0) return ret;   // corrupt payload: the reference returns before producing output
     SX_T_RESET
     SX_PAR(i, SX_FRAME) st->outBuf[i] = pOut[i];
     wv_sync();
-    sx_plc_glue_frames(st, pOut, SX_FRAME);
+    sx_plc_glue_frames(st, pOut, SX_FRAME, st->first_frame_after_reset ? 480 : SX_FRAME);
+    st->first_frame_after_reset = 0;     // (decode_frame.c:281; cleared here because the ramp length above still needs it)
     SX_T(4)
     sx_cng(st, w, pOut, SX_FRAME);
     SX_T(5)

@@ -28,6 +28,15 @@ def md5(b):
     return hashlib.md5(bytes(b)).hexdigest()
 
 
+def cold_recv_mask(recv):
+    r = recv.copy()
+    for i in range(r.shape[0]):
+        k = 1 + (i * 5) % 6
+        r[i, :k] = 0
+        r[i, k] = (3, 1, 2)[i % 3]
+    return r
+
+
 def main():
     g = {}
     pcm = np.fromfile(os.path.join(HERE, "Ch_f1_raw.pcm"), np.int16)
@@ -71,6 +80,18 @@ def main():
             dec_loss[i, p], _ = d1.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
     np.savez_compressed(os.path.join(HERE, "synth8x25.npz"), pcm=spcm, bits=bits, nbytes=nb, recv=recv,
                         dec_clean=dec_clean, dec_loss=dec_loss)
+    # decoder cold start: the first 1..6 packets of each stream never arrive (the reference decoder is still at its initial
+    # 24 kHz then), the first packet that does arrive is complete / MD1 only / MD2 only by stream, later ones per `recv`
+    recv_cold = cold_recv_mask(recv)
+    dec_cold = np.zeros((N, P, 640), np.int16)
+    for i in range(N):
+        d = R.RefDecoder("fix")
+        for p, (pl, n0, n1) in enumerate(streams[i]):
+            m = int(recv_cold[i, p])
+            dec_cold[i, p], ret = d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0
+    np.savez_compressed(os.path.join(HERE, "synth8x25_cold.npz"), recv=recv_cold, dec=dec_cold)
+    g["synth_dec_cold_md5"] = md5(dec_cold.tobytes())
     g["synth_bits_md5"] = md5(bits.tobytes())
     g["synth_dec_clean_md5"] = md5(dec_clean.tobytes())
     g["synth_dec_loss_md5"] = md5(dec_loss.tobytes())

@@ -40,6 +40,46 @@ def test_synthetic_streams_bernoulli_loss():
                 assert np.array_equal(x, z[key][s, p]), (key, s, p)
 
 
+def test_cold_start_leading_packets_lost():
+    """Packets lost before anything was decoded: the reference decoder is still at its initial 24 kHz (create_init_destroy.c:41),
+    emits zeros through the 24 -> 8 kHz resampler and fades the first decoded frame in with the 480-sample slope (decode_frame.c:303,
+    PLC.c:405); the concealment LCG has advanced 480 steps per lost frame.  First arriving packet complete / MD1 only / MD2 only."""
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    c = np.load(T.GOLDEN + "/synth8x25_cold.npz")
+    bits, nb, recv = z["bits"], z["nbytes"], c["recv"]
+    N, P = recv.shape
+    assert (recv[:, 0] == 0).all() and T.md5(c["dec"]) == T.golden_json()["synth_dec_cold_md5"]
+    for s in range(N):
+        dec = T.EmuDecoder()
+        for p in range(P):
+            n0, n1 = int(nb[s, p, 0]), int(nb[s, p, 1])
+            m = int(recv[s, p])
+            x, ret = dec.decode(*R.map_loss(bits[s, p, :n0].tobytes(), n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0
+            assert np.array_equal(x, c["dec"][s, p]), (s, p)
+            if m == 0 and (recv[s, :p] == 0).all():
+                assert not x.any()
+
+
+def test_cold_start_joint_mode_vs_reference():
+    """Same corner with one 40 ms high-band frame per packet (joint_mode 1), against the compiled reference directly."""
+    import pytest
+    if not R.have_ref("fix"):
+        pytest.skip("oracle/_ref not built")
+    P = 12
+    pcm = R.synth_stream(4242, P)
+    enc = R.RefEncoder("fix", joint=1)
+    recs = [enc.encode(pcm[p]) for p in range(P)]
+    for k, first in ((1, 3), (3, 1), (2, 2)):
+        dr, de = R.RefDecoder("fix", joint=1), T.EmuDecoder(2)
+        for p, (pl, n0, n1) in enumerate(recs):
+            m = 0 if (p < k or p == 8) else (first if p == k else 3)
+            a = R.map_loss(pl, n0, n1, not (m & 1), not (m & 2))
+            x, r1 = dr.decode(*a)
+            y, r2 = de.decode(*a)
+            assert r1 == r2 == 0 and np.array_equal(x, y), (k, first, p)
+
+
 def test_decoder_rejects_empty_payload():
     dec = T.EmuDecoder()
     x, ret = dec.decode(b"", 0, 0, 4)

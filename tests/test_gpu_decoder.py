@@ -36,6 +36,25 @@ def test_synthetic_goldens_clean_and_lossy(torch_cuda):
     assert np.array_equal(out, z["dec_loss"])
 
 
+def test_cold_start_leading_packets_lost(torch_cuda):
+    """Leading packets of a stream lost (decoder still at the reference's initial 24 kHz): zeros out, then the first decoded
+    frame faded in with the 480-sample slope; one call and packet-by-packet calls."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    c = np.load(T.GOLDEN + "/synth8x25_cold.npz")
+    out = _gpu_decode(torch, z["bits"], z["nbytes"], c["recv"])
+    assert np.array_equal(out, c["dec"])
+    bits, nb, recv = z["bits"], z["nbytes"], c["recv"]
+    N, P, S = bits.shape
+    b = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=S)
+    for p in range(8):
+        pcm, st = b.decode(torch.from_numpy(np.ascontiguousarray(bits[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(nb[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(recv[:, p:p + 1])).to(b.device))
+        assert np.array_equal(pcm.cpu().numpy()[:, 0], c["dec"][:, p]), p
+
+
 def test_ch_f1_md5_cli_loss(torch_cuda):
     g = T.golden_json()
     recs = T.parse_bit_container(open(T.GOLDEN + "/ch_f1.bit", "rb").read())

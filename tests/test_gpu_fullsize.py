@@ -111,7 +111,7 @@ def test_8192_streams_decode_only_with_30pct_loss(torch_cuda):
     bits_all = bits.repeat(reps, 1, 1).contiguous()
     nb_all = nb.repeat(reps, 1, 1).contiguous()
     recv = T.bernoulli_recv(DISTINCT, P, 0.3, 4242)
-    recv[:, 0] = 3                                                # first packet received (a lost FIRST packet is out of scope)
+    recv[:, 0] = 3                                                # first packet of every stream received
     recv_all = np.ascontiguousarray(np.tile(recv, (reps, 1)))
     dec = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=512)
     out, st2 = dec.decode(bits_all, nb_all, torch.from_numpy(recv_all).to(dec.device))
