@@ -90,7 +90,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
-    ap.add_argument("--packets", type=int, default=10, help="40 ms packets per stream per step")
+    ap.add_argument("--packets", type=int, default=50, help="40 ms packets per stream per step (SURVEY 8(d): P >= 50 = 2 s of audio)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true", help="decode of step k on a second stream beside the encode of step k+1 (+1 %)")
     ap.add_argument("--cpu-packets", type=int, default=0, help="0: 400 packets per host CPU")

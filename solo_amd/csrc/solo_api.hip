@@ -206,7 +206,7 @@ extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, v
 // ---------------------------------------------------------------------------------------------------
 // host side: handle + C ABI
 // ---------------------------------------------------------------------------------------------------
-#define SOLO_MAX_CHUNKS 32
+#define SOLO_MAX_CHUNKS 64
 struct solo_batch {
     int32_t n_streams;
     int32_t slot;

@@ -25,7 +25,6 @@ struct SxRangeDec {
     u32 base_Q32;
     u32 range_Q16;
     i32 error;
-    i32 sym;            // (out-of-line decoder: the decoded symbol travels back in the state)
 #ifdef SX_RC_LOG
     i32* log; i32 nlog;
 #endif
@@ -49,7 +48,7 @@ SX_HD void sx_rc_dec_init(SxRangeDec* rc, const u8* buf, i32 len) {
 }
 
 // SKP_Silk_range_decoder, SKP_Silk_range_coder.c:115.  Returns the decoded symbol (0 on error).
-SX_HD i32 sx_rc_dec_inl(SxRangeDec* rc, const u16* prob, i32 probIx) {
+SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
     u32 low_Q16 = 0, high_Q16, range_Q32;
     u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16;
     i32 bufferIx = rc->bufferIx;
@@ -110,7 +109,7 @@ SX_HD i32 sx_rc_dec_inl(SxRangeDec* rc, const u16* prob, i32 probIx) {
 
 // sx_rc_dec for a two-symbol model {0, p, 65535} started at index 1, the threshold kept in a register (the sign / LSB decoders):
 // same arithmetic and the same error exits as the general search above
-SX_HD i32 sx_rc_dec_bin_inl(SxRangeDec* rc, u32 p) {
+SX_HD i32 sx_rc_dec_bin(SxRangeDec* rc, u32 p) {
     u32 base_Q32 = rc->base_Q32, range_Q16 = rc->range_Q16, range_Q32, low_Q16, high_Q16;
     i32 bufferIx = rc->bufferIx, sym;
     if (rc->error) return 0;
@@ -146,24 +145,6 @@ SX_HD i32 sx_rc_dec_bin_inl(SxRangeDec* rc, u32 p) {
 #endif
     return sym;
 }
-
-#if defined(SX_RC_CALL) && defined(__HIP_DEVICE_COMPILE__)
-// out-of-line form: the decoder has ~100 decode sites; as real calls (state passed and returned in registers) the parser shrinks
-// from ~57 KB to a few KB of code
-static __device__ __attribute__((noinline)) SxRangeDec sx_rc_dec_call(SxRangeDec r, const u16* prob, i32 probIx) {
-    r.sym = sx_rc_dec_inl(&r, prob, probIx);
-    return r;
-}
-static __device__ __attribute__((noinline)) SxRangeDec sx_rc_dec_bin_call(SxRangeDec r, u32 p) {
-    r.sym = sx_rc_dec_bin_inl(&r, p);
-    return r;
-}
-#define sx_rc_dec(rc, prob, ix) ((*(rc) = sx_rc_dec_call(*(rc), (prob), (ix))), (rc)->sym)
-#define sx_rc_dec_bin(rc, p) ((*(rc) = sx_rc_dec_bin_call(*(rc), (p))), (rc)->sym)
-#else
-#define sx_rc_dec(rc, prob, ix) sx_rc_dec_inl((rc), (prob), (ix))
-#define sx_rc_dec_bin(rc, p) sx_rc_dec_bin_inl((rc), (p))
-#endif
 
 // SKP_Silk_range_coder_get_length, SKP_Silk_range_coder.c:288 (shared by both directions)
 SX_HD i32 sx_rc_length_bits(i32 bufferIx, u32 range_Q16, i32* nBytes) {

@@ -11,7 +11,7 @@ import os
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-packets_step = int(sys.argv[3]) if len(sys.argv) > 3 else 40960
+packets_step = int(sys.argv[3]) if len(sys.argv) > 3 else 204800
 out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
        "packets_per_step": packets_step, "kernels": {}}
 st = os.path.join(src, "trace", "r01_kernel_stats.csv")
