@@ -60,21 +60,23 @@ def load_ref(kind="fix"):
     return _libs[kind]
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0):
-    # defaults of the reference CLI: JC1_SDK_SRC_ARM/test/enc_main.c:92-99; joint=1: `-joint 1` (40 ms high-band frame)
-    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=1 if dtx else 0,
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000):
+    # defaults of the reference CLI: JC1_SDK_SRC_ARM/test/enc_main.c:92-99; joint=1: `-joint 1` (40 ms high-band frame);
+    # samplerate=32000: `-Fs_API 32000` (16 kHz bands, SILK wide band)
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=samplerate, dtx_enable=1 if dtx else 0,
                          framesize_ms=40, joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
-def default_dec_ctrl(use_md_index=0, joint=0):
-    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=16000, framesize_ms=40,
+def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=40,
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
 class RefEncoder:
-    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0):
+    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0, samplerate=16000):
         self.lib = load_ref(kind)
-        self.ctrl = default_enc_ctrl(rate, joint=joint, dtx=dtx)
+        self.ctrl = default_enc_ctrl(rate, joint=joint, dtx=dtx, samplerate=samplerate)
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
         self.h = self.lib.AGR_Sate_Encoder_Init(C.byref(self.ctrl))
         assert self.h
         self._bits = np.zeros(MAX_FRAME_BYTES, np.uint8)
@@ -83,7 +85,7 @@ class RefEncoder:
     def encode(self, pcm640):
         """-> (payload bytes, nBytes0 total, nBytes1 = len(MD2)+HB)"""
         pcm = np.ascontiguousarray(pcm640, dtype=np.int16)
-        assert pcm.size == PACKET_SAMPLES
+        assert pcm.size == self.packet_samples
         self._nb[:] = 0
         n = self.lib.AGR_Sate_Encoder_Encode(self.h, pcm.ctypes.data, self._bits.ctypes.data,
                                              MAX_FRAME_BYTES, self._nb.ctypes.data)
@@ -98,9 +100,10 @@ class RefEncoder:
 
 
 class RefDecoder:
-    def __init__(self, kind="fix", joint=0):
+    def __init__(self, kind="fix", joint=0, samplerate=16000):
         self.lib = load_ref(kind)
-        self.ctrl = default_dec_ctrl(joint=joint)
+        self.ctrl = default_dec_ctrl(joint=joint, samplerate=samplerate)
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
         self.h = self.lib.AGR_Sate_Decoder_Init(C.byref(self.ctrl))
         assert self.h
         self._pcm = np.zeros(1920, np.int16)
@@ -117,7 +120,7 @@ class RefDecoder:
         self._nb[1] = nbytes1
         ret = self.lib.AGR_Sate_Decoder_Decode(self.h, self._pcm.ctypes.data, self._ns.ctypes.data,
                                                buf.ctypes.data, self._nb.ctypes.data, int(lostflag))
-        return self._pcm[:PACKET_SAMPLES].copy(), ret
+        return self._pcm[:self.packet_samples].copy(), ret
 
     def close(self):
         if self.h:

@@ -98,15 +98,17 @@ def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0):
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
-def default_dec_ctrl(use_md_index=0, joint=0):
-    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=16000, framesize_ms=40, joint_enable=1 if joint else 0,
+def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=40, joint_enable=1 if joint else 0,
                          joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
 class SoloBatch:
     """N independent SOLO streams on the current HIP device (one wavefront per stream)."""
 
-    def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0, dtx=0):
+    def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0, dtx=0,
+                 samplerate=16000):
+        """samplerate = 32000: the 32 kHz mode of the reference (`-Fs_API 32000`: 1280-sample packets, SILK wide band) -- decoder only."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("solo_amd needs a HIP device (MI355X); there is no CPU path")
@@ -115,7 +117,10 @@ class SoloBatch:
         self.n_streams = int(n_streams)
         self.slot = int(slot_bytes)
         self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx) if encoder else None
-        self._dec = default_dec_ctrl(use_md_index, joint) if decoder else None
+        if samplerate not in (16000, 32000) or (samplerate == 32000 and encoder):
+            raise ValueError("samplerate must be 16000, or 32000 with encoder=False (the wide-band encoder is not built)")
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
+        self._dec = default_dec_ctrl(use_md_index, joint, samplerate) if decoder else None
         self.h = self.lib.solo_batch_create(self.n_streams, C.byref(self._enc) if encoder else None,
                                             C.byref(self._dec) if decoder else None, self.slot)
         if not self.h:
@@ -174,7 +179,7 @@ class SoloBatch:
         return int(self.lib.solo_batch_last_encode_chunks(self.h))
 
     def decode(self, bits, nbytes, recv=None, pcm=None, status=None):
-        """bits uint8 [N,P,slot], nbytes int16 [N,P,2], recv uint8 [N,P] (bit0 MD1, bit1 MD2) -> pcm int16 [N,P,640]"""
+        """bits uint8 [N,P,slot], nbytes int16 [N,P,2], recv uint8 [N,P] (bit0 MD1, bit1 MD2) -> pcm int16 [N,P,640] (1280 in the 32 kHz mode)"""
         t = self.torch
         assert bits.is_cuda and bits.dtype == t.uint8 and bits.is_contiguous()
         assert nbytes.dtype == t.int16 and nbytes.is_contiguous()
@@ -183,7 +188,7 @@ class SoloBatch:
         if recv is not None:
             assert recv.dtype == t.uint8 and recv.is_contiguous() and tuple(recv.shape) == (N, P)
         if pcm is None:
-            pcm = t.zeros((N, P, PACKET_SAMPLES), dtype=t.int16, device=bits.device)
+            pcm = t.zeros((N, P, self.packet_samples), dtype=t.int16, device=bits.device)
         if status is None:
             status = t.zeros((N,), dtype=t.int32, device=bits.device)
         r = self.lib.solo_batch_decode(self.h, bits.data_ptr(), nbytes.data_ptr(), recv.data_ptr() if recv is not None else None,
@@ -201,7 +206,7 @@ class SoloBatch:
         N, P, S = desc_a.shape
         assert N == self.n_streams and tuple(desc_b.shape) == (N, P, S) and tuple(len_a.shape) == (N, P) == tuple(len_b.shape)
         if pcm is None:
-            pcm = t.zeros((N, P, PACKET_SAMPLES), dtype=t.int16, device=desc_a.device)
+            pcm = t.zeros((N, P, self.packet_samples), dtype=t.int16, device=desc_a.device)
         if status is None:
             status = t.zeros((N,), dtype=t.int32, device=desc_a.device)
         r = self.lib.solo_batch_decode_split(self.h, desc_a.data_ptr(), len_a.data_ptr(), desc_b.data_ptr(), len_b.data_ptr(), S, P,

@@ -25,115 +25,18 @@
 // ---------------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(64) solo_dec_init_kernel(SxDecState* states, int n_streams, int hb_joint) {
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    sx_dec_state_init(&states[s], hb_joint);
-}
+#include "solo_dec_kernels.h"
 
-// Decoder: rows D0-D8.  blockIdx.x = stream.
-// state record HBM <-> LDS (whole launch) and the entropy tables
-__device__ __forceinline__ void solo_dec_enter(SxDecWork* w, const SxDecState* rec) {
-    const i32* src = (const i32*)rec;
-    i32* dst = (i32*)&w->st;
-    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
-    sx_cdf_load_dec(&w->cdf);
-    wv_sync();
-}
-__device__ __forceinline__ void solo_dec_leave(SxDecWork* w, SxDecState* rec) {
-    wv_sync();
-    const i32* src = (const i32*)&w->st;
-    i32* dst = (i32*)rec;
-    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
-}
-
-__global__ void __launch_bounds__(64, 4) solo_decode_kernel(SxDecState* states, const u8* __restrict__ bits,
-                                                         const i16* __restrict__ nbytes, const u8* __restrict__ recv,
-                                                         int n_streams, int n_packets, int slot, int useMDIndex,
-                                                         i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    solo_dec_enter(&w, &states[s]);
-    i32 first_err = 0;
-    for (int p = 0; p < n_packets; p++) {
-        const size_t pk = (size_t)s * n_packets + p;
-        const u8* b = bits + pk * (size_t)slot;
-        const i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
-        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);      // an empty (DTX) packet is a lost packet, like test/dec_main.c:236-252
-        // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
-        int lostflag;
-        i32 a0, a1;
-        const u8* ptr = b;
-        if (m == 3) { lostflag = 4; a0 = n0; a1 = n1; }
-        else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
-        else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
-        else { lostflag = 1; a0 = n0 > 0 ? n0 : 16; a1 = n0 > 0 ? n1 : 0; }
-        i16* out = pcm + pk * SX_PACKET;
-        int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
-        if (ret < 0 && first_err == 0) first_err = ret;
-        wv_sync();
-    }
-    solo_dec_leave(&w, &states[s]);
-    if (status && SX_LANE == 0) status[s] = first_err;
-}
-
-// Receiver front end: the two descriptions of a 40 ms packet arrive as separate network packets (MD1, and
-// MD2 || HB), possibly only one of them, possibly swapped.  descA / descB are the two arrival slots of every (stream, packet):
-// uint8 [N][P][slot], lenA / lenB int16 [N][P] (0 = nothing arrived).  With useMDIndex = 1 every description carries its index
-// as its first range-coded symbol (SKP_Silk_decode_parameters.c:55-57): the kernel reads it and sorts the arrivals itself
-// (two copies of the same description count once); with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.  The kernel then
-// builds the (ptr, nBytes, lostflag) triple of test/dec_main.c:255-378 and decodes.  Packets above the LDS staging size
-// (252 B; 13.6 kbps packets are ~80 B) are rejected with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11).
-__global__ void __launch_bounds__(64, 4) solo_decode_split_kernel(SxDecState* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
-                                                               const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
-                                                               int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    solo_dec_enter(&w, &states[s]);
-    i32 first_err = 0;
-    for (int p = 0; p < n_packets; p++) {
-        const size_t pk = (size_t)s * n_packets + p;
-        const u8* pa = descA + pk * (size_t)slot;
-        const u8* pb = descB + pk * (size_t)slot;
-        i32 la = lenA[pk], lb = lenB[pk];
-        if (la < 0 || la > slot) la = 0;
-        if (lb < 0 || lb > slot) lb = 0;
-        const u8 *p1 = pa, *p2 = pb;
-        i32 l1 = la, l2 = lb;
-        if (useMDIndex == 1) {
-            int ia = -1, ib = -1;
-            if (la > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
-            if (lb > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
-            p1 = pa; l1 = 0; p2 = pb; l2 = 0;
-            if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
-            if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
-        }
-        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
-        if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
-        i16* out = pcm + pk * SX_PACKET;
-        int ret;
-        if (l1 + l2 > SX_DEC_PAYLOAD_LDS) {
-            ret = -11;
-        } else {
-            wv_sync();
-            SX_PAR(i, l1) w.payload[i] = p1[i];
-            SX_PAR(i, l2) w.payload[l1 + i] = p2[i];
-            wv_sync();
-            int lostflag;
-            i32 a0, a1;
-            if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
-            else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
-            else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
-            else { lostflag = 1; a0 = hbb + 1; a1 = 0; }
-            ret = sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
-        }
-        if (ret < 0 && first_err == 0) first_err = ret;
-        wv_sync();
-    }
-    solo_dec_leave(&w, &states[s]);
-    if (status && SX_LANE == 0) status[s] = first_err;
+// the same decoder compiled for the 32 kHz API rate (SILK wide band, 16 kHz bands): solo_api_wb.hip
+extern "C" {
+size_t solo_wb_dec_state_bytes();
+hipError_t solo_wb_dec_launch_init(void* states, int n_streams, int hb_joint, hipStream_t s);
+hipError_t solo_wb_dec_launch(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets, int slot,
+                              int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
+hipError_t solo_wb_dec_launch_split(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB, const int16_t* lenB, int n_streams,
+                                    int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
+hipError_t solo_wb_dec_launch_raw(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm, int32_t* status,
+                                  hipStream_t s);
 }
 
 #ifdef SOLO_WITH_ENCODER
@@ -232,7 +135,8 @@ struct solo_batch {
     unsigned int* d_started;         // per chunk slot: workgroups of the quantiser launches that have started (running count)
     unsigned int started_target[SOLO_MAX_CHUNKS];
     int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
-    SxDecState* d_dec_state;
+    void* d_dec_state;               // SxDecState[n_streams] of the build that matches `wb`
+    int wb;                          // decoder control asked for samplerate 32000: 1280-sample packets, SILK at 16 kHz (decoder only)
 };
 
 // joint_enable = 0, or joint_mode 1 (one 40 ms high-band frame per packet, AGR_BWE_SDK_API.c:64-67); the other joint modes are
@@ -241,7 +145,8 @@ static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
     return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
 }
 static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
-    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
+    // 32000: the wide-band decoder (solo_api_wb.hip); a stream whose internal rate is not 16 kHz is rejected packet by packet
+    return (c->samplerate == 16000 || c->samplerate == 32000) && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
 }
 static int ctrl_hb_joint(int joint_enable, int joint_mode) { return joint_enable != 0 && joint_mode == 1; }
 
@@ -332,9 +237,8 @@ int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
     if (!b) return -1;
     hipStream_t s = (hipStream_t)hip_stream;
     if (b->have_dec) {
-        hipLaunchKernelGGL(solo_dec_init_kernel, dim3(b->n_streams), dim3(64), 0, s, b->d_dec_state, b->n_streams,
-                           ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode));
-        SOLO_CHECK(hipGetLastError());
+        const int hbj = ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode);
+        SOLO_CHECK(b->wb ? solo_wb_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s) : solo_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s));
     }
 #ifdef SOLO_WITH_ENCODER
     if (b->have_enc) {
@@ -373,7 +277,9 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
     if (dec) {
         b->have_dec = 1;
         b->dec_ctrl = *dec;
-        if (hipMalloc((void**)&b->d_dec_state, sizeof(SxDecState) * (size_t)n_streams) != hipSuccess) { solo_batch_destroy(b); return NULL; }
+        b->wb = dec->samplerate == 32000;
+        if (b->wb && enc) { solo_batch_destroy(b); return NULL; }     // (a handle has one rate; the wide-band ENCODER is not built)
+        if (hipMalloc(&b->d_dec_state, (b->wb ? solo_wb_dec_state_bytes() : solo_dec_state_bytes()) * (size_t)n_streams) != hipSuccess) { solo_batch_destroy(b); return NULL; }
     }
     if (solo_batch_reset(b, NULL) != 0 || hipDeviceSynchronize() != hipSuccess) { solo_batch_destroy(b); return NULL; }
     return b;
@@ -404,10 +310,10 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
     const bool tm = b->timing && b->ev_ready;
     if (tm) (void)hipEventRecord(b->ev[4], (hipStream_t)hip_stream);
-    hipLaunchKernelGGL(solo_decode_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state,
-                       d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot, b->dec_ctrl.useMDIndex, d_pcm, d_status);
+    const hipError_t e = (b->wb ? solo_wb_dec_launch : solo_dec_launch)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot,
+                                                                         b->dec_ctrl.useMDIndex, d_pcm, d_status, (hipStream_t)hip_stream);
     if (tm) { (void)hipEventRecord(b->ev[5], (hipStream_t)hip_stream); b->ev_dec = 1; }
-    SOLO_CHECK(hipGetLastError());
+    SOLO_CHECK(e);
     return 0;
 }
 
@@ -415,9 +321,8 @@ int32_t solo_batch_decode_split(solo_batch_t* b, const uint8_t* d_descA, const i
                                 const int16_t* d_lenB, int32_t slot_bytes, int32_t n_packets, int16_t* d_pcm, int32_t* d_status,
                                 void* hip_stream) {
     if (!b || !b->have_dec || !d_descA || !d_lenA || !d_descB || !d_lenB || !d_pcm || n_packets <= 0 || slot_bytes <= 0) return -1;
-    hipLaunchKernelGGL(solo_decode_split_kernel, dim3(b->n_streams), dim3(64), 0, (hipStream_t)hip_stream, b->d_dec_state, d_descA, d_lenA,
-                       d_descB, d_lenB, b->n_streams, n_packets, slot_bytes, b->dec_ctrl.useMDIndex, d_pcm, d_status);
-    SOLO_CHECK(hipGetLastError());
+    SOLO_CHECK((b->wb ? solo_wb_dec_launch_split : solo_dec_launch_split)(b->d_dec_state, d_descA, d_lenA, d_descB, d_lenB, b->n_streams, n_packets,
+                                                                          slot_bytes, b->dec_ctrl.useMDIndex, d_pcm, d_status, (hipStream_t)hip_stream));
     return 0;
 }
 
@@ -550,7 +455,7 @@ static solo_single* single_new(const USER_Ctrl_enc* e, const USER_Ctrl_dec* d) {
     if (!h) return NULL;
     h->is_enc = e != NULL;
     h->b = solo_batch_create(1, e, d, 1024 + 64);   // MAX_FRAME_BYTES of the reference harness + slack
-    if (!h->b || hipMalloc((void**)&h->d_pcm, SX_PACKET * 2) != hipSuccess || hipMalloc((void**)&h->d_bits, h->b->slot) != hipSuccess ||
+    if (!h->b || hipMalloc((void**)&h->d_pcm, 2 * SX_PACKET * 2) != hipSuccess || hipMalloc((void**)&h->d_bits, h->b->slot) != hipSuccess ||
         hipMalloc((void**)&h->d_nbytes, 4) != hipSuccess || hipMalloc((void**)&h->d_recv, 4) != hipSuccess ||
         hipMalloc((void**)&h->d_status, 4) != hipSuccess) {
         single_free(h);
@@ -593,16 +498,6 @@ void* AGR_Sate_Decoder_Init(USER_Ctrl_dec* dec_Ctrl) {
     return single_new(NULL, dec_Ctrl);
 }
 
-// single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
-__global__ void __launch_bounds__(64) solo_decode_raw_kernel(SxDecState* st, const u8* bits, int n0, int n1, int lostflag,
-                                                             int useMDIndex, i16* pcm, i32* status) {
-    __shared__ SxDecWork w;
-    solo_dec_enter(&w, st);
-    int ret = sx_decode_packet(&w, bits, n0, n1, lostflag, useMDIndex, pcm);
-    solo_dec_leave(&w, st);
-    if (SX_LANE == 0) *status = ret;
-}
-
 int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, const uint8_t* bits, int16_t nBytes[], int32_t lostflag) {
     solo_single* h = (solo_single*)st;
     if (!h || h->is_enc) return -1;
@@ -613,8 +508,8 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
         if (n0 > h->b->slot) return -11;                                      // SKP_SILK_DEC_PAYLOAD_TOO_LARGE
         if (hipMemcpy(h->d_bits, bits, n0, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
-    hipLaunchKernelGGL(solo_decode_raw_kernel, dim3(1), dim3(64), 0, 0, h->b->d_dec_state, h->d_bits, n0, n1, lostflag,
-                       h->b->dec_ctrl.useMDIndex, h->d_pcm, h->d_status);
+    if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,
+                                                                  h->d_status, (hipStream_t)0) != hipSuccess) return -1;
     int32_t ret = 0;
     if (hipMemcpy(&ret, h->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     // the reference rewrites the caller's nBytes[] with the low-band lengths (AGR_BWE_decode_frame_FIX.c:150-169)
@@ -624,8 +519,9 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
     nBytes[0] = (int16_t)(nb0 - nb1);
     nBytes[1] = (int16_t)nb1;
     if (ret < 0) return ret;
-    if (hipMemcpy(pcm, h->d_pcm, SX_PACKET * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    *nSamplesOut = SX_PACKET;
+    const int ns = h->b->wb ? 2 * SX_PACKET : SX_PACKET;                      // JC1_FrameSize (AGR_BWE_SDK_API.c:277)
+    if (hipMemcpy(pcm, h->d_pcm, ns * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    *nSamplesOut = (int16_t)ns;
     return 0;
 }
 

@@ -12,11 +12,60 @@
 #endif
 #include "solo_tables.inc"
 
+// SILK's internal rate is a compile-time parameter of the whole kernel source: 8 (16 kHz API rate: the benchmark
+// configuration) or 16 (32 kHz API rate, `samplerate == 32000` in the control structs, libBWE/AGR_BWE_SDK_API.c:86-89,197).
+// The rate-dependent tables keep one set of names in the code below.
+#ifndef SX_FS_KHZ
+#define SX_FS_KHZ 8
+#endif
+#if SX_FS_KHZ == 8
 #define SX_LPC 10          // predictLPCOrder at fs_kHz == 8   (SKP_Silk_control_codec_FIX.c:278)
+#define SX_NLSF_STAGES 6   // stages of SKP_Silk_NLSF_CB0_10 / CB1_10
+#define SX_N_NLSF_CB0_CDF 126
+#define SX_N_NLSF_CB1_CDF 78
+#define SX_N_PITCH_LAG_CDF 130
+#define SX_N_PITCH_CONTOUR_CDF 12
+#define SX_PITCH_CB_N 11   // contours of SKP_Silk_CB_lags_stage2 (decode_pitch.c:43)
+#define T_cdf_pitch_lag T_cdf_pitch_lag_nb
+#define T_cdf_pitch_contour T_cdf_pitch_contour_nb
+#define T_CDF_MID_PITCH_LAG T_CDF_MID_PITCH_LAG_NB
+#define T_CDF_MID_PITCH_CONTOUR T_CDF_MID_PITCH_CONTOUR_NB
+#define T_pitch_cb_dec T_pitch_cb_stage2
+#elif SX_FS_KHZ == 16
+#include "solo_tables_wb.inc"
+#define SX_LPC 16          // decoder_set_fs.c:45
+#define SX_NLSF_STAGES 10  // stages of SKP_Silk_NLSF_CB0_16 / CB1_16
+#define SX_N_NLSF_CB0_CDF 226
+#define SX_N_NLSF_CB1_CDF 114
+#define SX_N_PITCH_LAG_CDF 258
+#define SX_N_PITCH_CONTOUR_CDF 35
+#define SX_PITCH_CB_N 34   // contours of SKP_Silk_CB_lags_stage3 (decode_pitch.c:52)
+#define T_cdf_pitch_lag T_cdf_pitch_lag_wb
+#define T_cdf_pitch_contour T_cdf_pitch_contour_wb
+#define T_CDF_MID_PITCH_LAG T_CDF_MID_PITCH_LAG_WB
+#define T_CDF_MID_PITCH_CONTOUR T_CDF_MID_PITCH_CONTOUR_WB
+#define T_pitch_cb_dec T_pitch_cb_stage3
+#define T_nlsf_cb0_Q15 T_nlsf16_cb0_Q15
+#define T_nlsf_cb1_Q15 T_nlsf16_cb1_Q15
+#define T_nlsf_cb0_rates_Q5 T_nlsf16_cb0_rates_Q5
+#define T_nlsf_cb1_rates_Q5 T_nlsf16_cb1_rates_Q5
+#define T_nlsf_cb0_cdf T_nlsf16_cb0_cdf
+#define T_nlsf_cb1_cdf T_nlsf16_cb1_cdf
+#define T_nlsf_cb0_cdf_mid T_nlsf16_cb0_cdf_mid
+#define T_nlsf_cb1_cdf_mid T_nlsf16_cb1_cdf_mid
+#define T_nlsf_cb0_ndelta_min_Q15 T_nlsf16_cb0_ndelta_min_Q15
+#define T_nlsf_cb1_ndelta_min_Q15 T_nlsf16_cb1_ndelta_min_Q15
+#undef T_NLSF_CB0_NVEC
+#undef T_NLSF_CB1_NVEC
+#define T_NLSF_CB0_NVEC T_NLSF16_CB0_NVEC
+#define T_NLSF_CB1_NVEC T_NLSF16_CB1_NVEC
+#else
+#error "SX_FS_KHZ must be 8 or 16"
+#endif
 #define SX_MAX_LPC 16      // MAX_LPC_ORDER                    (SKP_Silk_define.h:200)
 #define SX_HB_LPC 8        // BWE_LPCOrder                     (libBWE/AGR_BWE_SDK_API.c:106)
-#define SX_FRAME 160       // 20 ms @ 8 kHz
-#define SX_SUBFR 40
+#define SX_FRAME (20 * SX_FS_KHZ)   // 20 ms
+#define SX_SUBFR (5 * SX_FS_KHZ)
 #define SX_NB_SUBFR 4
 #define SX_LTP_ORDER 5
 

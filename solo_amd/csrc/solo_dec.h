@@ -18,8 +18,8 @@
 #include "solo_rc.h"
 #include "solo_cdf.h"
 
-#define SX_PACKET 640            // 40 ms @ 16 kHz
-#define SX_BAND 320              // samples per band per packet
+#define SX_PACKET (80 * SX_FS_KHZ)   // 40 ms at the API rate (16 kHz: 640, 32 kHz: 1280)
+#define SX_BAND (40 * SX_FS_KHZ)     // samples per band per packet
 #define SX_HB_BYTES 8            // 2 x HB_BYTE (libBWE/AGR_BWE_defines.h:39)
 #define SX_QMF_HIST 32           // synthesis memory per band (M2)
 // first-failure trace of the range decoder (debug aid, costs one compare per stage)
@@ -255,7 +255,7 @@ SX_HD void sx_nlsf_msvq_decode_cb(i32* pNLSF_Q15, const IDX* idx, const i16* cb,
     const i16* e = &cb[idx[0] * SX_LPC];
     for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] = e[i];
     int base = nvec[0];
-    for (int s = 1; s < 6; s++) {
+    for (int s = 1; s < SX_NLSF_STAGES; s++) {
         e = &cb[(base + idx[s]) * SX_LPC];
         for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] += e[i];
         base += nvec[s];
@@ -263,7 +263,7 @@ SX_HD void sx_nlsf_msvq_decode_cb(i32* pNLSF_Q15, const IDX* idx, const i16* cb,
     sx_nlsf_stabilize(pNLSF_Q15, ndelta_min_Q15, SX_LPC);
 }
 SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
-    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+    const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
     sx_nlsf_msvq_decode_cb(pNLSF_Q15, idx, sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15, sigtype == 0 ? nvec0 : nvec1,
                            sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15);
 }
@@ -277,13 +277,13 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io,
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp);
     SxRangeDec rc_local = *rc_io;
     SxRangeDec* rc = &rc_local;
-    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[6], DeltaGainIndices;
+    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[SX_NLSF_STAGES], DeltaGainIndices;
     i32 *pNLSF0_Q15 = nlsf_out, *pNLSF_Q15 = nlsf_out + SX_LPC;
     SxDecDesc* md = &st->md[kDesp];
     if (st->nFramesDecoded == 0) {
         if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, cdf->cdf_mdindex, T_CDF_MID_MDINDEX);
         Ix = sx_rc_dec(rc, cdf->cdf_fs, T_CDF_MID_FS);
-        if (Ix != 0) {  // only the 8 kHz NB mode exists in this build (reference: decoder_set_fs to 12/16/24 kHz)
+        if (Ix != (SX_FS_KHZ == 8 ? 0 : 2)) {  // index into {8, 12, 16, 24} kHz: this build decodes ONE internal rate (reference: decoder_set_fs)
             if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
             lane_out[3] = rc->error;
             *rc_io = rc_local;
@@ -312,12 +312,12 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io,
 
     // NLSF path: 6 stages, per-stage CDFs laid out back to back (nvec+1 entries each)
     {
-        const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+        const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
         const i32* nvec = c->sigtype == 0 ? nvec0 : nvec1;
         const u16* ncdf = c->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
         const i32* mid = c->sigtype == 0 ? T_nlsf_cb0_cdf_mid : T_nlsf_cb1_cdf_mid;
         int off = 0;
-        for (int s = 0; s < 6; s++) {
+        for (int s = 0; s < SX_NLSF_STAGES; s++) {
             NLSFIndices[s] = sx_rc_dec(rc, ncdf + off, mid[s]);
             off += nvec[s] + 1;
         }
@@ -334,10 +334,10 @@ SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io,
     for (int i = 0; i < SX_LPC; i++) md->prevNLSF_Q15[i] = pNLSF_Q15[i];
 
     if (c->sigtype == 0) {
-        i32 lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag_nb, T_CDF_MID_PITCH_LAG_NB);
-        i32 conIx = sx_rc_dec(rc, cdf->cdf_pitch_contour_nb, T_CDF_MID_PITCH_CONTOUR_NB);
-        i32 lag = 2 * 8 + lagIx;   // SKP_Silk_decode_pitch.c:43-50
-        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_stage2[i * 11 + conIx];
+        i32 lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag, T_CDF_MID_PITCH_LAG);
+        i32 conIx = sx_rc_dec(rc, cdf->cdf_pitch_contour, T_CDF_MID_PITCH_CONTOUR);
+        i32 lag = 2 * SX_FS_KHZ + lagIx;   // SKP_Silk_decode_pitch.c:43-58 (8 kHz: stage-2 contours, above: stage-3 contours)
+        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_dec[i * SX_PITCH_CB_N + conIx];
         c->PERIndex = sx_rc_dec(rc, cdf->cdf_ltp_per, T_CDF_MID_LTP_PER);
         const i16* cbk = c->PERIndex == 0 ? T_ltp_vq0_Q14 : (c->PERIndex == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
         const u16* gcdf = c->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (c->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
@@ -515,7 +515,7 @@ SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
             for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = (i16)(sx_smulbb(p->LTPCoef_Q14[i], scale_Q14) >> 14);
         }
     } else {
-        p->pitchL_Q8 = sx_shl(sx_smulbb(8, 18), 8);
+        p->pitchL_Q8 = sx_shl(sx_smulbb(SX_FS_KHZ, 18), 8);
         for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = 0;
     }
     for (int i = 0; i < SX_LPC; i++) p->prevLPC_Q12[i] = c->PredCoef_Q12[1][i];
@@ -593,7 +593,7 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
         for (int j = 0; j < SX_LTP_ORDER; j++) B_Q14[j] = (i16)(sx_smulbb(harm_Gain_Q15, B_Q14[j]) >> 15);
         rand_scale_Q14 = (i16)(sx_smulbb(rand_scale_Q14, rand_Gain_Q15) >> 15);
         p->pitchL_Q8 += sx_smulwb(p->pitchL_Q8, 655);
-        p->pitchL_Q8 = sx_min(p->pitchL_Q8, sx_shl(sx_smulbb(18, 8), 8));
+        p->pitchL_Q8 = sx_min(p->pitchL_Q8, sx_shl(sx_smulbb(18, SX_FS_KHZ), 8));
         lag = sx_rshift_round(p->pitchL_Q8, 8);
     }
     // LPC synthesis
@@ -624,9 +624,9 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
 
 // SKP_Silk_PLC, SKP_Silk_PLC.c:43
 SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
-    if (st->plc.fs_kHz != 8) {
+    if (st->plc.fs_kHz != SX_FS_KHZ) {
         st->plc.pitchL_Q8 = SX_FRAME >> 1;   // SKP_Silk_PLC_Reset
-        st->plc.fs_kHz = 8;
+        st->plc.fs_kHz = SX_FS_KHZ;
     }
     if (lost) {
         sx_plc_conceal(st, w, signal);
@@ -695,12 +695,12 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(signal);
     SxCNG* g = &st->cng;
     SxDecCtrl* c = &w->ctrl;
-    if (g->fs_kHz != 8) {
+    if (g->fs_kHz != SX_FS_KHZ) {
         i32 step = 32767 / (SX_LPC + 1), acc = 0;      // SKP_Silk_CNG_Reset, CNG.c:58
         for (int i = 0; i < SX_LPC; i++) { acc += step; g->smth_NLSF_Q15[i] = acc; }
         g->smth_Gain_Q16 = 0;
         g->rand_seed = 3176576;
-        g->fs_kHz = 8;
+        g->fs_kHz = SX_FS_KHZ;
     }
     if (st->lossCnt == 0 && st->vadFlag == 0) {
         for (int i = 0; i < SX_LPC; i++)
@@ -710,18 +710,18 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
         for (int i = 0; i < SX_NB_SUBFR; i++) {
             if (c->Gains_Q16[i] > max_Gain_Q16) { max_Gain_Q16 = c->Gains_Q16[i]; subfr = i; }
         }
-        // memmove( &buf[40], buf, 120 ) then memcpy( buf, &exc[subfr*40], 40 ): read everything first
-        i32 v0 = 0, v1 = 0, v2 = 0;
+        // memmove( &buf[subfr_length], buf, 3 * subfr_length ) then memcpy( buf, &exc[subfr * subfr_length], subfr_length ):
+        // read everything first (3 * SX_SUBFR <= 4 * 64)
         const int l = SX_LANE;
         if (SX_NLANES == 1) {
             for (int i = 3 * SX_SUBFR - 1; i >= 0; i--) g->exc_buf_Q10[SX_SUBFR + i] = g->exc_buf_Q10[i];
         } else {
-            if (l < 3 * SX_SUBFR) v0 = g->exc_buf_Q10[l];
-            if (l + 64 < 3 * SX_SUBFR) v1 = g->exc_buf_Q10[l + 64];
-            (void)v2;
+            i32 v[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) v[j] = (l + 64 * j < 3 * SX_SUBFR) ? g->exc_buf_Q10[l + 64 * j] : 0;
             wv_sync();
-            if (l < 3 * SX_SUBFR) g->exc_buf_Q10[SX_SUBFR + l] = v0;
-            if (l + 64 < 3 * SX_SUBFR) g->exc_buf_Q10[SX_SUBFR + l + 64] = v1;
+#pragma unroll
+            for (int j = 0; j < 4; j++) if (l + 64 * j < 3 * SX_SUBFR) g->exc_buf_Q10[SX_SUBFR + l + 64 * j] = v[j];
         }
         wv_sync();
         SX_PAR(i, SX_SUBFR) g->exc_buf_Q10[i] = st->exc_Q10[subfr * SX_SUBFR + i];
@@ -772,7 +772,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         // in (PLC.c:375-413), and the 24 kHz tags that force PLC_Reset / CNG_Reset on the first decoded frame.
         {   // (wave-uniform: every lane stores the same values)
             st->plc.fs_kHz = 24;
-            st->plc.rand_seed = sx_rand_skip(sx_rand_skip(st->plc.rand_seed, 240), 240);    // 480 steps (sx_rand_skip takes n < 256)
+            st->plc.rand_seed = sx_rand_skip(st->plc.rand_seed, 480);
             st->plc.randScale_Q14 = 0;           // (1 << 14) * prevLTP_scale_Q14 (= 0) >> 14, PLC.c:213
             st->plc.conc_energy = 0;
             st->plc.conc_energy_shift = 0;

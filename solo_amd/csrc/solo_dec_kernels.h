@@ -1,0 +1,157 @@
+// solo_dec_kernels.h -- the decoder's kernels and their launchers, compiled once per internal rate: solo_api.hip includes it
+// with SX_FS_KHZ = 8 (16 kHz API rate), solo_api_wb.hip with SX_FS_KHZ = 16 (32 kHz API rate); SX_K() keeps the symbols apart.
+#pragma once
+#include <hip/hip_runtime.h>
+#include "solo_dec.h"
+
+#if SX_FS_KHZ == 8
+#define SX_K(name) name
+#else
+#define SX_K(name) name##_wb
+#endif
+
+__global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecState* states, int n_streams, int hb_joint) {
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    sx_dec_state_init(&states[s], hb_joint);
+}
+
+// Decoder: rows D0-D8.  blockIdx.x = stream.
+// state record HBM <-> LDS (whole launch) and the entropy tables
+__device__ __forceinline__ void SX_K(solo_dec_enter)(SxDecWork* w, const SxDecState* rec) {
+    const i32* src = (const i32*)rec;
+    i32* dst = (i32*)&w->st;
+    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
+    sx_cdf_load_dec(&w->cdf);
+    wv_sync();
+}
+__device__ __forceinline__ void SX_K(solo_dec_leave)(SxDecWork* w, SxDecState* rec) {
+    wv_sync();
+    const i32* src = (const i32*)&w->st;
+    i32* dst = (i32*)rec;
+    SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
+}
+
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecState* states, const u8* __restrict__ bits,
+                                                         const i16* __restrict__ nbytes, const u8* __restrict__ recv,
+                                                         int n_streams, int n_packets, int slot, int useMDIndex,
+                                                         i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SX_K(solo_dec_enter)(&w, &states[s]);
+    i32 first_err = 0;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const u8* b = bits + pk * (size_t)slot;
+        const i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
+        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);      // an empty (DTX) packet is a lost packet, like test/dec_main.c:236-252
+        // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
+        int lostflag;
+        i32 a0, a1;
+        const u8* ptr = b;
+        if (m == 3) { lostflag = 4; a0 = n0; a1 = n1; }
+        else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
+        else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
+        else { lostflag = 1; a0 = n0 > 0 ? n0 : 16; a1 = n0 > 0 ? n1 : 0; }
+        i16* out = pcm + pk * SX_PACKET;
+        int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    SX_K(solo_dec_leave)(&w, &states[s]);
+    if (status && SX_LANE == 0) status[s] = first_err;
+}
+
+// Receiver front end: the two descriptions of a 40 ms packet arrive as separate network packets (MD1, and
+// MD2 || HB), possibly only one of them, possibly swapped.  descA / descB are the two arrival slots of every (stream, packet):
+// uint8 [N][P][slot], lenA / lenB int16 [N][P] (0 = nothing arrived).  With useMDIndex = 1 every description carries its index
+// as its first range-coded symbol (SKP_Silk_decode_parameters.c:55-57): the kernel reads it and sorts the arrivals itself
+// (two copies of the same description count once); with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.  The kernel then
+// builds the (ptr, nBytes, lostflag) triple of test/dec_main.c:255-378 and decodes.  Packets above the LDS staging size
+// (252 B; 13.6 kbps packets are ~80 B) are rejected with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11).
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecState* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
+                                                               const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
+                                                               int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SX_K(solo_dec_enter)(&w, &states[s]);
+    i32 first_err = 0;
+    for (int p = 0; p < n_packets; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const u8* pa = descA + pk * (size_t)slot;
+        const u8* pb = descB + pk * (size_t)slot;
+        i32 la = lenA[pk], lb = lenB[pk];
+        if (la < 0 || la > slot) la = 0;
+        if (lb < 0 || lb > slot) lb = 0;
+        const u8 *p1 = pa, *p2 = pb;
+        i32 l1 = la, l2 = lb;
+        if (useMDIndex == 1) {
+            int ia = -1, ib = -1;
+            if (la > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
+            if (lb > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
+            p1 = pa; l1 = 0; p2 = pb; l2 = 0;
+            if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
+            if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
+        }
+        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+        if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
+        i16* out = pcm + pk * SX_PACKET;
+        int ret;
+        if (l1 + l2 > SX_DEC_PAYLOAD_LDS) {
+            ret = -11;
+        } else {
+            wv_sync();
+            SX_PAR(i, l1) w.payload[i] = p1[i];
+            SX_PAR(i, l2) w.payload[l1 + i] = p2[i];
+            wv_sync();
+            int lostflag;
+            i32 a0, a1;
+            if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
+            else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
+            else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
+            else { lostflag = 1; a0 = hbb + 1; a1 = 0; }
+            ret = sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
+        }
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    SX_K(solo_dec_leave)(&w, &states[s]);
+    if (status && SX_LANE == 0) status[s] = first_err;
+}
+
+// single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
+__global__ void __launch_bounds__(64) SX_K(solo_decode_raw_kernel)(SxDecState* st, const u8* bits, int n0, int n1, int lostflag,
+                                                             int useMDIndex, i16* pcm, i32* status) {
+    __shared__ SxDecWork w;
+    SX_K(solo_dec_enter)(&w, st);
+    int ret = sx_decode_packet(&w, bits, n0, n1, lostflag, useMDIndex, pcm);
+    SX_K(solo_dec_leave)(&w, st);
+    if (SX_LANE == 0) *status = ret;
+}
+
+// launchers (host): same signature for both rates
+static inline hipError_t SX_K(solo_dec_launch_init)(void* states, int n_streams, int hb_joint, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_dec_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, n_streams, hb_joint);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_dec_launch)(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
+                                               int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_decode_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, bits, nbytes, recv, n_streams,
+                       n_packets, slot, useMDIndex, pcm, status);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_dec_launch_split)(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB,
+                                                     const int16_t* lenB, int n_streams, int n_packets, int slot, int useMDIndex,
+                                                     int16_t* pcm, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_decode_split_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, descA, lenA, descB, lenB,
+                       n_streams, n_packets, slot, useMDIndex, pcm, status);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_dec_launch_raw)(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm,
+                                                   int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_decode_raw_kernel), dim3(1), dim3(64), 0, s, (SxDecState*)state, bits, n0, n1, lostflag, useMDIndex, pcm, status);
+    return hipGetLastError();
+}
+static inline size_t SX_K(solo_dec_state_bytes)() { return sizeof(SxDecState); }

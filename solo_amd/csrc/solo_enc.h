@@ -195,8 +195,8 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
     }
     sx_rc_enc(rc, x->NLSFInterpCoef_Q2, cdf->cdf_nlsf_interp);
     if (x->sigtype == 0) {
-        sx_rc_enc(rc, x->lagIndex, cdf->cdf_pitch_lag_nb);
-        sx_rc_enc(rc, x->contourIndex, cdf->cdf_pitch_contour_nb);
+        sx_rc_enc(rc, x->lagIndex, cdf->cdf_pitch_lag);
+        sx_rc_enc(rc, x->contourIndex, cdf->cdf_pitch_contour);
         sx_rc_enc(rc, x->PERIndex, cdf->cdf_ltp_per);
         const u16* gcdf = x->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (x->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
         for (int k = 0; k < SX_NB_SUBFR; k++) sx_rc_enc(rc, x->LTPIndex[k], gcdf);

@@ -191,7 +191,7 @@ SX_HD i32 sx_rand(i32 seed) { return (i32)(907633515u + (u32)seed * 196314165u);
 SX_HD i32 sx_rand_skip(i32 seed, u32 n) {
     u32 Ar = 1u, Cr = 0u, Ab = 196314165u, Cb = 907633515u;
 #pragma unroll
-    for (int bit = 0; bit < 8; bit++) {          // n < 256
+    for (int bit = 0; bit < 9; bit++) {          // n < 512 (a 20 ms frame at 16 kHz has 320 samples)
         if (n & (1u << bit)) { Ar = Ab * Ar; Cr = Ab * Cr + Cb; }
         Cb = Ab * Cb + Cb;
         Ab = Ab * Ab;

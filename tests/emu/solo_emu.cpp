@@ -7,11 +7,16 @@
 #include <stdlib.h>
 #include <string.h>
 #include <stdint.h>
+// -DSX_FS_KHZ=16 -DEMU_DEC_ONLY builds the 32 kHz-mode decoder (libsolo_emu_wb.so): same entry points, 1280-sample packets.
+#ifndef EMU_DEC_ONLY
 struct SxEncState; struct SxEncWork;
 static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const int16_t* sig);
 #define SX_ENC_TAP(stage, st, w, sig) emu_tap(stage, st, w, sig)
+#endif
 #include "../../solo_amd/csrc/solo_dec.h"
+#ifndef EMU_DEC_ONLY
 #include "../../solo_amd/csrc/solo_enc.h"
+#endif
 
 extern "C" {
 
@@ -34,12 +39,14 @@ int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int l
 }
 int emu_sizeof_dec_state() { return (int)sizeof(SxDecState); }
 int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
+int emu_packet_samples() { return SX_PACKET; }
 
 }  // extern "C"
 
 // debug aid: raw view of the decoder state (tests only)
 extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 
+#ifndef EMU_DEC_ONLY
 // ---- encoder ----
 extern "C" {
 struct EmuEnc { SxEncStream rec; SxEncWork w; SxCodeIn cin; };
@@ -102,3 +109,5 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
         p += 320 + 160;                             // pulses / excitation now live in the stream's HBM record, see test hooks
     }
 }
+
+#endif  // EMU_DEC_ONLY

@@ -92,6 +92,31 @@ def main():
             assert ret == 0
     np.savez_compressed(os.path.join(HERE, "synth8x25_cold.npz"), recv=recv_cold, dec=dec_cold)
     g["synth_dec_cold_md5"] = md5(dec_cold.tobytes())
+    # 32 kHz mode (decoder): 4 streams x 20 packets of 1280 samples at 24 kbps through the reference encoder (SILK wide band),
+    # reference decodes clean and with description loss (stream 1 starts with two lost packets, stream 3 is joint_mode 1)
+    NW, PW = 4, 20
+    wpcm = np.stack([T.synth_stream_32k(500 + i, PW) for i in range(NW)])
+    wstreams = []
+    for i in range(NW):
+        e = R.RefEncoder("fix", rate=24000, samplerate=32000, joint=1 if i == 3 else 0)
+        wstreams.append([e.encode(wpcm[i, p]) for p in range(PW)])
+    wbits, wnb = T.pack_slots(wstreams)
+    wrecv = T.bernoulli_recv(NW, PW, 0.3, 4321)
+    wrecv[1, :2] = 0
+    wdec_clean = np.zeros((NW, PW, 1280), np.int16)
+    wdec_loss = np.zeros((NW, PW, 1280), np.int16)
+    for i in range(NW):
+        d0, d1 = (R.RefDecoder("fix", samplerate=32000, joint=1 if i == 3 else 0) for _ in range(2))
+        for p, (pl, n0, n1) in enumerate(wstreams[i]):
+            wdec_clean[i, p], r0 = d0.decode(pl, n0, n1, 4)
+            m = int(wrecv[i, p])
+            wdec_loss[i, p], r1 = d1.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert r0 == 0 and r1 == 0
+    np.savez_compressed(os.path.join(HERE, "wb4x20.npz"), bits=wbits, nbytes=wnb, recv=wrecv, dec_clean=wdec_clean, dec_loss=wdec_loss)
+    g["wb_bits_md5"] = md5(wbits.tobytes())
+    g["wb_dec_clean_md5"] = md5(wdec_clean.tobytes())
+    g["wb_dec_loss_md5"] = md5(wdec_loss.tobytes())
+    g["wb_mean_payload"] = float(wnb[..., 0].mean())
     g["synth_bits_md5"] = md5(bits.tobytes())
     g["synth_dec_clean_md5"] = md5(dec_clean.tobytes())
     g["synth_dec_loss_md5"] = md5(dec_loss.tobytes())

@@ -70,8 +70,16 @@ def bernoulli_recv(n_streams, n_packets, p_loss, seed):
     return ((~lost[..., 0]).astype(np.uint8) | ((~lost[..., 1]).astype(np.uint8) << 1)).astype(np.uint8)
 
 
+def synth_stream_32k(seed, n_packets):
+    """32 kHz test material [n_packets, 1280]: the 16 kHz workload generator read at twice the rate (pitch and formants double,
+    which is fine for exercising the codec: voiced / unvoiced / silence all occur)."""
+    from solo_amd.synth import synth_stream
+    return synth_stream(seed, 2 * n_packets).reshape(n_packets, 1280)
+
+
 # ---- host emulation of the kernel source (tests/emu) ------------------------------------------------
 _emu = None
+_emu_wb = None
 
 
 def load_emu():
@@ -93,16 +101,33 @@ def load_emu():
     return _emu
 
 
+def load_emu_wb():
+    """32 kHz-mode build of the decoder source (-DSX_FS_KHZ=16): same entry points, 1280-sample packets."""
+    global _emu_wb
+    if _emu_wb is None:
+        d = os.path.join(ROOT, "tests", "emu")
+        subprocess.check_call(["make", "-s", "-C", d, "libsolo_emu_wb.so"])
+        lib = C.CDLL(os.path.join(d, "libsolo_emu_wb.so"))
+        lib.emu_dec_create.restype = C.c_void_p
+        lib.emu_dec_create.argtypes = [C.c_int]
+        lib.emu_dec_destroy.argtypes = [C.c_void_p]
+        lib.emu_dec_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
+        assert lib.emu_packet_samples() == 1280
+        _emu_wb = lib
+    return _emu_wb
+
+
 class EmuDecoder:
-    def __init__(self, use_md_index=0):
-        self.lib = load_emu()
+    def __init__(self, use_md_index=0, wb=False):
+        self.lib = load_emu_wb() if wb else load_emu()
+        self.n = 1280 if wb else 640
         self.h = self.lib.emu_dec_create(use_md_index)
 
     def decode(self, payload, n0, n1, lostflag):
         buf = np.zeros(1100, np.uint8)
         b = np.frombuffer(payload, np.uint8)
         buf[:b.size] = b
-        out = np.zeros(640, np.int16)
+        out = np.zeros(self.n, np.int16)
         ret = self.lib.emu_dec_packet(self.h, buf.ctypes.data, n0, n1, lostflag, out.ctypes.data)
         return out, ret
 

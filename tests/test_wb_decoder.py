@@ -1,0 +1,159 @@
+"""32 kHz mode of the decoder (`samplerate == 32000`, libBWE/AGR_BWE_SDK_API.c:197 -- 16 kHz bands, SILK wide
+band: fs_kHz 16, LPC order 16, order-16 NLSF codebooks, stage-3 pitch contours, 1280-sample packets).  The kernel source is the
+same as for the 16 kHz rate, compiled with SX_FS_KHZ = 16.  CPU tests: host emulation of that build against the committed
+goldens (made by the compiled reference, tests/golden/make_golden.py) and against the reference itself; GPU tests: the HIP
+kernels through the C ABI."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+import refcodec as R
+import solo_testlib as T
+
+
+def _wb():
+    return np.load(T.GOLDEN + "/wb4x20.npz")
+
+
+def test_wb_goldens_pinned():
+    z, g = _wb(), T.golden_json()
+    assert T.md5(z["bits"]) == g["wb_bits_md5"] and T.md5(z["dec_clean"]) == g["wb_dec_clean_md5"] and T.md5(z["dec_loss"]) == g["wb_dec_loss_md5"]
+    assert (z["recv"][1, :2] == 0).all()              # stream 1 starts with lost packets (decoder cold start at 24 kHz -> 16 kHz)
+
+
+def test_wb_emulation_vs_goldens():
+    z = _wb()
+    bits, nb, recv = z["bits"], z["nbytes"], z["recv"]
+    N, P = recv.shape
+    for mask, key in ((None, "dec_clean"), (recv, "dec_loss")):
+        for s in range(N):
+            dec = T.EmuDecoder(2 if s == 3 else 0, wb=True)           # stream 3 was coded with joint_mode 1
+            for p in range(P):
+                n0, n1 = int(nb[s, p, 0]), int(nb[s, p, 1])
+                m = 3 if mask is None else int(mask[s, p])
+                x, ret = dec.decode(*R.map_loss(bits[s, p, :n0].tobytes(), n0, n1, not (m & 1), not (m & 2)))
+                assert ret == 0 and x.size == 1280
+                assert np.array_equal(x, z[key][s, p]), (key, s, p)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rate,joint", [(16000, 0), (24000, 0), (32000, 1), (40000, 0)])
+def test_wb_emulation_vs_reference(rate, joint):
+    """Rates from the lowest that keeps the reference encoder at 16 kHz internally (SILK rate >= WB2MB_BITRATE_BPS,
+    SKP_Silk_control_audio_bandwidth.c:44) upwards; 30 % description loss, leading losses, both high-band framings."""
+    P = 30
+    pcm = T.synth_stream_32k(900 + rate // 1000, P)
+    enc = R.RefEncoder("fix", rate=rate, samplerate=32000, joint=joint)
+    recs = [enc.encode(pcm[p]) for p in range(P)]
+    for variant in range(2):
+        lost = np.random.default_rng(rate + variant).random((P, 2)) < 0.3
+        if variant == 1:
+            lost[:3] = True
+        dr, de = R.RefDecoder("fix", samplerate=32000, joint=joint), T.EmuDecoder(2 if joint else 0, wb=True)
+        for p, (pl, n0, n1) in enumerate(recs):
+            a = R.map_loss(pl, n0, n1, bool(lost[p, 0]), bool(lost[p, 1]))
+            x, r1 = dr.decode(*a)
+            y, r2 = de.decode(*a)
+            assert r1 == r2 == 0 and np.array_equal(x, y), (rate, joint, variant, p)
+
+
+def test_wb_decoder_rejects_other_internal_rates():
+    """A narrow-band stream (16 kHz API rate) handed to the 32 kHz decoder: the reference would switch its SILK core to 8 kHz
+    and resample; this build decodes one internal rate per handle and reports a payload error instead of producing audio."""
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    n0, n1 = int(z["nbytes"][0, 0, 0]), int(z["nbytes"][0, 0, 1])
+    dec = T.EmuDecoder(wb=True)
+    x, ret = dec.decode(z["bits"][0, 0, :n0].tobytes(), n0, n1, 4)
+    assert ret < 0
+
+
+# ---- GPU -------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    return torch
+
+
+def _gpu_decode(torch, bits, nb, recv, joint=0):
+    import solo_amd
+    N, P, S = bits.shape
+    b = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=S, samplerate=32000, joint=joint)
+    pcm, status = b.decode(torch.from_numpy(np.ascontiguousarray(bits)).to(b.device), torch.from_numpy(np.ascontiguousarray(nb)).to(b.device),
+                           None if recv is None else torch.from_numpy(np.ascontiguousarray(recv)).to(b.device))
+    torch.cuda.synchronize()
+    assert tuple(pcm.shape) == (N, P, 1280) and int(status.abs().max()) == 0
+    return pcm.cpu().numpy()
+
+
+@pytest.mark.gpu
+def test_wb_gpu_goldens(torch_cuda):
+    z = _wb()
+    for recv, key in ((None, "dec_clean"), (z["recv"], "dec_loss")):
+        out = _gpu_decode(torch_cuda, z["bits"][:3], z["nbytes"][:3], None if recv is None else recv[:3])
+        assert np.array_equal(out, z[key][:3]), key
+        out = _gpu_decode(torch_cuda, z["bits"][3:], z["nbytes"][3:], None if recv is None else recv[3:], joint=1)
+        assert np.array_equal(out, z[key][3:]), key + " joint"
+
+
+@pytest.mark.gpu
+def test_wb_gpu_packetwise_and_wrong_rate(torch_cuda):
+    import solo_amd
+    torch = torch_cuda
+    z = _wb()
+    bits, nb, recv = z["bits"][:3], z["nbytes"][:3], z["recv"][:3]
+    N, P, S = bits.shape
+    b = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=S, samplerate=32000)
+    for p in range(P):                      # state carries in HBM between launches
+        pcm, st = b.decode(torch.from_numpy(np.ascontiguousarray(bits[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(nb[:, p:p + 1])).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(recv[:, p:p + 1])).to(b.device))
+        assert np.array_equal(pcm.cpu().numpy()[:, 0], z["dec_loss"][:3, p]), p
+    nbz = np.load(T.GOLDEN + "/synth8x25.npz")      # narrow-band streams into the 32 kHz decoder: rejected, not decoded
+    b2 = solo_amd.SoloBatch(8, encoder=False, decoder=True, slot_bytes=nbz["bits"].shape[2], samplerate=32000)
+    pcm, st = b2.decode(torch.from_numpy(nbz["bits"][:, :1].copy()).to(b2.device), torch.from_numpy(nbz["nbytes"][:, :1].copy()).to(b2.device))
+    assert (st.cpu().numpy() < 0).all()
+    with pytest.raises(ValueError):
+        solo_amd.SoloBatch(4, encoder=True, decoder=True, samplerate=32000)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_wb_gpu_many_streams_vs_reference_and_legacy_api(torch_cuda):
+    """64 streams x 10 packets, 30 % description loss, against the compiled reference; and the legacy single-stream entry points
+    (AGR_Sate_Decoder_Init / Decode with samplerate = 32000) for one stream."""
+    import solo_amd
+    N, P = 64, 10
+    streams = []
+    for i in range(N):
+        e = R.RefEncoder("fix", rate=20000 + 1000 * (i % 8), samplerate=32000)
+        pcm = T.synth_stream_32k(3000 + i, P)
+        streams.append([e.encode(pcm[p]) for p in range(P)])
+    bits, nb = T.pack_slots(streams)
+    recv = T.bernoulli_recv(N, P, 0.3, 77)
+    recv[::7, 0] = 0
+    out = _gpu_decode(torch_cuda, bits, nb, recv)
+    for i in range(N):
+        d = R.RefDecoder("fix", samplerate=32000)
+        for p, (pl, n0, n1) in enumerate(streams[i]):
+            m = int(recv[i, p])
+            x, ret = d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0 and np.array_equal(out[i, p], x), (i, p)
+    lib = solo_amd.load_library()
+    ctrl = solo_amd.default_dec_ctrl(samplerate=32000)
+    h = lib.AGR_Sate_Decoder_Init(C.byref(ctrl))
+    assert h
+    d = R.RefDecoder("fix", samplerate=32000)
+    pcm = np.zeros(1920, np.int16)
+    ns = C.c_int16(0)
+    for p, (pl, n0, n1) in enumerate(streams[0]):
+        m = int(recv[1, p])
+        a = R.map_loss(pl, n0, n1, not (m & 1), not (m & 2))
+        x, ret = d.decode(*a)
+        buf = np.zeros(1100, np.uint8)
+        buf[:len(a[0])] = np.frombuffer(a[0], np.uint8)
+        nbv = (C.c_int16 * 6)(a[1], a[2], 0, 0, 0, 0)
+        r = lib.AGR_Sate_Decoder_Decode(h, pcm.ctypes.data_as(C.c_void_p), C.byref(ns), buf.ctypes.data_as(C.c_void_p), nbv, a[3])
+        assert r == ret == 0 and ns.value == 1280 and np.array_equal(pcm[:1280], x), p
+    lib.AGR_Sate_Decoder_Uninit(h)

@@ -119,6 +119,25 @@ SCALAR_ARRAYS = [("SKP_Silk_LTP_gain_CDF_offsets", I32, "cdf_mid_ltp_gain", "SKP
                  ("SKP_Silk_LTP_vq_sizes", I32, "ltp_vq_sizes", "SKP_Silk_tables_LTP.c:322")]
 
 
+# --- 32 kHz mode: SILK runs wide band (fs_kHz = 16, LPC order 16); the tables that depend on the internal rate ---
+TABLES_WB = [
+    ("SKP_Silk_pitch_lag_WB_CDF", U16, "cdf_pitch_lag_wb", "SKP_Silk_tables_pitch_lag.c"),
+    ("SKP_Silk_pitch_contour_CDF", U16, "cdf_pitch_contour_wb", "SKP_Silk_tables_pitch_lag.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB0_16_Q15", I16, "nlsf16_cb0_Q15", "SKP_Silk_tables_NLSF_CB0_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB0_16_rates_Q5", I16, "nlsf16_cb0_rates_Q5", "SKP_Silk_tables_NLSF_CB0_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB0_16_CDF", U16, "nlsf16_cb0_cdf", "SKP_Silk_tables_NLSF_CB0_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB0_16_CDF_middle_idx", I32, "nlsf16_cb0_cdf_mid", "SKP_Silk_tables_NLSF_CB0_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB0_16_ndelta_min_Q15", I32, "nlsf16_cb0_ndelta_min_Q15", "SKP_Silk_tables_NLSF_CB0_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB1_16_Q15", I16, "nlsf16_cb1_Q15", "SKP_Silk_tables_NLSF_CB1_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB1_16_rates_Q5", I16, "nlsf16_cb1_rates_Q5", "SKP_Silk_tables_NLSF_CB1_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB1_16_CDF", U16, "nlsf16_cb1_cdf", "SKP_Silk_tables_NLSF_CB1_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB1_16_CDF_middle_idx", I32, "nlsf16_cb1_cdf_mid", "SKP_Silk_tables_NLSF_CB1_16.c"),
+    ("SKP_Silk_NLSF_MSVQ_CB1_16_ndelta_min_Q15", I32, "nlsf16_cb1_ndelta_min_Q15", "SKP_Silk_tables_NLSF_CB1_16.c"),
+    ("TargetRate_table_WB", I32, "target_rate_wb", "SKP_Silk_tables_other.c"),
+]
+SCALARS_WB = [("SKP_Silk_pitch_lag_WB_CDF_offset", "CDF_MID_PITCH_LAG_WB"), ("SKP_Silk_pitch_contour_CDF_offset", "CDF_MID_PITCH_CONTOUR_WB")]
+
+
 def symtab():
     out = subprocess.check_output(["nm", "-S", "--defined-only", LIB], text=True)
     tab = {}
@@ -171,6 +190,26 @@ def main():
     with open(os.path.join(ROOT, "solo_amd", "csrc", "solo_tables.inc"), "w") as f:
         f.write(hdr + "/* the including translation unit defines SOLO_TAB (e.g. `static __device__ const`) */\n" + text)
     print("wrote tables: %d arrays" % (len(TABLES) + len(SCALAR_ARRAYS)))
+    body = []
+    for sym, (cname, ct), ours, where in TABLES_WB:
+        vals = read(sym, ct)
+        body.append("/* %s  (values of %s, %s) */" % (ours, sym, where))
+        body.append("SOLO_TAB %s T_%s[%d] = {" % (cname, ours, len(vals)))
+        for i in range(0, len(vals), 12):
+            body.append("    " + ", ".join(str(v) for v in vals[i:i + 12]) + ",")
+        body.append("};")
+    body.append("")
+    for sym, ours in SCALARS_WB:
+        body.append("#define T_%s %d  /* %s */" % (ours, read(sym, C.c_int32)[0], sym))
+    for cb, n_st in (("CB0_16", 10), ("CB1_16", 10)):
+        addr, size = tab["SKP_Silk_NLSF_%s_Stage_info" % cb]
+        assert size == 24 * n_st
+        nv = [C.c_int32.from_address(base + addr + 24 * s).value for s in range(n_st)]
+        body.append("#define T_NLSF16_%s_NVEC { %s }" % (cb[:3], ", ".join(map(str, nv))))
+    with open(os.path.join(ROOT, "solo_amd", "csrc", "solo_tables_wb.inc"), "w") as f:
+        f.write("/* GENERATED by tools/gen_tables.py -- numeric tables read out of the compiled reference: the ones that\n"
+                "   depend on SILK's internal rate, for the 32 kHz mode (fs_kHz = 16, order 16). Do not edit. */\n" + "\n".join(body) + "\n")
+    print("wrote WB tables: %d arrays" % len(TABLES_WB))
 
 
 if __name__ == "__main__":
