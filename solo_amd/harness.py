@@ -3,7 +3,7 @@ test/enc_main.c and read by test/dec_main.c, and the loss simulator of the decod
 interoperate with the stock reference binaries and their known-answer md5s can be matched end to end.
 
   python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1]
-  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-MDI 0/1] [-joint 1]
+  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-MDI 0/1] [-joint 1] [-Fs_API 32000]
 
 Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per 40 ms packet  int16 total, int16 len(MD2)+8, `total` payload bytes
 (payload = MD1 || MD2 || HB(8)).  Loss simulator (test/dec_main.c:24,236-252): rand_seed = 1, the LCG
@@ -82,8 +82,8 @@ def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0)
     return [(hb[p, :hn[p, 0]].tobytes(), int(hn[p, 0]), int(hn[p, 1])) for p in range(P)]
 
 
-def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0):
-    """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation"""
+def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, samplerate=16000):
+    """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation (samplerate 32000 = `-Fs_API 32000`)"""
     import torch
     from . import SoloBatch
     P = len(recs)
@@ -97,7 +97,7 @@ def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0):
         bits[0, p, :n0] = np.frombuffer(pl[:n0], np.uint8)
         nb[0, p] = (n0, n1)
     mask = recv_mask(cli_loss_pattern(P, loss_perc, [(r[1], r[2]) for r in recs]))[None, :]
-    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint)
+    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, samplerate=samplerate)
     pcm, st = b.decode(torch.from_numpy(bits).to(b.device), torch.from_numpy(nb).to(b.device),
                        torch.from_numpy(np.ascontiguousarray(mask)).to(b.device))
     torch.cuda.synchronize()
@@ -119,6 +119,10 @@ def main(argv=None):
         print(__doc__)
         return 2
     mdi = _opt(argv, "-MDI", 0)
+    fs = _opt(argv, "-Fs_API", 16000)
+    if fs not in (16000, 32000) or (fs == 32000 and argv[0] == "enc"):
+        print("-Fs_API: 16000, or 32000 for dec (the 32 kHz encoder is not built)")
+        return 2
     if argv[0] == "enc":
         recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi,
                           joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0))
@@ -126,9 +130,9 @@ def main(argv=None):
         print("%d packets, %.3f kbps" % (len(recs), sum(r[1] for r in recs) * 8 / max(len(recs), 1) / 40.0))
     else:
         pcm = decode_records(parse_bit_container(open(argv[1], "rb").read()), loss_perc=_opt(argv, "-loss", 0), use_md_index=mdi,
-                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0)
+                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0, samplerate=fs)
         pcm.astype(np.int16).tofile(argv[2])
-        print("%d packets decoded" % (pcm.size // PACKET_SAMPLES))
+        print("%d packets decoded" % (pcm.size // (PACKET_SAMPLES * fs // 16000)))
     return 0
 
 
