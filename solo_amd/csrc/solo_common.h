@@ -21,6 +21,10 @@
 #if SX_FS_KHZ == 8
 #define SX_LPC 10          // predictLPCOrder at fs_kHz == 8   (SKP_Silk_control_codec_FIX.c:278)
 #define SX_NLSF_STAGES 6   // stages of SKP_Silk_NLSF_CB0_10 / CB1_10
+#define SX_NLSF_CB0_NVEC_TOTAL 120
+#define SX_NLSF_CB1_NVEC_TOTAL 72
+#define SX_NLSF_CB_MAXVEC 120
+#define SX_MSVQ_ROW 16
 #define SX_N_NLSF_CB0_CDF 126
 #define SX_N_NLSF_CB1_CDF 78
 #define SX_N_PITCH_LAG_CDF 130
@@ -31,10 +35,16 @@
 #define T_CDF_MID_PITCH_LAG T_CDF_MID_PITCH_LAG_NB
 #define T_CDF_MID_PITCH_CONTOUR T_CDF_MID_PITCH_CONTOUR_NB
 #define T_pitch_cb_dec T_pitch_cb_stage2
+#define T_target_rate T_target_rate_nb       // control_codec_FIX.c:338-346
+#define K_MU_LTP_QUANT_Q8 K_MU_LTP_QUANT_NB_Q8   // control_codec_FIX.c:300-316
 #elif SX_FS_KHZ == 16
 #include "solo_tables_wb.inc"
 #define SX_LPC 16          // decoder_set_fs.c:45
 #define SX_NLSF_STAGES 10  // stages of SKP_Silk_NLSF_CB0_16 / CB1_16
+#define SX_NLSF_CB0_NVEC_TOTAL 216
+#define SX_NLSF_CB1_NVEC_TOTAL 104
+#define SX_NLSF_CB_MAXVEC 216
+#define SX_MSVQ_ROW 32
 #define SX_N_NLSF_CB0_CDF 226
 #define SX_N_NLSF_CB1_CDF 114
 #define SX_N_PITCH_LAG_CDF 258
@@ -45,6 +55,8 @@
 #define T_CDF_MID_PITCH_LAG T_CDF_MID_PITCH_LAG_WB
 #define T_CDF_MID_PITCH_CONTOUR T_CDF_MID_PITCH_CONTOUR_WB
 #define T_pitch_cb_dec T_pitch_cb_stage3
+#define T_target_rate T_target_rate_wb
+#define K_MU_LTP_QUANT_Q8 K_MU_LTP_QUANT_WB_Q8
 #define T_nlsf_cb0_Q15 T_nlsf16_cb0_Q15
 #define T_nlsf_cb1_Q15 T_nlsf16_cb1_Q15
 #define T_nlsf_cb0_rates_Q5 T_nlsf16_cb0_rates_Q5
@@ -68,6 +80,7 @@
 #define SX_SUBFR (5 * SX_FS_KHZ)
 #define SX_NB_SUBFR 4
 #define SX_LTP_ORDER 5
+#define SX_FCH ((SX_FRAME + 63) / 64)   // 64-lane chunks of a frame (lane-register streaming of per-sample recursions)
 
 // SKP_Silk_bwexpander, SKP_Silk_bwexpander.c:31
 SX_HD void sx_bwexpander(i16* ar, int d, i32 chirp_Q16) {

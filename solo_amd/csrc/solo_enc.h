@@ -13,7 +13,7 @@
 struct SxFrameIdx {
     i32 sigtype, QuantOffsetType;
     i32 GainsIndices[SX_NB_SUBFR], DeltaGainsIndices;
-    i32 NLSFIndices[6], NLSFInterpCoef_Q2;
+    i32 NLSFIndices[SX_NLSF_STAGES], NLSFInterpCoef_Q2;
     i32 lagIndex, contourIndex, PERIndex, LTPIndex[SX_NB_SUBFR], LTP_scaleIndex;
     i32 Seed, vadFlag;
     i32 inDTX, pad_;                 // DTX state after this frame (SKP_Silk_encode_frame_FIX.c:155-171); the packet is dropped if set after frame 1
@@ -40,7 +40,7 @@ struct SxFrontWork {                 // LDS scratch of the per-frame analysis ch
 
 struct SxHbWork {                    // LDS scratch of the high-band encoder
     i16 x_hb_buf[SX_HB_XBUF];
-    i16 lpc_in[4 * 88];
+    i16 lpc_in[4 * (10 * SX_FS_KHZ + SX_HB_LPC)];
     i16 exc[2 * SX_FRAME];
     i32 NLSF_Q15[SX_MAX_LPC];
     i32 weight[SX_MAX_LPC];
@@ -174,7 +174,7 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
     SxRangeEnc* rc = &rc_local;
     if (frame == 0) {
         if (writeMDIndex == 1) sx_rc_enc(rc, md, cdf->cdf_mdindex);
-        sx_rc_enc(rc, 0, cdf->cdf_fs);                          // SamplingRates_table[0] == 8
+        sx_rc_enc(rc, SX_FS_KHZ == 8 ? 0 : 2, cdf->cdf_fs);      // index of fs_kHz in SamplingRates_table = {8, 12, 16, 24}
     }
     const int typeOffset = 2 * x->sigtype + x->QuantOffsetType;
     if (frame == 0) sx_rc_enc(rc, typeOffset, cdf->cdf_type_offset);
@@ -184,11 +184,11 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
     for (int i = 1; i < SX_NB_SUBFR; i++) sx_rc_enc(rc, x->GainsIndices[i], cdf->cdf_delta_gain);
     if (frame == 0) sx_rc_enc(rc, x->DeltaGainsIndices, cdf->cdf_md_delta_gain);
     {
-        const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+        const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
         const i32* nvec = x->sigtype == 0 ? nvec0 : nvec1;
         const u16* ncdf = x->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
         int off = 0;
-        for (int s = 0; s < 6; s++) {
+        for (int s = 0; s < SX_NLSF_STAGES; s++) {
             sx_rc_enc(rc, x->NLSFIndices[s], ncdf + off);
             off += nvec[s] + 1;
         }
@@ -215,28 +215,30 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
 // 320 = the 40 ms frame of joint_mode 1, AGR_BWE_SDK_API.c:64-67); writes its 4 payload bytes.
 // `high`: N new high-band samples; residue0 / residue1: centre excitation Q10 of the SILK frame(s) under it (HBM; sample n of the
 // high-band frame takes residue0[n] for n < 160, residue1[n - 160] after)
+#define SX_HB_DELAY (5 * SX_FS_KHZ)                 // lb_Delay * hb_KHz: the high band is delayed 5 ms to stay in step with SILK
+#define SX_HB_LPCBLK (10 * SX_FS_KHZ + SX_HB_LPC)   // BWE_LPCFrameSize + BWE_LPCOrder: one 10 ms analysis block with its history
 SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue0, const i32* residue1, SxHbWork* hw, u8* out4, int N) {
     SX_IN_LDS(hw); SX_IN_LDS(out4);
     i16* xb = hw->x_hb_buf;
     i16* lpc_in = hw->lpc_in;
     i16* exc = hw->exc;
     const int sub_len = N >> 2;                  // BWE_SubFrameSize
-    SX_PAR(i, N + 40) xb[i] = hist->x_hb_buf[i];
-    SX_PAR(i, N) xb[N + 40 + i] = high[i];
+    SX_PAR(i, N + SX_HB_DELAY) xb[i] = hist->x_hb_buf[i];
+    SX_PAR(i, N) xb[N + SX_HB_DELAY + i] = high[i];
     wv_sync();
     // AGR_Sate_find_HB_LPC_FIX: four 10 ms blocks, each with 8 samples of history; the window runs past the
     // written part of the reference's buffer (zeros)
-    SX_PAR(t, 4 * 88) {
-        const int k = t / 88, j = t - k * 88;
-        const int src = N - SX_HB_LPC + k * 80 + j;
-        lpc_in[t] = src < 2 * N + 40 ? xb[src] : (i16)0;
+    SX_PAR(t, 4 * SX_HB_LPCBLK) {
+        const int k = t / SX_HB_LPCBLK, j = t - k * SX_HB_LPCBLK;
+        const int src = N - SX_HB_LPC + k * (SX_HB_LPCBLK - SX_HB_LPC) + j;
+        lpc_in[t] = src < 2 * N + SX_HB_DELAY ? xb[src] : (i16)0;
     }
     wv_sync();
     i32 res_nrg, res_nrg_Q;
     i32* weight = hw->weight;
     i32* a_Q16 = hw->lpc.a_Q16;
     i32* NLSF_Q15 = hw->NLSF_Q15;
-    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, 88, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
+    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, SX_HB_LPCBLK, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
     sx_bwexpander_32(a_Q16, SX_HB_LPC, K_FIND_LPC_CHIRP_Q16);
     wv_sync();
     sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q, &hw->lpc.u.grid);
@@ -323,7 +325,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     }
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
     // slide the buffer: the last 200 samples are the next frame's history
-    SX_PAR(i, N + 40) hist->x_hb_buf[i] = xb[N + i];
+    SX_PAR(i, N + SX_HB_DELAY) hist->x_hb_buf[i] = xb[N + i];
     wv_sync();
 }
 
@@ -410,7 +412,7 @@ SX_FN void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, 
     x->sigtype = c->sigtype; x->QuantOffsetType = c->QuantOffsetType;
     for (int i = 0; i < 4; i++) { x->GainsIndices[i] = c->GainsIndices[i]; x->LTPIndex[i] = c->LTPIndex[i]; }
     x->DeltaGainsIndices = c->DeltaGainsIndices;
-    for (int i = 0; i < 6; i++) x->NLSFIndices[i] = c->NLSFIndices[i];
+    for (int i = 0; i < SX_NLSF_STAGES; i++) x->NLSFIndices[i] = c->NLSFIndices[i];
     x->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
     x->lagIndex = c->lagIndex; x->contourIndex = c->contourIndex; x->PERIndex = c->PERIndex;
     x->LTP_scaleIndex = c->LTP_scaleIndex;

@@ -460,7 +460,7 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         c->QuantOffsetType = 0;
         c->sparseness_Q8 = 0;
     } else {
-        const int nSamples = 16;
+        const int nSamples = 2 * SX_FS_KHZ;      // energy per 2 ms (noise_shape_analysis_FIX.c:253)
         i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
         for (int k = 0; k < 10; k++) {
             i32 e, sh;
@@ -508,7 +508,9 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         SX_PAR(t, SX_NB_SUBFR * SX_SHAPE_WIN) {
             const int k = t / SX_SHAPE_WIN, i = t - k * SX_SHAPE_WIN;
             const i16 v = x_ptr[k * SX_SUBFR + i];
-            sw->xw[k][i] = i < 40 ? (i16)sx_smulwb(sw->win[0][i], v) : (i < 80 ? v : (i16)sx_smulwb(sw->win[1][i - 80], v));
+            // slope_part = la_shape samples of sine window either side of a flat 5 ms (noise_shape_analysis_FIX.c:312-323)
+            sw->xw[k][i] = i < SX_LA_SHAPE ? (i16)sx_smulwb(sw->win[0][i], v)
+                                           : (i < SX_LA_SHAPE + 5 * SX_FS_KHZ ? v : (i16)sx_smulwb(sw->win[1][i - (SX_LA_SHAPE + 5 * SX_FS_KHZ)], v));
         }
         wv_sync();
         sx_warped_autocorr4(sw, (i16)warping_Q16);
@@ -570,15 +572,22 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         st->avgGain_Q16 = sx_add_sat32(st->avgGain_Q16, sx_smulwb(c->Gains_Q16[k] - st->avgGain_Q16,
                                        sx_rshift_round(sx_smulbb(st->speech_activity_Q8, K_GAIN_SMOOTHING_COEF_Q10), 2)));
     }
-    // de-essing: only for fs 16 / 24 kHz -> nothing at 8 kHz
+    // de-essing (noise_shape_analysis_FIX.c:435-454): only at fs 16 / 24 kHz
     gain_mult_Q16 = K_1p0_Q16 + sx_rshift_round(sx_add(K_INPUT_TILT_Q26, sx_mul(c->coding_quality_Q14, K_HIGH_RATE_INPUT_TILT_Q12)), 10);
+#if SX_FS_KHZ == 16
+    if (c->input_tilt_Q15 <= 0 && c->sigtype == 1) {
+        const i32 essStrength_Q15 = sx_smulww(-c->input_tilt_Q15, sx_smulbb(st->speech_activity_Q8, K_1p0_Q8 - c->sparseness_Q8));
+        tmp32 = sx_log2lin(K_16p0_Q7 - sx_smulwb(essStrength_Q15, sx_smulwb(K_DE_ESSER_COEF_WB_dB_Q7, K_0p16_Q17)));
+        gain_mult_Q16 = sx_smulww(gain_mult_Q16, tmp32);
+    }
+#endif
     for (int k = 0; k < SX_NB_SUBFR; k++) c->GainsPre_Q14[k] = sx_smulwb(gain_mult_Q16, c->GainsPre_Q14[k]);
     // low-frequency shaping and tilt
     strength_Q16 = sx_mul(K_LOW_FREQ_SHAPING_Q0, K_1p0_Q16 + sx_smulbb(K_LOW_QUALITY_LOW_FREQ_SHAPING_DECR_Q1,
                                                                         c->input_quality_bands_Q15[0] - K_1p0_Q15));
     i32 Tilt_Q16;
     if (c->sigtype == 0) {
-        i32 fs_kHz_inv = K_0p2_Q14 / 8;
+        i32 fs_kHz_inv = K_0p2_Q14 / SX_FS_KHZ;
         for (int k = 0; k < SX_NB_SUBFR; k++) {
             i32 b_Q14 = fs_kHz_inv + K_3p0_Q14 / c->pitchL[k];
             c->LF_shp_Q14[k] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, b_Q14), 16);
@@ -586,7 +595,7 @@ SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitc
         }
         Tilt_Q16 = -K_HP_NOISE_COEF_Q16 - sx_smulwb(K_1p0_Q16 - K_HP_NOISE_COEF_Q16, sx_smulwb(K_HARM_HP_NOISE_COEF_Q24, st->speech_activity_Q8));
     } else {
-        i32 b_Q14 = 21299 / 8;
+        i32 b_Q14 = 21299 / SX_FS_KHZ;
         c->LF_shp_Q14[0] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, sx_smulwb(K_0p6_Q16, b_Q14)), 16);
         c->LF_shp_Q14[0] |= (i32)(u16)(b_Q14 - K_1p0_Q14);
         for (int k = 1; k < SX_NB_SUBFR; k++) c->LF_shp_Q14[k] = c->LF_shp_Q14[0];
@@ -1849,14 +1858,14 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
     i32 RateDist_Q18[16];
 #endif
     i32 Sorted_Q18[16];
-    i16 cb[1200], rates[120];         // the signal type's codebook and rate table, staged from HBM once per frame
-    i32 ndelta[12], nvec[6];
+    i16 cb[SX_NLSF_CB_MAXVEC * SX_LPC], rates[SX_NLSF_CB_MAXVEC];   // the signal type's codebook and rate table, staged from HBM once per frame
+    i32 ndelta[SX_LPC + 2], nvec[SX_NLSF_STAGES];
     i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
     i32 NLSF0[SX_MAX_LPC], W0_Q6[SX_MAX_LPC];
     i32 ws[2][SX_NLSF2A_WS];
     i32 Rate_Q5[16], Rate_new_Q5[16];
     i32 TempIndices[16];
-    u8 Path[16 * 6], Path_new[16 * 6];
+    u8 Path[16 * SX_NLSF_STAGES], Path_new[16 * SX_NLSF_STAGES];
     i32 Res_Q15[16 * SX_LPC], Res_new_Q15[16 * SX_LPC];
 };
 
@@ -1885,20 +1894,20 @@ SX_HD i64 wv_min_key(i64 k) {
 SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
                                i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
     SX_IN_LDS(w); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
-    const i32 nvec0[6] = T_NLSF_CB0_NVEC, nvec1[6] = T_NLSF_CB1_NVEC;
+    const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
     const i32* nvec = w->nvec;
-    const int nStages = 6, S = SX_MSVQ_SURVIVORS;
+    const int nStages = SX_NLSF_STAGES, S = SX_MSVQ_SURVIVORS;
     {   // stage the codebook of this signal type in LDS (32-bit words, coalesced)
         const u32* gcb = (const u32*)(sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15);
         const u32* grt = (const u32*)(sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5);
         const i32* gnd = sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15;
-        const int nv = sigtype == 0 ? 120 : 72;
+        const int nv = sigtype == 0 ? SX_NLSF_CB0_NVEC_TOTAL : SX_NLSF_CB1_NVEC_TOTAL;
         u32* lcb = (u32*)w->cb;
         u32* lrt = (u32*)w->rates;
         SX_PAR(i, nv * SX_LPC / 2) lcb[i] = gcb[i];
         SX_PAR(i, nv / 2) lrt[i] = grt[i];
         SX_PAR(i, SX_LPC + 1) w->ndelta[i] = gnd[i];
-        SX_PAR(i, 6) w->nvec[i] = sigtype == 0 ? nvec0[i] : nvec1[i];
+        SX_PAR(i, SX_NLSF_STAGES) w->nvec[i] = sigtype == 0 ? nvec0[i] : nvec1[i];
         wv_sync();
     }
     const i16* cb = w->cb;
@@ -1988,8 +1997,9 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
             while (w->RateDist_Q18[cur_survivors - 1] > thr && cur_survivors > min_survivors) cur_survivors--;
         }
         // new residuals, rates and paths of the survivors: lane (k, i)
-        SX_PAR(ki, cur_survivors * 16) {
-            const int k = ki >> 4, i = ki & 15;
+        // (a row of SX_MSVQ_ROW lanes per survivor: SX_LPC residual entries, the rate, up to nStages - 1 inherited path entries, the new one)
+        SX_PAR(ki, cur_survivors * SX_MSVQ_ROW) {
+            const int k = ki / SX_MSVQ_ROW, i = ki % SX_MSVQ_ROW;
             int input_index = 0, cb_index = w->TempIndices[k];
             if (s > 0) {
                 input_index = cb_index / K;
@@ -1998,7 +2008,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
             if (i < SX_LPC) w->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
             if (i == SX_LPC) w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
             if (i > SX_LPC && i - SX_LPC - 1 < s) w->Path_new[k * nStages + (i - SX_LPC - 1)] = w->Path[input_index * nStages + (i - SX_LPC - 1)];
-            if (i == 15) w->Path_new[k * nStages + s] = (u8)cb_index;
+            if (i == SX_MSVQ_ROW - 1) w->Path_new[k * nStages + s] = (u8)cb_index;
         }
         wv_sync();
         if (s < nStages - 1) {
@@ -2142,7 +2152,7 @@ SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, co
     wv_sync();
     if (c->sigtype == 0) {
         sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15, &w->u.ltp);
-        sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_NB_Q8, w->u.vq.rd, w->u.vq.best);
+        sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_Q8, w->u.vq.rd, w->u.vq.best);
         sx_LTP_scale_ctrl(st, c);
         sx_LTP_analysis_filter(w->LPC_in_pre, x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
         wv_sync();

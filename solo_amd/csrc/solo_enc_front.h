@@ -188,7 +188,7 @@ SX_FN void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSN
 SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(out);
     if (st->prev_sigtype == 0) {
-        i32 pitch_freq_Hz_Q16 = sx_shl(8 * 1000, 16) / st->prevLag;
+        i32 pitch_freq_Hz_Q16 = sx_shl(SX_FS_KHZ * 1000, 16) / st->prevLag;
         i32 pitch_freq_log_Q7 = sx_lin2log(pitch_freq_Hz_Q16) - (16 << 7);
         i32 quality_Q15 = c->input_quality_bands_Q15[0];
         pitch_freq_log_Q7 = sx_sub(pitch_freq_log_Q7, sx_smulwb(sx_smulwb(sx_shl(quality_Q15, 2), quality_Q15), pitch_freq_log_Q7 - 809));
@@ -203,7 +203,7 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
                                           K_VARIABLE_HP_SMTH_COEF2_Q16);
     c->pitch_freq_low_Hz = sx_log2lin(st->variable_HP_smth2_Q15 >> 8);
     c->pitch_freq_low_Hz = sx_limit(c->pitch_freq_low_Hz, K_VARIABLE_HP_MIN_FREQ_Q0, K_VARIABLE_HP_MAX_FREQ_Q0);
-    i32 Fc_Q19 = sx_smulbb(1482, c->pitch_freq_low_Hz) / 8;
+    i32 Fc_Q19 = sx_smulbb(1482, c->pitch_freq_low_Hz) / SX_FS_KHZ;
     i32 r_Q28 = K_1p0_Q28 - sx_mul(K_0p92_Q9, Fc_Q19);
     i32 B0 = r_Q28, B1 = sx_shl(sx_neg(r_Q28), 1), B2 = r_Q28;
     i32 r_Q22 = r_Q28 >> 6;
@@ -216,11 +216,11 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
     B0 = SX_UNI(B0); B1 = SX_UNI(B1); B2 = SX_UNI(B2);
     i32 S0 = SX_UNI(st->In_HP_State[0]), S1 = SX_UNI(st->In_HP_State[1]);
 #ifdef SX_LANE_STREAM
-    i32 r[3], o[3] = {0, 0, 0};
+    i32 r[SX_FCH], o[SX_FCH];
 #pragma unroll
-    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; r[j] = i < SX_FRAME ? (i32)in[i] : 0; }
+    for (int j = 0; j < SX_FCH; j++) { const int i = SX_LANE + 64 * j; r[j] = i < SX_FRAME ? (i32)in[i] : 0; o[j] = 0; }
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < SX_FCH; c++) {
         const int kend = sx_min(SX_FRAME, 64 * (c + 1));
         for (int k = 64 * c; k < kend; k++) {
             i32 inval = SX_RDLANE(r[c], k & 63);
@@ -235,7 +235,7 @@ SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i < SX_FRAME) out[i] = (i16)o[j]; }
+    for (int j = 0; j < SX_FCH; j++) { const int i = SX_LANE + 64 * j; if (i < SX_FRAME) out[i] = (i16)o[j]; }
 #else
     for (int k = 0; k < SX_FRAME; k++) {
         i32 inval = in[k];
@@ -347,16 +347,19 @@ SX_HD void sx_k2a(i32* A_Q24, const i16* rc_Q15, int order) {
 }
 
 // SKP_Silk_resampler_down2, SKP_Silk_resampler_down2.c:41 (zero initial state, serial)
+#define SX_DOWN2_MAXIN (40 * SX_FS_KHZ)      // the longest input: the pitch analysis buffer, 40 ms at the internal rate
 SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
     i32 S0 = 0, S1 = 0;
     const i32 c0 = SX_UNI(T_down2_c0[0]), c1 = SX_UNI(T_down2_c1[0]);
 #ifdef SX_LANE_STREAM
-    // inLen <= 320 samples in (5 lane registers), inLen/2 <= 160 out (3)
-    i32 r[5], o[3] = {0, 0, 0};
+    // inLen <= SX_DOWN2_MAXIN samples in (lane registers), half as many out
+    i32 r[SX_DOWN2_MAXIN / 64], o[(SX_DOWN2_MAXIN / 2 + 63) / 64];
 #pragma unroll
-    for (int j = 0; j < 5; j++) { const int i = SX_LANE + 64 * j; r[j] = i < inLen ? (i32)in[i] : 0; }
+    for (int j = 0; j < (SX_DOWN2_MAXIN / 2 + 63) / 64; j++) o[j] = 0;
 #pragma unroll
-    for (int c = 0; c < 5; c++) {
+    for (int j = 0; j < SX_DOWN2_MAXIN / 64; j++) { const int i = SX_LANE + 64 * j; r[j] = i < inLen ? (i32)in[i] : 0; }
+#pragma unroll
+    for (int c = 0; c < SX_DOWN2_MAXIN / 64; c++) {
         const int kend = sx_min(inLen >> 1, 32 * (c + 1));
         for (int k = 32 * c; k < kend; k++) {
             i32 in32 = sx_shl(SX_RDLANE(r[c], (2 * k) & 63), 10);
@@ -374,7 +377,7 @@ SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
         }
     }
 #pragma unroll
-    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; if (i < (inLen >> 1)) out[i] = (i16)o[j]; }
+    for (int j = 0; j < (SX_DOWN2_MAXIN / 2 + 63) / 64; j++) { const int i = SX_LANE + 64 * j; if (i < (inLen >> 1)) out[i] = (i16)o[j]; }
 #else
     for (int k = 0; k < (inLen >> 1); k++) {
         i32 in32 = sx_shl((i32)in[2 * k], 10);
@@ -414,6 +417,10 @@ struct SxPitchWork {                 // LDS scratch of the pitch analysis
     i16 d_comp[221];
     i32 d_srch[24];
     i32 tmp32[160];
+#if SX_FS_KHZ == 16
+    i16 sig16[640];                  // third stage: the (scaled) 16 kHz input
+    i32 corr3[4][24], nrg3[4][24];   // per subframe: cross-correlation / basis energy over its stage-3 lag range (SCRATCH_SIZE = 22)
+#endif
 };
 
 // SKP_Silk_pitch_analysis_core, SKP_Silk_pitch_analysis_core.c:65, Fs = 8 kHz, complexity 2 (so the
@@ -423,8 +430,13 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     SX_IN_LDS(signal); SX_IN_LDS(pitch_out); SX_IN_LDS(lagIndex); SX_IN_LDS(contourIndex); SX_IN_LDS(LTPCorr_Q15); SX_IN_LDS(w);
     const int min_lag_4 = 8, max_lag_4 = 72, min_lag_8 = 16, max_lag_8 = 144, sf8 = 40;
     SX_PAR(i, 4 * 221) (&w->C[0][0])[i] = 0;
+#if SX_FS_KHZ == 8
     SX_PAR(i, 320) w->sig8[i] = signal[i];
     wv_sync();
+#else
+    sx_down2_zero_state(w->sig8, signal, 640);      // 16 -> 8 kHz (pitch_analysis_core.c:127-129)
+    wv_sync();
+#endif
     sx_down2_zero_state(w->sig4, w->sig8, 320);
 #if SX_NLANES == 1
     for (int i = 159; i > 0; i--) w->sig4[i] = (i16)sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]);
@@ -615,9 +627,12 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
     wv_sync();
     i32 CCmax = SX_I32_MIN, CCmax_b = SX_I32_MIN;
     int CBimax = 0, lag = -1;
+#if SX_FS_KHZ == 16
+    if (prevLag > 0) prevLag = prevLag >> 1;            // the previous lag on the 8 kHz grid (pitch_analysis_core.c:362-368)
+#endif
     i32 prevLag_log2_Q7 = prevLag > 0 ? sx_lin2log(prevLag) : 0;
     i32 corr_thres_Q15 = sx_smulbb(search_thres2_Q15, search_thres2_Q15) >> 13;
-    const int nb_cbks = 11;
+    const int nb_cbks = SX_FS_KHZ == 8 ? 11 : 3;        // PITCH_EST_NB_CBKS_STAGE2_EXT when 8 kHz is the last stage, else _STAGE2
 #if SX_NLANES == 1
     for (int k = 0; k < length_d_srch; k++) {
         int d = w->d_srch[k];
@@ -685,12 +700,89 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
         *LTPCorr_Q15 = 0; *lagIndex = 0; *contourIndex = 0;
         return 1;
     }
+#if SX_FS_KHZ == 8
     CCmax = sx_max(CCmax, 0);
     *LTPCorr_Q15 = sx_sqrt_approx(sx_shl(CCmax, 13));
     for (int k = 0; k < 4; k++) pitch_out[k] = lag + T_pitch_cb_stage2[k * 11 + CBimax];
     *lagIndex = lag - min_lag_8;
     *contourIndex = CBimax;
     return 0;
+#else
+    // ---- third stage (16 kHz), pitch_analysis_core.c:445-548 with SKP_FIX_P_Ana_calc_corr_st3 / _calc_energy_st3 (complexity 2:
+    // all 34 contours, five lags around twice the stage-2 lag).  The reference tabulates [subframe][contour][lag]; here the
+    // per-subframe lag-range vectors are kept and indexed by contour offset + lag when the candidates are scored.
+    const int min_lag = 2 * 16, max_lag = 18 * 16, sf = 80;
+    shift = sx_pitch_find_scaling(signal, 640, sf);
+    SX_PAR(i, 640) w->sig16[i] = (i16)(shift > 0 ? (signal[i] >> shift) : signal[i]);
+    lag = sx_limit(lag << 1, min_lag, max_lag);
+    const int start_lag = sx_max(lag - 2, min_lag), end_lag = sx_min(lag + 2, max_lag);
+    int lag_new = lag;
+    *LTPCorr_Q15 = sx_sqrt_approx(sx_shl(CCmax, 13));
+    wv_sync();
+    const i16* lr = &T_pitch_lag_range_stage3[2 * 4 * 2];       // [complexity 2][subframe][lo, hi]
+    SX_PAR(t, 4 * 24) {
+        const int k = t / 24, jj = t - k * 24, lo = lr[2 * k], hi = lr[2 * k + 1];
+        if (jj <= hi - lo) {
+            const i16* tp = &w->sig16[4 * sf + k * sf];
+            const i16* bp = tp - (start_lag + lo + jj);
+            i32 cc = 0;
+            for (int n = 0; n < sf; n++) cc = sx_smlabb(cc, tp[n], bp[n]);
+            w->corr3[k][jj] = cc;
+        }
+    }
+    SX_PAR(k, 4) {      // basis energies: recursive over the lag range, with the reference's saturating add
+        const int lo = lr[2 * k], hi = lr[2 * k + 1];
+        const i16* bp = &w->sig16[4 * sf + k * sf] - (start_lag + lo);
+        i32 e = 0;
+        for (int n = 0; n < sf; n++) e = sx_smlabb(e, bp[n], bp[n]);
+        w->nrg3[k][0] = e;
+        for (int i = 1; i < hi - lo + 1; i++) {
+            e -= sx_smulbb(bp[sf - i], bp[sf - i]);
+            e = sx_add_sat32(e, sx_smulbb(bp[-i], bp[-i]));
+            w->nrg3[k][i] = e;
+        }
+    }
+    wv_sync();
+    const i32 contour_bias = 52429 / lag;                       // PITCH_EST_FLATCONTOUR_BIAS_Q20 / lag
+    const int cbk_size = T_pitch_cbk_sizes_stage3[2], cbk_offset = T_pitch_cbk_offsets_stage3[2];
+    // candidates in the reference's order (lag-major, contour-minor); the FIRST largest score wins (strict '>')
+    i32 best_v = SX_I32_MIN, best_t = SX_I32_MAX;
+    const int ncand = (end_lag - start_lag + 1) * cbk_size;
+    SX_PAR(t, ncand) {
+        const int lc = t / cbk_size, j = cbk_offset + (t - lc * cbk_size), d = start_lag + lc;
+        i32 cross = 0, energy = 0;
+        for (int k = 0; k < 4; k++) {
+            const int idx = T_pitch_cb_stage3[k * 34 + j] - lr[2 * k] + lc;
+            energy += w->nrg3[k][idx] >> 2;
+            cross += w->corr3[k][idx] >> 2;
+        }
+        i32 cn = 0;
+        if (cross > 0) {
+            const i32 lz = sx_clz32(cross);
+            const i32 lshift = sx_limit(lz - 1, 0, 13);
+            cn = sx_shl(cross, lshift) / ((energy >> (13 - lshift)) + 1);
+            cn = sx_sat16(cn);
+            cn = sx_smulwb(cross, cn);
+            cn = cn > (SX_I32_MAX >> 3) ? SX_I32_MAX : sx_shl(cn, 3);
+            i32 diff = j - (34 >> 1);
+            diff = sx_mul(diff, diff);
+            diff = 32767 - (sx_mul(contour_bias, diff) >> 5);
+            cn = sx_shl(sx_smulwb(cn, diff), 1);
+        }
+        if (d + (int)T_pitch_cb_stage3[j] <= max_lag && (cn > best_v || (cn == best_v && t < best_t))) { best_v = cn; best_t = t; }
+    }
+    wv_argmax(&best_v, &best_t);
+    CBimax = 0;
+    if (best_t != SX_I32_MAX && best_v > SX_I32_MIN) {
+        const int lc = best_t / cbk_size;
+        lag_new = start_lag + lc;
+        CBimax = cbk_offset + (best_t - lc * cbk_size);
+    }
+    for (int k = 0; k < 4; k++) pitch_out[k] = lag_new + T_pitch_cb_stage3[k * 34 + CBimax];
+    *lagIndex = lag_new - min_lag;
+    *contourIndex = CBimax;
+    return 0;
+#endif
 }
 
 // SKP_Silk_find_pitch_lags_FIX, SKP_Silk_find_pitch_lags_FIX.c:32.  x = x_buf + frame_length.

@@ -9,20 +9,20 @@
 #include "solo_dec.h"     // SX_PACKET / SX_BAND, sx_nlsf_msvq_decode (shared with the decoder)
 
 #define SX_SHAPE_ORDER 16            // shapingLPCOrder (setup_complexity.h:76)
-#define SX_LA_SHAPE 40               // la_shape = 5 * fs_kHz
-#define SX_LA_PITCH 16               // la_pitch = 2 * fs_kHz
-#define SX_SHAPE_WIN 120             // shapeWinLength = 5*fs_kHz + 2*la_shape
-#define SX_PITCH_LPC_WIN 192         // pitch_LPC_win_length = (20 + 2*2) * 8
-#define SX_PITCH_LPC_ORDER 10        // min(16, predictLPCOrder)
+#define SX_LA_SHAPE (5 * SX_FS_KHZ)   // la_shape = 5 * fs_kHz                         (control_codec_FIX.c:285)
+#define SX_LA_PITCH (2 * SX_FS_KHZ)   // la_pitch = 2 * fs_kHz
+#define SX_SHAPE_WIN (15 * SX_FS_KHZ) // shapeWinLength = 5*fs_kHz + 2*la_shape          (setup_complexity.h:78)
+#define SX_PITCH_LPC_WIN (24 * SX_FS_KHZ)   // pitch_LPC_win_length = (20 + 2*2) * fs_kHz (setup_complexity.h:84)
+#define SX_PITCH_LPC_ORDER SX_LPC    // min(16, predictLPCOrder)                        (setup_complexity.h:86)
 #define SX_XBUF (2 * SX_FRAME + SX_LA_SHAPE)   // 360
 #define SX_LTP_BUF 512
 #define SX_LTP_MASK (SX_LTP_BUF - 1)
 #define SX_DD_STATES 4               // nStatesDelayedDecision
 #define SX_DD_DELAY 32               // DECISION_DELAY
 #define SX_N_TRACKS 3                // centre, MD1, MD2
-#define SX_WARPING_Q16 (8 * K_WARPING_MULTIPLIER_Q16)    // setup_complexity.h:82
+#define SX_WARPING_Q16 (SX_FS_KHZ * K_WARPING_MULTIPLIER_Q16)    // setup_complexity.h:82
 #define SX_MSVQ_SURVIVORS 16
-#define SX_HB_XBUF 680               // x_hb_buf_fix: BWE_FrameSize*2 + lb_Delay*hb_KHz (360 live words with 20 ms high-band frames, 680 with joint_mode 1)
+#define SX_HB_XBUF (85 * SX_FS_KHZ)   // x_hb_buf_fix: BWE_FrameSize*2 + lb_Delay*hb_KHz (360 live words with 20 ms high-band frames, 680 with joint_mode 1)
 
 struct SxVAD {                       // SKP_Silk_VAD_state, SKP_Silk_structs.h:69
     i32 AnaState[2], AnaState1[2], AnaState2[2];
@@ -121,7 +121,7 @@ struct SxEncStream {                 // one record per stream in HBM
 struct SxEncCtrl {
     i32 lagIndex, contourIndex, PERIndex;
     i32 LTPIndex[SX_NB_SUBFR];
-    i32 NLSFIndices[6];
+    i32 NLSFIndices[SX_NLSF_STAGES];
     i32 NLSFInterpCoef_Q2;
     i32 GainsIndices[SX_NB_SUBFR];
     i32 DeltaGainsIndices;
@@ -180,15 +180,15 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
     silk_rate_bps = sx_limit(silk_rate_bps, 5000, 100000);           // enc_API.c:187
     i32 md_rate = silk_rate_bps / 2;
     for (int k = 1; k < 8; k++) {
-        if (md_rate < T_target_rate_nb[k]) {
-            i32 frac_Q6 = sx_shl(md_rate - T_target_rate_nb[k - 1], 6) / (T_target_rate_nb[k] - T_target_rate_nb[k - 1]);
+        if (md_rate < T_target_rate[k]) {
+            i32 frac_Q6 = sx_shl(md_rate - T_target_rate[k - 1], 6) / (T_target_rate[k] - T_target_rate[k - 1]);
             st->SNRPerMD_dB_Q7 = sx_shl(T_snr_table_Q1[k - 1], 6) + sx_mul(frac_Q6, T_snr_table_Q1[k] - T_snr_table_Q1[k - 1]);
             break;
         }
     }
     for (int k = 1; k < 8; k++) {
-        if (silk_rate_bps <= T_target_rate_nb[k]) {
-            i32 frac_Q6 = sx_shl(silk_rate_bps - T_target_rate_nb[k - 1], 6) / (T_target_rate_nb[k] - T_target_rate_nb[k - 1]);
+        if (silk_rate_bps <= T_target_rate[k]) {
+            i32 frac_Q6 = sx_shl(silk_rate_bps - T_target_rate[k - 1], 6) / (T_target_rate[k] - T_target_rate[k - 1]);
             st->SNR_dB_Q7 = sx_shl(T_snr_table_Q1[k - 1], 6) + sx_mul(frac_Q6, T_snr_table_Q1[k] - T_snr_table_Q1[k - 1]);
             break;
         }

@@ -112,7 +112,7 @@ def main():
             m = int(wrecv[i, p])
             wdec_loss[i, p], r1 = d1.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
             assert r0 == 0 and r1 == 0
-    np.savez_compressed(os.path.join(HERE, "wb4x20.npz"), bits=wbits, nbytes=wnb, recv=wrecv, dec_clean=wdec_clean, dec_loss=wdec_loss)
+    np.savez_compressed(os.path.join(HERE, "wb4x20.npz"), pcm=wpcm, bits=wbits, nbytes=wnb, recv=wrecv, dec_clean=wdec_clean, dec_loss=wdec_loss)
     g["wb_bits_md5"] = md5(wbits.tobytes())
     g["wb_dec_clean_md5"] = md5(wdec_clean.tobytes())
     g["wb_dec_loss_md5"] = md5(wdec_loss.tobytes())

@@ -113,6 +113,11 @@ def load_emu_wb():
         lib.emu_dec_destroy.argtypes = [C.c_void_p]
         lib.emu_dec_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]
         assert lib.emu_packet_samples() == 1280
+        if hasattr(lib, "emu_enc_create"):
+            lib.emu_enc_create.restype = C.c_void_p
+            lib.emu_enc_create.argtypes = [C.c_int, C.c_int]
+            lib.emu_enc_destroy.argtypes = [C.c_void_p]
+            lib.emu_enc_packet.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
         _emu_wb = lib
     return _emu_wb
 
@@ -138,8 +143,8 @@ class EmuDecoder:
 
 
 class EmuEncoder:
-    def __init__(self, rate=13600, use_md_index=0):
-        self.lib = load_emu()
+    def __init__(self, rate=13600, use_md_index=0, wb=False):
+        self.lib = load_emu_wb() if wb else load_emu()
         self.h = self.lib.emu_enc_create(rate, use_md_index)
 
     def encode(self, pcm640):

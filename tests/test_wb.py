@@ -58,6 +58,34 @@ def test_wb_emulation_vs_reference(rate, joint):
             assert r1 == r2 == 0 and np.array_equal(x, y), (rate, joint, variant, p)
 
 
+def test_wb_encoder_emulation_vs_goldens():
+    """The ENCODER source compiled for the 32 kHz mode (16 kHz pitch stage 3, order-16 Burg / NLSF quantiser, wide-band de-esser,
+    order-16 prediction in the quantiser, high band on 320-sample frames) reproduces the reference bitstreams byte for byte."""
+    z = _wb()
+    N, P = z["recv"].shape
+    for s in range(N):
+        e = T.EmuEncoder(24000, 2 if s == 3 else 0, wb=True)
+        for p in range(P):
+            pl, n0, n1 = e.encode(z["pcm"][s, p])
+            assert (n0, n1) == tuple(int(v) for v in z["nbytes"][s, p]), (s, p)
+            assert pl == z["bits"][s, p, :n0].tobytes(), (s, p)
+
+
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not built")
+@pytest.mark.parametrize("rate,joint,dtx", [(15600, 0, 0), (20000, 1, 1), (32000, 0, 0), (40000, 0, 1)])
+def test_wb_encoder_emulation_vs_reference(rate, joint, dtx):
+    P = 25
+    pcm = T.synth_stream_32k(1200 + rate // 1000, P)
+    rng = np.random.default_rng(rate)
+    t = np.arange(1280 * 4) / 32000.0
+    edge = [np.zeros(1280 * 4), rng.integers(-32768, 32767, 1280 * 4), 25000 * np.sin(2 * np.pi * 180 * t), 30000 * np.sign(np.sin(2 * np.pi * 110 * t))]
+    pcm = np.concatenate([pcm] + [np.asarray(x).astype(np.int16).reshape(4, 1280) for x in edge])
+    er = R.RefEncoder("fix", rate=rate, samplerate=32000, joint=joint, dtx=dtx)
+    ee = T.EmuEncoder(rate, (2 if joint else 0) | (4 if dtx else 0), wb=True)
+    for p in range(pcm.shape[0]):
+        assert ee.encode(pcm[p]) == er.encode(pcm[p]), (rate, joint, dtx, p)
+
+
 def test_wb_decoder_rejects_other_internal_rates():
     """A narrow-band stream (16 kHz API rate) handed to the 32 kHz decoder: the reference would switch its SILK core to 8 kHz
     and resample; this build decodes one internal rate per handle and reports a payload error instead of producing audio."""
