@@ -91,10 +91,10 @@ def load_library():
     return lib
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0):
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000):
     """Defaults of the reference CLI (JC1_SDK_SRC_ARM/test/enc_main.c:92-99); joint=1 is its `-joint 1`: one 40 ms high-band
     frame per packet (4 high-band bytes instead of 8)."""
-    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=16000, dtx_enable=1 if dtx else 0, framesize_ms=40,
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=samplerate, dtx_enable=1 if dtx else 0, framesize_ms=40,
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
@@ -108,7 +108,7 @@ class SoloBatch:
 
     def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0, dtx=0,
                  samplerate=16000):
-        """samplerate = 32000: the 32 kHz mode of the reference (`-Fs_API 32000`: 1280-sample packets, SILK wide band) -- decoder only."""
+        """samplerate = 32000: the 32 kHz mode of the reference (`-Fs_API 32000`: 1280-sample packets, SILK wide band; rate >= 15600)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("solo_amd needs a HIP device (MI355X); there is no CPU path")
@@ -116,9 +116,9 @@ class SoloBatch:
         self.lib = load_library()
         self.n_streams = int(n_streams)
         self.slot = int(slot_bytes)
-        self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx) if encoder else None
-        if samplerate not in (16000, 32000) or (samplerate == 32000 and encoder):
-            raise ValueError("samplerate must be 16000, or 32000 with encoder=False (the wide-band encoder is not built)")
+        self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx, samplerate) if encoder else None
+        if samplerate not in (16000, 32000):
+            raise ValueError("samplerate must be 16000 or 32000")
         self.packet_samples = PACKET_SAMPLES * samplerate // 16000
         self._dec = default_dec_ctrl(use_md_index, joint, samplerate) if decoder else None
         self.h = self.lib.solo_batch_create(self.n_streams, C.byref(self._enc) if encoder else None,
@@ -140,7 +140,7 @@ class SoloBatch:
         t = self.torch
         assert pcm.is_cuda and pcm.dtype == t.int16 and pcm.is_contiguous()
         N, P, L = pcm.shape
-        assert N == self.n_streams and L == PACKET_SAMPLES
+        assert N == self.n_streams and L == self.packet_samples
         if bits is None:
             bits = t.zeros((N, P, self.slot), dtype=t.uint8, device=pcm.device)
         if nbytes is None:

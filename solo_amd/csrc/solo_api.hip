@@ -40,70 +40,9 @@ hipError_t solo_wb_dec_launch_raw(void* state, const uint8_t* bits, int n0, int 
 }
 
 #ifdef SOLO_WITH_ENCODER
-__global__ void __launch_bounds__(64) solo_enc_init_kernel(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX) {
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX);
-}
-
-// Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
-//   A  solo_enc_analysis_kernel  one wavefront per stream: QMF split + analysis chain of every frame of the launch
-//   B  solo_nsq_kernel           four streams per wavefront (solo_nsq16.hip): the delayed-decision quantiser
-//   C  solo_enc_coding_kernel    one wavefront per stream: high-band encoder, range coding, payload assembly
-__device__ __forceinline__ void solo_enc_enter(SxEncWork* w, const SxEncStream* rec) {
-    const i32* src = (const i32*)&rec->core;
-    i32* dst = (i32*)&w->st;
-    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
-    wv_sync();
-}
-__device__ __forceinline__ void solo_enc_leave(SxEncWork* w, SxEncStream* rec) {
-    wv_sync();
-    const i32* src = (const i32*)&w->st;
-    i32* dst = (i32*)&rec->core;
-    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
-}
-
-// (waves-per-SIMD target 5 = at most 104 VGPRs: two of these waves share a SIMD with one quantiser wave of ~288 VGPRs)
-__global__ void __launch_bounds__(64, 5) solo_enc_analysis_kernel(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
-                                                                  int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
-                                                                  SxCodeIn* __restrict__ code_in) {
-    __shared__ SxEncWork w;
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    SxEncStream* rec = &states[s];
-    solo_enc_enter(&w, rec);
-    for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
-        const size_t pk = (size_t)s * n_packets + p;
-        sx_enc_stage_a(rec, &w, pcm + pk * SX_PACKET, nsq_in + pk * 2, code_in + pk);
-        wv_sync();
-    }
-    solo_enc_leave(&w, rec);
-}
-
-__global__ void __launch_bounds__(64, 5) solo_enc_coding_kernel(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
-                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
-                                                                int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
-    __shared__ SxEncWork w;
-    const int s = blockIdx.x;
-    if (s >= n_streams) return;
-    SxEncStream* rec = &states[s];
-    solo_enc_enter(&w, rec);
-    i32 first_err = 0;
-    for (int p = p0; p < p0 + pc; p++) {
-        const size_t pk = (size_t)s * n_packets + p;
-        i32 ret = sx_enc_stage_c(rec, &w, code_in + pk, nsq_out + pk * 2, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
-        if (ret < 0 && first_err == 0) first_err = ret;
-        wv_sync();
-    }
-    if (status && SX_LANE == 0) {                  // first error of the call (the chunks of a call run in order)
-        if (p0 == 0) status[s] = first_err;
-        else if (first_err != 0 && status[s] == 0) status[s] = first_err;
-    }
-}
-
-extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
-                               void* hip_stream);   // solo_nsq16.hip
-extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);
+#include "solo_enc_kernels.h"
+extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq16.hip
+extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_api_wb.hip
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -117,6 +56,9 @@ struct solo_batch {
     USER_Ctrl_enc enc_ctrl;
     USER_Ctrl_dec dec_ctrl;
     void* d_enc_state;
+#ifdef SOLO_WITH_ENCODER
+    const solo_enc_ops* eops;        // launch table of the build that matches the encoder's rate (solo_enc_kernels.h)
+#endif
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
     int32_t enc_work_packets;        // P the hand-over area is sized for
     int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
@@ -136,13 +78,20 @@ struct solo_batch {
     unsigned int started_target[SOLO_MAX_CHUNKS];
     int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
     void* d_dec_state;               // SxDecState[n_streams] of the build that matches `wb`
-    int wb;                          // decoder control asked for samplerate 32000: 1280-sample packets, SILK at 16 kHz (decoder only)
+    int wb;                          // decoder control asked for samplerate 32000: 1280-sample packets, SILK at 16 kHz
 };
 
 // joint_enable = 0, or joint_mode 1 (one 40 ms high-band frame per packet, AGR_BWE_SDK_API.c:64-67); the other joint modes are
 // "reserved" in the reference as well
 static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
-    return c->samplerate == 16000 && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
+    if (c->framesize_ms != 40 || !(c->joint_enable == 0 || c->joint_mode == 1)) return false;
+    if (c->samplerate == 16000) return true;
+    // 32 kHz input: SILK runs wide band.  Below WB2MB_BITRATE_BPS (14 kbps for SILK = 15.6 kbps total, 14.8 kbps with the 40 ms
+    // high-band frame) the reference starts at, or switches down to, 12 / 8 kHz internally (SKP_Silk_control_audio_bandwidth.c:44-76):
+    // those rates and the switching are not built, so such a configuration is refused instead of coded differently
+    const int hb_bps = (c->joint_enable != 0 && c->joint_mode == 1) ? 800 : 1600;
+    const int rate = c->targetRate_bps <= 0 ? 15600 : c->targetRate_bps;
+    return c->samplerate == 32000 && rate - hb_bps >= 14000;
 }
 static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
     // 32000: the wide-band decoder (solo_api_wb.hip); a stream whose internal rate is not 16 kHz is rejected packet by packet
@@ -152,15 +101,14 @@ static int ctrl_hb_joint(int joint_enable, int joint_mode) { return joint_enable
 
 #ifdef SOLO_WITH_ENCODER
 static int32_t solo_enc_alloc(solo_batch* b) {
-    SOLO_CHECK(hipMalloc(&b->d_enc_state, sizeof(SxEncStream) * (size_t)b->n_streams));
+    SOLO_CHECK(hipMalloc(&b->d_enc_state, b->eops->state_bytes * (size_t)b->n_streams));
     return 0;
 }
 static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
     // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the high-band share, 1600 * 20 / bwe_framesize_ms
     const int joint = ctrl_hb_joint(b->enc_ctrl.joint_enable, b->enc_ctrl.joint_mode);
-    hipLaunchKernelGGL(solo_enc_init_kernel, dim3(b->n_streams), dim3(64), 0, s, (SxEncStream*)b->d_enc_state, b->n_streams,
-                       b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint, b->enc_ctrl.dtx_enable ? 1 : 0);
-    SOLO_CHECK(hipGetLastError());
+    SOLO_CHECK(b->eops->init(b->d_enc_state, b->n_streams, b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint,
+                             b->enc_ctrl.dtx_enable ? 1 : 0, s));
     return 0;
 }
 static void solo_enc_free(solo_batch* b) {
@@ -268,6 +216,7 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
         b->have_enc = 1;
         b->enc_ctrl = *enc;
         if (b->enc_ctrl.targetRate_bps <= 0) b->enc_ctrl.targetRate_bps = 15600;  // AGR_BWE_SDK_API.c:35
+        b->eops = enc->samplerate == 32000 ? solo_wb_enc_ops() : &solo_enc_ops_table;
         if (solo_enc_alloc(b) != 0) { solo_batch_destroy(b); return NULL; }
 #else
         delete b;
@@ -278,7 +227,7 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
         b->have_dec = 1;
         b->dec_ctrl = *dec;
         b->wb = dec->samplerate == 32000;
-        if (b->wb && enc) { solo_batch_destroy(b); return NULL; }     // (a handle has one rate; the wide-band ENCODER is not built)
+        if (enc && enc->samplerate != dec->samplerate) { solo_batch_destroy(b); return NULL; }     // a handle has one rate
         if (hipMalloc(&b->d_dec_state, (b->wb ? solo_wb_dec_state_bytes() : solo_dec_state_bytes()) * (size_t)n_streams) != hipSuccess) { solo_batch_destroy(b); return NULL; }
     }
     if (solo_batch_reset(b, NULL) != 0 || hipDeviceSynchronize() != hipSuccess) { solo_batch_destroy(b); return NULL; }
@@ -332,7 +281,8 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     if (!b || !b->have_enc || !d_pcm || !d_bits || !d_nbytes || n_packets <= 0) return -1;
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t np = (size_t)b->n_streams * (size_t)n_packets;
-    const size_t sz_in = np * 2 * sizeof(SxNsqIn), sz_out = np * 2 * sizeof(SxNsqOut), sz_code = np * sizeof(SxCodeIn);
+    const solo_enc_ops* ops = b->eops;
+    const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
         if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); }
@@ -341,10 +291,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));
         b->enc_work_packets = n_packets;
     }
-    SxNsqIn* nin = (SxNsqIn*)b->d_enc_work;
-    SxNsqOut* nout = (SxNsqOut*)((char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63));
-    SxCodeIn* cin = (SxCodeIn*)((char*)nout + ((sz_out + 63) & ~(size_t)63));
-    SxEncStream* states = (SxEncStream*)b->d_enc_state;
+    void* nin = b->d_enc_work;
+    void* nout = (char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63);
+    void* cin = (char*)nout + ((sz_out + 63) & ~(size_t)63);
+    void* states = b->d_enc_state;
     // Pipeline: chunk c of the call's packets goes analysis (stream sA) -> quantiser (sB) -> coding (sC).  A_c follows A_{c-1},
     // B_c follows A_c and B_{c-1}, C_c follows B_c and C_{c-1}; so the quantiser of chunk c (one wave per SIMD, latency bound)
     // runs next to the analysis of chunk c + 1 and the coding of chunk c - 1 (instruction bound): they share the SIMDs.  The
@@ -394,19 +344,18 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         if (c < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
         if (c > 0 && b->gate) (void)solo_launch_gate(&b->d_started[c - 1], b->started_target[c - 1], b->sA);
         if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-        hipLaunchKernelGGL(solo_enc_analysis_kernel, dim3(b->n_streams), dim3(64), 0, b->sA, states, d_pcm, b->n_streams, n_packets, p0, pc, nin, cin);
+        (void)ops->analysis(states, d_pcm, b->n_streams, n_packets, p0, pc, nin, cin, b->sA);
         if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
         SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
         SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
         if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
         b->started_target[c] += (unsigned int)((b->n_streams + 3) / 4);          // workgroups of this launch (4 streams each)
-        if (solo_launch_nsq(states, nin, nout, b->n_streams, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
+        if (ops->nsq(states, nin, nout, b->n_streams, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
         if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
         SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
         SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
         if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-        hipLaunchKernelGGL(solo_enc_coding_kernel, dim3(b->n_streams), dim3(64), 0, b->sC, states, cin, nout, b->n_streams, n_packets, p0, pc,
-                           b->slot, d_bits, d_nbytes, d_status);
+        (void)ops->coding(states, cin, nout, b->n_streams, n_packets, p0, pc, b->slot, d_bits, d_nbytes, d_status, b->sC);
         if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
         SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
     }
@@ -473,7 +422,7 @@ void* AGR_Sate_Encoder_Init(USER_Ctrl_enc* enc_Ctrl) {
 int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int32_t bufSize, int16_t* nBytesOut) {
     solo_single* h = (solo_single*)st;
     if (!h || !h->is_enc) return -1;
-    if (hipMemcpy(h->d_pcm, pcm, SX_PACKET * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (hipMemcpy(h->d_pcm, pcm, h->b->eops->packet_samples * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;      // JC1_FrameSize samples
     if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
     int16_t nb[2];
     if (hipMemcpy(nb, h->d_nbytes, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;

@@ -1,9 +1,13 @@
-// solo_api_wb.hip -- the decoder kernels compiled for the 32 kHz API rate (`samplerate == 32000` in USER_Ctrl_dec,
+// solo_api_wb.hip -- the decoder and encoder (analysis / coding) kernels compiled for the 32 kHz API rate (`samplerate == 32000` in USER_Ctrl_dec,
 // libBWE/AGR_BWE_SDK_API.c:197): 16 kHz bands, SILK running wide band (fs_kHz = 16, LPC order 16, order-16 NLSF codebooks,
 // stage-3 pitch contours, 320-sample frames), 1280-sample packets.  Same source as the 16 kHz build (solo_dec.h), other
 // compile-time constants; solo_api.hip dispatches here when a handle's decoder control asks for it.
 #define SX_FS_KHZ 16
 #include "solo_dec_kernels.h"
+#ifdef SOLO_WITH_ENCODER
+#include "solo_enc_kernels.h"
+extern "C" const solo_enc_ops* solo_wb_enc_ops() { return &solo_enc_ops_table_wb; }
+#endif
 
 extern "C" {
 size_t solo_wb_dec_state_bytes() { return solo_dec_state_bytes_wb(); }

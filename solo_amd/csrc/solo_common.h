@@ -74,6 +74,12 @@
 #else
 #error "SX_FS_KHZ must be 8 or 16"
 #endif
+// kernels / launchers of the two builds get distinct symbols
+#if SX_FS_KHZ == 8
+#define SX_K(name) name
+#else
+#define SX_K(name) name##_wb
+#endif
 #define SX_MAX_LPC 16      // MAX_LPC_ORDER                    (SKP_Silk_define.h:200)
 #define SX_HB_LPC 8        // BWE_LPCOrder                     (libBWE/AGR_BWE_SDK_API.c:106)
 #define SX_FRAME (20 * SX_FS_KHZ)   // 20 ms

@@ -4,12 +4,6 @@
 #include <hip/hip_runtime.h>
 #include "solo_dec.h"
 
-#if SX_FS_KHZ == 8
-#define SX_K(name) name
-#else
-#define SX_K(name) name##_wb
-#endif
-
 __global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecState* states, int n_streams, int hb_joint) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;

@@ -728,7 +728,9 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
         pw->x_filt_Q12[n] = sx_add(sx_smulbb(pw->st_res[1 + n], B_lo), sx_smulbb(pw->st_res[n], B_hi));
     }
     wv_sync();
-#ifdef SX_LANE_STREAM
+#if defined(SX_LANE_STREAM) && SX_FS_KHZ == 8
+    // (8 kHz only: at 16 kHz the span lag + frame = 288 + 2 + 320 exceeds the 512-entry ring, the writes of a frame would run
+    // over entries its first samples still have to read; the wide-band build takes the sample-serial form below)
     // prefilt_FIX's low-frequency recursion (sLF_AR, sLF_MA) only consumes x_filt; the harmonic term is a FIR over the ring of
     // past sLF_MA values that never feeds back.  So: the scalar recursion streams its 160 samples through lane registers,
     // then the ring update and the harmonic FIR + output run lane-parallel.  (Sample n reads ring entries written by samples
@@ -1284,7 +1286,9 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     bw->CAf[0] = CA0;
     bw->CAb[0] = CA0;
     wv_sync();
-#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64 && SX_FS_KHZ == 8
+    // (orders <= 15: element k of every vector sits in column k of a 16-lane row; the order-16 analysis of the wide-band build needs
+    // 17 correlation entries and takes the LDS form below)
     // Register-resident recursion: lane (s, k) = (row, column) of the wave.  Column k of EVERY row holds coefficient / correlation
     // element k (Af, first / last row correlations Cf / Cl, CAf, CAb: the rows are redundant copies), so the per-subframe terms
     // reduce inside a row (DPP) and index reversals n-1-k are one lane gather; nothing goes through LDS but the signal.

@@ -40,13 +40,15 @@ SX_FN void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16*
 SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
     const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
 #ifdef SX_LANE_STREAM
-    // N <= 192 samples in, N/2 <= 96 out per band (in may alias outL: everything is read before anything is stored)
-    i32 r[3], oL[2] = {0, 0}, oH[2] = {0, 0};
+    // N <= 64 * SX_FCH samples in (a frame), half as many out per band (in may alias outL: everything is read before anything is stored)
+    i32 r[SX_FCH], oL[(SX_FCH + 1) / 2], oH[(SX_FCH + 1) / 2];
 #pragma unroll
-    for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; r[j] = i < N ? (i32)in[i] : 0; }
+    for (int j = 0; j < (SX_FCH + 1) / 2; j++) { oL[j] = 0; oH[j] = 0; }
+#pragma unroll
+    for (int j = 0; j < SX_FCH; j++) { const int i = SX_LANE + 64 * j; r[j] = i < N ? (i32)in[i] : 0; }
     i32 s0 = SX_UNI(S[0]), s1 = SX_UNI(S[1]);
 #pragma unroll
-    for (int c = 0; c < 3; c++) {
+    for (int c = 0; c < SX_FCH; c++) {
         const int kend = sx_min(N >> 1, 32 * (c + 1));
         for (int k = 32 * c; k < kend; k++) {
             i32 in32 = sx_shl(SX_RDLANE(r[c], (2 * k) & 63), 10);
@@ -64,7 +66,7 @@ SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N
         }
     }
 #pragma unroll
-    for (int j = 0; j < 2; j++) {
+    for (int j = 0; j < (SX_FCH + 1) / 2; j++) {
         const int i = SX_LANE + 64 * j;
         if (i < (N >> 1)) { outL[i] = (i16)oL[j]; outH[i] = (i16)oH[j]; }
     }

@@ -1,0 +1,104 @@
+// solo_enc_kernels.h -- the encoder's analysis / coding kernels and the launch table of one build (the quantiser kernel lives in
+// solo_nsq16.hip).  Compiled once per internal rate like solo_dec_kernels.h: solo_api.hip (SX_FS_KHZ = 8, 16 kHz API rate) and
+// solo_api_wb.hip (SX_FS_KHZ = 16, 32 kHz API rate).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "solo_enc.h"
+
+__global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX) {
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX);
+}
+
+// Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
+//   A  solo_enc_analysis_kernel  one wavefront per stream: QMF split + analysis chain of every frame of the launch
+//   B  solo_nsq_kernel           four streams per wavefront (solo_nsq16.hip): the delayed-decision quantiser
+//   C  solo_enc_coding_kernel    one wavefront per stream: high-band encoder, range coding, payload assembly
+__device__ __forceinline__ void SX_K(solo_enc_enter)(SxEncWork* w, const SxEncStream* rec) {
+    const i32* src = (const i32*)&rec->core;
+    i32* dst = (i32*)&w->st;
+    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+    wv_sync();
+}
+__device__ __forceinline__ void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
+    wv_sync();
+    const i32* src = (const i32*)&w->st;
+    i32* dst = (i32*)&rec->core;
+    SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
+}
+
+// (waves-per-SIMD target 5 = at most 104 VGPRs: two of these waves share a SIMD with one quantiser wave of ~288 VGPRs)
+__global__ void __launch_bounds__(64, 5) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
+                                                                  int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
+                                                                  SxCodeIn* __restrict__ code_in) {
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SxEncStream* rec = &states[s];
+    SX_K(solo_enc_enter)(&w, rec);
+    for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
+        const size_t pk = (size_t)s * n_packets + p;
+        sx_enc_stage_a(rec, &w, pcm + pk * SX_PACKET, nsq_in + pk * 2, code_in + pk);
+        wv_sync();
+    }
+    SX_K(solo_enc_leave)(&w, rec);
+}
+
+__global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
+                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
+                                                                int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SxEncStream* rec = &states[s];
+    SX_K(solo_enc_enter)(&w, rec);
+    i32 first_err = 0;
+    for (int p = p0; p < p0 + pc; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        i32 ret = sx_enc_stage_c(rec, &w, code_in + pk, nsq_out + pk * 2, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    if (status && SX_LANE == 0) {                  // first error of the call (the chunks of a call run in order)
+        if (p0 == 0) status[s] = first_err;
+        else if (first_err != 0 && status[s] == 0) status[s] = first_err;
+    }
+}
+
+
+extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
+                                     void* hip_stream);   // solo_nsq16.hip / solo_nsq16_wb.hip
+
+// what the host-side pipeline (solo_api.hip) needs of one build: record sizes and launchers
+#ifndef SOLO_ENC_OPS_DEFINED
+#define SOLO_ENC_OPS_DEFINED
+struct solo_enc_ops {
+    size_t state_bytes, nsq_in_bytes, nsq_out_bytes, code_in_bytes;      // sizeof SxEncStream / SxNsqIn / SxNsqOut / SxCodeIn
+    int packet_samples;
+    hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s);
+    hipError_t (*analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in, void* code_in, hipStream_t s);
+    int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* hip_stream);
+    hipError_t (*coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc, int slot,
+                         uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s);
+};
+#endif
+static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX);
+    return hipGetLastError();
+}
+static hipError_t SX_K(solo_enc_launch_analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in,
+                                                 void* code_in, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_enc_analysis_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, pcm, n_streams, n_packets, p0, pc,
+                       (SxNsqIn*)nsq_in, (SxCodeIn*)code_in);
+    return hipGetLastError();
+}
+static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc,
+                                               int slot, uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_enc_coding_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, (const SxCodeIn*)code_in,
+                       (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, slot, bits, nbytes, status);
+    return hipGetLastError();
+}
+static const solo_enc_ops SX_K(solo_enc_ops_table) = {
+    sizeof(SxEncStream), sizeof(SxNsqIn), sizeof(SxNsqOut), sizeof(SxCodeIn), SX_PACKET,
+    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding)};

@@ -14,7 +14,7 @@
 #ifndef SX_NSQ_WAVES
 #define SX_NSQ_WAVES 1        // ~288 VGPRs; the analysis / coding kernels are held to <= 104 so that two of their waves fit beside it
 #endif
-extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) solo_nsq_kernel(SxEncStream* states, const SxNsqIn* __restrict__ in,
+extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
                                                                  SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
                                                                  unsigned int* started) {
     __shared__ SxNsqWork w[SX_PER_WAVE];
@@ -34,6 +34,7 @@ extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) solo_nsq_kernel(S
     }
 }
 
+#if SX_FS_KHZ == 8
 // gate: holds a stream until `*flag` has reached `target` (modulo 2^32), i.e. until all workgroups of the quantiser launch that
 // counts into it are resident; gives up after ~20 ms so that a runtime that serialises the streams cannot hang
 extern "C" __global__ void __launch_bounds__(64) solo_gate_kernel(const unsigned int* flag, unsigned int target) {
@@ -49,15 +50,16 @@ extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, v
     return (int)hipGetLastError();
 }
 
+#endif
 // host-side launcher (called from solo_api.hip)
-extern "C" int solo_launch_nsq(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
+extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
                                void* hip_stream) {
-    hipLaunchKernelGGL(solo_nsq_kernel, dim3((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)states,
+    hipLaunchKernelGGL(SX_K(solo_nsq_kernel), dim3((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)states,
                        (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets, p0, pc, started);
     return (int)hipGetLastError();
 }
 
-#if defined(SX_PROF)
+#if defined(SX_PROF) && SX_FS_KHZ == 8
 extern "C" int32_t solo_debug_prof_nsq(unsigned long long* out32, int32_t reset) {
     if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sx_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {

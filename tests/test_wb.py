@@ -142,8 +142,62 @@ def test_wb_gpu_packetwise_and_wrong_rate(torch_cuda):
     b2 = solo_amd.SoloBatch(8, encoder=False, decoder=True, slot_bytes=nbz["bits"].shape[2], samplerate=32000)
     pcm, st = b2.decode(torch.from_numpy(nbz["bits"][:, :1].copy()).to(b2.device), torch.from_numpy(nbz["nbytes"][:, :1].copy()).to(b2.device))
     assert (st.cpu().numpy() < 0).all()
-    with pytest.raises(ValueError):
-        solo_amd.SoloBatch(4, encoder=True, decoder=True, samplerate=32000)
+    with pytest.raises(RuntimeError):       # below 15.6 kbps the reference leaves 16 kHz internally: refused, not approximated
+        solo_amd.SoloBatch(4, rate=13600, encoder=True, decoder=False, samplerate=32000)
+
+
+@pytest.mark.gpu
+def test_wb_gpu_encoder_goldens_and_round_trip(torch_cuda):
+    """The 32 kHz ENCODER on the GPU (three-kernel pipeline of the wide-band build): reference bitstreams byte for byte, then the
+    round trip through the wide-band decoder; one call and packet-by-packet calls."""
+    import solo_amd
+    torch = torch_cuda
+    z = _wb()
+    for sl, joint in ((slice(0, 3), 0), (slice(3, 4), 1)):
+        pcm, bits_ref, nb_ref = z["pcm"][sl], z["bits"][sl], z["nbytes"][sl]
+        N, P, S = bits_ref.shape
+        b = solo_amd.SoloBatch(N, rate=24000, encoder=True, decoder=True, slot_bytes=S, samplerate=32000, joint=joint)
+        bits, nb, st = b.encode(torch.from_numpy(np.ascontiguousarray(pcm)).to(b.device))
+        torch.cuda.synchronize()
+        assert int(st.abs().max()) == 0
+        nbh, bh = nb.cpu().numpy(), bits.cpu().numpy()
+        assert np.array_equal(nbh, nb_ref), joint
+        for i in range(N):
+            for p in range(P):
+                n0 = int(nb_ref[i, p, 0])
+                assert np.array_equal(bh[i, p, :n0], bits_ref[i, p, :n0]), (joint, i, p)
+        out, st2 = b.decode(bits, nb)
+        torch.cuda.synchronize()
+        assert int(st2.abs().max()) == 0 and np.array_equal(out.cpu().numpy(), z["dec_clean"][sl])
+        b2 = solo_amd.SoloBatch(N, rate=24000, encoder=True, decoder=False, slot_bytes=S, samplerate=32000, joint=joint)
+        for p in range(6):
+            bits1, nb1, st1 = b2.encode(torch.from_numpy(np.ascontiguousarray(pcm[:, p:p + 1])).to(b2.device))
+            assert np.array_equal(nb1.cpu().numpy()[:, 0], nb_ref[:, p])
+            for i in range(N):
+                n0 = int(nb_ref[i, p, 0])
+                assert np.array_equal(bits1.cpu().numpy()[i, 0, :n0], bits_ref[i, p, :n0]), (joint, i, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present on this box")
+def test_wb_gpu_encoder_many_streams_vs_reference(torch_cuda):
+    """96 streams x 8 packets at 15.6 .. 40 kbps with DTX on half of them... one configuration per batch: two batches."""
+    import solo_amd
+    torch = torch_cuda
+    for rate, dtx in ((15600, 0), (36000, 1)):
+        N, P = 48, 8
+        pcm = np.stack([T.synth_stream_32k(7000 + rate // 100 + i, P) for i in range(N)])
+        b = solo_amd.SoloBatch(N, rate=rate, encoder=True, decoder=False, slot_bytes=512, samplerate=32000, dtx=dtx)
+        bits, nb, st = b.encode(torch.from_numpy(pcm).to(b.device))
+        torch.cuda.synchronize()
+        assert int(st.abs().max()) == 0
+        bh, nbh = bits.cpu().numpy(), nb.cpu().numpy()
+        for i in range(N):
+            e = R.RefEncoder("fix", rate=rate, samplerate=32000, dtx=dtx)
+            for p in range(P):
+                pl, n0, n1 = e.encode(pcm[i, p])
+                assert (int(nbh[i, p, 0]), int(nbh[i, p, 1])) == (n0, n1), (rate, i, p)
+                assert bh[i, p, :n0].tobytes() == pl[:n0], (rate, i, p)
 
 
 @pytest.mark.gpu
