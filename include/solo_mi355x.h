@@ -28,7 +28,7 @@ extern "C" {
 typedef struct {            /* AGR_JC1_SDK_API.h:11-21 */
     int32_t mode;           /* ignored by the library (as in the reference)            */
     int32_t targetRate_bps; /* <=0 -> 15600 (AGR_BWE_SDK_API.c:35-37); CLI default 13600 */
-    int32_t samplerate;     /* 16000 (the encoder implements this rate only)           */
+    int32_t samplerate;     /* 16000, or 32000 (1280-sample packets, SILK wide band; targetRate_bps >= 15600) */
     int32_t dtx_enable;     /* 0 / 1                                                    */
     int32_t framesize_ms;   /* 40                                                       */
     int32_t joint_enable;   /* 0, or 1 with joint_mode 1 (one 40 ms high-band frame)   */
@@ -38,7 +38,7 @@ typedef struct {            /* AGR_JC1_SDK_API.h:11-21 */
 
 typedef struct {            /* AGR_JC1_SDK_API.h:23-31 */
     int32_t packetLoss_perc;
-    int32_t samplerate;     /* 16000, or 32000 (decoder: 1280-sample packets, SILK wide band at 16 kHz) */
+    int32_t samplerate;     /* 16000, or 32000 (1280-sample packets, SILK wide band at 16 kHz) */
     int32_t framesize_ms;
     int32_t joint_enable;
     int32_t joint_mode;
@@ -46,9 +46,9 @@ typedef struct {            /* AGR_JC1_SDK_API.h:23-31 */
 } USER_Ctrl_dec;
 
 /* AGR_JC1_SDK_API.h:33  (impl. libBWE/AGR_BWE_SDK_API.c:11).  NULL if the configuration is not the
- * supported one (samplerate 16000, framesize 40, joint off or joint_mode 1) or no GPU is available. */
+ * supported one (samplerate 16000 or 32000, framesize 40, joint off or joint_mode 1) or no GPU is available. */
 void *AGR_Sate_Encoder_Init(USER_Ctrl_enc *enc_Ctrl);
-/* AGR_JC1_SDK_API.h:37  (impl. AGR_BWE_SDK_API.c:129).  pcm: 640 samples; returns total bytes,
+/* AGR_JC1_SDK_API.h:37  (impl. AGR_BWE_SDK_API.c:129).  pcm: 640 samples (1280 at 32 kHz); returns total bytes,
  * nBytesOut[0] = total, nBytesOut[1] = len(MD2)+8 (MD1 = first nBytesOut[0]-nBytesOut[1] bytes). */
 int32_t AGR_Sate_Encoder_Encode(void *SATEEnc_State, const int16_t *AGR_Sate_PCM, uint8_t *AGR_Sate_Bit,
                                 int32_t AGR_Sate_Buf_Size, int16_t *nBytesOut);

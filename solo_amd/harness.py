@@ -2,7 +2,7 @@
 test/enc_main.c and read by test/dec_main.c, and the loss simulator of the decoder CLI, so that files produced here
 interoperate with the stock reference binaries and their known-answer md5s can be matched end to end.
 
-  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1]
+  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1] [-Fs_API 32000]
   python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-MDI 0/1] [-joint 1] [-Fs_API 32000]
 
 Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per 40 ms packet  int16 total, int16 len(MD2)+8, `total` payload bytes
@@ -64,16 +64,18 @@ def recv_mask(pattern):
     return np.array([(0 if l1 else 1) | (0 if l2 else 2) for l1, l2 in pattern], np.uint8)
 
 
-def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0):
-    """int16 array (16 kHz mono) -> [(payload, total, len(MD2)+8)]; a trailing partial packet is dropped like the CLI does"""
+def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0, samplerate=16000):
+    """int16 array (16 kHz mono, or 32 kHz with samplerate=32000) -> [(payload, total, len(MD2)+8)]; a trailing partial packet is dropped like the CLI does"""
     import torch
     from . import SoloBatch
     pcm = np.asarray(pcm, np.int16)
-    P = pcm.size // PACKET_SAMPLES
+    L = PACKET_SAMPLES * samplerate // 16000
+    P = pcm.size // L
     if P == 0:
         return []
-    b = SoloBatch(1, rate=rate, encoder=True, decoder=False, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, dtx=dtx)
-    x = torch.from_numpy(np.ascontiguousarray(pcm[:P * PACKET_SAMPLES].reshape(1, P, PACKET_SAMPLES))).to(b.device)
+    b = SoloBatch(1, rate=rate, encoder=True, decoder=False, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, dtx=dtx,
+                  samplerate=samplerate)
+    x = torch.from_numpy(np.ascontiguousarray(pcm[:P * L].reshape(1, P, L))).to(b.device)
     bits, nb, st = b.encode(x)
     torch.cuda.synchronize()
     if int(st[0]) != 0:
@@ -120,12 +122,12 @@ def main(argv=None):
         return 2
     mdi = _opt(argv, "-MDI", 0)
     fs = _opt(argv, "-Fs_API", 16000)
-    if fs not in (16000, 32000) or (fs == 32000 and argv[0] == "enc"):
-        print("-Fs_API: 16000, or 32000 for dec (the 32 kHz encoder is not built)")
+    if fs not in (16000, 32000):
+        print("-Fs_API: 16000 or 32000")
         return 2
     if argv[0] == "enc":
         recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi,
-                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0))
+                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0), samplerate=fs)
         open(argv[2], "wb").write(write_bit_container(recs))
         print("%d packets, %.3f kbps" % (len(recs), sum(r[1] for r in recs) * 8 / max(len(recs), 1) / 40.0))
     else:
