@@ -18,11 +18,11 @@ def torch_cuda():
     return torch
 
 
-def _scenario(torch, mdi, seed):
+def _scenario(torch, mdi, seed, fs=16000):
     import solo_amd
     N, P, S = 24, 10, 256
-    pcm = np.stack([R.synth_stream(300 + i, P) for i in range(N)])
-    enc = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512, use_md_index=mdi)
+    pcm = np.stack([(R.synth_stream if fs == 16000 else T.synth_stream_32k)(300 + i, P) for i in range(N)])
+    enc = solo_amd.SoloBatch(N, rate=13600 if fs == 16000 else 24000, encoder=True, decoder=False, slot_bytes=512, use_md_index=mdi, samplerate=fs)
     bits, nb, st = enc.encode(torch.from_numpy(pcm).to(enc.device))
     torch.cuda.synchronize()
     hb, hn = bits.cpu().numpy(), nb.cpu().numpy()
@@ -49,16 +49,16 @@ def _scenario(torch, mdi, seed):
     return hb, hn, recv, dA, lA, dB, lB
 
 
-@pytest.mark.parametrize("mdi", [0, 1])
-def test_split_arrivals_equal_masked_decode(torch_cuda, mdi):
+@pytest.mark.parametrize("mdi,fs", [(0, 16000), (1, 16000), (1, 32000)])
+def test_split_arrivals_equal_masked_decode(torch_cuda, mdi, fs):
     import solo_amd
     torch = torch_cuda
-    hb, hn, recv, dA, lA, dB, lB = _scenario(torch, mdi, 11 + mdi)
+    hb, hn, recv, dA, lA, dB, lB = _scenario(torch, mdi, 11 + mdi, fs)
     N, P = recv.shape
-    d1 = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=512, use_md_index=mdi)
+    d1 = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=512, use_md_index=mdi, samplerate=fs)
     dev = d1.device
     want, st = d1.decode(torch.from_numpy(hb).to(dev), torch.from_numpy(hn).to(dev), torch.from_numpy(recv).to(dev))
-    d2 = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=512, use_md_index=mdi)
+    d2 = solo_amd.SoloBatch(N, encoder=False, decoder=True, slot_bytes=512, use_md_index=mdi, samplerate=fs)
     got, st2 = d2.decode_split(torch.from_numpy(dA).to(dev), torch.from_numpy(lA).to(dev), torch.from_numpy(dB).to(dev),
                                torch.from_numpy(lB).to(dev))
     torch.cuda.synchronize()
@@ -68,7 +68,7 @@ def test_split_arrivals_equal_masked_decode(torch_cuda, mdi):
     if mdi:                                                       # the masked decode itself, against the host emulation
         w = want.cpu().numpy()
         for i in range(0, N, 6):
-            d = T.EmuDecoder(use_md_index=1)
+            d = T.EmuDecoder(use_md_index=1, wb=fs == 32000)
             for p in range(P):
                 n0, n1 = int(hn[i, p, 0]), int(hn[i, p, 1])
                 m = int(recv[i, p])

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Quick A/B timing of encode / decode for a given build of the library (SOLO_LIB_OVERRIDE), with a parity check
-against the committed goldens first.   SOLO_LIB_OVERRIDE=build/x.so python tools/quick_bench.py [streams] [packets]"""
+against the committed goldens first.   SOLO_LIB_OVERRIDE=build/x.so python tools/quick_bench.py [streams] [packets] [16000|32000]
+(32000: the wide-band build, 1280-sample packets at 24 kbps)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,15 +10,27 @@ import torch, solo_amd
 from solo_amd.synth import synth_batch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-z = np.load(os.path.join(ROOT, "tests/golden/synth8x25.npz"))
-b = solo_amd.SoloBatch(8, encoder=True, decoder=True, slot_bytes=512)
-bits, nb, st = b.encode(torch.from_numpy(z["pcm"]).cuda())
-ok = np.array_equal(nb.cpu().numpy(), z["nbytes"]) and all(
-    np.array_equal(bits[i, p, :int(nb[i, p, 0])].cpu().numpy(), z["bits"][i, p, :int(nb[i, p, 0])]) for i in range(8) for p in range(25))
-pcm, st2 = b.decode(bits, nb, torch.from_numpy(z["recv"]).cuda())
-ok2 = np.array_equal(pcm.cpu().numpy(), z["dec_loss"])
-b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
-x = torch.from_numpy(synth_batch(0, N, P, workers=16)).cuda()
+FS = int(sys.argv[3]) if len(sys.argv) > 3 else 16000
+if FS == 16000:
+    z = np.load(os.path.join(ROOT, "tests/golden/synth8x25.npz"))
+    b = solo_amd.SoloBatch(8, encoder=True, decoder=True, slot_bytes=512)
+    bits, nb, st = b.encode(torch.from_numpy(z["pcm"]).cuda())
+    ok = np.array_equal(nb.cpu().numpy(), z["nbytes"]) and all(
+        np.array_equal(bits[i, p, :int(nb[i, p, 0])].cpu().numpy(), z["bits"][i, p, :int(nb[i, p, 0])]) for i in range(8) for p in range(25))
+    pcm, st2 = b.decode(bits, nb, torch.from_numpy(z["recv"]).cuda())
+    ok2 = np.array_equal(pcm.cpu().numpy(), z["dec_loss"])
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
+    x = torch.from_numpy(synth_batch(0, N, P, workers=16)).cuda()
+else:
+    z = np.load(os.path.join(ROOT, "tests/golden/wb4x20.npz"))
+    b = solo_amd.SoloBatch(3, rate=24000, encoder=True, decoder=True, slot_bytes=512, samplerate=32000)
+    bits, nb, st = b.encode(torch.from_numpy(z["pcm"][:3].copy()).cuda())
+    ok = np.array_equal(nb.cpu().numpy(), z["nbytes"][:3]) and all(
+        np.array_equal(bits[i, p, :int(nb[i, p, 0])].cpu().numpy(), z["bits"][i, p, :int(nb[i, p, 0])]) for i in range(3) for p in range(20))
+    pcm, st2 = b.decode(bits, nb, torch.from_numpy(z["recv"][:3].copy()).cuda())
+    ok2 = np.array_equal(pcm.cpu().numpy(), z["dec_loss"][:3])
+    b = solo_amd.SoloBatch(N, rate=24000, encoder=True, decoder=True, slot_bytes=512, samplerate=32000)
+    x = torch.from_numpy(synth_batch(0, N, 2 * P, workers=16).reshape(N, P, 1280)).cuda()
 bits, nb, st = b.encode(x); out, st2 = b.decode(bits, nb); torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 R = 3
