@@ -80,6 +80,46 @@ def test_cold_start_joint_mode_vs_reference():
             assert r1 == r2 == 0 and np.array_equal(x, y), (k, first, p)
 
 
+def test_corrupted_payloads_vs_reference():
+    """Bit errors in the payload: a corrupted packet that the range decoder still accepts must decode to the same (garbage) PCM and
+    leave the same state as in the reference, and a rejected one must return the same negative code.  After a rejected packet the
+    reference's own state is not defined by its inputs (AGR_Sate_decode_process copies an uninitialised stack buffer into the
+    decoder's output history, SKP_Silk_decode_frame.c:358), so a stream is compared up to and including its first rejection.
+    One documented difference: a corrupted rate index can make the payload claim another internal rate (12 / 16 / 24 kHz), which
+    the reference then decodes and resamples; this build has one internal rate per handle and rejects it (payload error)."""
+    import pytest
+    if not R.have_ref("fix"):
+        pytest.skip("oracle/_ref not built")
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    bits, nb = z["bits"], z["nbytes"]
+    rng = np.random.default_rng(5)
+    n_rejected = n_garbage = n_other_rate = 0
+    for trial in range(48):
+        s = trial % 8
+        dr, de = R.RefDecoder(), T.EmuDecoder()
+        for p in range(25):
+            n0, n1 = int(nb[s, p, 0]), int(nb[s, p, 1])
+            pl = bytearray(bits[s, p, :n0].tobytes())
+            hit = rng.random() < 0.25
+            if hit:
+                for _ in range(rng.integers(1, 4)):
+                    pl[rng.integers(0, n0)] = rng.integers(0, 256)
+            mode = rng.integers(0, 4)
+            a = R.map_loss(bytes(pl), n0, n1, mode == 1, mode == 2)
+            x, r1 = dr.decode(*a)
+            y, r2 = de.decode(*a)
+            if r1 == 0 and r2 == -12 and hit:
+                n_other_rate += 1
+                break
+            assert r1 == r2, (trial, p, r1, r2)
+            if r1 < 0:
+                n_rejected += 1
+                break
+            assert np.array_equal(x, y), (trial, p)
+            n_garbage += int(hit)
+    assert n_rejected >= 10 and n_garbage >= 40 and n_other_rate <= 4, (n_rejected, n_garbage, n_other_rate)
+
+
 def test_decoder_rejects_empty_payload():
     dec = T.EmuDecoder()
     x, ret = dec.decode(b"", 0, 0, 4)
