@@ -76,6 +76,7 @@ struct solo_batch {
     int tev_ready, last_chunks;
     unsigned int* d_started;         // per chunk slot: workgroups of the quantiser launches that have started (running count)
     unsigned int started_target[SOLO_MAX_CHUNKS];
+    int group_streams;               // env SOLO_ENC_GROUP (default 4096): streams per launch group of the encoder pipeline (0 = all)
     int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
     void* d_dec_state;               // SxDecState[n_streams] of the build that matches `wb`
     int wb;                          // decoder control asked for samplerate 32000: 1280-sample packets, SILK at 16 kHz
@@ -319,6 +320,8 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         b->chunk_packets = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_GATE");
         b->gate = e ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_GROUP");
+        b->group_streams = e ? atoi(e) : 4096;
         SOLO_CHECK(hipMalloc((void**)&b->d_started, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
         SOLO_CHECK(hipMemset(b->d_started, 0, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
         memset(b->started_target, 0, sizeof(b->started_target));
@@ -327,8 +330,8 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     int cp = b->chunk_packets > 0 ? b->chunk_packets : n_packets;
     int nchunks = (n_packets + cp - 1) / cp;
     if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
-    const bool tm = b->timing && b->tev_ready;
-    if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp)) {
+    const bool tm_req = b->timing && b->tev_ready;
+    if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp || b->evC_valid == 0)) {
         // the previous call laid its hand-over records out differently: no chunk-wise reuse, wait for all of its coding
         SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
         b->evC_valid = 0;
@@ -339,27 +342,47 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
-    for (int c = 0; c < nchunks; c++) {
-        const int p0 = c * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
-        if (c < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
-        if (c > 0 && b->gate) (void)solo_launch_gate(&b->d_started[c - 1], b->started_target[c - 1], b->sA);
-        if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-        (void)ops->analysis(states, d_pcm, b->n_streams, n_packets, p0, pc, nin, cin, b->sA);
-        if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
-        SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
-        SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
-        if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-        b->started_target[c] += (unsigned int)((b->n_streams + 3) / 4);          // workgroups of this launch (4 streams each)
-        if (ops->nsq(states, nin, nout, b->n_streams, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
-        if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
-        SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
-        SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
-        if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-        (void)ops->coding(states, cin, nout, b->n_streams, n_packets, p0, pc, b->slot, d_bits, d_nbytes, d_status, b->sC);
-        if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
-        SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
+    // Streams beyond one full round of workgroups (4096 = 16 analysis workgroups x 256 CUs, 1024 quantiser waves = one per SIMD) are
+    // processed group after group: measured 2.04 M packets/s at 4096 streams per launch against 1.80 M at 8192 and 1.70 M at 16384.
+    // All per-stream arrays are stream-major, so a group is the same launch on offset pointers.
+    const int G = b->group_streams > 0 ? b->group_streams : b->n_streams;
+    const int ngroups = (b->n_streams + G - 1) / G;
+    const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
+    int idx = 0;
+    for (int g = 0; g < ngroups; g++) {
+        const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
+        const size_t pk0 = (size_t)s0 * (size_t)n_packets;                               // first packet record of the group
+        void* g_states = (char*)states + (size_t)s0 * ops->state_bytes;
+        const int16_t* g_pcm = d_pcm + pk0 * (size_t)ops->packet_samples;
+        void* g_nin = (char*)nin + pk0 * 2 * ops->nsq_in_bytes;
+        void* g_nout = (char*)nout + pk0 * 2 * ops->nsq_out_bytes;
+        void* g_cin = (char*)cin + pk0 * ops->code_in_bytes;
+        uint8_t* g_bits = d_bits + pk0 * (size_t)b->slot;
+        int16_t* g_nbytes = d_nbytes + pk0 * 2;
+        int32_t* g_status = d_status ? d_status + s0 : NULL;
+        for (int cc = 0; cc < nchunks; cc++, idx++) {
+            const int c = idx % SOLO_MAX_CHUNKS, cprev = (idx + SOLO_MAX_CHUNKS - 1) % SOLO_MAX_CHUNKS;     // event / counter slot
+            const int p0 = cc * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
+            if (ngroups == 1 && cc < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
+            if (idx > 0 && b->gate) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
+            if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
+            (void)ops->analysis(g_states, g_pcm, ns, n_packets, p0, pc, g_nin, g_cin, b->sA);
+            if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
+            SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
+            SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
+            if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
+            b->started_target[c] += (unsigned int)((ns + 3) / 4);          // workgroups of this launch (4 streams each)
+            if (ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
+            if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
+            SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
+            SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
+            if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
+            (void)ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->sC);
+            if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
+            SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
+        }
     }
-    b->evC_valid = nchunks;
+    b->evC_valid = ngroups == 1 ? nchunks : 0;       // chunk-wise hand-over guards only for single-group calls
     const int js = (int)(b->enc_seq & 1u);
     b->enc_seq++;
     SOLO_CHECK(hipEventRecord(b->evJoinA[js], b->sA));
@@ -368,7 +391,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA[js], 0));
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC[js], 0));
     }
-    b->last_chunks = nchunks;
+    b->last_chunks = tm ? ngroups * nchunks : (ngroups == 1 ? nchunks : 0);
     if (tm) b->ev_enc = 1;
     SOLO_CHECK(hipGetLastError());
     return 0;

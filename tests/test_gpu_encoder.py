@@ -252,3 +252,26 @@ def test_async_join_pipelines_consecutive_calls(torch_cuda):
     nb = np.concatenate([o[1].cpu().numpy() for o in outs], axis=1)
     _assert_streams_equal(bits, nb, z["bits"], z["nbytes"])
     assert np.array_equal(np.concatenate([p.cpu().numpy() for p in pcms], axis=1), z["dec_clean"])
+
+
+def test_stream_groups_of_the_pipeline(torch_cuda, monkeypatch):
+    """More streams than one launch group (default 4096, here forced to 16 through SOLO_ENC_GROUP): the pipeline walks the groups
+    one after the other on offset pointers; 40 streams = 5 copies of the golden batch in groups of 16 / 16 / 8, two calls."""
+    import solo_amd
+    torch = torch_cuda
+    monkeypatch.setenv("SOLO_ENC_GROUP", "16")
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    pcm = np.concatenate([z["pcm"]] * 5)
+    N, P, S = pcm.shape[0], 12, z["bits"].shape[2]
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=S)
+    for half in range(2):
+        x = torch.from_numpy(np.ascontiguousarray(pcm[:, half * P:(half + 1) * P])).to(b.device)
+        bits, nb, st = b.encode(x)
+        torch.cuda.synchronize()
+        assert int(st.abs().max()) == 0
+        bh, nh = bits.cpu().numpy(), nb.cpu().numpy()
+        for i in range(N):
+            assert np.array_equal(nh[i], z["nbytes"][i % 8, half * P:(half + 1) * P]), (half, i)
+            for p in range(P):
+                n0 = int(nh[i, p, 0])
+                assert np.array_equal(bh[i, p, :n0], z["bits"][i % 8, half * P + p, :n0]), (half, i, p)
