@@ -117,6 +117,18 @@ def main():
     g["wb_dec_clean_md5"] = md5(wdec_clean.tobytes())
     g["wb_dec_loss_md5"] = md5(wdec_loss.tobytes())
     g["wb_mean_payload"] = float(wnb[..., 0].mean())
+    # file-level known answers of the 32 kHz mode (`-Fs_API 32000 -rate 24000`): .bit container of stream 0 of the batch above and
+    # its decode at 0 % and 30 % CLI loss
+    kat_bit = T.write_bit_container(wstreams[0])
+    g["wb_kat_bit_md5"] = md5(kat_bit)
+    for loss in (0, 30):
+        dec = R.RefDecoder("fix", samplerate=32000)
+        pat = R.cli_loss_pattern(PW, loss, [(r[1], r[2]) for r in wstreams[0]])
+        outp = bytearray()
+        for p, (pl, n0, n1) in enumerate(wstreams[0]):
+            x, ret = dec.decode(*R.map_loss(pl, n0, n1, *pat[p]))
+            outp += x.tobytes()
+        g["wb_kat_dec_loss%d_md5" % loss] = md5(outp)
     g["synth_bits_md5"] = md5(bits.tobytes())
     g["synth_dec_clean_md5"] = md5(dec_clean.tobytes())
     g["synth_dec_loss_md5"] = md5(dec_loss.tobytes())

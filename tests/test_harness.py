@@ -33,3 +33,19 @@ def test_file_level_known_answers():
     for loss in (0, 30):
         pcm = H.decode_records(recs, loss_perc=loss)
         assert T.md5(pcm) == g["ch_f1_dec_loss%d_md5" % loss]
+
+
+@pytest.mark.gpu
+def test_file_level_known_answers_32k():
+    """`-Fs_API 32000`: .bit container and decoded PCM (0 % and 30 % CLI loss) of a 32 kHz stream against the md5s obtained with
+    the compiled reference (tests/golden/make_golden.py)."""
+    import torch
+    assert torch.cuda.is_available()
+    g = T.golden_json()
+    z = np.load(T.GOLDEN + "/wb4x20.npz")
+    recs = H.encode_pcm(z["pcm"][0].reshape(-1), rate=24000, samplerate=32000)
+    bit = H.write_bit_container(recs)
+    assert T.md5(bit) == g["wb_kat_bit_md5"]
+    for loss in (0, 30):
+        pcm = H.decode_records(H.parse_bit_container(bit), loss_perc=loss, samplerate=32000)
+        assert pcm.size == 20 * 1280 and T.md5(pcm) == g["wb_kat_dec_loss%d_md5" % loss]

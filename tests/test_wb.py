@@ -86,6 +86,19 @@ def test_wb_encoder_emulation_vs_reference(rate, joint, dtx):
         assert ee.encode(pcm[p]) == er.encode(pcm[p]), (rate, joint, dtx, p)
 
 
+def test_wb_file_level_known_answers_emulation():
+    """.bit container of a 32 kHz stream and its decode at 0 % / 30 % CLI loss against the md5s made with the compiled reference."""
+    g, z = T.golden_json(), _wb()
+    e = T.EmuEncoder(24000, wb=True)
+    recs = [e.encode(z["pcm"][0, p]) for p in range(20)]
+    assert T.md5(T.write_bit_container(recs)) == g["wb_kat_bit_md5"]
+    for loss in (0, 30):
+        d = T.EmuDecoder(wb=True)
+        pat = R.cli_loss_pattern(20, loss, [(r[1], r[2]) for r in recs])
+        out = np.concatenate([d.decode(*R.map_loss(pl, n0, n1, *pat[p]))[0] for p, (pl, n0, n1) in enumerate(recs)])
+        assert T.md5(out) == g["wb_kat_dec_loss%d_md5" % loss]
+
+
 def test_wb_decoder_rejects_other_internal_rates():
     """A narrow-band stream (16 kHz API rate) handed to the 32 kHz decoder: the reference would switch its SILK core to 8 kHz
     and resample; this build decodes one internal rate per handle and reports a payload error instead of producing audio."""
