@@ -252,3 +252,26 @@ def test_wb_gpu_many_streams_vs_reference_and_legacy_api(torch_cuda):
         r = lib.AGR_Sate_Decoder_Decode(h, pcm.ctypes.data_as(C.c_void_p), C.byref(ns), buf.ctypes.data_as(C.c_void_p), nbv, a[3])
         assert r == ret == 0 and ns.value == 1280 and np.array_equal(pcm[:1280], x), p
     lib.AGR_Sate_Decoder_Uninit(h)
+
+
+@pytest.mark.gpu
+def test_wb_gpu_legacy_encoder_api(torch_cuda):
+    """AGR_Sate_Encoder_Init / _Encode with samplerate = 32000 (1280 samples per call) against the golden bitstreams; a rate below
+    15.6 kbps is refused by Init like any other unsupported configuration."""
+    import solo_amd
+    lib = solo_amd.load_library()
+    z = _wb()
+    ctrl = solo_amd.default_enc_ctrl(rate=24000, samplerate=32000)
+    h = lib.AGR_Sate_Encoder_Init(C.byref(ctrl))
+    assert h
+    bits = np.zeros(1100, np.uint8)
+    nb = np.zeros(6, np.int16)
+    for p in range(6):
+        pcm = np.ascontiguousarray(z["pcm"][0, p])
+        n = lib.AGR_Sate_Encoder_Encode(h, pcm.ctypes.data_as(C.c_void_p), bits.ctypes.data_as(C.c_void_p), 1024, nb.ctypes.data_as(C.c_void_p))
+        n0 = int(z["nbytes"][0, p, 0])
+        assert n == n0 and (int(nb[0]), int(nb[1])) == (n0, int(z["nbytes"][0, p, 1]))
+        assert np.array_equal(bits[:n0], z["bits"][0, p, :n0]), p
+    lib.AGR_Sate_Encoder_Uninit(h)
+    low = solo_amd.default_enc_ctrl(rate=13600, samplerate=32000)
+    assert not lib.AGR_Sate_Encoder_Init(C.byref(low))
