@@ -57,7 +57,11 @@ int AGR_Sate_Encoder_Uninit(void *SATEEnc_State);
 /* AGR_JC1_SDK_API.h:49  (impl. AGR_BWE_SDK_API.c:166) */
 void *AGR_Sate_Decoder_Init(USER_Ctrl_dec *dec_Ctrl);
 /* AGR_JC1_SDK_API.h:53  (impl. AGR_BWE_SDK_API.c:249).  lostflag: 1 lost, 2 MD1 only, 3 MD2(+HB) only,
- * 4 both.  Like the reference, nBytes[0..1] are overwritten with the low-band description lengths. */
+ * 4 both.  Like the reference: -1 for nBytes[0] <= 0 with nothing touched; otherwise nBytes[0..1] are overwritten with the
+ * low-band description lengths and *nSamplesOut is always written.  Unlike the reference, lengths that do not fit the buffer
+ * contract (nBytes[0] > 1088, nBytes[1] outside [0, nBytes[0]], a second description shorter than its high-band bytes) are
+ * refused with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11) / SKP_SILK_DEC_PAYLOAD_ERROR (-12) instead of read out of bounds; on a
+ * decoder error the PCM buffer is left untouched. */
 int32_t AGR_Sate_Decoder_Decode(void *SATEDec_State, int16_t *AGR_Sate_PCM, int16_t *nSamplesOut,
                                 const uint8_t *AGR_Sate_Bit, int16_t nBytes[], int32_t lostflag);
 /* AGR_JC1_SDK_API.h:62 */
@@ -74,6 +78,12 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  *                                                       pointer/length mapping of test/dec_main.c:255-378
  *                                                       is done on the device)
  *   d_status   int32  [n_streams]                      0, or the first negative SILK error of the call
+ *
+ * Length records are validated on the device (0 <= len(MD2)+HB <= total <= slot): a record that violates this is never
+ * dereferenced, the packet is concealed as lost and d_status reports -11 / -12.  DELIBERATE CONVENTION (not reference
+ * behaviour): an empty record (total <= 0, e.g. a DTX packet that was not sent) is concealed as a lost packet (lostflag 1);
+ * the reference library returns -1 for it without touching its state (AGR_BWE_SDK_API.c:266) and its CLI repeats the previous
+ * output buffer -- the legacy AGR_Sate_Decoder_Decode symbol above keeps that behaviour.
  *
  * Streams keep their codec state in HBM inside the handle between calls (a call with n_packets = P
  * is identical to P calls with n_packets = 1).  Work is enqueued on `hip_stream` (a hipStream_t, may
@@ -128,6 +138,14 @@ const char *solo_kernel_name(int32_t which);
 int32_t solo_batch_set_timing(solo_batch_t *b, int32_t on);
 int32_t solo_batch_last_kernel_ms(solo_batch_t *b, float *ms4);
 int32_t solo_batch_last_encode_chunks(const solo_batch_t *b);
+/* Conformance probes (tests only; DEVICE pointers, default stream, synchronous).  solo_debug_l0: the fixed-point vocabulary of
+ * solo_amd/csrc/solo_fix.h (the reference's SKP_SMULWB .. SKP_INVERSE32_varQ, SKP_Silk_macros.h:33-122 / SKP_Silk_Inlines.h:71-220)
+ * as compiled for gfx950, out[i] = op(a[i], b[i], c[i]) with the op numbers of solo_amd/csrc/solo_l0_probe.h.
+ * solo_debug_sum_sqr_shift: SKP_Silk_sum_sqr_shift (SKP_Silk_sum_sqr_shift.c:40) in its wave-cooperative form, one result pair
+ * per row of `len` <= 1024 int16 samples (`stride` samples between rows). */
+int32_t solo_debug_l0(int32_t op, int32_t n, const int32_t *d_a, const int32_t *d_b, const int32_t *d_c, int32_t *d_out);
+int32_t solo_debug_sum_sqr_shift(const int16_t *d_x, int32_t rows, int32_t len, int32_t stride, int32_t odd_start,
+                                 int32_t *d_energy, int32_t *d_shift);
 /* Library version string. */
 const char *solo_version(void);
 

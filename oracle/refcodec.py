@@ -73,9 +73,10 @@ def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000):
 
 
 class RefEncoder:
-    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0, samplerate=16000):
+    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0, samplerate=16000, use_md_index=0):
+        # use_md_index = 1: every description starts with its range-coded index (SKP_Silk_encode_parameters.c:50-51)
         self.lib = load_ref(kind)
-        self.ctrl = default_enc_ctrl(rate, joint=joint, dtx=dtx, samplerate=samplerate)
+        self.ctrl = default_enc_ctrl(rate, use_md_index=use_md_index, joint=joint, dtx=dtx, samplerate=samplerate)
         self.packet_samples = PACKET_SAMPLES * samplerate // 16000
         self.h = self.lib.AGR_Sate_Encoder_Init(C.byref(self.ctrl))
         assert self.h
@@ -100,9 +101,10 @@ class RefEncoder:
 
 
 class RefDecoder:
-    def __init__(self, kind="fix", joint=0, samplerate=16000):
+    def __init__(self, kind="fix", joint=0, samplerate=16000, use_md_index=0):
+        # use_md_index = 1: the decoder reads the description index first (SKP_Silk_decode_parameters.c:55-57)
         self.lib = load_ref(kind)
-        self.ctrl = default_dec_ctrl(joint=joint, samplerate=samplerate)
+        self.ctrl = default_dec_ctrl(use_md_index=use_md_index, joint=joint, samplerate=samplerate)
         self.packet_samples = PACKET_SAMPLES * samplerate // 16000
         self.h = self.lib.AGR_Sate_Decoder_Init(C.byref(self.ctrl))
         assert self.h
@@ -120,6 +122,9 @@ class RefDecoder:
         self._nb[1] = nbytes1
         ret = self.lib.AGR_Sate_Decoder_Decode(self.h, self._pcm.ctypes.data, self._ns.ctypes.data,
                                                buf.ctypes.data, self._nb.ctypes.data, int(lostflag))
+        # what the call left in the caller's nBytes[0..1] (AGR_BWE_decode_frame_FIX.c:150-169) and *nSamplesOut
+        self.nbytes_after = (int(self._nb[0]), int(self._nb[1]))
+        self.nsamples_out = int(self._ns[0])
         return self._pcm[:self.packet_samples].copy(), ret
 
     def close(self):

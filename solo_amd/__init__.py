@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
     "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split", "solo_batch_set_async_join",
-    "solo_batch_wait_encode",
+    "solo_batch_wait_encode", "solo_debug_l0", "solo_debug_sum_sqr_shift",
 ]
 
 

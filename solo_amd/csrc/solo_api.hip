@@ -26,6 +26,23 @@
 // kernels
 // ---------------------------------------------------------------------------------------------------
 #include "solo_dec_kernels.h"
+#include "solo_l0_probe.h"
+
+// conformance probe of the L0 fixed-point vocabulary as compiled for gfx950 (solo_debug_l0 below): out[i] = op(a[i], b[i], c[i])
+__global__ void __launch_bounds__(64) solo_l0_probe_kernel(int op, int n, const i32* a, const i32* b, const i32* c, i32* out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i < n) out[i] = sx_l0_probe(op, a[i], b[i], c[i]);
+}
+// SKP_Silk_sum_sqr_shift in its wave-cooperative form (solo_common.h): one wavefront per row of `len` samples
+__global__ void __launch_bounds__(64) solo_sum_sqr_probe_kernel(const i16* x, int len, int stride, int odd_start, i32* energy, i32* shift) {
+    __shared__ i16 buf[1024];
+    const i16* row = x + (size_t)blockIdx.x * stride;
+    SX_PAR(i, len) buf[i] = row[i];
+    wv_sync();
+    i32 e, s;
+    sx_sum_sqr_shift_wv(&e, &s, buf, len, odd_start);
+    if (SX_LANE == 0) { energy[blockIdx.x] = e; shift[blockIdx.x] = s; }
+}
 
 // the same decoder compiled for the 32 kHz API rate (SILK wide band, 16 kHz bands): solo_api_wb.hip
 extern "C" {
@@ -185,6 +202,16 @@ int32_t solo_batch_last_encode_chunks(const solo_batch_t* b) { return b ? b->las
 int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
     if (!b) return -1;
     hipStream_t s = (hipStream_t)hip_stream;
+    if (b->pipe_ready && b->enc_seq > 0) {
+        // kernels of the most recent encode calls may still run on the internal streams (always so with async joins, and when
+        // reset is issued on another stream than the encode was): the init kernels must not overtake them
+        for (int i = 0; i < 2; i++) {
+            if (b->enc_seq <= (unsigned int)i) break;
+            const int js = (int)((b->enc_seq - 1u - (unsigned int)i) & 1u);
+            SOLO_CHECK(hipStreamWaitEvent(s, b->evJoinA[js], 0));
+            SOLO_CHECK(hipStreamWaitEvent(s, b->evJoinC[js], 0));
+        }
+    }
     if (b->have_dec) {
         const int hbj = ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode);
         SOLO_CHECK(b->wb ? solo_wb_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s) : solo_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s));
@@ -349,6 +376,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const int ngroups = (b->n_streams + G - 1) / G;
     const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
     int idx = 0;
+    hipError_t lerr = hipSuccess;
     for (int g = 0; g < ngroups; g++) {
         const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
         const size_t pk0 = (size_t)s0 * (size_t)n_packets;                               // first packet record of the group
@@ -366,21 +394,37 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             if (ngroups == 1 && cc < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
             if (idx > 0 && b->gate) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
             if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-            (void)ops->analysis(g_states, g_pcm, ns, n_packets, p0, pc, g_nin, g_cin, b->sA);
+            if ((lerr = ops->analysis(g_states, g_pcm, ns, n_packets, p0, pc, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
             if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
             SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-            b->started_target[c] += (unsigned int)((ns + 3) / 4);          // workgroups of this launch (4 streams each)
-            if (ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->sB) != 0) return -2;
+            if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->sB)) != hipSuccess) goto launch_failed;
+            b->started_target[c] += (unsigned int)ops->nsq_workgroups(ns);     // workgroups of this launch, counted once it is enqueued
             if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
             SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
             if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-            (void)ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->sC);
+            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->sC)) != hipSuccess) goto launch_failed;
             if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
             SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
         }
+    }
+    if (0) {
+launch_failed:
+        // a kernel launch was refused: whatever was enqueued so far still runs; join the internal streams back into the
+        // caller's stream so that nothing of this call is left forked, drop the chunk-wise guards, report the HIP error
+        const int jf = (int)(b->enc_seq & 1u);
+        b->enc_seq++;
+        b->evC_valid = 0;
+        b->last_chunks = 0;
+        (void)hipEventRecord(b->evJoinA[jf], b->sA);
+        (void)hipEventRecord(b->evJoinC[jf], b->sC);
+        (void)hipStreamWaitEvent(st, b->evJoinA[jf], 0);
+        (void)hipStreamWaitEvent(st, b->evJoinC[jf], 0);
+        (void)hipEventRecord(b->evFork, b->sB);
+        (void)hipStreamWaitEvent(st, b->evFork, 0);
+        return -(int32_t)lerr;
     }
     b->evC_valid = ngroups == 1 ? nchunks : 0;       // chunk-wise hand-over guards only for single-group calls
     const int js = (int)(b->enc_seq & 1u);
@@ -473,11 +517,16 @@ void* AGR_Sate_Decoder_Init(USER_Ctrl_dec* dec_Ctrl) {
 int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, const uint8_t* bits, int16_t nBytes[], int32_t lostflag) {
     solo_single* h = (solo_single*)st;
     if (!h || h->is_enc) return -1;
-    if (nBytes[0] <= 0) return -1;                                           // AGR_BWE_SDK_API.c:266
+    if (nBytes[0] <= 0) return -1;                                           // AGR_BWE_SDK_API.c:266 (state untouched, outputs unwritten)
     if (lostflag < 1 || lostflag > 4) return -1;
+    const int ns = h->b->wb ? 2 * SX_PACKET : SX_PACKET;                      // JC1_FrameSize (AGR_BWE_SDK_API.c:277)
+    const int32_t hbb = ctrl_hb_joint(h->b->dec_ctrl.joint_enable, h->b->dec_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     int32_t n0 = nBytes[0], n1 = nBytes[1];
     if (lostflag != 1) {
-        if (n0 > h->b->slot) return -11;                                      // SKP_SILK_DEC_PAYLOAD_TOO_LARGE
+        // lengths that do not describe bytes inside the caller's buffer are refused before anything is read (the reference would
+        // read out of bounds): too long -> SKP_SILK_DEC_PAYLOAD_TOO_LARGE, inconsistent -> SKP_SILK_DEC_PAYLOAD_ERROR
+        if (n0 > h->b->slot) { *nSamplesOut = (int16_t)ns; return -11; }
+        if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
         if (hipMemcpy(h->d_bits, bits, n0, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,
@@ -485,21 +534,38 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
     int32_t ret = 0;
     if (hipMemcpy(&ret, h->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     // the reference rewrites the caller's nBytes[] with the low-band lengths (AGR_BWE_decode_frame_FIX.c:150-169)
-    const int32_t hbb = ctrl_hb_joint(h->b->dec_ctrl.joint_enable, h->b->dec_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     int32_t nb0 = (lostflag == 2) ? n0 : n0 - hbb;
     int32_t nb1 = n1 ? n1 - hbb : 0;
     nBytes[0] = (int16_t)(nb0 - nb1);
     nBytes[1] = (int16_t)nb1;
-    if (ret < 0) return ret;
-    const int ns = h->b->wb ? 2 * SX_PACKET : SX_PACKET;                      // JC1_FrameSize (AGR_BWE_SDK_API.c:277)
-    if (hipMemcpy(pcm, h->d_pcm, ns * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    // like the reference, *nSamplesOut is always written (AGR_BWE_SDK_API.c:277); on a decoder error the PCM buffer is left
+    // untouched (the reference leaves whatever its aborted synthesis produced there, which is not defined by its inputs)
     *nSamplesOut = (int16_t)ns;
+    if (ret < 0) return ret;
+    if (hipMemcpy(pcm, h->d_pcm, ns * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
     return 0;
 }
 
 int32_t AGR_Sate_Decoder_Uninit(void* st) {
     if (!st) return -1;
     single_free((solo_single*)st);
+    return 0;
+}
+
+// Conformance probes (tests only; device pointers, default stream, synchronous): the L0 vocabulary of solo_fix.h evaluated by the
+// gfx950 build, element-wise; and SKP_Silk_sum_sqr_shift in its wave-cooperative form over `rows` rows of `len` <= 1024 samples.
+int32_t solo_debug_l0(int32_t op, int32_t n, const int32_t* d_a, const int32_t* d_b, const int32_t* d_c, int32_t* d_out) {
+    if (n <= 0 || !d_a || !d_b || !d_c || !d_out) return -1;
+    hipLaunchKernelGGL(solo_l0_probe_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)0, op, n, d_a, d_b, d_c, d_out);
+    SOLO_CHECK(hipGetLastError());
+    SOLO_CHECK(hipDeviceSynchronize());
+    return 0;
+}
+int32_t solo_debug_sum_sqr_shift(const int16_t* d_x, int32_t rows, int32_t len, int32_t stride, int32_t odd_start, int32_t* d_energy, int32_t* d_shift) {
+    if (rows <= 0 || len <= 0 || len > 1024 || !d_x || !d_energy || !d_shift) return -1;
+    hipLaunchKernelGGL(solo_sum_sqr_probe_kernel, dim3(rows), dim3(64), 0, (hipStream_t)0, d_x, len, stride, odd_start, d_energy, d_shift);
+    SOLO_CHECK(hipGetLastError());
+    SOLO_CHECK(hipDeviceSynchronize());
     return 0;
 }
 

@@ -38,8 +38,20 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecState* st
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
         const u8* b = bits + pk * (size_t)slot;
-        const i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
-        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);      // an empty (DTX) packet is a lost packet, like test/dec_main.c:236-252
+        i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
+        // The lengths come from the network: a record that does not describe two descriptions inside its own slot
+        // (0 <= len(MD2)+HB <= total <= slot, MD2 carrying at least its high-band bytes) is never dereferenced; the packet is
+        // concealed as lost and the stream's status reports SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11) / _PAYLOAD_ERROR (-12).
+        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+        int bad = 0;
+        if (n0 > slot) bad = -11;
+        else if (n0 > 0 && (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb))) bad = -12;
+        if (bad) { n0 = 0; n1 = 0; }
+        // DELIBERATE CONVENTION of the batched API (not reference behaviour): an EMPTY record (n0 <= 0, e.g. a DTX packet that
+        // was never sent) is concealed like a lost packet, i.e. decoded with lostflag = 1.  The reference library itself returns
+        // -1 for nBytes[0] <= 0 without touching its state (AGR_BWE_SDK_API.c:266) and its CLI then writes the previous output
+        // buffer again (test/dec_main.c:365-381); the legacy AGR_Sate_Decoder_Decode symbol of this library keeps that behaviour.
+        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);
         // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
         int lostflag;
         i32 a0, a1;
@@ -48,8 +60,11 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecState* st
         else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
         else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
         else { lostflag = 1; a0 = n0 > 0 ? n0 : 16; a1 = n0 > 0 ? n1 : 0; }
+        if (lostflag == 2 && a0 <= 0) { lostflag = 1; a0 = 16; a1 = 0; }          // nothing but the second description in the record
+        if (lostflag == 3 && a0 <= hbb) { lostflag = 1; a0 = 16; a1 = 0; }
         i16* out = pcm + pk * SX_PACKET;
         int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
+        if (ret == 0 && bad) ret = bad;
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }

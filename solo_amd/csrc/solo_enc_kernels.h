@@ -69,6 +69,7 @@ __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStrea
 
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
                                      void* hip_stream);   // solo_nsq16.hip / solo_nsq16_wb.hip
+extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
 
 // what the host-side pipeline (solo_api.hip) needs of one build: record sizes and launchers
 #ifndef SOLO_ENC_OPS_DEFINED
@@ -81,6 +82,7 @@ struct solo_enc_ops {
     int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* hip_stream);
     hipError_t (*coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc, int slot,
                          uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s);
+    int (*nsq_workgroups)(int n_streams);                                // workgroups of one quantiser launch (they count into the residency gate)
 };
 #endif
 static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s) {
@@ -101,4 +103,4 @@ static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in
 }
 static const solo_enc_ops SX_K(solo_enc_ops_table) = {
     sizeof(SxEncStream), sizeof(SxNsqIn), sizeof(SxNsqOut), sizeof(SxCodeIn), SX_PACKET,
-    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding)};
+    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_nsq_workgroups)};

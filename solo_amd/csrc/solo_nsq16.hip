@@ -51,6 +51,7 @@ extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, v
 }
 
 #endif
+extern "C" int SX_K(solo_nsq_workgroups)(int n_streams) { return (n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE; }
 // host-side launcher (called from solo_api.hip)
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
                                void* hip_stream) {

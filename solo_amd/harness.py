@@ -85,27 +85,47 @@ def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0,
 
 
 def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, samplerate=16000):
-    """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation (samplerate 32000 = `-Fs_API 32000`)"""
+    """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation (samplerate 32000 = `-Fs_API 32000`).
+
+    Empty records (total == 0: DTX packets the encoder did not send) are handled like the reference CLI does: the library call
+    returns -1 without touching the decoder (AGR_BWE_SDK_API.c:266) and the CLI writes its output buffer again unchanged
+    (test/dec_main.c:365-381), i.e. the previous packet's PCM is repeated and the decoder state does not move.  (The batched
+    device API on its own would conceal an empty record as a lost packet; see include/solo_mi355x.h.)  The file is therefore
+    decoded in runs of consecutive non-empty packets; the state carries across the calls."""
     import torch
     from . import SoloBatch
     P = len(recs)
     if P == 0:
         return np.zeros(0, np.int16)
-    bits = np.zeros((1, P, slot_bytes), np.uint8)
-    nb = np.zeros((1, P, 2), np.int16)
-    for p, (pl, n0, n1) in enumerate(recs):
-        if n0 > slot_bytes:
-            raise ValueError("packet %d: %d bytes exceed the slot" % (p, n0))
-        bits[0, p, :n0] = np.frombuffer(pl[:n0], np.uint8)
-        nb[0, p] = (n0, n1)
-    mask = recv_mask(cli_loss_pattern(P, loss_perc, [(r[1], r[2]) for r in recs]))[None, :]
+    ns = PACKET_SAMPLES * samplerate // 16000
+    mask = recv_mask(cli_loss_pattern(P, loss_perc, [(r[1], r[2]) for r in recs]))
     b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, samplerate=samplerate)
-    pcm, st = b.decode(torch.from_numpy(bits).to(b.device), torch.from_numpy(nb).to(b.device),
-                       torch.from_numpy(np.ascontiguousarray(mask)).to(b.device))
-    torch.cuda.synchronize()
-    if int(st[0]) != 0:
-        raise RuntimeError("decoder status %d" % int(st[0]))
-    return pcm.cpu().numpy().reshape(-1)
+    out = np.zeros((P, ns), np.int16)
+    p = 0
+    while p < P:
+        if recs[p][1] <= 0:
+            out[p] = out[p - 1] if p > 0 else 0
+            p += 1
+            continue
+        e = p
+        while e < P and recs[e][1] > 0:
+            e += 1
+        n = e - p
+        bits = np.zeros((1, n, slot_bytes), np.uint8)
+        nb = np.zeros((1, n, 2), np.int16)
+        for k, (pl, n0, n1) in enumerate(recs[p:e]):
+            if n0 > slot_bytes:
+                raise ValueError("packet %d: %d bytes exceed the slot" % (p + k, n0))
+            bits[0, k, :n0] = np.frombuffer(pl[:n0], np.uint8)
+            nb[0, k] = (n0, n1)
+        pcm, st = b.decode(torch.from_numpy(bits).to(b.device), torch.from_numpy(nb).to(b.device),
+                           torch.from_numpy(np.ascontiguousarray(mask[None, p:e])).to(b.device))
+        torch.cuda.synchronize()
+        if int(st[0]) != 0:
+            raise RuntimeError("decoder status %d" % int(st[0]))
+        out[p:e] = pcm.cpu().numpy()[0]
+        p = e
+    return out.reshape(-1)
 
 
 def _opt(argv, name, default):

@@ -14,6 +14,7 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
 #define SX_ENC_TAP(stage, st, w, sig) emu_tap(stage, st, w, sig)
 #endif
 #include "../../solo_amd/csrc/solo_dec.h"
+#include "../../solo_amd/csrc/solo_l0_probe.h"
 #ifndef EMU_DEC_ONLY
 #include "../../solo_amd/csrc/solo_enc.h"
 #endif
@@ -37,6 +38,11 @@ int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int l
     d->st = d->w.st;
     return r;
 }
+// L0 vocabulary, operand by operand (tests/test_l0_primitives.py)
+void emu_l0(int op, int n, const int32_t* a, const int32_t* b, const int32_t* c, int32_t* out) {
+    for (int i = 0; i < n; i++) out[i] = sx_l0_probe(op, a[i], b[i], c[i]);
+}
+void emu_sum_sqr_shift(const int16_t* x, int len, int odd_start, int32_t* energy, int32_t* shift) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
 int emu_sizeof_dec_state() { return (int)sizeof(SxDecState); }
 int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
 int emu_packet_samples() { return SX_PACKET; }

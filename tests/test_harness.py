@@ -49,3 +49,36 @@ def test_file_level_known_answers_32k():
     for loss in (0, 30):
         pcm = H.decode_records(H.parse_bit_container(bit), loss_perc=loss, samplerate=32000)
         assert pcm.size == 20 * 1280 and T.md5(pcm) == g["wb_kat_dec_loss%d_md5" % loss]
+
+
+REF_ENC = os.path.join(T.ROOT, "oracle", "_ref", "JC1Encoder_ref")
+REF_DEC = os.path.join(T.ROOT, "oracle", "_ref", "JC1Decoder_ref")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF_ENC) and os.path.exists(REF_DEC)), reason="oracle/_ref/JC1*_ref not built")
+def test_dtx_file_against_the_reference_cli(tmp_path):
+    """`-DTX 1` files: the reference CLI (test/enc_main.c / dec_main.c linked with the compiled reference) against this package's
+    harness on the GPU.  Empty packets make the reference decoder return -1 untouched and the CLI repeat its previous output
+    buffer (AGR_BWE_SDK_API.c:266, dec_main.c:365-381); the harness must produce the same file, with and without simulated loss."""
+    import subprocess
+    import torch
+    assert torch.cuda.is_available()
+    P = 60
+    rng = np.random.default_rng(12)
+    pcm = R.synth_stream(811, P).copy()
+    pcm[5:31] = (rng.standard_normal((26, 640)) * 3).astype(np.int16)
+    pcm[40:52] = (rng.standard_normal((12, 640)) * 2).astype(np.int16)
+    src, bit = str(tmp_path / "in.pcm"), str(tmp_path / "ref.bit")
+    pcm.tofile(src)
+    subprocess.run([REF_ENC, src, bit, "-Fs_API", "16000", "-rate", "13600", "-DTX", "1"], check=True, stdout=subprocess.DEVNULL, timeout=300)
+    raw = open(bit, "rb").read()
+    recs = H.encode_pcm(pcm.reshape(-1), dtx=1)
+    assert H.write_bit_container(recs) == raw
+    assert sum(1 for r in recs if r[1] == 0) >= 12 and recs[0][1] > 0
+    for loss in (0, 20):
+        out = str(tmp_path / ("ref%d.pcm" % loss))
+        subprocess.run([REF_DEC, bit, out, "-Fs_API", "16000", "-loss", str(loss)], check=True, stdout=subprocess.DEVNULL, timeout=300)
+        want = np.fromfile(out, np.int16)
+        got = H.decode_records(H.parse_bit_container(raw), loss_perc=loss)
+        assert got.size == want.size and np.array_equal(got, want), loss
