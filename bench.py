@@ -1,24 +1,35 @@
 #!/usr/bin/env python3
-"""Headline benchmark: 40 ms packets/s, encode + decode round trip (BASELINE.json configs[2]).
+"""Headline benchmark: 40 ms packets/s, encode + decode round trip.
 
   python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = every stream of the batch encodes `--packets` consecutive 40 ms packets (AGR_Sate_Encoder_Encode
-semantics: QMF split, SILK analysis, 3-track delayed-decision NSQ, range coding of both descriptions, high band)
-and decodes them again (AGR_Sate_Decoder_Decode, both descriptions received, BWE resynthesis + QMF), through the
-C ABI of solo_amd/libsolo_mi355x.so.  Inputs are resident in HBM before the timed region; codec state stays in
-HBM between steps.  Streams shard over ranks with no data-path collective ("weak" scaling: 4096 streams per GPU);
-RCCL is used only for the barrier and the max-over-ranks time.
+One "step" = every stream of the batch encodes `--packets` consecutive 40 ms packets (AGR_Sate_Encoder_Encode semantics:
+QMF split, SILK analysis, 3-track delayed-decision NSQ, range coding of both descriptions, high band) and decodes them again
+(AGR_Sate_Decoder_Decode, both descriptions received, BWE resynthesis + QMF), through the C ABI of
+solo_amd/libsolo_mi355x.so.  Inputs are resident in HBM before the timed region; codec state stays in HBM between steps.
 
-Prints ONE JSON line (rank 0).  The encoder is a three-kernel pipeline (analysis -> quantiser -> coding) that the library
-runs over chunks of the step's packets on three internal streams, so its kernels overlap in time; `roofline` is for the
-kernel with the largest summed duration per step: algorithmic HBM bytes of that kernel per launch /
-its average launch duration, measured with HIP events recorded by the library around every launch on its stream
-(solo_batch_set_timing).  `kernels` lists all four kernels the same way.  `cpu_baseline` times the compiled reference (oracle/_ref, fixed-point tree)
-on the host cores for a bounded sample of the same workload.
+  N = 1   BASELINE.json configs[2]: 4096 synthetic streams, round trip                     (the configuration `metric` is quoted on)
+  N > 1   BASELINE.json configs[4]: 8192 streams PER GPU (65 536 on 8), encode + decode per rank, streams sharded contiguously
+          over the ranks with NO data-path collective; RCCL carries the barrier and ONE all_gather of the per-rank record
+          {packets, seconds, payload_bytes, payload_md5, pcm_md5}.  The line reports per-GPU and whole-node packets/s; a rank's
+          hashes equal those of a single-GPU run of the same global streams (`--first-stream r*8192 --streams 8192`).
+
+Prints ONE JSON line (rank 0):
+  value      whole-job packets/s = packets all ranks processed / max-over-ranks time of the K timed steps
+  roofline   SURVEY 8(d): the dominant kernel's ALGORITHMIC HBM bytes per launch -- what crosses the boundary: 1280 B PCM +
+             payload + 4 B of lengths per packet, nothing else -- / its average launch duration, measured live with HIP events
+             that the library records around every launch on the launch stream (solo_batch_set_timing), against 8 TB/s.
+             The kernel-to-kernel hand-over records and the per-stream state are implementation traffic: they show up in
+             `traffic` (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, from profiles/hbm_traffic.json), not in `achieved`.
+  valu_issue the limiter that actually binds (serial fixed-point recursions): VALU wave-instructions per second of the whole
+             step (SQ_INSTS_VALU per packet from the rocprofv3 counter pass in profiles/, x measured packets/s) against the
+             chip's VALU issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)
+  cpu_baseline  the compiled reference (oracle/_ref, fixed-point tree) timed on the host cores this process may use (affinity and
+             cgroup quota respected), >= 10 s of work per worker
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -29,53 +40,98 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
+N_SIMD, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 2.0       # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
+PCM_BYTES = 1280.0             # 640 int16 samples per 40 ms packet
 
 
-def _cpu_gen(args):
-    from solo_amd.synth import synth_stream
-    return synth_stream(args[0], args[1])
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the compiled reference on the host cores (fresh interpreter, no torch / HIP)
+# ---------------------------------------------------------------------------------------------------------------------
+def effective_cores():
+    """CPUs this process can actually use: the scheduler affinity mask, capped by the cgroup CPU quota (cpu.max / cfs_quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    info = {"os_cpu_count": os.cpu_count(), "affinity": n, "cgroup_quota_cpus": None}
+    quota = None
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if q != "max":
+            quota = float(q) / float(p)
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / p
+        except Exception:
+            pass
+    if quota:
+        info["cgroup_quota_cpus"] = round(quota, 2)
+        n = max(1, min(n, int(math.floor(quota + 1e-9))))
+    info["effective"] = n
+    return n, info
 
 
-def _cpu_run(pcm):
+def _cpu_worker_main(args):
+    """One worker process: round-trips whole streams of the synthetic workload through the compiled reference encoder + decoder
+    (both descriptions received) for `passes` passes over its streams.  Returns packets, wall and CPU seconds."""
+    widx, n_streams, P, passes, t_start = args
     sys.path.insert(0, os.path.join(HERE, "oracle"))
     import refcodec as R
-    e, d = R.RefEncoder("fix"), R.RefDecoder("fix")
-    for p in range(pcm.shape[0]):
-        pl, n0, n1 = e.encode(pcm[p])
-        d.decode(*R.map_loss(pl, n0, n1, False, False))
-    e.close()
-    return pcm.shape[0]
+    from solo_amd.synth import synth_stream
+    pcm = [synth_stream(widx * n_streams + i, P) for i in range(n_streams)]
+
+    def run(x):
+        e, d = R.RefEncoder("fix"), R.RefDecoder("fix")
+        for p in range(x.shape[0]):
+            pl, n0, n1 = e.encode(x[p])
+            d.decode(*R.map_loss(pl, n0, n1, False, False))
+        e.close(); d.close()
+        return x.shape[0]
+    run(pcm[0][:8])                                           # library load, page-in
+    while time.time() < t_start:                              # common start line
+        time.sleep(0.001)
+    w0, c0 = time.perf_counter(), time.process_time()
+    done = 0
+    for _ in range(passes):
+        for x in pcm:
+            done += run(x)
+    return done, time.perf_counter() - w0, time.process_time() - c0
 
 
-def cpu_worker(n_packets_total, packets_per_stream):
-    """Runs in a fresh interpreter (no torch / HIP): one process per host CPU, each looping whole streams through the
-    compiled reference encoder + decoder (both descriptions received)."""
+def cpu_worker(target_seconds, packets_per_stream):
     import multiprocessing as mp
     sys.path.insert(0, os.path.join(HERE, "oracle"))
     import refcodec as R
     if not R.have_ref("fix"):
         print(json.dumps(None))
         return
-    cores = os.cpu_count() or 1
-    P = packets_per_stream
-    n_streams = max(cores, n_packets_total // P)
-    n_streams = (n_streams + cores - 1) // cores * cores
+    cores, info = effective_cores()
+    P, S = packets_per_stream, 2
+    # calibrate one pass on one core, then size every worker's job to ~target_seconds
+    t = _cpu_worker_main((0, 1, min(P, 100), 1, 0.0))
+    per_packet = t[1] / t[0]
+    passes = max(1, int(math.ceil(target_seconds / (per_packet * P * S))))
     with mp.get_context("fork").Pool(cores) as pool:
-        pcm = pool.map(_cpu_gen, [(i, P) for i in range(n_streams)])
-        pool.map(_cpu_run, [x[:2] for x in pcm[:cores]])      # warm every worker (library load, page-in)
-        t0 = time.perf_counter()
-        done = sum(pool.map(_cpu_run, pcm, chunksize=1))
-        dt = time.perf_counter() - t0
-    print(json.dumps({"value": round(done / dt, 1), "unit": "40ms packets/s (encode+decode)", "cores": cores, "kind": "reference",
-                      "sample": "%d streams x %d packets of the same synthetic workload through the compiled fixed-point "
-                                "reference (oracle/_ref/libsolo_ref_fix.so, gcc -O2), %d processes, %.1f s wall"
-                                % (n_streams, P, cores, dt)}))
+        t_start = time.time() + 1.5 + 0.02 * cores
+        res = pool.map(_cpu_worker_main, [(w, S, P, passes, t_start) for w in range(cores)], chunksize=1)
+    packets = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    cpu_s = [r[2] for r in res]
+    per_core = float(np.mean([r[0] / r[2] for r in res]))      # packets per CPU-second of a worker
+    print(json.dumps({
+        "value": round(packets / wall, 1), "unit": "40ms packets/s (encode+decode)", "cores": cores, "kind": "reference",
+        "per_core_packets_per_s": round(per_core, 1), "worker_cpu_seconds": [round(min(cpu_s), 2), round(float(np.mean(cpu_s)), 2), round(max(cpu_s), 2)],
+        "wall_seconds": round(wall, 2), "host": info,
+        "sample": "%d worker processes (= usable host CPUs: affinity %s, cgroup quota %s of %s hardware threads), each %d passes over %d "
+                  "streams x %d packets of the same synthetic workload through the compiled fixed-point reference "
+                  "(oracle/_ref/libsolo_ref_fix.so, gcc -O2): %d packets in %.1f s wall; worker_cpu_seconds = [min, mean, max]"
+                  % (cores, info["affinity"], info["cgroup_quota_cpus"], info["os_cpu_count"], passes, S, P, packets, wall)}))
 
 
-def cpu_baseline(n_packets_total, packets_per_stream):
+def cpu_baseline(target_seconds, packets_per_stream):
     import subprocess
-    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-packets", str(n_packets_total),
-                        "--cpu-packets-per-stream", str(packets_per_stream)], capture_output=True, text=True, timeout=600)
+    r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-worker", "--cpu-seconds", str(target_seconds),
+                        "--cpu-packets-per-stream", str(packets_per_stream)], capture_output=True, text=True, timeout=900)
     for line in reversed(r.stdout.strip().splitlines()):
         try:
             return json.loads(line)
@@ -84,23 +140,30 @@ def cpu_baseline(n_packets_total, packets_per_stream):
     return None
 
 
+def _profile_json(name):
+    try:
+        return json.load(open(os.path.join(HERE, "profiles", name)))
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--streams", type=int, default=4096, help="streams per GPU")
+    ap.add_argument("--streams", type=int, default=0, help="streams per GPU (default: 4096 = configs[2] at N = 1, 8192 = configs[4] at N > 1)")
+    ap.add_argument("--first-stream", type=int, default=-1, help="global index of this process's first stream (default: rank * streams)")
     ap.add_argument("--packets", type=int, default=50, help="40 ms packets per stream per step (SURVEY 8(d): P >= 50 = 2 s of audio)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true", help="decode of step k on a second stream beside the encode of step k+1 (+1 %)")
-    ap.add_argument("--cpu-packets", type=int, default=0, help="0: 400 packets per host CPU")
+    ap.add_argument("--no-hash", action="store_true", help="skip the payload / PCM md5 of the record (saves the device-to-host copy)")
+    ap.add_argument("--overlap", action="store_true", help="decode of step k on a second stream beside the encode of step k+1")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: seconds of work per worker process")
     ap.add_argument("--cpu-packets-per-stream", type=int, default=400)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
-    if args.cpu_packets <= 0:
-        args.cpu_packets = 400 * (os.cpu_count() or 1)
     if args.cpu_worker:
-        cpu_worker(args.cpu_packets, args.cpu_packets_per_stream)
+        cpu_worker(args.cpu_seconds, args.cpu_packets_per_stream)
         return
 
     import torch
@@ -120,10 +183,12 @@ def main():
     assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    N, P = args.streams, args.packets
+    N = args.streams if args.streams > 0 else (4096 if world == 1 else 8192)
+    P = args.packets
     from solo_amd.synth import synth_batch
-    first = sdist.stream_range(rank, N)[0]
-    pcm = torch.from_numpy(synth_batch(first, N, P, workers=min(16, os.cpu_count() or 1))).to(dev)
+    first = args.first_stream if args.first_stream >= 0 else sdist.stream_range(rank, N)[0]
+    ncpu, _ = effective_cores()
+    pcm = torch.from_numpy(synth_batch(first, N, P, workers=max(1, min(16, ncpu // max(1, min(world, 8)))))).to(dev)
     batch = solo_amd.SoloBatch(N, rate=13600, encoder=True, decoder=True, slot_bytes=512)
     bits = torch.zeros((N, P, 512), dtype=torch.uint8, device=dev)
     nb = torch.zeros((N, P, 2), dtype=torch.int16, device=dev)
@@ -138,7 +203,7 @@ def main():
     # chunk of step k + 1 starts while the last quantiser / coding chunks of step k still run) and the decode of step k is issued
     # after the encode of step k + 1; the bitstream buffers are double-buffered.  Default: encode then decode, one stream.
     overlap = args.overlap
-    bits2, nb2 = [bits, torch.zeros_like(bits)], [nb, torch.zeros_like(nb)]
+    bits2, nb2 = [bits, torch.zeros_like(bits) if overlap else bits], [nb, torch.zeros_like(nb) if overlap else nb]
     step_no = [0]
     if overlap:
         batch.set_async_join(True)
@@ -167,7 +232,14 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    # The first step after a reset is the one a single-GPU run of the same streams reproduces bit for bit: hash its outputs
+    # (outside the timed region).  Later steps continue the streams' state with the same input, so their bytes differ.
+    step()
+    drain()
+    torch.cuda.synchronize()
+    mean_payload = float(nb[:, :, 0].float().mean().item())
+    first_step = (None, None, None) if args.no_hash else (nb.cpu().numpy(), bits.cpu().numpy(), out.cpu().numpy())
+    for _ in range(max(0, args.warmup - 1)):
         step()
     drain()
     barrier()
@@ -176,7 +248,7 @@ def main():
         step(k)
     drain()                                               # (the last step's decode: every packet is encoded AND decoded in the timed region)
     barrier()
-    dt = time.perf_counter() - t0
+    dt_local = time.perf_counter() - t0
     # per-kernel durations: a few extra steps outside the timed region (reading the events synchronises the stream)
     if overlap:
         batch.set_async_join(False)
@@ -186,8 +258,7 @@ def main():
         for name, v in batch.last_kernel_ms().items():
             kms[name].append(v)
     enc_chunks = max(1, batch.last_encode_chunks())
-    if world > 1:
-        dt = sdist.max_over_ranks(dt, dist, dev)
+    dt = sdist.max_over_ranks(dt_local, dist, dev) if world > 1 else dt_local
 
     assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
     kavg = {n: float(np.mean(v)) for n, v in kms.items()}
@@ -199,56 +270,93 @@ def main():
         batch.encode(pcm, bits, nb, st_e)
     torch.cuda.synchronize()
     enc_only_ms = (time.perf_counter() - t1) / 3 * 1e3
-    mean_payload = float(nb[:, :, 0].float().mean().item())
     packets_step = N * P
     value = world * packets_step * args.steps / dt
 
+    # ONE all_gather of the per-rank record (RCCL); no other collective besides the barriers and the max time
+    record = sdist.result_record(rank, first, N, packets_step * args.steps, dt_local, *first_step)
+    record["payload_bytes"] = int(round(mean_payload * packets_step)) * args.steps
+    records = sdist.gather_records(record, dist) if world > 1 else [record]
+
     if rank == 0:
-        # algorithmic HBM bytes per packet of each kernel: stage input + stage output that has to cross HBM
-        rec_in, rec_out, rec_code = 660.0, 964.0, 848.0       # sizeof SxNsqIn / SxNsqOut / SxCodeIn
-        alg = {"analysis": 1280.0 + 2 * rec_in + rec_code, "quantiser": 2 * rec_in + 2 * rec_out,
-               "coding": 2 * rec_out + rec_code + mean_payload + 4.0, "decode": mean_payload + 4.0 + 1280.0}
+        # ALGORITHMIC bytes per packet: what crosses the boundary, with the run's mean payload
+        enc_alg = PCM_BYTES + mean_payload + 4.0
+        dec_alg = mean_payload + 4.0 + PCM_BYTES
+        # the three encoder kernels are stages of ONE pass over the boundary data of a packet (PCM in, payload + lengths out): each
+        # is priced with the encode-only boundary bytes of the packets it handles per launch; the hand-over records between them are
+        # implementation traffic
+        alg = {"analysis": enc_alg, "quantiser": enc_alg, "coding": enc_alg, "decode": dec_alg}
         kname = {"analysis": "solo_enc_analysis_kernel", "quantiser": "solo_nsq_kernel", "coding": "solo_enc_coding_kernel",
                  "decode": "solo_decode_kernel"}
+        traffic = _profile_json("hbm_traffic.json") or {}
+        insts = _profile_json("wave_instructions.json") or {}
         # the encoder kernels run as a pipeline over chunks of the step's packets: kavg = sum over the launches of a step
         nl = {n: (enc_chunks if n != "decode" else 1) for n in kavg}
-        kernels = {kname[n]: {"launches_per_step": nl[n], "avg_launch_ms": round(kavg[n] / nl[n], 3),
+
+        def tr_launch(n):
+            v = traffic.get(kname[n] + "_bytes_per_packet")
+            return None if v is None else int(v * packets_step / nl[n])
+        kernels = {kname[n]: {"launches_per_step": nl[n], "avg_launch_ms": round(kavg[n] / nl[n], 4),
+                              "packets_per_launch": packets_step // nl[n],
                               "algorithmic_bytes_per_launch": int(alg[n] * packets_step / nl[n]),
-                              "achieved_GBps": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9, 4)} for n in kavg}
+                              "achieved_GBps": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9, 4),
+                              "frac_of_hbm_peak": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9 / HBM_PEAK_GBS, 7),
+                              "traffic_bytes_per_launch": tr_launch(n)} for n in kavg}
         dom = max(kavg, key=kavg.get)
-        enc_bytes = packets_step * alg[dom] / nl[dom]
-        achieved = enc_bytes / (kavg[dom] / nl[dom] * 1e-3) / 1e9
+        alg_launch = alg[dom] * packets_step / nl[dom]
+        achieved = alg_launch / (kavg[dom] / nl[dom] * 1e-3) / 1e9
+        step_alg = (enc_alg + dec_alg) * packets_step
+        step_gbs = step_alg / (dt / args.steps) / 1e9
         res = {
             "metric": "40 ms frames/sec (encode+decode) per GPU; concurrent real-time WB streams @1/2/4/8 MI355X",
             "value": round(value, 1), "unit": "40ms packets/s (encode+decode)", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "int32 fixed point (int16 PCM, Q-format arithmetic, bit-exact)", "data": "synthetic",
-            "config": {"workload": "BASELINE configs[2]: %d synthetic 16 kHz WB streams per GPU, full encode -> two-description "
-                                   "bitstream -> decode round trip with BWE resynthesis, 13.6 kbps, %d packets/stream/step" % (N, P),
+            "config": {"workload": ("BASELINE configs[2]: %d synthetic 16 kHz WB streams, full encode -> two-description bitstream -> decode "
+                                    "round trip with BWE resynthesis, 13.6 kbps, %d packets/stream/step" % (N, P)) if world == 1 else
+                                   ("BASELINE configs[4]: %d synthetic 16 kHz WB streams sharded evenly across %d x MI355X (%d per GPU), encode + "
+                                    "decode per rank, RCCL gather only, 13.6 kbps, %d packets/stream/step" % (N * world, world, N, P)),
                        "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2),
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
                                     "(solo_batch_set_async_join, double-buffered bitstreams)" if args.overlap
                                     else "encode then decode on one stream")},
             "realtime_streams": round(value / 25.0, 1),
+            "per_gpu_packets_per_s": [r["packets_per_s"] for r in records],
+            "whole_node_packets_per_s": round(value, 1),
+            "ranks": records,
             "encode_only_packets_per_s": round(packets_step / (enc_only_ms * 1e-3), 1),
             "decode_only_packets_per_s": round(packets_step / (dec_ms * 1e-3), 1),
             "roofline": {"kernel": kname[dom], "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": None,
-                         "avg_launch_ms": round(kavg[dom] / nl[dom], 3), "launches_per_step": nl[dom],
-                         "algorithmic_bytes_per_launch": int(enc_bytes),
-                         "note": "serial fixed-point recursions: latency / issue bound, not HBM bound (DESIGN.md section 4)"},
+                         "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": tr_launch(dom),
+                         "avg_launch_ms": round(kavg[dom] / nl[dom], 4), "launches_per_step": nl[dom],
+                         "packets_per_launch": packets_step // nl[dom],
+                         "algorithmic_bytes_per_packet": round(alg[dom], 2),
+                         "algorithmic_bytes_per_launch": int(alg_launch),
+                         "formula": "achieved = packets_per_launch x (1280 + mean_payload + 4) B / avg_launch_ms; frac = achieved / 8 TB/s "
+                                    "(SURVEY 8(d); hand-over records and stream state count as traffic, not as algorithmic bytes)",
+                         "whole_step": {"algorithmic_bytes_per_packet": round(enc_alg + dec_alg, 2), "achieved": round(step_gbs, 4),
+                                        "frac": round(step_gbs / HBM_PEAK_GBS, 7)},
+                         "note": "serial fixed-point recursions: instruction-issue / latency bound, not HBM bound -- see valu_issue"},
             "kernels": kernels,
         }
-        tr = os.path.join(HERE, "profiles", "hbm_traffic.json")   # PMC-derived bytes per launch, collected separately
-        if os.path.exists(tr):
-            try:
-                res["roofline"]["traffic"] = int(json.load(open(tr)).get(kname[dom] + "_bytes_per_packet") * packets_step / nl[dom])   # per launch
-            except Exception:
-                pass
+        peak_issue = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU
+        if insts.get("valu_per_packet_round_trip"):
+            v = insts["valu_per_packet_round_trip"] * (value / world)
+            res["valu_issue"] = {"bound": "valu_issue", "achieved": round(v / 1e9, 2), "peak": round(peak_issue / 1e9, 1),
+                                 "unit": "G wave-instructions/s (VALU)", "frac": round(v / peak_issue, 4),
+                                 "valu_wave_instructions_per_packet": insts.get("valu_per_packet"),
+                                 "all_wave_instructions_per_packet": insts.get("all_per_packet"),
+                                 "source": insts.get("source"),
+                                 "note": "SQ_INSTS_VALU per packet of each kernel (rocprofv3 --pmc pass) x packets/s of this run, per GPU; "
+                                         "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction"}
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.cpu_packets, args.cpu_packets_per_stream)
+            cb = cpu_baseline(args.cpu_seconds, args.cpu_packets_per_stream)
+            if cb and cb.get("per_core_packets_per_s"):
+                cb["gpu_equals_reference_cores"] = round(value / cb["per_core_packets_per_s"], 1)
+            res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -97,6 +97,18 @@ struct SxDecState {
     i32 dbg[8];                  // first-failure trace: {stage, rc error, bufferIx, bufferLength, range, base, frame, desc}
 };
 
+// Shadow of the reference's two internal range-decoder buffers (SKP_Silk_range_coder_state.buffer of sMD[0] / sMD[1],
+// SKP_Silk_structs.h:85-92; sMD[0] takes whichever description is decoded first, SKP_Silk_decode_frame.c:93-99): only the four
+// bytes behind the current description are ever read back (solo_rc.h: sx_rc_byte).  Lives in HBM next to the state record and is
+// never staged in LDS: per packet the received description bytes are written once and eight bytes are read.
+struct SxDecShadow {
+    u8 b[2][SX_MAX_ARITHM_BYTES + 8];
+};
+struct SxDecStream {             // one record per stream in HBM
+    SxDecState st;
+    SxDecShadow sh;
+};
+
 // ---- per-packet working set (LDS) ----------------------------------------------------------------
 struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h:362
     i32 pitchL[SX_NB_SUBFR];
@@ -112,6 +124,7 @@ struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h
 // Phases of a packet reuse the same LDS (the decoder's occupancy is LDS-bound): see the lifetimes in the comments
 struct SxDecWork {
     SxDecState st;                  // the stream's state: HBM record -> LDS at launch start, back at the end
+    SxDecShadow* shadow;            // the stream's range-decoder buffer shadow (HBM)
     SxCdfDec cdf;                   // entropy-coding tables (loaded once per launch)
     u8 payload[SX_DEC_PAYLOAD_LDS + 4];
     SxDecCtrl ctrl;
@@ -1035,6 +1048,24 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     SxRangeDec rc[2];
     rc[0].error = 0; rc[1].error = 0;
     rc[0].bufferLength = 0; rc[1].bufferLength = 0;
+    rc[0].tail = 0; rc[1].tail = 0;
+    if (lostflag != 1) {
+        // what the reference's range_dec_init leaves behind (see SxDecShadow): the four stale bytes behind each description are
+        // fetched first, then the description bytes overwrite the head of "its" buffer
+        SxDecShadow* sh = w->shadow;
+        const i32 len[2] = {nB0, lostflag == 4 ? nB1 : -1};
+        const i32 off[2] = {0, nB0};
+        for (int d = 0; d < 2; d++) {
+            if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) {
+                const u8* t = &sh->b[d][len[d]];
+                rc[d].tail = (u32)t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+            }
+        }
+        wv_sync();
+        for (int d = 0; d < 2; d++) {
+            if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) { SX_PAR(i, len[d]) sh->b[d][i] = bits[off[d] + i]; }
+        }
+    }
     // the payload is read byte by byte by a serial coder: stage it in LDS
     if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS) {
         SX_PAR(i, nBytes0) w->payload[i] = bits[i];

@@ -4,29 +4,32 @@
 #include <hip/hip_runtime.h>
 #include "solo_dec.h"
 
-__global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecState* states, int n_streams, int hb_joint) {
+__global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecStream* states, int n_streams, int hb_joint) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    sx_dec_state_init(&states[s], hb_joint);
+    sx_dec_state_init(&states[s].st, hb_joint);
+    u32* sh = (u32*)&states[s].sh;
+    SX_PAR(i, (int)(sizeof(SxDecShadow) / 4)) sh[i] = 0;
 }
 
 // Decoder: rows D0-D8.  blockIdx.x = stream.
 // state record HBM <-> LDS (whole launch) and the entropy tables
-__device__ __forceinline__ void SX_K(solo_dec_enter)(SxDecWork* w, const SxDecState* rec) {
-    const i32* src = (const i32*)rec;
+__device__ __forceinline__ void SX_K(solo_dec_enter)(SxDecWork* w, SxDecStream* rec) {
+    const i32* src = (const i32*)&rec->st;
     i32* dst = (i32*)&w->st;
     SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
+    w->shadow = &rec->sh;
     sx_cdf_load_dec(&w->cdf);
     wv_sync();
 }
-__device__ __forceinline__ void SX_K(solo_dec_leave)(SxDecWork* w, SxDecState* rec) {
+__device__ __forceinline__ void SX_K(solo_dec_leave)(SxDecWork* w, SxDecStream* rec) {
     wv_sync();
     const i32* src = (const i32*)&w->st;
-    i32* dst = (i32*)rec;
+    i32* dst = (i32*)&rec->st;
     SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
 }
 
-__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecState* states, const u8* __restrict__ bits,
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* states, const u8* __restrict__ bits,
                                                          const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                          int n_streams, int n_packets, int slot, int useMDIndex,
                                                          i16* __restrict__ pcm, i32* status) {
@@ -79,7 +82,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecState* st
 // (two copies of the same description count once); with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.  The kernel then
 // builds the (ptr, nBytes, lostflag) triple of test/dec_main.c:255-378 and decodes.  Packets above the LDS staging size
 // (252 B; 13.6 kbps packets are ~80 B) are rejected with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11).
-__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecState* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecStream* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
                                                                const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
                                                                int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
     __shared__ SxDecWork w;
@@ -98,8 +101,8 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecSta
         i32 l1 = la, l2 = lb;
         if (useMDIndex == 1) {
             int ia = -1, ib = -1;
-            if (la > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
-            if (lb > 0) { SxRangeDec r; r.error = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
+            if (la > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
+            if (lb > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
             p1 = pa; l1 = 0; p2 = pb; l2 = 0;
             if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
             if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
@@ -131,7 +134,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecSta
 }
 
 // single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
-__global__ void __launch_bounds__(64) SX_K(solo_decode_raw_kernel)(SxDecState* st, const u8* bits, int n0, int n1, int lostflag,
+__global__ void __launch_bounds__(64) SX_K(solo_decode_raw_kernel)(SxDecStream* st, const u8* bits, int n0, int n1, int lostflag,
                                                              int useMDIndex, i16* pcm, i32* status) {
     __shared__ SxDecWork w;
     SX_K(solo_dec_enter)(&w, st);
@@ -142,25 +145,25 @@ __global__ void __launch_bounds__(64) SX_K(solo_decode_raw_kernel)(SxDecState* s
 
 // launchers (host): same signature for both rates
 static inline hipError_t SX_K(solo_dec_launch_init)(void* states, int n_streams, int hb_joint, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_dec_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, n_streams, hb_joint);
+    hipLaunchKernelGGL(SX_K(solo_dec_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, n_streams, hb_joint);
     return hipGetLastError();
 }
 static inline hipError_t SX_K(solo_dec_launch)(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
                                                int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_decode_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, bits, nbytes, recv, n_streams,
+    hipLaunchKernelGGL(SX_K(solo_decode_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, bits, nbytes, recv, n_streams,
                        n_packets, slot, useMDIndex, pcm, status);
     return hipGetLastError();
 }
 static inline hipError_t SX_K(solo_dec_launch_split)(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB,
                                                      const int16_t* lenB, int n_streams, int n_packets, int slot, int useMDIndex,
                                                      int16_t* pcm, int32_t* status, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_decode_split_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecState*)states, descA, lenA, descB, lenB,
+    hipLaunchKernelGGL(SX_K(solo_decode_split_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, descA, lenA, descB, lenB,
                        n_streams, n_packets, slot, useMDIndex, pcm, status);
     return hipGetLastError();
 }
 static inline hipError_t SX_K(solo_dec_launch_raw)(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm,
                                                    int32_t* status, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_decode_raw_kernel), dim3(1), dim3(64), 0, s, (SxDecState*)state, bits, n0, n1, lostflag, useMDIndex, pcm, status);
+    hipLaunchKernelGGL(SX_K(solo_decode_raw_kernel), dim3(1), dim3(64), 0, s, (SxDecStream*)state, bits, n0, n1, lostflag, useMDIndex, pcm, status);
     return hipGetLastError();
 }
-static inline size_t SX_K(solo_dec_state_bytes)() { return sizeof(SxDecState); }
+static inline size_t SX_K(solo_dec_state_bytes)() { return sizeof(SxDecStream); }

@@ -25,16 +25,21 @@ struct SxRangeDec {
     u32 base_Q32;
     u32 range_Q16;
     i32 error;
+    u32 tail;           // the four bytes that FOLLOW this description in the reference decoder's internal buffer (see sx_rc_byte)
 #ifdef SX_RC_LOG
     i32* log; i32 nlog;
 #endif
 };
 
-// Bytes past the end of a description read as 0.  (The reference reads whatever its internal buffer
-// held there from earlier packets -- SKP_Silk_range_coder.c:129,205-216 -- which cannot change any
-// decoded symbol of a valid stream: the encoder's wrap-up makes the stream uniquely decodable for
-// every continuation.)
-SX_HD u32 sx_rc_byte(const SxRangeDec* rc, i32 pos) { return pos < rc->bufferLength ? (u32)rc->buf[pos] : 0u; }
+// The reference copies a description into its per-description buffer (range_dec_init: memcpy of bufferLength bytes) and its
+// decoder then reads buffer[4 + ix] for ix < bufferLength (SKP_Silk_range_coder.c:129,205-216): up to FOUR bytes past the end
+// of the description, which are whatever EARLIER packets left at those positions of that buffer.  A valid stream decodes the
+// same for every continuation (the encoder's wrap-up guarantees it), a corrupted one need not -- so the decoder keeps a shadow
+// of the reference's two buffers per stream (SxDecShadow, HBM) and hands the four bytes behind the current description over in
+// `tail` (byte k = the byte at position bufferLength + k).  Probes that only read a first symbol leave tail = 0.
+SX_HD u32 sx_rc_byte(const SxRangeDec* rc, i32 pos) {
+    return pos < rc->bufferLength ? (u32)rc->buf[pos] : ((rc->tail >> (8 * ((pos - rc->bufferLength) & 3))) & 0xFFu);
+}
 
 // SKP_Silk_range_dec_init, SKP_Silk_range_coder.c:262
 SX_HD void sx_rc_dec_init(SxRangeDec* rc, const u8* buf, i32 len) {

@@ -36,3 +36,23 @@ def gather_records(record, dist):
     out = [None] * dist.get_world_size()
     dist.all_gather_object(out, record)
     return out
+
+
+def result_record(rank, first_stream, n_streams, packets, seconds, nbytes, bits, pcm):
+    """The per-rank record of SURVEY 8(e) / BASELINE.md section 4 row 5: {packets, seconds, payload_bytes, hashes}.
+    nbytes int16 [N,P,2], bits uint8 [N,P,slot] (bytes past a payload must be zero), pcm int16 [N,P,640] -- numpy arrays of ONE
+    step from freshly reset streams, or None to skip the hashes.  The hashes depend only on the streams' global indices, so a rank
+    of an N-GPU run and a single-GPU run over the same `first_stream .. first_stream + n_streams` must agree."""
+    import hashlib
+    rec = {"rank": int(rank), "first_stream": int(first_stream), "streams": int(n_streams), "packets": int(packets),
+           "seconds": round(float(seconds), 6), "packets_per_s": round(packets / seconds, 1) if seconds > 0 else None,
+           "payload_bytes": None, "payload_md5": None, "pcm_md5": None}
+    if nbytes is not None:
+        rec["payload_bytes_per_step"] = int(nbytes[:, :, 0].astype("int64").sum())
+        h = hashlib.md5()
+        h.update(nbytes.tobytes())
+        h.update(bits.tobytes())
+        rec["payload_md5"] = h.hexdigest()
+    if pcm is not None:
+        rec["pcm_md5"] = hashlib.md5(pcm.tobytes()).hexdigest()
+    return rec

@@ -21,7 +21,7 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
 
 extern "C" {
 
-struct EmuDec { SxDecState st; SxDecWork w; int useMDIndex; };
+struct EmuDec { SxDecState st; SxDecWork w; SxDecShadow sh; int useMDIndex; };
 
 void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argument: joint_mode 1 (40 ms high-band frame)
     EmuDec* d = (EmuDec*)calloc(1, sizeof(EmuDec));
@@ -33,6 +33,7 @@ void emu_dec_destroy(void* h) { free(h); }
 int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int lostflag, int16_t* pcm) {
     EmuDec* d = (EmuDec*)h;
     d->w.st = d->st;                                      // the kernel keeps state + tables in LDS for a launch
+    d->w.shadow = &d->sh;
     sx_cdf_load_dec(&d->w.cdf);
     int r = sx_decode_packet(&d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm);
     d->st = d->w.st;

@@ -131,3 +131,58 @@ def test_8192_streams_decode_only_with_30pct_loss(torch_cuda):
         ref = _pool_map(_ref_decode_stream, jobs)
         for i, d in zip(idx, ref):
             assert np.array_equal(ho[i], d), "stream %d" % i
+
+
+def test_8192_streams_x_50_packets_encode_and_decode_config5_share(torch_cuda):
+    """configs[4]: the per-GPU share of the 8-GPU configuration -- 8192 streams x 50 packets (2 s of audio per stream: voiced /
+    unvoiced / pauses, long-run state), encode + decode on one GPU.  A sample of the streams goes through the compiled reference
+    (bitstreams, clean decode, and a second decode pass with 10 % packet loss so that concealment and comfort noise run long);
+    every stream equals its duplicates; the per-rank record of bench.py (solo_amd.dist.result_record) is repeatable."""
+    import solo_amd
+    from solo_amd import dist as sdist
+    torch = torch_cuda
+    N, P = 8192, 50
+    pcm = _batch_pcm(N, P)
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
+    x = torch.from_numpy(pcm).to(b.device)
+    bits, nb, st = b.encode(x)
+    out, st2 = b.decode(bits, nb, None)
+    torch.cuda.synchronize()
+    assert int(st.abs().max()) == 0 and int(st2.abs().max()) == 0
+    hb, hn, ho = bits.cpu().numpy(), nb.cpu().numpy(), out.cpu().numpy()
+    rec = sdist.result_record(0, 7000, N, N * P, 1.0, hn, hb, ho)
+    for r in range(1, N // DISTINCT):
+        sl = slice(r * DISTINCT, (r + 1) * DISTINCT)
+        assert np.array_equal(hn[sl], hn[:DISTINCT]) and np.array_equal(hb[sl], hb[:DISTINCT]) and np.array_equal(ho[sl], ho[:DISTINCT])
+    # lossy second pass (10 % of the packets lost entirely, 10 % reduced to one description)
+    rng = np.random.default_rng(77)
+    recv = np.full((DISTINCT, P), 3, np.uint8)
+    u = rng.random((DISTINCT, P))
+    recv[u < 0.10] = 0
+    recv[(u >= 0.10) & (u < 0.15)] = 1
+    recv[(u >= 0.15) & (u < 0.20)] = 2
+    recv[:, 0] = 3
+    recv_all = np.ascontiguousarray(np.tile(recv, (N // DISTINCT, 1)))
+    b.reset()
+    bits_b, nb_b, _ = b.encode(x)                                  # second run of the same handle after a reset: same record
+    out_l, st3 = b.decode(bits_b, nb_b, torch.from_numpy(recv_all).to(b.device))
+    torch.cuda.synchronize()
+    assert int(st3.abs().max()) == 0
+    hol = out_l.cpu().numpy()
+    rec2 = sdist.result_record(0, 7000, N, N * P, 1.0, nb_b.cpu().numpy(), bits_b.cpu().numpy(), None)
+    assert rec2["payload_md5"] == rec["payload_md5"] and rec["payload_bytes_per_step"] == int(hn[:, :, 0].astype(np.int64).sum())
+    for r in range(1, N // DISTINCT):
+        assert np.array_equal(hol[r * DISTINCT:(r + 1) * DISTINCT], hol[:DISTINCT])
+    if R.have_ref("fix"):
+        idx = list(range(0, DISTINCT, 8))                           # 64 streams x 50 packets through the compiled reference
+        ref = _pool_map(_ref_encode_stream, [(7000 + i, P) for i in idx])
+        for i, recs in zip(idx, ref):
+            for p, (pl, r0, r1) in enumerate(recs):
+                assert hn[i, p, 0] == r0 and hn[i, p, 1] == r1, (i, p)
+                assert hb[i, p, :r0].tobytes() == pl, (i, p)
+        dec = _pool_map(_ref_decode_stream, [(recs, [3] * P) for recs in ref])
+        for i, d in zip(idx, dec):
+            assert np.array_equal(ho[i], d), i
+        dec = _pool_map(_ref_decode_stream, [(recs, [int(m) for m in recv[i]]) for i, recs in zip(idx, ref)])
+        for i, d in zip(idx, dec):
+            assert np.array_equal(hol[i], d), i

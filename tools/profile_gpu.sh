@@ -1,6 +1,6 @@
 #!/bin/bash
 # rocprofv3 passes over the default bench command; run on the GPU box through gpurun:
-#   gpurun --timeout 900 -- 'bash tools/profile_gpu.sh [trace fetch write sq inst]'
+#   gpurun --timeout 900 -- 'bash tools/profile_gpu.sh [trace fetch write sq inst lane]'
 # then, back in the container:   python tools/summarize_profile.py gpurun_out/prof profiles/r01_bench_v2
 # The counter passes are separate from the trace pass and from each other (the TCC block cannot hold FETCH_SIZE and
 # WRITE_SIZE at once; the SQ block holds 8 counters).  Every pass runs under its own timeout: a rejected counter set makes
@@ -11,7 +11,7 @@ OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
-PASSES=${*:-trace fetch write sq inst}
+PASSES=${*:-trace fetch write sq inst lane}
 cd /tmp
 for p in $PASSES; do
   rm -rf "$OUT/$p"
@@ -21,6 +21,7 @@ for p in $PASSES; do
     write) ARGS="--pmc WRITE_SIZE" ;;
     sq)    ARGS="--pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" ;;
     inst)  ARGS="--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" ;;
+    lane)  ARGS="--pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES" ;;
     *) echo "unknown pass $p"; continue ;;
   esac
   timeout -k 5 150 rocprofv3 $ARGS -d "$OUT/$p" -o r01 --output-format csv -- $CMD > "$OUT/bench_$p.log" 2>&1

@@ -23,7 +23,7 @@ for r in csv.DictReader(open(st)):
                                                         "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                                                         "percent": float(r["Percentage"])}
     lines.append(",".join([name[:60], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
-for d in ("fetch", "write", "sq", "inst"):
+for d in ("fetch", "write", "sq", "inst", "lane"):
     f = os.path.join(src, d, "r01_counter_collection.csv")
     if not os.path.exists(f):
         continue
@@ -59,6 +59,10 @@ for k, e in out["kernels"].items():
         e["hbm_bytes_per_packet_corrected"] = e["hbm_bytes_per_launch_corrected"] / packets
     if "SQ_INSTS_VALU" in p:
         e["wave_instructions_per_packet"] = {c[9:]: p[c] / packets for c in p if c.startswith("SQ_INSTS_")}
+    if "SQ_THREAD_CYCLES_VALU" in p and p.get("SQ_ACTIVE_INST_VALU"):
+        # lanes that are switched on while a VALU instruction executes / 64: SQ_THREAD_CYCLES_VALU counts active lanes x cycles,
+        # SQ_ACTIVE_INST_VALU the cycles (quad-cycle units, the same for both)
+        e["valu_lane_utilisation"] = p["SQ_THREAD_CYCLES_VALU"] / (64.0 * p["SQ_ACTIVE_INST_VALU"])
     if "SQ_WAVE_CYCLES" in p:
         wc = p["SQ_WAVE_CYCLES"]
         e["wave_cycle_split"] = {"active_inst_any": p.get("SQ_ACTIVE_INST_ANY", 0) / wc, "wait_any(memory/barrier)": p.get("SQ_WAIT_ANY", 0) / wc,
@@ -72,4 +76,15 @@ for k, e in out["kernels"].items():
     if "hbm_bytes_per_packet_corrected" in e:
         tr[k + "_bytes_per_packet"] = e["hbm_bytes_per_packet_corrected"]
 json.dump(tr, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
+# VALU / all wave-instructions per packet (bench.py's valu_issue block reads this)
+wi = {"source": os.path.basename(dst) + "_summary.json (rocprofv3 --pmc SQ_INSTS_* pass)", "valu_per_packet": {}, "all_per_packet": {}}
+for k, e in out["kernels"].items():
+    w = e.get("wave_instructions_per_packet")
+    if w and "gate" not in k:
+        wi["valu_per_packet"][k] = round(w.get("VALU", 0.0), 1)
+        wi["all_per_packet"][k] = round(sum(w.get(c, 0.0) for c in ("VALU", "SALU", "LDS", "SMEM", "VMEM_RD", "VMEM_WR")), 1)
+if wi["valu_per_packet"]:
+    wi["valu_per_packet_round_trip"] = round(sum(wi["valu_per_packet"].values()), 1)
+    wi["all_per_packet_round_trip"] = round(sum(wi["all_per_packet"].values()), 1)
+    json.dump(wi, open(os.path.join(os.path.dirname(dst) or ".", "wave_instructions.json"), "w"), indent=1)
 print(json.dumps(out, indent=1)[:6000])
