@@ -40,6 +40,10 @@ struct SxDecDesc {               // SKP_Silk_md_decoder_state, SKP_Silk_structs.
     i32 prevNLSF_Q15[SX_LPC];
     i32 typeOffsetPrev;
     i32 prevDeltaGainIndex;
+    // the reference's range decoder of this description lives in its state (sMD[k].sRC, SKP_Silk_structs.h:296) and survives the
+    // packet: see sx_decode_packet
+    i32 rc_bufferLength, rc_bufferIx, rc_error;
+    u32 rc_base_Q32, rc_range_Q16, rc_tail;
 };
 struct SxPLC {                   // SKP_Silk_PLC_struct, SKP_Silk_structs.h:268
     i32 pitchL_Q8;
@@ -802,10 +806,30 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
     } else {
         const int desp_type = action - 2;
         const int ndesc = desp_type > 1 ? 2 : 1;
+        u32 tails[2] = {0u, 0u};
+        if (st->nFramesDecoded == 0) {
+            // what the reference's range_dec_init leaves behind (see SxDecShadow): the four stale bytes behind each description
+            // are fetched first, then the description bytes overwrite the head of "its" buffer
+            SxDecShadow* sh = w->shadow;
+            const i32 len[2] = {nB0, ndesc > 1 ? nB1 : -1};
+            const i32 off[2] = {0, nB0};
+            for (int d = 0; d < 2; d++) {
+                if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) {
+                    const u8* t = &sh->b[d][len[d]];
+                    tails[d] = (u32)t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+                }
+            }
+            wv_sync();
+            for (int d = 0; d < 2; d++) {
+                if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) { SX_PAR(i, len[d]) sh->b[d][i] = payload[off[d] + i]; }
+            }
+            wv_sync();
+        }
         // the two descriptions are independent range-coded streams: description md is parsed by lane md
         SX_PAR(md, ndesc) {
             SxRangeDec* r = &rc[SX_NLANES == 1 ? md : 0];
             if (st->nFramesDecoded == 0) {
+                r->tail = tails[md];
                 if (md == 0) sx_rc_dec_init(r, payload, nB0);
                 else sx_rc_dec_init(r, payload + nB0, nB1);
             }
@@ -1045,33 +1069,32 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     i32 nB1 = nBytes1 ? nBytes1 - hb_bytes : 0;
     const i32 hb_pos = nB0;
     nB0 -= nB1;
+    // The reference's two range decoders are part of its state and are only re-initialised when a call starts a new packet
+    // (nFramesDecoded == 0).  A payload whose frame-termination symbol announces more than two frames -- only a corrupted one does --
+    // makes the NEXT call go on decoding the OLD buffer (SKP_Silk_dec_API.c:125-150, SKP_Silk_decode_frame.c:93-99): the coder
+    // registers are therefore kept in the state record, and the old buffer is the shadow (SxDecShadow).
     SxRangeDec rc[2];
-    rc[0].error = 0; rc[1].error = 0;
-    rc[0].bufferLength = 0; rc[1].bufferLength = 0;
-    rc[0].tail = 0; rc[1].tail = 0;
-    if (lostflag != 1) {
-        // what the reference's range_dec_init leaves behind (see SxDecShadow): the four stale bytes behind each description are
-        // fetched first, then the description bytes overwrite the head of "its" buffer
-        SxDecShadow* sh = w->shadow;
-        const i32 len[2] = {nB0, lostflag == 4 ? nB1 : -1};
-        const i32 off[2] = {0, nB0};
-        for (int d = 0; d < 2; d++) {
-            if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) {
-                const u8* t = &sh->b[d][len[d]];
-                rc[d].tail = (u32)t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
-            }
-        }
-        wv_sync();
-        for (int d = 0; d < 2; d++) {
-            if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) { SX_PAR(i, len[d]) sh->b[d][i] = bits[off[d] + i]; }
-        }
+#if SX_NLANES == 1
+    for (int d = 0; d < 2; d++) {
+        const SxDecDesc* m = &st->md[d];
+#else
+    {
+        const int d = 0;
+        const SxDecDesc* m = &st->md[SX_LANE == 1 ? 1 : 0];              // description md is parsed by lane md
+#endif
+        rc[d].bufferLength = m->rc_bufferLength; rc[d].bufferIx = m->rc_bufferIx; rc[d].error = m->rc_error;
+        rc[d].base_Q32 = m->rc_base_Q32; rc[d].range_Q16 = m->rc_range_Q16; rc[d].tail = m->rc_tail;
     }
     // the payload is read byte by byte by a serial coder: stage it in LDS
     if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS) {
         SX_PAR(i, nBytes0) w->payload[i] = bits[i];
         bits = w->payload;
     }
-    rc[0].buf = bits; rc[1].buf = bits;
+#if SX_NLANES == 1
+    rc[0].buf = w->shadow->b[0]; rc[1].buf = w->shadow->b[1];               // (replaced by the payload when the coder is initialised)
+#else
+    rc[0].buf = w->shadow->b[SX_LANE == 1 ? 1 : 0];
+#endif
 #ifdef SX_RC_LOG
     rc[0].log = st->rclog; rc[0].nlog = 0; rc[1].log = 0; rc[1].nlog = 0;
 #endif
@@ -1079,6 +1102,19 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     wv_sync();
     for (int f = 0; f < 2; f++) {
         int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME]);
+        wv_sync();
+#if SX_NLANES == 1
+        for (int d = 0; d < 2; d++) {
+            SxDecDesc* m = &st->md[d];
+#else
+        if (SX_LANE < 2) {
+            const int d = 0;
+            SxDecDesc* m = &st->md[SX_LANE];
+#endif
+            m->rc_bufferLength = rc[d].bufferLength; m->rc_bufferIx = rc[d].bufferIx; m->rc_error = rc[d].error;
+            m->rc_base_Q32 = rc[d].base_Q32; m->rc_range_Q16 = rc[d].range_Q16; m->rc_tail = rc[d].tail;
+        }
+        wv_sync();
         if (ret < 0) { st->last_error = ret; return ret; }
         if (f == 0) { SX_PAR(i, SX_FRAME) w->exc0_Q10[i] = st->exc_Q10[i]; }
         wv_sync();

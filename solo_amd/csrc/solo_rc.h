@@ -59,11 +59,30 @@ SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
     i32 bufferIx = rc->bufferIx;
     if (rc->error) return 0;
 
-    // CDF search from the start index.  probIx always names the entry holding low_Q16.  (Written
-    // without the reference's ++/-- overshoot and with loop vectorisation disabled: hipcc 7.2 at
-    // -O2/-O3 mis-compiled the overshooting form of this early-exit search on gfx950 -- the symbol
-    // came out one too high after long upward scans -- found by GPU-vs-host symbol traces.)
+    // CDF search from the start index.  probIx always names the entry holding low_Q16.  Written without the reference's ++/--
+    // overshoot.  (Round 1 blamed hipcc for a symbol that "came out one too high" with the overshooting form; round 2 could not
+    // reproduce that with either form -- stand-alone in tools/debug/rc_loop_repro.hip, or in this decoder built with
+    // -DSX_RC_REFERENCE_LOOP, at -O2 / -O3, inlined or not: tests/test_alt_build.py keeps that build under test.  What was real:
+    // the coder's registers were not kept across packets, so a corrupted payload announcing a third frame decoded from
+    // uninitialised registers; see sx_decode_packet.)
     high_Q16 = prob[probIx];
+#ifdef SX_RC_REFERENCE_LOOP
+    if (range_Q16 * high_Q16 > base_Q32) {                    // the reference's form, SKP_Silk_range_coder.c:136-170
+        while (1) {
+            low_Q16 = prob[--probIx];
+            if (range_Q16 * low_Q16 <= base_Q32) break;
+            high_Q16 = low_Q16;
+            if (high_Q16 == 0) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        }
+    } else {
+        while (1) {
+            low_Q16 = high_Q16;
+            high_Q16 = prob[++probIx];
+            if (range_Q16 * high_Q16 > base_Q32) { probIx--; break; }
+            if (high_Q16 == 0xFFFF) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        }
+    }
+#else
     if (range_Q16 * high_Q16 > base_Q32) {
         SX_PLAIN_LOOP
         for (;;) {
@@ -83,6 +102,7 @@ SX_HD i32 sx_rc_dec(SxRangeDec* rc, const u16* prob, i32 probIx) {
             if (high_Q16 == 0xFFFF) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
         }
     }
+#endif
     base_Q32 -= range_Q16 * low_Q16;
     range_Q32 = range_Q16 * (high_Q16 - low_Q16);
 

@@ -1,0 +1,29 @@
+"""The kernel source under the ALTERNATE compilation mode: every stage function inlined (-DSX_INLINE_ALL) and the range decoder's
+symbol search in the reference's own ++/-- form (-DSX_RC_REFERENCE_LOOP), built by __graft_entry__.build() into
+build/libsolo_mi355x_alt.so.  Round 1 reported that full inlining "broke decoder parity" and that hipcc mis-compiled the reference
+form of the search loop; the cause turned out to be the range decoder's registers not being kept across packets (a corrupted payload
+that announces a third frame then decoded from uninitialised registers -- garbage that depended on how the code was laid out).  With
+that fixed both compilation modes must give identical, reference-exact results: this test runs the decoder / encoder / corrupted-payload
+parity tests through the alternate library in a child process (the library is chosen at import time by SOLO_LIB_OVERRIDE)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+import solo_testlib as T
+
+ALT = os.path.join(T.ROOT, "build", "libsolo_mi355x_alt.so")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(ALT), reason="build/libsolo_mi355x_alt.so not built (python -c 'import __graft_entry__ as g; g.build()')")
+def test_parity_suite_through_the_alternate_build():
+    env = dict(os.environ, SOLO_LIB_OVERRIDE=ALT)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(T.ROOT, "tests", "test_gpu_decoder.py"), os.path.join(T.ROOT, "tests", "test_gpu_encoder.py"),
+                        os.path.join(T.ROOT, "tests", "test_pinned_corners.py"), os.path.join(T.ROOT, "tests", "test_gpu_receiver.py")],
+                       env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
