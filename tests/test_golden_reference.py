@@ -45,13 +45,25 @@ def test_golden_json_matches_kat():
 def test_stated_tolerance_against_the_floating_point_tree():
     """north_star: bit-exact against the fixed-point tree, 'within a stated PCM tolerance against the FLP path'.  The GPU path
     equals the fixed-point tree bit for bit (tests/test_gpu_*), so its distance to the FLP tree IS the distance between the
-    two reference builds.  Stated here and checked on the synthetic workload:
-      * same bitstream through the fixed-point decoder vs the FLP tree's decoder (its BWE runs in float): SNR >= 20 dB;
+    two reference builds.  THE STATED TOLERANCE (BASELINE.md section 4 row 3 carries the same numbers):
+      * same bitstream through the fixed-point decoder vs the FLP tree's decoder (the low band is integer in both trees, the
+        FLP tree's BWE + QMF run in float): SNR >= 28 dB on the reference's own speech sample Ch_f1_raw (measured 30.0 dB) and
+        >= 24 dB on every stream of the synthetic workload (measured 24.3 .. 26.8 dB: its 1/h harmonic source puts relatively
+        more energy into the 4-8 kHz band, where the two trees differ);
       * fixed-point encode + decode vs FLP encode + decode of the same input (different analysis decisions, different
-        bitstreams): SNR >= 12 dB between the two decoded signals."""
+        bitstreams): SNR >= 12 dB between the two decoded signals (measured 17 dB)."""
+    def snr(a, b):
+        return 10 * np.log10((a * a).sum() / max(((a - b) ** 2).sum(), 1e-9))
+    pcm = T.load_ch_f1()
+    ef = R.RefEncoder("fix")
+    rf = [ef.encode(pcm[p * 640:(p + 1) * 640]) for p in range(pcm.size // 640)]
+    d1, d2 = R.RefDecoder("fix"), R.RefDecoder("flp")
+    a = np.concatenate([d1.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
+    b = np.concatenate([d2.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
+    assert snr(a, b) >= 28.0, snr(a, b)
     snr_dec, snr_chain = [], []
-    for seed in (77, 78, 79):
-        P = 12
+    for seed in (77, 78, 79, 80, 81, 82):
+        P = 16
         pcm = R.synth_stream(seed, P)
         ef, el = R.RefEncoder("fix"), R.RefEncoder("flp")
         rf = [ef.encode(pcm[p]) for p in range(P)]
@@ -60,7 +72,7 @@ def test_stated_tolerance_against_the_floating_point_tree():
         a = np.concatenate([d1.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
         b = np.concatenate([d2.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rf]).astype(np.float64)
         c = np.concatenate([d3.decode(pl, n0, n1, 4)[0] for pl, n0, n1 in rl]).astype(np.float64)
-        snr_dec.append(10 * np.log10((a * a).sum() / max(((a - b) ** 2).sum(), 1e-9)))
-        snr_chain.append(10 * np.log10((a * a).sum() / max(((a - c) ** 2).sum(), 1e-9)))
-    assert min(snr_dec) >= 20.0, snr_dec
+        snr_dec.append(snr(a, b))
+        snr_chain.append(snr(a, c))
+    assert min(snr_dec) >= 24.0, snr_dec
     assert min(snr_chain) >= 12.0, snr_chain
