@@ -76,6 +76,7 @@ struct solo_batch {
 #ifdef SOLO_WITH_ENCODER
     const solo_enc_ops* eops;        // launch table of the build that matches the encoder's rate (solo_enc_kernels.h)
 #endif
+    void* d_nsq_ring;                // emission-ring scratch of the quantiser launches (one launch group of streams; frame-local data)
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
     int32_t enc_work_packets;        // P the hand-over area is sized for
     int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
@@ -132,6 +133,8 @@ static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
 static void solo_enc_free(solo_batch* b) {
     if (b->d_enc_state) (void)hipFree(b->d_enc_state);
     if (b->d_enc_work) (void)hipFree(b->d_enc_work);
+    if (b->d_nsq_ring) (void)hipFree(b->d_nsq_ring);
+    b->d_nsq_ring = NULL;
     b->d_enc_state = NULL;
     b->d_enc_work = NULL;
 }
@@ -349,6 +352,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         b->gate = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_GROUP");
         b->group_streams = e ? atoi(e) : 4096;
+        {   // the quantiser launches of a call run one after the other on sB: one ring, sized for the largest launch group
+            const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
+            SOLO_CHECK(hipMalloc(&b->d_nsq_ring, ops->nsq_ring_bytes(gs)));
+        }
         SOLO_CHECK(hipMalloc((void**)&b->d_started, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
         SOLO_CHECK(hipMemset(b->d_started, 0, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
         memset(b->started_target, 0, sizeof(b->started_target));
@@ -399,7 +406,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-            if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->sB)) != hipSuccess) goto launch_failed;
+            if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->d_nsq_ring, b->sB)) != hipSuccess) goto launch_failed;
             b->started_target[c] += (unsigned int)ops->nsq_workgroups(ns);     // workgroups of this launch, counted once it is enqueued
             if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));

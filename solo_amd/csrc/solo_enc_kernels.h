@@ -68,8 +68,9 @@ __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStrea
 
 
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
-                                     void* hip_stream);   // solo_nsq16.hip / solo_nsq16_wb.hip
+                                     void* ring, void* hip_stream);   // solo_nsq16.hip / solo_nsq16_wb.hip
 extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
+extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams);
 
 // what the host-side pipeline (solo_api.hip) needs of one build: record sizes and launchers
 #ifndef SOLO_ENC_OPS_DEFINED
@@ -79,10 +80,11 @@ struct solo_enc_ops {
     int packet_samples;
     hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s);
     hipError_t (*analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in, void* code_in, hipStream_t s);
-    int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* hip_stream);
+    int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* ring, void* hip_stream);
     hipError_t (*coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc, int slot,
                          uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s);
     int (*nsq_workgroups)(int n_streams);                                // workgroups of one quantiser launch (they count into the residency gate)
+    size_t (*nsq_ring_bytes)(int n_streams);                             // emission-ring scratch of one quantiser launch
 };
 #endif
 static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s) {
@@ -103,4 +105,4 @@ static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in
 }
 static const solo_enc_ops SX_K(solo_enc_ops_table) = {
     sizeof(SxEncStream), sizeof(SxNsqIn), sizeof(SxNsqOut), sizeof(SxCodeIn), SX_PACKET,
-    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_nsq_workgroups)};
+    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_nsq_workgroups), SX_K(solo_nsq_ring_bytes)};

@@ -66,7 +66,7 @@ struct SxEncState {
     i32 prev_NLSFq_Q15[SX_LPC];
 };
 
-struct SxNsqGlobal {                 // per-stream NSQ arrays that live in HBM / L2 (predictable addresses, prefetched by the lanes)
+struct alignas(16) SxNsqGlobal {     // per-stream NSQ arrays that live in HBM / L2 (rows 16-byte aligned: the frame shift moves 16 bytes at a time)
     i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
     i32 shp[SX_N_TRACKS][2 * SX_FRAME + 8];      // sLTP_shp_Q10 of the three tracks: previous frame | current frame (+8: a side track
                                                  // with lag 0 reads one entry past the frame, always 0 in the reference)
@@ -96,19 +96,14 @@ struct SxNsqOut {                    // what the quantiser produces for one fram
     i8 q[2][SX_FRAME];               // pulses of MD1 / MD2 (the centre stream is never coded)
     i32 r[SX_FRAME];                 // centre excitation Q10 (high-band gain reference)
 };
-struct SxNsqRingG {                  // decision-delay histories that are only read when a sample is emitted (HBM, frame-local):
-    i32 Xq_Q10[SX_N_TRACKS][32][4];  // one cell per (track, ring position, state slot); the quantiser prefetches a sample ahead
-    i32 Pred_Q16[SX_N_TRACKS][32][4];
-    i32 exc_Q10[32][4];              // excitation cells of the CENTRE track (high-band gain reference)
-};
-struct SxNsqPersist {                // quantiser state of one stream
+struct alignas(16) SxNsqPersist {    // quantiser state of one stream
     SxNSQ nsq[SX_N_TRACKS];
     SxNsqGlobal g;
-    SxNsqRingG rg;
-    i16 xq[SX_N_TRACKS][2 * SX_FRAME];           // quantised signal: previous frame | current frame
+    alignas(16) i16 xq[SX_N_TRACKS][2 * SX_FRAME];   // quantised signal: previous frame | current frame
 };
+static_assert((sizeof(i32) * (2 * SX_FRAME + 8)) % 16 == 0 && (sizeof(i32) * SX_FRAME) % 16 == 0 && (sizeof(i16) * SX_FRAME) % 16 == 0, "history rows must stay 16-byte aligned");
 
-struct SxEncStream {                 // one record per stream in HBM
+struct alignas(16) SxEncStream {     // one record per stream in HBM
     SxEncState core;
     SxEncHist hist;
     SxNsqPersist nsq;

@@ -1,10 +1,11 @@
 // solo_nsq16.hip -- stage B of the encoder: the multiple-description delayed-decision quantiser (solo_enc_nsq.h), compiled
-// with FOUR streams per wavefront.  The quantiser's per-sample work occupies 12 lanes (3 tracks x 4 survivor states), so a
-// 64-lane wavefront carries four independent streams in its four 16-lane rows; everything that is "wave-uniform" in the
-// one-stream-per-wave model is uniform within a row here, and shuffles stay inside a row.  The recursion is serial in time,
-// so one row works through its stream's frames in order: packet by packet, two frames each.
+// with SIXTEEN streams per wavefront: one lane = one delayed-decision state of one stream (all three tracks in its registers),
+// a stream = one DPP quad.  Everything that is "wave-uniform" in the one-stream-per-wave model is uniform within a quad here, and
+// the cross-lane exchanges stay inside the quad.  The recursion is serial in time, so one quad works through its stream's frames in
+// order: packet by packet, two frames each.  4096 streams = 256 wavefronts = one per CU: the quantiser leaves three SIMDs of every
+// CU (and most issue slots of the fourth) to the analysis / coding kernels of the neighbouring chunks of the pipeline.
 #ifndef SX_NSQ_GROUP
-#define SX_NSQ_GROUP 16       // lanes per stream: 16 -> four streams per wavefront
+#define SX_NSQ_GROUP 4        // lanes per stream: 4 -> sixteen streams per wavefront
 #endif
 #define SX_GROUP SX_NSQ_GROUP
 #define SX_PER_WAVE (64 / SX_GROUP)
@@ -12,23 +13,25 @@
 #include "solo_enc_nsq.h"
 
 #ifndef SX_NSQ_WAVES
-#define SX_NSQ_WAVES 1        // ~288 VGPRs; the analysis / coding kernels are held to <= 104 so that two of their waves fit beside it
+#define SX_NSQ_WAVES 1
 #endif
+// ring: SX_NSQ_RING_CELLS(64) cells per workgroup (the emission ring of its sixteen streams, rows of 64 lanes = 1 KB)
 extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
                                                                  SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
-                                                                 unsigned int* started) {
+                                                                 unsigned int* started, SxNsqCell* __restrict__ ring) {
     __shared__ SxNsqWork w[SX_PER_WAVE];
     const int g = threadIdx.x / SX_GROUP;
     const int s = blockIdx.x * SX_PER_WAVE + g;
     if (started && threadIdx.x == 0) atomicAdd(started, 1u);     // lets the host-side pipeline start the next analysis chunk once this kernel is resident
     if (s >= n_streams) return;
-    // one latency-bound wave per SIMD that shares it with the analysis / coding kernels of neighbouring chunks: issue first
+    // a latency-bound wave that shares its SIMD with the analysis / coding kernels of neighbouring chunks: issue first
     __builtin_amdgcn_s_setprio(3);
     SxNsqPersist* P = &states[s].nsq;
+    SxNsqCell* rg = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS(64) + g * SX_GROUP;
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
         for (int f = 0; f < 2; f++) {
             const size_t r = ((size_t)s * n_packets + p) * 2 + f;
-            sx_nsq_del_dec(P, &in[r], &out[r], &w[g]);
+            sx_nsq_del_dec(P, &in[r], &out[r], &w[g], rg, 64);
             wv_sync();
         }
     }
@@ -52,11 +55,14 @@ extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, v
 
 #endif
 extern "C" int SX_K(solo_nsq_workgroups)(int n_streams) { return (n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE; }
-// host-side launcher (called from solo_api.hip)
+// host-side launcher (called from solo_api.hip); ring: SX_K(solo_nsq_ring_bytes)(n_streams) bytes of device memory (scratch of a launch)
+extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams) {
+    return (size_t)((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE) * SX_NSQ_RING_CELLS(64) * sizeof(SxNsqCell);
+}
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
-                               void* hip_stream) {
+                               void* ring, void* hip_stream) {
     hipLaunchKernelGGL(SX_K(solo_nsq_kernel), dim3((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)states,
-                       (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets, p0, pc, started);
+                       (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets, p0, pc, started, (SxNsqCell*)ring);
     return (int)hipGetLastError();
 }
 
