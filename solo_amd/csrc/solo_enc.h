@@ -542,7 +542,7 @@ SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, SxCodeIn* cin, const 
     sx_enc_stage_a(rec, w, pcm, rec->nsq_in, cin);
     wv_sync();
     for (int frame = 0; frame < 2; frame++) {
-        sx_nsq_del_dec(&rec->nsq, &rec->nsq_in[frame], &rec->nsq_out[frame], &w->u.nsq, w->u.nsq.ring_emu, 4);
+        sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, 4);
         wv_sync();
     }
     return sx_enc_stage_c(rec, w, cin, rec->nsq_out, bits, buf_size, nBytesOut);

@@ -24,6 +24,7 @@
 // The same source compiles for the host (tests/emu, SX_NLANES == 1): lane-private variables become arrays over the four
 // states and the quad exchanges become array reads.
 #pragma once
+#include <stddef.h>
 #include "solo_enc_state.h"
 
 #define SX_JOINT_LAMBDA 90000        // INTERNAL_JOINT_LAMBDA, SKP_Silk_define.h:48 (LARS_LAMBDA_AGR == 0)
@@ -99,11 +100,11 @@ struct alignas(16) SxNsqCell {
     i32 Pred_Q16;                    // LPC excitation << 6 (becomes the long-term prediction history)
     i32 Shape_Q10;                   // shaping history sample
     i32 exc_Q10;                     // centre track: excitation (high-band gain reference); side tracks: unused
-};
-#define SX_NSQ_RING_CELLS(stride) (SX_N_TRACKS * SX_DD_DELAY * (stride))      // cells of one ring with `stride` lanes per row
+};                                   // (row SX_N_TRACKS of a ring position holds the random states instead: {centre, MD1, MD2, -})
+#define SX_NSQ_RING_ROWS (SX_N_TRACKS + 1)                   // per ring position: one row of cells per track + one row of random states
+#define SX_NSQ_RING_CELLS(stride) (SX_NSQ_RING_ROWS * SX_DD_DELAY * (stride))      // cells of one ring with `stride` lanes per row
 
 struct alignas(16) SxNsqWork {       // LDS, per stream
-    i32 Rand[SX_N_TRACKS][SX_DD_DELAY][SX_DD_STATES];     // random-state history (read by the expiry test of every sample)
     // Tap windows of the current subframe, per track: the history entries the subframe's taps can reach, staged from HBM when the
     // subframe starts; a sample emitted during the subframe is also written to its place in the window.  Tap j of iteration i is
     // then ONE LDS read at a fixed place: tapL[i - j + 4] / tapS[i - j + 2].
@@ -242,12 +243,20 @@ SX_HD void sx_copy_v4(SxV4* dst, const SxV4* src, int n) {       // n 16-byte el
 #endif
 // SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  c->xfw: prefiltered input; out->q: pulses of MD1 / MD2, out->r: centre excitation Q10.
 // ring: the stream's emission ring, cell (track, position, slot) at ring[(track * SX_DD_DELAY + position) * rstride + slot].
-SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, SxNsqWork* w, SxNsqCell* ring, int rstride) {
+// Addressing: the stores of the sample loop (ring cells, emitted samples) are written as  wave-uniform base + 32-bit lane offset,
+// so that the base stays in scalar registers and no 64-bit per-lane pointers have to be kept alive across the loop:
+//   Pu + pOff    the stream's SxNsqPersist,      Ou + oOff   its SxNsqOut of this frame,
+//   ringu        the emission ring of the wavefront's streams, cell (row, position, slot) at index (row * SX_DD_DELAY + position) * rstride + rlane + slot
+#define SX_AT(T, ubase, off) (*(T*)((char*)(ubase) + (size_t)(u32)(off)))
+SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u32 oOff, SxNsqWork* w, SxNsqCell* ringu, u32 rlane, int rstride) {
     SX_IN_LDS(w);
+    SxNsqPersist* P = (SxNsqPersist*)(Pu + pOff);
+    SxNsqOut* out = (SxNsqOut*)(Ou + oOff);
     SxNsqGlobal* g = &P->g;
     const i16* x = w->x;
-    i8* q = &out->q[0][0];
-    i32* r = out->r;
+    const u32 oR = oOff + (u32)offsetof(SxNsqOut, r), oQ = oOff + (u32)offsetof(SxNsqOut, q);
+    const u32 pXq = pOff + (u32)offsetof(SxNsqPersist, xq), pShp = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, shp)),
+              pLtp = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, sLTP_Q16));
     SX_TA_BEGIN
     const int voiced = c->sigtype == 0;
     int lagT[SX_N_TRACKS];
@@ -264,7 +273,7 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
     }
     const int LSF_interpolation_flag = c->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
     const i32 Lambda_Q10 = c->Lambda_Q10;
-#define SX_CELL(t_, pos_, slot_) ring[((t_) * SX_DD_DELAY + (pos_)) * rstride + (slot_)]
+#define SX_CELL(t_, pos_, slot_) SX_AT(SxNsqCell, ringu, ((u32)(((t_) * SX_DD_DELAY + (pos_)) * rstride) + rlane + (u32)(slot_)) * (u32)sizeof(SxNsqCell))
 
     // ---- lane-private state: one delayed-decision state, all three tracks (registers on the GPU) ----
     i32 sAR2[SX_NK][SX_N_TRACKS][SX_SHAPE_ORDER], sLPC[SX_NK][SX_N_TRACKS][SX_LPC];       // sLPC[0] = newest quantised sample (Q14)
@@ -275,7 +284,9 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
     i32 dith[SX_NK], myRand[SX_NK][SX_N_TRACKS];
     i32 cRD[SX_NK][SX_N_TRACKS][2], cQ0[SX_NK][SX_N_TRACKS][2], cQ10[SX_NK][SX_N_TRACKS][2];
     i32 curL[SX_NK][SX_N_TRACKS][SX_LTP_ORDER], curS[SX_NK][SX_N_TRACKS][3];      // long-term prediction / harmonic shaping taps of the sample
-    SxNsqCell pf[SX_NK][SX_N_TRACKS];                             // own-slot cells of the ring position the sample emits
+    // own-slot cells of the ring position the sample emits / tests (pf: track cells, pfR: random states), and those of the NEXT
+    // sample: the ring is a delay line in HBM, its reads are issued two samples before they are used (see the rotation in phase F)
+    SxNsqCell pf[SX_NK][SX_N_TRACKS], pfR[SX_NK], nx[SX_NK][SX_N_TRACKS], nxR[SX_NK];
     // scratch of the joint decision
     i32 jv[SX_NK], mv[SX_NK], mi[SX_NK], mv2[SX_NK], mi2[SX_NK], tq[SX_NK], par[SX_NK], csrc[SX_NK], csel[SX_NK], c0[SX_NK], c1[SX_NK], nrep[SX_NK];
     i32 gq[SX_NK];
@@ -297,16 +308,15 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
 #pragma unroll
             for (int j = 0; j < 3; j++) curS[a][t][j] = 0;
             pf[a][t].xqQ = pf[a][t].Pred_Q16 = pf[a][t].Shape_Q10 = pf[a][t].exc_Q10 = 0;
+            pfR[a] = pf[a][t];
+            nx[a][t] = pf[a][t];
+            nxR[a] = pf[a][t];
         }
     }
 
     // Agora_Silk_Init_DelDecState (NSQ_del_dec.c:148): every track starts from the same seed.  Only the random-state history is
-    // ever read before it is written (the expiry test of the first decisionDelay samples): it starts from zero.
+    // ever read before it is written (the expiry test of the first decisionDelay samples of a frame): those reads give zero, see phase A.
     {
-        SxV4* p = (SxV4*)&w->Rand[0][0][0];                            // (one ring position = the four slots = 16 bytes)
-        const SxV4 z4 = {{0, 0, 0, 0}};
-#pragma unroll 8
-        SX_PAR(i, SX_N_TRACKS * SX_DD_DELAY) p[i] = z4;
         const i32* xs = (const i32*)c->xfw;                            // two samples per word (the record keeps xfw 4-byte aligned)
         i32* xd = (i32*)w->x;
 #pragma unroll 8
@@ -330,6 +340,14 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
         }
         wv_sync();
     }
+    SX_FORK(kk) {       // prime the ring's read queue: the cells samples 0 and 1 look back at (not written by this frame; never used as such)
+        const int ki = SX_KI(kk);
+        const int l0 = (SX_DD_MASK + decisionDelay) & SX_DD_MASK;
+#pragma unroll
+        for (int t = 0; t < SX_N_TRACKS; t++) { pf[ki][t] = SX_CELL(t, l0, kk); nx[ki][t] = SX_CELL(t, (l0 - 1) & SX_DD_MASK, kk); }
+        pfR[ki] = SX_CELL(SX_N_TRACKS, l0, kk);
+        nxR[ki] = SX_CELL(SX_N_TRACKS, (l0 - 1) & SX_DD_MASK, kk);
+    }
     int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
     int subfr = 0;
 
@@ -347,10 +365,10 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
     // outputs of one emitted sample of track t_ (Agora_Silk_GetWinner{,_Side} / the flush loops); cell_ = the winner's ring cell
 #define SX_NSQ_EMIT_OUT(t_, cell_, pos_, shape_)                                                                             \
     {                                                                                                                        \
-        if ((t_) == 0) r[pos_] = (cell_).exc_Q10;                                                                            \
-        else q[((t_)-1) * SX_FRAME + (pos_)] = (i8)((cell_).xqQ >> 16);                                                      \
-        P->xq[t_][SX_FRAME + (pos_)] = (i16)(cell_).xqQ;                                                                     \
-        g->shp[t_][SX_FRAME + (pos_)] = (shape_);                                                                            \
+        if ((t_) == 0) SX_AT(i32, Ou, oR + (u32)(pos_) * 4u) = (cell_).exc_Q10;                                              \
+        else SX_AT(i8, Ou, oQ + (u32)(((t_)-1) * SX_FRAME + (pos_))) = (i8)((cell_).xqQ >> 16);                              \
+        SX_AT(i16, Pu, pXq + (u32)((t_) * 2 * SX_FRAME + SX_FRAME + (pos_)) * 2u) = (i16)(cell_).xqQ;                        \
+        SX_AT(i32, Pu, pShp + (u32)((t_) * (2 * SX_FRAME + 8) + SX_FRAME + (pos_)) * 4u) = (shape_);                         \
     }
 
     for (int k = 0; k < SX_NB_SUBFR; k++) {
@@ -525,11 +543,6 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
             // phase A: predictions, shaping, residual, dither -- the three tracks of the lane's state
             SX_FORK(kk) {
                 const int ki = SX_KI(kk);
-                {   // the delayed random-state cells of this state's lineage (the expiry test needs them after the candidates)
-                    const int rs = SX_LIN_SLOT(linLo[ki], linHi[ki], last_smple_idx);
-#pragma unroll
-                    for (int t = 0; t < SX_N_TRACKS; t++) myRand[ki][t] = w->Rand[t][last_smple_idx][rs];
-                }
                 // The taps of this sample (long-term prediction: 5, harmonic shaping: 3, per track): one LDS read each at a fixed place of
                 // the staged windows.  Issued first, consumed after the shaping filters of the three tracks.  (Unvoiced frame: the
                 // prediction coefficients are zero; no pitch lag: the shaping gains were zeroed above -- whatever the windows hold.)
@@ -539,10 +552,6 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
                     for (int j = 0; j < SX_LTP_ORDER; j++) curL[ki][t][j] = w->tapL[t][i + (SX_LTP_ORDER - 1) - j];
 #pragma unroll
                     for (int j = 0; j < 3; j++) curS[ki][t][j] = w->tapS[t][i + 2 - j];
-                }
-                if (emitted) {
-#pragma unroll
-                    for (int t = 0; t < SX_N_TRACKS; t++) pf[ki][t] = SX_CELL(t, last_smple_idx, kk);
                 }
                 const i32 x_sc_Q10 = sx_smulbb(x[k * SX_SUBFR + i], inv_gain_Q16) >> 6;        // Agora_Silk_DelDecScale (NSQ_del_dec.c:1668)
                 Seed2[ki] = sx_rand(Seed2[ki]);                                                // Agora_Silk_Dither (NSQ_del_dec.c:520)
@@ -670,6 +679,19 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
             {
                 const i32 PEN = SX_I32_MAX >> 4;
                 SXQ_ARGMIN(jv, mv, mi)                                   // mi = the joint winner
+                // the delayed random state of this state's lineage: held by the lane that owns the lineage's slot of that ring position;
+                // before the frame has written that position (first decisionDelay samples) the reference reads its zero-initialised ring
+                {
+                    const bool written = k * SX_SUBFR + i >= decisionDelay;
+                    SX_FORK(kk) { gq[SX_KI(kk)] = SX_LIN_SLOT(linLo[SX_KI(kk)], linHi[SX_KI(kk)], last_smple_idx); }
+                    SX_FORK(kk) { tq[SX_KI(kk)] = pfR[SX_KI(kk)].xqQ; }
+                    SXQ_GATHER(c0, tq, gq)
+                    SX_FORK(kk) { myRand[SX_KI(kk)][0] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = pfR[SX_KI(kk)].Pred_Q16; }
+                    SXQ_GATHER(c0, tq, gq)
+                    SX_FORK(kk) { myRand[SX_KI(kk)][1] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = pfR[SX_KI(kk)].Shape_Q10; }
+                    SXQ_GATHER(c0, tq, gq)
+                    SX_FORK(kk) { myRand[SX_KI(kk)][2] = written ? c0[SX_KI(kk)] : 0; }
+                }
                 i32 wr[SX_NK][SX_N_TRACKS];
 #pragma unroll
                 for (int t = 0; t < SX_N_TRACKS; t++) {
@@ -770,6 +792,20 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
             // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
             // that owns the winner's slot of the emitted ring position holds the three cells in its prefetch registers.
             SXQ_ARGMIN(jv, mv, mi)
+            // The ring's read queue moves on BEFORE this sample's stores are issued: vector memory operations complete in order, so the
+            // only wait of the sample (for the cells requested one sample ago) then has nothing younger than a sample in front of it.
+            SxNsqCell em[SX_NK][SX_N_TRACKS];
+            SX_FORK(kk) {
+                const int ki = SX_KI(kk);
+#pragma unroll
+                for (int t = 0; t < SX_N_TRACKS; t++) {
+                    em[ki][t] = pf[ki][t];
+                    pf[ki][t] = nx[ki][t];
+                    nx[ki][t] = SX_CELL(t, (last_smple_idx - 2) & SX_DD_MASK, kk);
+                }
+                pfR[ki] = nxR[ki];
+                nxR[ki] = SX_CELL(SX_N_TRACKS, (last_smple_idx - 2) & SX_DD_MASK, kk);
+            }
             if (emitted) {
                 SXQ_GATHER(tq, linLo, mi)
                 SXQ_GATHER(gq, linHi, mi)
@@ -780,10 +816,10 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
                         const int pos = k * SX_SUBFR + i - decisionDelay;
 #pragma unroll
                         for (int t = 0; t < SX_N_TRACKS; t++) {
-                            const i32 pv = crossed ? sx_smulww(gadjT[t], pf[ki][t].Pred_Q16) : pf[ki][t].Pred_Q16;
-                            const i32 sv = crossed ? sx_smulww(gadjT[t], pf[ki][t].Shape_Q10) : pf[ki][t].Shape_Q10;
-                            SX_NSQ_EMIT_OUT(t, pf[ki][t], pos, sv)
-                            g->sLTP_Q16[t][pred_base + i - decisionDelay] = pv;
+                            const i32 pv = crossed ? sx_smulww(gadjT[t], em[ki][t].Pred_Q16) : em[ki][t].Pred_Q16;
+                            const i32 sv = crossed ? sx_smulww(gadjT[t], em[ki][t].Shape_Q10) : em[ki][t].Shape_Q10;
+                            SX_NSQ_EMIT_OUT(t, em[ki][t], pos, sv)
+                            SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = pv;
                             const int D = lagT[t] - decisionDelay - (SX_LTP_ORDER / 2 + 1);
                             if ((unsigned)(i + D + 5) < (unsigned)SX_TAPL_N) w->tapL[t][i + D + 5] = pv;
                             if ((unsigned)(i + D + 4) < (unsigned)SX_TAPS_N) w->tapS[t][i + D + 4] = sv;
@@ -801,7 +837,6 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
                     sLPC[ki][t][0] = cXq14[ki][t];
                     lastShp[ki][t] = cShp[ki][t];
                     Seed[ki][t] = sx_add(Seed[ki][t], fQ0[ki][t]);
-                    w->Rand[t][smpl_buf_idx][kk] = Seed[ki][t];
                     RD[ki][t] = fRD[ki][t];
                     SxNsqCell cell;
                     const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[ki][t] >> 4, Gain_Q16), 10));
@@ -810,6 +845,11 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
                     cell.Shape_Q10 = cShp[ki][t];
                     cell.exc_Q10 = t == 0 ? cExc10[ki] : 0;
                     SX_CELL(t, smpl_buf_idx, kk) = cell;
+                }
+                {
+                    SxNsqCell cr;
+                    cr.xqQ = Seed[ki][0]; cr.Pred_Q16 = Seed[ki][1]; cr.Shape_Q10 = Seed[ki][2]; cr.exc_Q10 = 0;
+                    SX_CELL(SX_N_TRACKS, smpl_buf_idx, kk) = cr;
                 }
                 // the state's own slot now holds its newest ring entry
                 const u32 m = 3u << (2 * (smpl_buf_idx & 15));
@@ -885,4 +925,5 @@ SX_NSQ_FN void sx_nsq_del_dec(SxNsqPersist* P, const SxNsqIn* c, SxNsqOut* out, 
     SX_TA_END
 #undef SX_NSQ_EMIT_OUT
 #undef SX_CELL
+#undef SX_AT
 }

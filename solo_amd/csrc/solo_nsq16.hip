@@ -26,12 +26,16 @@ extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) SX_K(solo_nsq_ker
     if (s >= n_streams) return;
     // a latency-bound wave that shares its SIMD with the analysis / coding kernels of neighbouring chunks: issue first
     __builtin_amdgcn_s_setprio(3);
-    SxNsqPersist* P = &states[s].nsq;
-    SxNsqCell* rg = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS(64) + g * SX_GROUP;
+    // wave-uniform bases + 32-bit lane offsets (solo_enc_nsq.h): the states / records of the wavefront's sixteen streams
+    char* Pu = (char*)&states[(size_t)blockIdx.x * SX_PER_WAVE];
+    const u32 pOff = (u32)g * (u32)sizeof(SxEncStream) + (u32)offsetof(SxEncStream, nsq);
+    const u32 rec_stride = (u32)n_packets * 2u;                     // hand-over records between consecutive streams
+    SxNsqCell* rgu = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS(64);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
         for (int f = 0; f < 2; f++) {
-            const size_t r = ((size_t)s * n_packets + p) * 2 + f;
-            sx_nsq_del_dec(P, &in[r], &out[r], &w[g], rg, 64);
+            const size_t r0 = ((size_t)blockIdx.x * SX_PER_WAVE * n_packets + p) * 2 + f;       // record of the wavefront's first stream
+            sx_nsq_del_dec(Pu, pOff, &in[r0 + (size_t)g * rec_stride], (char*)&out[r0], (u32)g * rec_stride * (u32)sizeof(SxNsqOut), &w[g], rgu,
+                           (u32)(g * SX_GROUP), 64);
             wv_sync();
         }
     }
