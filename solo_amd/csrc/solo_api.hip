@@ -77,6 +77,8 @@ struct solo_batch {
     const solo_enc_ops* eops;        // launch table of the build that matches the encoder's rate (solo_enc_kernels.h)
 #endif
     void* d_nsq_ring;                // emission-ring scratch of the quantiser launches (one launch group of streams; frame-local data)
+    void* d_rc_scratch;              // range-coder byte buffers of one coding launch (the launches of a call run in order on sC)
+    size_t rc_scratch_bytes;
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
     int32_t enc_work_packets;        // P the hand-over area is sized for
     int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
@@ -135,6 +137,8 @@ static void solo_enc_free(solo_batch* b) {
     if (b->d_enc_work) (void)hipFree(b->d_enc_work);
     if (b->d_nsq_ring) (void)hipFree(b->d_nsq_ring);
     b->d_nsq_ring = NULL;
+    if (b->d_rc_scratch) (void)hipFree(b->d_rc_scratch);
+    b->d_rc_scratch = NULL;
     b->d_enc_state = NULL;
     b->d_enc_work = NULL;
 }
@@ -364,6 +368,20 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     int cp = b->chunk_packets > 0 ? b->chunk_packets : n_packets;
     int nchunks = (n_packets + cp - 1) / cp;
     if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
+    {   // scratch of one coding launch: the byte buffers of its descriptions
+        const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
+        const size_t need = ops->rc_scratch_bytes(gs, cp);
+        if (need > b->rc_scratch_bytes) {
+            if (b->d_rc_scratch) {
+                SOLO_CHECK(hipStreamSynchronize(b->sC));             // (a coding launch of the previous call may still read the old one)
+                (void)hipFree(b->d_rc_scratch);
+                b->d_rc_scratch = NULL;
+                b->rc_scratch_bytes = 0;
+            }
+            SOLO_CHECK(hipMalloc(&b->d_rc_scratch, need));
+            b->rc_scratch_bytes = need;
+        }
+    }
     const bool tm_req = b->timing && b->tev_ready;
     if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp || b->evC_valid == 0)) {
         // the previous call laid its hand-over records out differently: no chunk-wise reuse, wait for all of its coding
@@ -412,7 +430,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
             SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
             if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->sC)) != hipSuccess) goto launch_failed;
+            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
             if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
             SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
         }

@@ -19,11 +19,24 @@ struct SxFrameIdx {
     i32 inDTX, pad_;                 // DTX state after this frame (SKP_Silk_encode_frame_FIX.c:155-171); the packet is dropped if set after frame 1
 };
 
-struct SxCodeWork {                  // LDS: range-coder byte buffers of the two descriptions + the coding tables
-    u8 buf[2][SX_MAX_ARITHM_BYTES];
-    i16 pulses[2][SX_FRAME + 2 * (SX_FRAME / 16)];   // |pulse| per sample, then sum_pulses / nRshifts per shell block
-    i8 q[2][2][SX_FRAME];                            // staged pulses (frame, description)
+// Work area of ONE description's range coder (one lane of the entropy-coding kernel; host emulation: one after the other).
+// The entropy coder is a serial chain per description, so the GPU runs it lane-per-description: 64 descriptions (32 streams)
+// per wavefront, every lane with its own staged pulses and pulse work area in LDS.  The rows are an ODD number of dwords long
+// so that the 64 lanes, which mostly sit at the same offset of their own row, hit different LDS banks.
+#define SX_RC_Q_ROW (2 * SX_FRAME + 4)                          // staged pulses of both frames (+ pad: 81 dwords at 8 kHz)
+#define SX_RC_PW_ROW (SX_FRAME + 2 * (SX_FRAME / 16) + 8 - ((SX_FRAME + 2 * (SX_FRAME / 16)) & 7) + 4)   // |pulse|, block sums, block shifts
+static_assert(((SX_RC_Q_ROW / 4) & 1) == 1 && ((SX_RC_PW_ROW / 4) & 1) == 1 && SX_RC_Q_ROW % 4 == 0 && SX_RC_PW_ROW % 4 == 0, "odd dword rows");
+#define SX_RC_BUF_STRIDE (SX_MAX_ARITHM_BYTES + 16)             // HBM: byte buffer of one description
+struct SxRcInfo { i32 nBytes, error; };                        // HBM: what the coder of one description reports
+
+struct SxCodeWork {                  // host emulation of the coding kernels: both descriptions one after the other
+#if SX_NLANES == 1
+    u8 buf[2][SX_RC_BUF_STRIDE];
+    u8 pulses[SX_RC_PW_ROW];
     SxCdf cdf;
+#else
+    i32 unused_;
+#endif
 };
 
 struct SxFrontWork {                 // LDS scratch of the per-frame analysis chain
@@ -53,7 +66,6 @@ struct SxEncWork {
     // persistent over the launch / packet
     SxEncState st;                   // the stream's compact state (HBM record -> LDS at launch start, back at the end)
     SxEncCtrl ctrl;
-    SxFrameIdx idx[2];
     i16 xfw[SX_FRAME];
     u8 hb_bytes[8];
     // phase-local
@@ -76,9 +88,9 @@ SX_HD void sx_enc_split(SxRangeEnc* rc, int p_child1, int p, const u16* shell_ta
 }
 
 // SKP_Silk_shell_encoder, SKP_Silk_shell_coder.c:84
-SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i16* p0, const SxCdf* cdf) {
+SX_HD void sx_shell_encoder(SxRangeEnc* rc, const u8* p0, const SxCdf* cdf) {
     i32 p1[8], p2[4], p3[2], p4;
-    for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
+    for (int k = 0; k < 8; k++) p1[k] = (i32)p0[2 * k] + (i32)p0[2 * k + 1];
     for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
     for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
     p4 = p3[0] + p3[1];
@@ -95,15 +107,17 @@ SX_HD void sx_shell_encoder(SxRangeEnc* rc, const i16* p0, const SxCdf* cdf) {
 }
 
 // SKP_Silk_encode_pulses + SKP_Silk_encode_signs, SKP_Silk_encode_pulses.c:55, SKP_Silk_code_signs.c:40
-SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, i16* pw) {
+// pw: SX_FRAME + 2 * (SX_FRAME / 16) bytes of work space (|pulse| <= 128 and the final block sums / shifts fit a byte; a block
+// sum that overflows one is followed by another pass over the block, which overwrites it)
+SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, u8* pw) {
     SX_IN_LDS(cdf); SX_IN_LDS(pw); SX_IN_LDS(q);
     const int iter = SX_FRAME / 16;
-    i16 *abs_pulses = pw, *sum_pulses = pw + SX_FRAME, *nRshifts = pw + SX_FRAME + SX_FRAME / 16;
+    u8 *abs_pulses = pw, *sum_pulses = pw + SX_FRAME, *nRshifts = pw + SX_FRAME + SX_FRAME / 16;
     const i32 maxp0 = T_max_pulses[0], maxp1 = T_max_pulses[1], maxp2 = T_max_pulses[2], maxp3 = T_max_pulses[3];
-    for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = q[i] < 0 ? -(i32)q[i] : (i32)q[i];
+    for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = (u8)(q[i] < 0 ? -(i32)q[i] : (i32)q[i]);
     for (int i = 0; i < iter; i++) {
-        i16* ap = &abs_pulses[i * 16];
-        nRshifts[i] = 0;
+        u8* ap = &abs_pulses[i * 16];
+        int nrs = 0;
         for (;;) {
             // combine_and_check: 1+1 (max 3), 2+2 (max 6), 4+4 (max 8), 8+8 (max 12); the reference aborts each level at
             // the first overflow, which leaves its `pulses_comb` partly stale -- but any overflow forces another
@@ -111,7 +125,7 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
             i32 c1[8], c2[4], c3[2];
             int scale_down = 0, bad;
             bad = 0;
-            for (int k = 0; k < 8; k++) { c1[k] = ap[2 * k] + ap[2 * k + 1]; bad |= c1[k] > maxp0; }
+            for (int k = 0; k < 8; k++) { c1[k] = (i32)ap[2 * k] + (i32)ap[2 * k + 1]; bad |= c1[k] > maxp0; }
             scale_down += bad;
             bad = 0;
             for (int k = 0; k < 4; k++) { c2[k] = c1[2 * k] + c1[2 * k + 1]; bad |= c2[k] > maxp1; }
@@ -119,12 +133,13 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
             bad = 0;
             for (int k = 0; k < 2; k++) { c3[k] = c2[2 * k] + c2[2 * k + 1]; bad |= c3[k] > maxp2; }
             scale_down += bad;
-            sum_pulses[i] = c3[0] + c3[1];
-            if (sum_pulses[i] > maxp3) scale_down++;
-            if (!scale_down) break;
-            nRshifts[i]++;
+            const i32 sum = c3[0] + c3[1];
+            if (sum > maxp3) scale_down++;
+            if (!scale_down) { sum_pulses[i] = (u8)sum; break; }
+            nrs++;
             for (int k = 0; k < 16; k++) ap[k] >>= 1;
         }
+        nRshifts[i] = (u8)nrs;
     }
     int RateLevelIndex = 0;
     i32 minSumBits_Q6 = SX_I32_MAX;
@@ -147,15 +162,24 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
     }
     for (int i = 0; i < iter; i++)
         if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16], cdf);
+    // least significant bits of the blocks that were scaled down.  Few blocks are (at these rates), but some lane of a wavefront
+    // nearly always has one: every lane walks ITS OWN list of (block, sample, bit) symbols, so the wavefront's trip count is the
+    // longest list of a lane and not the union of the blocks
     const u32 p_lsb = cdf->cdf_lsb[1];
-    for (int i = 0; i < iter; i++) {
-        if (nRshifts[i] > 0) {
-            const i8* pp = &q[i * 16];
-            const int nLS = nRshifts[i] - 1;
-            for (int k = 0; k < 16; k++) {
-                i32 abs_q = (i8)(pp[k] < 0 ? -pp[k] : pp[k]);
-                for (int j = nLS; j > 0; j--) sx_rc_enc_bin(rc, (abs_q >> j) & 1, p_lsb);
-                sx_rc_enc_bin(rc, abs_q & 1, p_lsb);
+    {
+        int i = 0;
+        while (i < iter && nRshifts[i] == 0) i++;
+        int k = 0, j = i < iter ? (int)nRshifts[i] - 1 : 0;
+        while (i < iter) {
+            const i8 v = q[i * 16 + k];
+            const i32 abs_q = (i8)(v < 0 ? -v : v);
+            sx_rc_enc_bin(rc, (abs_q >> j) & 1, p_lsb);
+            if (--j < 0) {
+                if (++k == 16) {
+                    k = 0;
+                    do { i++; } while (i < iter && nRshifts[i] == 0);
+                }
+                j = i < iter ? (int)nRshifts[i] - 1 : 0;
             }
         }
     }
@@ -166,12 +190,13 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
     }
 }
 
-// SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`)
-SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
-                                const SxCdf* cdf, i16* pw) {
-    SX_IN_LDS(cdf); SX_IN_LDS(x); SX_IN_LDS(q);
-    SxRangeEnc rc_local = *rc_io;      // coder state in registers for the whole frame
-    SxRangeEnc* rc = &rc_local;
+// SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`).  x: the frame's indices (HBM record;
+// read once into registers)
+SX_HD void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* xp, int Seed, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
+                                const SxCdf* cdf, u8* pw) {
+    SX_IN_LDS(cdf); SX_IN_LDS(q);
+    const SxFrameIdx xv = *xp;
+    const SxFrameIdx* x = &xv;
     if (frame == 0) {
         if (writeMDIndex == 1) sx_rc_enc(rc, md, cdf->cdf_mdindex);
         sx_rc_enc(rc, SX_FS_KHZ == 8 ? 0 : 2, cdf->cdf_fs);      // index of fs_kHz in SamplingRates_table = {8, 12, 16, 24}
@@ -181,16 +206,17 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
     else sx_rc_enc(rc, typeOffset, &cdf->cdf_type_offset_joint[typeOffsetPrev * 5]);
     if (frame == 0) sx_rc_enc(rc, x->GainsIndices[0], &cdf->cdf_gain[x->sigtype * 65]);
     else sx_rc_enc(rc, x->GainsIndices[0], cdf->cdf_delta_gain);
+#pragma unroll
     for (int i = 1; i < SX_NB_SUBFR; i++) sx_rc_enc(rc, x->GainsIndices[i], cdf->cdf_delta_gain);
     if (frame == 0) sx_rc_enc(rc, x->DeltaGainsIndices, cdf->cdf_md_delta_gain);
     {
         const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
-        const i32* nvec = x->sigtype == 0 ? nvec0 : nvec1;
         const u16* ncdf = x->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
         int off = 0;
+#pragma unroll
         for (int s = 0; s < SX_NLSF_STAGES; s++) {
             sx_rc_enc(rc, x->NLSFIndices[s], ncdf + off);
-            off += nvec[s] + 1;
+            off += (x->sigtype == 0 ? nvec0[s] : nvec1[s]) + 1;
         }
     }
     sx_rc_enc(rc, x->NLSFInterpCoef_Q2, cdf->cdf_nlsf_interp);
@@ -199,13 +225,32 @@ SX_FN void sx_encode_parameters(SxRangeEnc* rc_io, const SxFrameIdx* x, int fram
         sx_rc_enc(rc, x->contourIndex, cdf->cdf_pitch_contour);
         sx_rc_enc(rc, x->PERIndex, cdf->cdf_ltp_per);
         const u16* gcdf = x->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (x->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
+#pragma unroll
         for (int k = 0; k < SX_NB_SUBFR; k++) sx_rc_enc(rc, x->LTPIndex[k], gcdf);
         sx_rc_enc(rc, x->LTP_scaleIndex, cdf->cdf_ltpscale);
     }
-    sx_rc_enc(rc, x->Seed, cdf->cdf_seed);
+    sx_rc_enc(rc, Seed, cdf->cdf_seed);
     sx_encode_pulses(rc, x->sigtype, x->QuantOffsetType, q, cdf, pw);
     sx_rc_enc(rc, x->vadFlag, cdf->cdf_vadflag);
-    *rc_io = rc_local;
+}
+
+// The range coder of ONE description of one packet: both frames' parameters and pulses -> `buf` (SX_RC_BUF_STRIDE bytes of HBM).
+// idx2: the two frames' indices (hand-over record of the analysis), Seed0 / Seed1: the dither seeds the quantiser chose,
+// q2: the description's pulses of frame 0 then frame 1 (LDS row).  Reports the byte count and the coder's error flag.
+SX_HD void sx_code_description(const SxFrameIdx* idx2, int Seed0, int Seed1, const i8* q2, int md, int writeMDIndex, const SxCdf* cdf, u8* pw,
+                               u8* buf, SxRcInfo* info) {
+    SxRangeEnc rc;
+    sx_rc_enc_init(&rc, buf);
+    const int prev = 2 * idx2[0].sigtype + idx2[0].QuantOffsetType;
+    sx_encode_parameters(&rc, &idx2[0], Seed0, 0, md, writeMDIndex, 0, q2, cdf, pw);
+    sx_rc_enc(&rc, 1, cdf->cdf_frame_term);                      // SKP_SILK_MORE_FRAMES = 1
+    sx_encode_parameters(&rc, &idx2[1], Seed1, 1, md, writeMDIndex, prev, q2 + SX_FRAME, cdf, pw);
+    sx_rc_enc(&rc, 0, cdf->cdf_frame_term);                      // SKP_SILK_LAST_FRAME = 0
+    i32 nb;
+    sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
+    sx_rc_enc_wrap_up(&rc);
+    info->nBytes = nb;
+    info->error = rc.error;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -452,13 +497,14 @@ SX_FN void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsqI
 
 // Stage C: high-band encoder (needs the centre excitation of the quantiser), range coding of the two descriptions,
 // payload assembly.  640 samples @ 16 kHz -> MD1 || MD2 || HB(8).  nBytesOut[0] = total, nBytesOut[1] = len(MD2) + 8.
-// Returns the total byte count, or a negative status if the payload does not fit `buf_size`.
-SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2, u8* bits, i32 buf_size, i16* nBytesOut) {
+// On the GPU the stage is two kernels: the range coder is a serial chain per description and runs LANE-per-description
+// (sx_code_description; 32 streams per wavefront, solo_enc_rc_kernel), the high-band encoder and the payload assembly run
+// wavefront-per-stream (sx_enc_stage_c_hb, sx_enc_stage_c_out; solo_enc_coding_kernel).  The host emulation calls the three in a row.
+SX_FN void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SX_T_BEGIN
-    const int hb_bytes = st->hb_joint ? 4 : 8;
     if (st->hb_joint) {
         sx_hb_encode_frame(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[0], 2 * SX_FRAME);
         wv_sync();
@@ -470,71 +516,66 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
             SX_T(9)
         }
     }
-    SX_PAR(i, (int)(2 * sizeof(SxFrameIdx) / 4)) ((i32*)&w->idx[0])[i] = ((const i32*)&cin->idx[0])[i];
-    wv_sync();
-    if (st->useDTX && w->idx[1].inDTX) {         // "DTX simulation" (SKP_Silk_enc_API.c:260-265): the packet is analysed, quantised
-        nBytesOut[0] = 0;                        // and its high band encoded (all states move on), but nothing is sent.
-        nBytesOut[1] = 0;                        // (The reference's bit buffer then holds just the high-band bytes and its Encode
-        SX_PAR(i, hb_bytes) bits[i] = w->hb_bytes[i];   // returns their count; mirrored: they sit at the start of the slot.)
+}
+
+// the packet is dropped ("DTX simulation", SKP_Silk_enc_API.c:260-265): it was analysed, quantised and its high band encoded (all
+// states moved on), but nothing is sent
+SX_HD bool sx_enc_packet_in_dtx(int useDTX, const SxCodeIn* cin) { return useDTX && SX_UNI(cin->idx[1].inDTX); }
+
+// Returns the total byte count, or a negative status if the payload does not fit `buf_size`.  buf0 / buf1: the range coder's
+// bytes of MD1 / MD2 (HBM), info2: their byte counts and error flags.
+SX_FN i32 sx_enc_stage_c_out(SxEncWork* w, const SxCodeIn* cin, const u8* buf0, const u8* buf1, const SxRcInfo* info2, u8* bits, i32 buf_size,
+                             i16* nBytesOut) {
+    SX_IN_LDS(w);
+    SxEncState* st = &w->st;
+    SX_T_BEGIN
+    const int hb_bytes = st->hb_joint ? 4 : 8;
+    if (sx_enc_packet_in_dtx(st->useDTX, cin)) {
+        nBytesOut[0] = 0;                        // (The reference's bit buffer then holds just the high-band bytes and its Encode
+        nBytesOut[1] = 0;                        // returns their count; mirrored: they sit at the start of the slot.)
+        SX_PAR(i, hb_bytes) bits[i] = w->hb_bytes[i];
         wv_sync();
         return hb_bytes;
     }
-    w->idx[0].Seed = out2[0].Seed;
-    w->idx[1].Seed = out2[1].Seed;
-    wv_sync();
-    // range coding of the two descriptions: description md on lane md, tables served from LDS
-    sx_cdf_load(&w->u.code.cdf);
-    SX_PAR(i, 2 * 2 * SX_FRAME) (&w->u.code.q[0][0][0])[i] = out2[i / (2 * SX_FRAME)].q[(i / SX_FRAME) & 1][i % SX_FRAME];
-    wv_sync();
-    const SxCdf* cdf = &w->u.code.cdf;
-    i32 nBytes_md[2] = {0, 0}, err_md[2] = {0, 0};
-    i32 nb_lane = 0, err_lane = 0;
-    SX_PAR(md, 2) {                     // lanes 0 and 1 only: the coder is a serial scalar chain
-        SxRangeEnc rc;
-        sx_rc_enc_init(&rc, w->u.code.buf[md]);
-        for (int frame = 0; frame < 2; frame++) {
-            const int prev = frame == 0 ? 0 : 2 * w->idx[0].sigtype + w->idx[0].QuantOffsetType;
-            sx_encode_parameters(&rc, &w->idx[frame], frame, md, st->useMDIndex, prev, &w->u.code.q[frame][md][0], cdf, w->u.code.pulses[md]);
-            sx_rc_enc(&rc, frame == 0 ? 1 : 0, cdf->cdf_frame_term);     // SKP_SILK_MORE_FRAMES = 1, LAST_FRAME = 0
-        }
-        i32 nb;
-        sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
-        sx_rc_enc_wrap_up(&rc);
-#if SX_NLANES == 1
-        nBytes_md[md] = nb;
-        err_md[md] = rc.error;
-#else
-        nb_lane = nb;
-        err_lane = rc.error;
-#endif
-    }
-#if SX_NLANES != 1
-    nBytes_md[0] = wv_bcast(nb_lane, 0); nBytes_md[1] = wv_bcast(nb_lane, 1);
-    err_md[0] = wv_bcast(err_lane, 0); err_md[1] = wv_bcast(err_lane, 1);
-#else
-    (void)nb_lane; (void)err_lane;
-#endif
-    wv_sync();
-    SX_T(10)
-    const i32 total = nBytes_md[0] + nBytes_md[1] + hb_bytes;
-    if (err_md[0] || err_md[1] || total > buf_size || nBytes_md[0] > SX_MAX_ARITHM_BYTES || nBytes_md[1] > SX_MAX_ARITHM_BYTES) {
+    const i32 nb0 = SX_UNI(info2[0].nBytes), nb1 = SX_UNI(info2[1].nBytes);
+    const i32 err = SX_UNI(info2[0].error | info2[1].error);
+    const i32 total = nb0 + nb1 + hb_bytes;
+    if (err || total > buf_size || nb0 > SX_MAX_ARITHM_BYTES || nb1 > SX_MAX_ARITHM_BYTES) {
         nBytesOut[0] = 0;
         nBytesOut[1] = 0;
         return -1;
     }
     SX_PAR(i, total) {
         u8 b;
-        if (i < nBytes_md[0]) b = w->u.code.buf[0][i];
-        else if (i < nBytes_md[0] + nBytes_md[1]) b = w->u.code.buf[1][i - nBytes_md[0]];
-        else b = w->hb_bytes[i - nBytes_md[0] - nBytes_md[1]];
+        if (i < nb0) b = buf0[i];
+        else if (i < nb0 + nb1) b = buf1[i - nb0];
+        else b = w->hb_bytes[i - nb0 - nb1];
         bits[i] = b;
     }
     nBytesOut[0] = (i16)total;
-    nBytesOut[1] = (i16)(nBytes_md[1] + hb_bytes);
+    nBytesOut[1] = (i16)(nb1 + hb_bytes);
     wv_sync();
     SX_T(11)
     return total;
 }
+
+#if SX_NLANES == 1
+// host emulation: high band, the two descriptions one after the other, assembly
+SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2, u8* bits, i32 buf_size, i16* nBytesOut) {
+    sx_enc_stage_c_hb(rec, w, cin, out2);
+    SxRcInfo info[2] = {{0, 0}, {0, 0}};
+    if (!sx_enc_packet_in_dtx(w->st.useDTX, cin)) {
+        sx_cdf_load(&w->u.code.cdf);
+        i8 q2[2 * SX_FRAME];
+        for (int md = 0; md < 2; md++) {
+            for (int i = 0; i < 2 * SX_FRAME; i++) q2[i] = out2[i / SX_FRAME].q[md][i % SX_FRAME];
+            sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, q2, md, w->st.useMDIndex, &w->u.code.cdf, w->u.code.pulses, w->u.code.buf[md],
+                                &info[md]);
+        }
+    }
+    return sx_enc_stage_c_out(w, cin, w->u.code.buf[0], w->u.code.buf[1], info, bits, buf_size, nBytesOut);
+}
+#endif
 
 #if SX_NLANES == 1
 // Fused single-stream form (host emulation / debugging): A, quantiser for both frames, C

@@ -1235,10 +1235,14 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
                             int D, SxBurgWork* bw) {
     SX_IN_LDS(x); SX_IN_LDS(bw); SX_IN_LDS(A_Q16);
     const int QA = 25, MAX_RSHIFTS = 32 - 25, MIN_RSHIFTS = -16;
+    // (arguments of a real call arrive in vector registers: tell the compiler they are wave-uniform, so that the control flow below
+    // becomes scalar branches instead of exec-mask regions that run both sides)
+    subfr_length = SX_UNI(subfr_length); nb_subfr = SX_UNI(nb_subfr); D = SX_UNI(D); WhiteNoiseFrac_Q32 = SX_UNI(WhiteNoiseFrac_Q32);
     const int L = subfr_length;
     i32 C0, rshifts;
     SX_T_BEGIN
     sx_sum_sqr_shift_wv(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
+    C0 = SX_UNI(C0); rshifts = SX_UNI(rshifts);
     SX_T(23)
     if (rshifts > MAX_RSHIFTS) {
         C0 = sx_shl(C0, rshifts - MAX_RSHIFTS);
@@ -1255,6 +1259,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         }
         rshifts += rshifts_extra;
     }
+    C0 = SX_UNI(C0); rshifts = SX_UNI(rshifts);
     // first row of the correlation matrix: lane (s, n) computes one inner product serially
     SX_PAR(sn, nb_subfr * 16) {
         const int s = sn >> 4, n = (sn & 15) + 1;

@@ -45,9 +45,57 @@ __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_analysis_kernel)(SxEncStr
     SX_K(solo_enc_leave)(&w, rec);
 }
 
+// Entropy coding, LANE per description: lane l of workgroup g codes description (l & 1) of stream 32 g + (l >> 1).  The coder is a
+// serial chain of table look-ups and byte writes; 64 of them advance together.  rcbuf / rcinfo: the launch's scratch, indexed
+// [(stream * pc + (p - p0)) * 2 + md] -- consumed by the coding kernel that follows on the same HIP stream.
+struct SxRcWork {
+    SxCdf cdf;
+    u32 q[64][SX_RC_Q_ROW / 4];
+    u32 pw[64][SX_RC_PW_ROW / 4];
+};
+__global__ void __launch_bounds__(64) SX_K(solo_enc_rc_kernel)(const SxEncStream* states, const SxCodeIn* __restrict__ code_in,
+                                                               const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0, int pc,
+                                                               u8* __restrict__ rcbuf, SxRcInfo* __restrict__ rcinfo) {
+    __shared__ SxRcWork w;
+    for (int i = threadIdx.x; i < (int)(sizeof(SxCdf) / 4); i += 64) ((u32*)&w.cdf)[i] = 0;      // (padding entries)
+    __syncthreads();
+    {
+        SxCdf* c = &w.cdf;
+#define X(type, name, n) for (int i = threadIdx.x; i < (n); i += 64) c->name[i] = T_##name[i];
+        SX_CDF_LIST(X) SX_CDF_LIST_ENC(X)
+#undef X
+    }
+    __syncthreads();
+    const int lane = threadIdx.x, md = lane & 1;
+    const int s = blockIdx.x * 32 + (lane >> 1);
+    if (s >= n_streams) return;
+    const SxEncState* st = &states[s].core;
+    const int useDTX = st->useDTX, useMDIndex = st->useMDIndex;
+    for (int p = p0; p < p0 + pc; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const size_t slot = ((size_t)s * pc + (size_t)(p - p0)) * 2 + (size_t)md;
+        const SxCodeIn* cin = code_in + pk;
+        const SxNsqOut* out2 = nsq_out + pk * 2;
+        SxRcInfo info = {0, 0};
+        if (!(useDTX && cin->idx[1].inDTX)) {
+#pragma unroll
+            for (int f = 0; f < 2; f++) {
+                const u32* src = (const u32*)&out2[f].q[md][0];           // (4-byte aligned: SxNsqOut = {i32, i8[2][SX_FRAME], i32[]})
+#pragma unroll 8
+                for (int j = 0; j < SX_FRAME / 4; j++) w.q[lane][f * (SX_FRAME / 4) + j] = src[j];
+            }
+            sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, (const i8*)&w.q[lane][0], md, useMDIndex, &w.cdf, (u8*)&w.pw[lane][0],
+                                rcbuf + slot * SX_RC_BUF_STRIDE, &info);
+        }
+        rcinfo[slot] = info;
+    }
+}
+
+// High-band encoder and payload assembly, one wavefront per stream; the descriptions' bytes come from solo_enc_rc_kernel
 __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
                                                                 const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
-                                                                int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status) {
+                                                                int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status,
+                                                                const u8* __restrict__ rcbuf, const SxRcInfo* __restrict__ rcinfo) {
     __shared__ SxEncWork w;
     const int s = blockIdx.x;
     if (s >= n_streams) return;
@@ -56,7 +104,11 @@ __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStrea
     i32 first_err = 0;
     for (int p = p0; p < p0 + pc; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        i32 ret = sx_enc_stage_c(rec, &w, code_in + pk, nsq_out + pk * 2, bits + pk * (size_t)slot, slot, nbytes + pk * 2);
+        const size_t rs = ((size_t)s * pc + (size_t)(p - p0)) * 2;
+        sx_enc_stage_c_hb(rec, &w, code_in + pk, nsq_out + pk * 2);
+        wv_sync();
+        i32 ret = sx_enc_stage_c_out(&w, code_in + pk, rcbuf + rs * SX_RC_BUF_STRIDE, rcbuf + (rs + 1) * SX_RC_BUF_STRIDE, rcinfo + rs,
+                                     bits + pk * (size_t)slot, slot, nbytes + pk * 2);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
@@ -81,8 +133,10 @@ struct solo_enc_ops {
     hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s);
     hipError_t (*analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in, void* code_in, hipStream_t s);
     int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* ring, void* hip_stream);
+    // entropy coding of the descriptions (lane per description) into rc_scratch, then high band + payload assembly
     hipError_t (*coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc, int slot,
-                         uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s);
+                         uint8_t* bits, int16_t* nbytes, int32_t* status, void* rc_scratch, hipStream_t s);
+    size_t (*rc_scratch_bytes)(int n_streams, int pc);                   // scratch of one coding launch (pc packets per stream)
     int (*nsq_workgroups)(int n_streams);                                // workgroups of one quantiser launch (they count into the residency gate)
     size_t (*nsq_ring_bytes)(int n_streams);                             // emission-ring scratch of one quantiser launch
 };
@@ -97,12 +151,22 @@ static hipError_t SX_K(solo_enc_launch_analysis)(void* states, const int16_t* pc
                        (SxNsqIn*)nsq_in, (SxCodeIn*)code_in);
     return hipGetLastError();
 }
+// rc_scratch: [n_streams * pc * 2] byte buffers of SX_RC_BUF_STRIDE, then as many SxRcInfo
+static size_t SX_K(solo_enc_rc_scratch_bytes)(int n_streams, int pc) {
+    return (size_t)n_streams * (size_t)pc * 2 * (SX_RC_BUF_STRIDE + sizeof(SxRcInfo)) + 64;
+}
 static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc,
-                                               int slot, uint8_t* bits, int16_t* nbytes, int32_t* status, hipStream_t s) {
+                                               int slot, uint8_t* bits, int16_t* nbytes, int32_t* status, void* rc_scratch, hipStream_t s) {
+    u8* rcbuf = (u8*)rc_scratch;
+    SxRcInfo* rcinfo = (SxRcInfo*)(rcbuf + (((size_t)n_streams * (size_t)pc * 2 * SX_RC_BUF_STRIDE + 63) & ~(size_t)63));
+    hipLaunchKernelGGL(SX_K(solo_enc_rc_kernel), dim3((n_streams + 31) / 32), dim3(64), 0, s, (const SxEncStream*)states, (const SxCodeIn*)code_in,
+                       (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, rcbuf, rcinfo);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
     hipLaunchKernelGGL(SX_K(solo_enc_coding_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, (const SxCodeIn*)code_in,
-                       (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, slot, bits, nbytes, status);
+                       (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, slot, bits, nbytes, status, (const u8*)rcbuf, (const SxRcInfo*)rcinfo);
     return hipGetLastError();
 }
 static const solo_enc_ops SX_K(solo_enc_ops_table) = {
     sizeof(SxEncStream), sizeof(SxNsqIn), sizeof(SxNsqOut), sizeof(SxCodeIn), SX_PACKET,
-    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_nsq_workgroups), SX_K(solo_nsq_ring_bytes)};
+    SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_enc_rc_scratch_bytes), SX_K(solo_nsq_workgroups), SX_K(solo_nsq_ring_bytes)};

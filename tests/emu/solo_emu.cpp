@@ -77,7 +77,7 @@ int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
 const void* emu_enc_ctrl_ptr(void* h) { return &((EmuEnc*)h)->w.ctrl; }
 int emu_sizeof_enc_ctrl() { return (int)sizeof(SxEncCtrl); }
 const void* emu_enc_q_ptr(void* h) { return &((EmuEnc*)h)->rec.nsq_out[0].q[0][0]; }
-const void* emu_enc_idx_ptr(void* h) { return &((EmuEnc*)h)->w.idx[0]; }
+const void* emu_enc_idx_ptr(void* h) { return &((EmuEnc*)h)->cin.idx[0]; }
 const void* emu_enc_state_ptr(void* h) { return &((EmuEnc*)h)->rec; }
 }
 

@@ -22,6 +22,8 @@ for p in $PASSES; do
     sq)    ARGS="--pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_ANY SQ_WAIT_INST_ANY" ;;
     inst)  ARGS="--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" ;;
     lane)  ARGS="--pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES" ;;
+    icache) ARGS="--pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH" ;;
+    scalar) ARGS="--pmc SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_SMEM SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_WAVE_CYCLES" ;;
     *) echo "unknown pass $p"; continue ;;
   esac
   timeout -k 5 150 rocprofv3 $ARGS -d "$OUT/$p" -o r01 --output-format csv -- $CMD > "$OUT/bench_$p.log" 2>&1
