@@ -50,6 +50,11 @@ size_t solo_wb_dec_state_bytes();
 hipError_t solo_wb_dec_launch_init(void* states, int n_streams, int hb_joint, hipStream_t s);
 hipError_t solo_wb_dec_launch(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets, int slot,
                               int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
+hipError_t solo_wb_dec_launch_extract(const void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets,
+                                      int p0, int pc, int slot, int useMDIndex, void* recs, hipStream_t s);
+hipError_t solo_wb_dec_launch_synth(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets, int p0,
+                                    int pc, int slot, int useMDIndex, const void* recs, int16_t* pcm, int32_t* status, hipStream_t s);
+size_t solo_wb_dec_extracted_bytes();
 hipError_t solo_wb_dec_launch_split(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB, const int16_t* lenB, int n_streams,
                                     int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
 hipError_t solo_wb_dec_launch_raw(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm, int32_t* status,
@@ -77,6 +82,12 @@ struct solo_batch {
     const solo_enc_ops* eops;        // launch table of the build that matches the encoder's rate (solo_enc_kernels.h)
 #endif
     void* d_nsq_ring;                // emission-ring scratch of the quantiser launches (one launch group of streams; frame-local data)
+    // decoder pipeline: symbol extraction (stream sP) one chunk of packets ahead of the decoder proper (stream sS)
+    hipStream_t sP, sS;
+    hipEvent_t evDFork, evDJoin, evP[2], evS[2];
+    void* d_parsed[2];               // extraction records of the chunk being extracted / being decoded
+    size_t parsed_bytes;             // size of each
+    int dec_pipe_ready, dec_split, dec_chunk;
     void* d_rc_scratch;              // range-coder byte buffers of one coding launch (the launches of a call run in order on sC)
     size_t rc_scratch_bytes;
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
@@ -271,6 +282,16 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
 
 void solo_batch_destroy(solo_batch_t* b) {
     if (!b) return;
+    if (b->dec_pipe_ready && b->dec_split) {
+        (void)hipStreamSynchronize(b->sP); (void)hipStreamSynchronize(b->sS);
+        (void)hipStreamDestroy(b->sP); (void)hipStreamDestroy(b->sS);
+        (void)hipEventDestroy(b->evDFork); (void)hipEventDestroy(b->evDJoin);
+        for (int i = 0; i < 2; i++) { (void)hipEventDestroy(b->evP[i]); (void)hipEventDestroy(b->evS[i]); }
+    }
+    for (int i = 0; i < 2; i++) {
+        if (b->d_parsed[i]) (void)hipFree(b->d_parsed[i]);
+        b->d_parsed[i] = NULL;
+    }
     if (b->d_dec_state) (void)hipFree(b->d_dec_state);
     if (b->ev_ready) for (int i = 0; i < 6; i++) (void)hipEventDestroy(b->ev[i]);
     if (b->tev_ready) for (int k = 0; k < 3; k++) for (int c = 0; c < SOLO_MAX_CHUNKS; c++) for (int e = 0; e < 2; e++) (void)hipEventDestroy(b->tev[k][c][e]);
@@ -292,12 +313,77 @@ void solo_batch_destroy(solo_batch_t* b) {
 int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
                           int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
     const bool tm = b->timing && b->ev_ready;
-    if (tm) (void)hipEventRecord(b->ev[4], (hipStream_t)hip_stream);
-    const hipError_t e = (b->wb ? solo_wb_dec_launch : solo_dec_launch)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot,
-                                                                         b->dec_ctrl.useMDIndex, d_pcm, d_status, (hipStream_t)hip_stream);
-    if (tm) { (void)hipEventRecord(b->ev[5], (hipStream_t)hip_stream); b->ev_dec = 1; }
-    SOLO_CHECK(e);
+    if (!b->dec_pipe_ready) {
+        const char* e = getenv("SOLO_DEC_SPLIT");
+        b->dec_split = e ? atoi(e) : 1;
+        e = getenv("SOLO_DEC_CHUNK");
+        b->dec_chunk = e ? atoi(e) : 5;
+        if (b->dec_chunk <= 0) b->dec_chunk = 1 << 30;
+        if (b->dec_split) {
+            SOLO_CHECK(hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking));
+            SOLO_CHECK(hipStreamCreateWithFlags(&b->sS, hipStreamNonBlocking));
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evDFork, hipEventDisableTiming));
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evDJoin, hipEventDisableTiming));
+            for (int i = 0; i < 2; i++) {
+                SOLO_CHECK(hipEventCreateWithFlags(&b->evP[i], hipEventDisableTiming));
+                SOLO_CHECK(hipEventCreateWithFlags(&b->evS[i], hipEventDisableTiming));
+            }
+        }
+        b->dec_pipe_ready = 1;
+    }
+    if (tm) (void)hipEventRecord(b->ev[4], st);
+    if (!b->dec_split) {
+        // single kernel: one wavefront per stream parses (two lanes) and synthesises
+        const hipError_t e = (b->wb ? solo_wb_dec_launch : solo_dec_launch)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, b->slot,
+                                                                             b->dec_ctrl.useMDIndex, d_pcm, d_status, st);
+        if (tm) { (void)hipEventRecord(b->ev[5], st); b->ev_dec = 1; }
+        SOLO_CHECK(e);
+        return 0;
+    }
+    // Two kernels: the symbols of every description of a chunk of packets are read off the range coder at once, one lane each; the
+    // decoder proper (one wavefront per stream, packets in order) follows a chunk behind on a second stream; the records go through
+    // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
+    const int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
+    const int nchunks = (n_packets + cp - 1) / cp;
+    const size_t need = (size_t)b->n_streams * (size_t)cp * (b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes());
+    if (need > b->parsed_bytes) {
+        SOLO_CHECK(hipStreamSynchronize(st));
+        (void)hipStreamSynchronize(b->sP);
+        (void)hipStreamSynchronize(b->sS);
+        for (int i = 0; i < 2; i++) {
+            if (b->d_parsed[i]) (void)hipFree(b->d_parsed[i]);
+            b->d_parsed[i] = NULL;
+        }
+        b->parsed_bytes = 0;
+        for (int i = 0; i < 2; i++) SOLO_CHECK(hipMalloc(&b->d_parsed[i], need));
+        b->parsed_bytes = need;
+    }
+    SOLO_CHECK(hipEventRecord(b->evDFork, st));
+    SOLO_CHECK(hipStreamWaitEvent(b->sP, b->evDFork, 0));
+    SOLO_CHECK(hipStreamWaitEvent(b->sS, b->evDFork, 0));
+    hipError_t lerr = hipSuccess;
+    for (int c = 0; c < nchunks && lerr == hipSuccess; c++) {
+        const int p0 = c * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0, k = c & 1;
+        if (c >= 2) SOLO_CHECK(hipStreamWaitEvent(b->sP, b->evS[k], 0));
+        lerr = (b->wb ? solo_wb_dec_launch_extract : solo_dec_launch_extract)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, p0, pc,
+                                                                              b->slot, b->dec_ctrl.useMDIndex, b->d_parsed[k], b->sP);
+        if (lerr != hipSuccess) break;
+        SOLO_CHECK(hipEventRecord(b->evP[k], b->sP));
+        SOLO_CHECK(hipStreamWaitEvent(b->sS, b->evP[k], 0));
+        lerr = (b->wb ? solo_wb_dec_launch_synth : solo_dec_launch_synth)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, p0, pc, b->slot,
+                                                                          b->dec_ctrl.useMDIndex, b->d_parsed[k], d_pcm, d_status, b->sS);
+        if (lerr != hipSuccess) break;
+        SOLO_CHECK(hipEventRecord(b->evS[k], b->sS));
+    }
+    // join both internal streams back into the caller's (also after a refused launch: nothing stays forked)
+    (void)hipEventRecord(b->evDJoin, b->sP);
+    (void)hipStreamWaitEvent(st, b->evDJoin, 0);
+    (void)hipEventRecord(b->evDJoin, b->sS);
+    (void)hipStreamWaitEvent(st, b->evDJoin, 0);
+    if (tm) { (void)hipEventRecord(b->ev[5], st); b->ev_dec = 1; }
+    SOLO_CHECK(lerr);
     return 0;
 }
 

@@ -18,6 +18,15 @@ hipError_t solo_wb_dec_launch(void* states, const uint8_t* bits, const int16_t* 
                               int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
     return solo_dec_launch_wb(states, bits, nbytes, recv, n_streams, n_packets, slot, useMDIndex, pcm, status, s);
 }
+hipError_t solo_wb_dec_launch_extract(const void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets,
+                                      int p0, int pc, int slot, int useMDIndex, void* recs, hipStream_t s) {
+    return solo_dec_launch_extract_wb(states, bits, nbytes, recv, n_streams, n_packets, p0, pc, slot, useMDIndex, recs, s);
+}
+hipError_t solo_wb_dec_launch_synth(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams, int n_packets, int p0,
+                                    int pc, int slot, int useMDIndex, const void* recs, int16_t* pcm, int32_t* status, hipStream_t s) {
+    return solo_dec_launch_synth_wb(states, bits, nbytes, recv, n_streams, n_packets, p0, pc, slot, useMDIndex, recs, pcm, status, s);
+}
+size_t solo_wb_dec_extracted_bytes() { return solo_dec_extracted_bytes_wb(); }
 hipError_t solo_wb_dec_launch_split(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB, const int16_t* lenB, int n_streams,
                                     int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
     return solo_dec_launch_split_wb(states, descA, lenA, descB, lenB, n_streams, n_packets, slot, useMDIndex, pcm, status, s);

@@ -28,9 +28,9 @@
 #endif
 #define SX_TRACE(stage)                                                                            \
     do {                                                                                           \
-        if ((rc->error && st->dbg[0] == 0) || SX_TRACE_ALWAYS) {                                                        \
-            st->dbg[0] = (stage); st->dbg[1] = rc->error; st->dbg[2] = rc->bufferIx; st->dbg[3] = rc->bufferLength; \
-            st->dbg[4] = (i32)rc->range_Q16; st->dbg[5] = (i32)rc->base_Q32; st->dbg[6] = st->nFramesDecoded; st->dbg[7] = kDesp; \
+        if (dbg && ((rc->error && dbg[0] == 0) || SX_TRACE_ALWAYS)) {                                                   \
+            dbg[0] = (stage); dbg[1] = rc->error; dbg[2] = rc->bufferIx; dbg[3] = rc->bufferLength; \
+            dbg[4] = (i32)rc->range_Q16; dbg[5] = (i32)rc->base_Q32; dbg[6] = nFramesDecoded; dbg[7] = kDesp; \
         }                                                                                          \
     } while (0)
 
@@ -124,6 +124,24 @@ struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h
     i32 LTP_scale_Q14;
     i32 PERIndex, RateLevelIndex, QuantOffsetType, sigtype, MDIndex, NLSFInterpCoef_Q2;
 };
+// symbols of one 20 ms frame of one description, in coding order (sx_extract_parameters)
+struct SxFrameSyms {
+    i32 fs_bad;                      // the sampling-rate symbol named another internal rate: nothing after it was read
+    i32 MDIndex, typeOffset;
+    i32 GainsIndices[SX_NB_SUBFR], DeltaGainIndices;
+    i32 NLSFIndices[SX_NLSF_STAGES], NLSFInterpCoef_Q2;
+    i32 NLSF_Q15[SX_LPC];            // the frame's NLSF vector (codebook sum, stabilised): needs nothing but the indices
+    i32 lagIx, conIx, PERIndex, LTPIx[SX_NB_SUBFR], LTPscaleIx;
+    i32 Seed, RateLevelIndex;
+    i32 vadFlag, FrameTermination, left, error, bufferLength;     // after the frame: flags, bytes left, coder error, description length
+};
+// what the batch path's extraction kernel leaves for ONE description slot of one packet (HBM): see sx_extract_desc
+struct alignas(16) SxExtracted {
+    i32 usable;                      // both frames were read without a coder error and the symbols do not depend on the stream's history
+    i32 pad_[3];
+    SxFrameSyms y[2];
+    i16 pulses[2][SX_FRAME];
+};
 #define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
 // Phases of a packet reuse the same LDS (the decoder's occupancy is LDS-bound): see the lifetimes in the comments
 struct SxDecWork {
@@ -152,6 +170,12 @@ struct SxDecWork {
     i32 exc0_Q10[SX_FRAME];         // low-band excitation of frame 0 (frame 1's is still in st.exc_Q10) -> high-band regeneration
     i16 lo[SX_QMF_HIST + SX_BAND];  // [history | packet] low band
 };
+
+// the frame's symbols as read off the range coder, per description slot: they live in the tail of the frame scratch until they are
+// de-quantised (the head holds the NLSF vectors and the pulse decoder's scratch at that time)
+#define SX_SYMS_AT (SX_FRAME - 2 * (int)(sizeof(SxFrameSyms) / 4))
+static_assert(SX_SYMS_AT >= 4 * SX_LPC + 4 * (SX_FRAME / 16), "frame scratch too small for the symbol records");
+SX_HD SxFrameSyms* sx_dec_syms(SxDecWork* w, int md) { return (SxFrameSyms*)&w->res_Q10[SX_SYMS_AT] + md; }
 
 // SKP_Silk_init_decoder + first decoder_set_fs(8) folded together (create_init_destroy.c:34,
 // decoder_set_fs.c:31).  The reference starts at 24 kHz and switches to 8 kHz when the first
@@ -187,7 +211,8 @@ SX_HD void sx_gains_dequant(i32* gain_Q16, const i32* ind, i32* prev_ind, int co
 }
 
 // decode_split + SKP_Silk_shell_decoder, SKP_Silk_shell_coder.c:59-155 (scalars stay in registers)
-SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* table, const SxCdf* cdf) {
+template <typename RC>
+SX_HD void sx_shell_split(i32* c1, i32* c2, RC* rc, i32 p, const u16* table, const SxCdf* cdf) {
     if (p > 0) {
         *c1 = sx_rc_dec(rc, &table[cdf->shell_offsets[p]], p >> 1);
         *c2 = p - *c1;
@@ -196,7 +221,8 @@ SX_HD void sx_shell_split(i32* c1, i32* c2, SxRangeDec* rc, i32 p, const u16* ta
         *c2 = 0;
     }
 }
-SX_HD void sx_shell_decoder(i16* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cdf) {
+template <typename RC>
+SX_HD void sx_shell_decoder(i16* q, RC* rc, i32 pulses4, const SxCdf* cdf) {
     i32 p3[2], p2[4], p1[8], a, b;
     sx_shell_split(&p3[0], &p3[1], rc, pulses4, cdf->cdf_shell3, cdf);
     sx_shell_split(&p2[0], &p2[1], rc, p3[0], cdf->cdf_shell2, cdf);
@@ -217,12 +243,14 @@ SX_HD void sx_shell_decoder(i16* q, SxRangeDec* rc, i32 pulses4, const SxCdf* cd
 
 // SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64).
 // tmp: 2 * SX_FRAME/16 words of per-description scratch (LDS)
-SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i16* q, const SxCdf* cdf, i32* tmp) {
-    SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
+// returns the rate level index
+template <typename RC>
+SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, i16* q, const SxCdf* cdf, i32* tmp) {
+    SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
     const int iter = SX_FRAME / 16;
     i32 *sum_pulses = tmp, *nLshifts = tmp + SX_FRAME / 16;
-    c->RateLevelIndex = sx_rc_dec(rc, &cdf->cdf_rate_levels[c->sigtype * 10], T_CDF_MID_RATE_LEVELS);
-    const u16* cdf_ptr = &cdf->cdf_pulses_per_block[c->RateLevelIndex * 21];
+    const i32 RateLevelIndex = sx_rc_dec(rc, &cdf->cdf_rate_levels[sigtype * 10], T_CDF_MID_RATE_LEVELS);
+    const u16* cdf_ptr = &cdf->cdf_pulses_per_block[RateLevelIndex * 21];
     for (int i = 0; i < iter; i++) {
         i32 nl = 0;
         i32 sp = sx_rc_dec(rc, cdf_ptr, T_CDF_MID_PULSES_PER_BLOCK);
@@ -256,7 +284,7 @@ SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i16* q, const SxCdf* c
         }
     }
     // signs
-    const u32 p_sign = cdf->cdf_sign[sx_smulbb(10 - 1, (c->sigtype << 1) + c->QuantOffsetType) + c->RateLevelIndex];
+    const u32 p_sign = cdf->cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
     for (int i = 0; i < SX_FRAME; i++) {
         const i32 v = q[i];
         if (v > 0) {
@@ -264,6 +292,7 @@ SX_HD void sx_decode_pulses(SxRangeDec* rc, SxDecCtrl* c, i16* q, const SxCdf* c
             q[i] = (i16)(v * ((data << 1) - 1));
         }
     }
+    return RateLevelIndex;
 }
 
 // SKP_Silk_NLSF_MSVQ_decode, SKP_Silk_NLSF_MSVQ_decode.c:31 (order 10, 6 stages); codebook / spacing table wherever the caller keeps them
@@ -285,108 +314,156 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
                            sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15);
 }
 
-// SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz)
-// The range-coder state is worked on in registers (local copy); the NLSF vectors (interpolated / final) are handed back in
-// nlsf_out[2][SX_LPC] -- their conversion to prediction coefficients only matters for the description that is used and is done
-// by the caller; tmp = per-description scratch of sx_decode_pulses (all LDS).
-SX_FN void sx_decode_parameters(SxDecState* st, SxDecCtrl* c, SxRangeDec* rc_io, i16* q, int kDesp, int useMDIndex, const SxCdf* cdf,
-                                i32* lane_out, i32* nlsf_out, i32* tmp) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp);
-    SxRangeDec rc_local = *rc_io;
-    SxRangeDec* rc = &rc_local;
-    i32 Ix, GainsIndices[SX_NB_SUBFR], NLSFIndices[SX_NLSF_STAGES], DeltaGainIndices;
-    i32 *pNLSF0_Q15 = nlsf_out, *pNLSF_Q15 = nlsf_out + SX_LPC;
-    SxDecDesc* md = &st->md[kDesp];
-    if (st->nFramesDecoded == 0) {
-        if (useMDIndex == 1) c->MDIndex = sx_rc_dec(rc, cdf->cdf_mdindex, T_CDF_MID_MDINDEX);
+// SKP_Silk_decode_parameters, SKP_Silk_decode_parameters.c:31 (fullDecoding = 1, fs pinned to 8 kHz), in two steps:
+//   sx_extract_parameters   reads the frame's symbols off the range coder, in coding order, into SxFrameSyms (+ the pulses).  Which
+//                           tables it uses depends only on symbols of the same packet (signal type, PER index, the previous frame's
+//                           type of the SAME packet), never on the decoder's history: the packets of a stream can be extracted
+//                           independently of each other (sx_extract_desc, the batch path's extraction kernel).
+//   sx_dequant_parameters   turns the symbols into the control block: gains (running index), NLSF vectors (interpolated with the
+//                           previous frame's), pitch lags, LTP taps -- the part that needs the description's history.
+// The reference interleaves the two; no symbol read depends on the arithmetic in between, and after a range-coder error every
+// later symbol reads as 0 either way, so the control block and the state come out the same.
+// typeOffsetPrev: signal type / offset symbol of the packet's previous frame (read when nFramesDecoded != 0, always written);
+// q / tmp: pulses and pulse-decoder scratch (LDS); dbg: first-failure trace record or NULL
+template <typename RC>
+SX_HD void sx_extract_parameters(int nFramesDecoded, i32* typeOffsetPrev, i32* dbg, RC* rc_io, i16* q, int kDesp, int useMDIndex, const SxCdf* cdf,
+                                 SxFrameSyms* y, i32* tmp) {
+    SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
+    RC rc_local = *rc_io;
+    RC* rc = &rc_local;
+    i32 Ix;
+    y->fs_bad = 0;
+    y->MDIndex = 0;
+    if (nFramesDecoded == 0) {
+        if (useMDIndex == 1) y->MDIndex = sx_rc_dec(rc, cdf->cdf_mdindex, T_CDF_MID_MDINDEX);
         Ix = sx_rc_dec(rc, cdf->cdf_fs, T_CDF_MID_FS);
         if (Ix != (SX_FS_KHZ == 8 ? 0 : 2)) {  // index into {8, 12, 16, 24} kHz: this build decodes ONE internal rate (reference: decoder_set_fs)
             if (!rc->error) rc->error = SX_RC_ILLEGAL_SAMPLING_RATE;
-            lane_out[3] = rc->error;
+            y->fs_bad = 1;
+            y->error = rc->error;
+            y->bufferLength = rc->bufferLength;
             *rc_io = rc_local;
             return;
         }
         Ix = sx_rc_dec(rc, cdf->cdf_type_offset, T_CDF_MID_TYPE_OFFSET);
     } else {
-        Ix = sx_rc_dec(rc, &cdf->cdf_type_offset_joint[md->typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
+        Ix = sx_rc_dec(rc, &cdf->cdf_type_offset_joint[*typeOffsetPrev * 5], T_CDF_MID_TYPE_OFFSET);
     }
     SX_TRACE(1);
-    c->sigtype = Ix >> 1;
-    c->QuantOffsetType = Ix & 1;
-    md->typeOffsetPrev = Ix;
+    y->typeOffset = Ix;
+    *typeOffsetPrev = Ix;
+    const int sigtype = Ix >> 1, QuantOffsetType = Ix & 1;
 
-    if (st->nFramesDecoded == 0) GainsIndices[0] = sx_rc_dec(rc, &cdf->cdf_gain[c->sigtype * 65], T_CDF_MID_GAIN);
-    else GainsIndices[0] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
-    for (int i = 1; i < SX_NB_SUBFR; i++) GainsIndices[i] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
-    if (st->nFramesDecoded == 0) {
-        DeltaGainIndices = sx_rc_dec(rc, cdf->cdf_md_delta_gain, T_CDF_MID_MD_DELTA_GAIN);
-        md->prevDeltaGainIndex = DeltaGainIndices;
-    } else {
-        DeltaGainIndices = md->prevDeltaGainIndex;
-    }
+    if (nFramesDecoded == 0) y->GainsIndices[0] = sx_rc_dec(rc, &cdf->cdf_gain[sigtype * 65], T_CDF_MID_GAIN);
+    else y->GainsIndices[0] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    for (int i = 1; i < SX_NB_SUBFR; i++) y->GainsIndices[i] = sx_rc_dec(rc, cdf->cdf_delta_gain, T_CDF_MID_DELTA_GAIN);
+    y->DeltaGainIndices = 0;
+    if (nFramesDecoded == 0) y->DeltaGainIndices = sx_rc_dec(rc, cdf->cdf_md_delta_gain, T_CDF_MID_MD_DELTA_GAIN);
     SX_TRACE(2);
-    sx_gains_dequant(c->Gains_Q16, GainsIndices, &md->LastGainIndex, st->nFramesDecoded, DeltaGainIndices, &c->DeltaGains_Q16);
-
     // NLSF path: 6 stages, per-stage CDFs laid out back to back (nvec+1 entries each)
     {
         const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
-        const i32* nvec = c->sigtype == 0 ? nvec0 : nvec1;
-        const u16* ncdf = c->sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
-        const i32* mid = c->sigtype == 0 ? T_nlsf_cb0_cdf_mid : T_nlsf_cb1_cdf_mid;
+        const i32* nvec = sigtype == 0 ? nvec0 : nvec1;
+        const u16* ncdf = sigtype == 0 ? cdf->nlsf_cb0_cdf : cdf->nlsf_cb1_cdf;
+        const i32* mid = sigtype == 0 ? T_nlsf_cb0_cdf_mid : T_nlsf_cb1_cdf_mid;
         int off = 0;
         for (int s = 0; s < SX_NLSF_STAGES; s++) {
-            NLSFIndices[s] = sx_rc_dec(rc, ncdf + off, mid[s]);
+            y->NLSFIndices[s] = sx_rc_dec(rc, ncdf + off, mid[s]);
             off += nvec[s] + 1;
         }
     }
     SX_TRACE(3);
-    sx_nlsf_msvq_decode(pNLSF_Q15, c->sigtype, NLSFIndices);
-    c->NLSFInterpCoef_Q2 = sx_rc_dec(rc, cdf->cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
-    if (st->first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
+    sx_nlsf_msvq_decode(y->NLSF_Q15, sigtype, y->NLSFIndices);
+    y->NLSFInterpCoef_Q2 = sx_rc_dec(rc, cdf->cdf_nlsf_interp, T_CDF_MID_NLSF_INTERP);
+    y->lagIx = y->conIx = y->PERIndex = y->LTPscaleIx = 0;
+    for (int k = 0; k < SX_NB_SUBFR; k++) y->LTPIx[k] = 0;
+    if (sigtype == 0) {
+        y->lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag, T_CDF_MID_PITCH_LAG);
+        y->conIx = sx_rc_dec(rc, cdf->cdf_pitch_contour, T_CDF_MID_PITCH_CONTOUR);
+        y->PERIndex = sx_rc_dec(rc, cdf->cdf_ltp_per, T_CDF_MID_LTP_PER);
+        const u16* gcdf = y->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (y->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
+        for (int k = 0; k < SX_NB_SUBFR; k++) y->LTPIx[k] = sx_rc_dec(rc, gcdf, T_cdf_mid_ltp_gain[y->PERIndex]);
+        y->LTPscaleIx = sx_rc_dec(rc, cdf->cdf_ltpscale, T_CDF_MID_LTPSCALE);
+    }
+    SX_TRACE(4);
+    y->Seed = sx_rc_dec(rc, cdf->cdf_seed, T_CDF_MID_SEED);
+    SX_TRACE(5);
+    y->RateLevelIndex = sx_decode_pulses(rc, sigtype, QuantOffsetType, q, cdf, tmp);
+    SX_TRACE(6);
+    y->vadFlag = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
+    y->FrameTermination = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
 
+    i32 nBytesUsed;
+    sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytesUsed);
+    const i32 left = rc->bufferLength - nBytesUsed;
+    y->left = left;
+    if (left < 0) rc->error = SX_RC_READ_BEYOND_BUFFER;
+    if (left == 0) sx_rc_check_after_decoding(rc);
+    y->error = rc->error;
+    y->bufferLength = rc->bufferLength;
+    SX_TRACE(7);
+    *rc_io = rc_local;
+}
+
+// md: the state of the description slot being decoded; c: its control block; lane_out: {vadFlag, FrameTermination, bytes left, coder
+// error}; nlsf_out[2][SX_LPC]: interpolated / final NLSF vector -- their conversion to prediction coefficients only matters for the
+// description that is used and is done by the caller (all LDS)
+SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int first_frame_after_reset, int useMDIndex, SxDecDesc* md, SxDecCtrl* c,
+                                 i32* lane_out, i32* nlsf_out) {
+    SX_IN_LDS(y); SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out);
+    if (y->fs_bad) { lane_out[3] = y->error; return; }
+    i32 *pNLSF0_Q15 = nlsf_out, *pNLSF_Q15 = nlsf_out + SX_LPC;
+    if (nFramesDecoded == 0 && useMDIndex == 1) c->MDIndex = y->MDIndex;
+    c->sigtype = y->typeOffset >> 1;
+    c->QuantOffsetType = y->typeOffset & 1;
+    md->typeOffsetPrev = y->typeOffset;
+    i32 DeltaGainIndices;
+    if (nFramesDecoded == 0) {
+        DeltaGainIndices = y->DeltaGainIndices;
+        md->prevDeltaGainIndex = DeltaGainIndices;
+    } else {
+        DeltaGainIndices = md->prevDeltaGainIndex;
+    }
+    sx_gains_dequant(c->Gains_Q16, y->GainsIndices, &md->LastGainIndex, nFramesDecoded, DeltaGainIndices, &c->DeltaGains_Q16);
+    for (int i = 0; i < SX_LPC; i++) pNLSF_Q15[i] = y->NLSF_Q15[i];
+    c->NLSFInterpCoef_Q2 = y->NLSFInterpCoef_Q2;
+    if (first_frame_after_reset == 1) c->NLSFInterpCoef_Q2 = 4;
     if (c->NLSFInterpCoef_Q2 < 4) {
         for (int i = 0; i < SX_LPC; i++)
             pNLSF0_Q15[i] = md->prevNLSF_Q15[i] + (sx_mul(c->NLSFInterpCoef_Q2, pNLSF_Q15[i] - md->prevNLSF_Q15[i]) >> 2);
     }
     for (int i = 0; i < SX_LPC; i++) md->prevNLSF_Q15[i] = pNLSF_Q15[i];
-
     if (c->sigtype == 0) {
-        i32 lagIx = sx_rc_dec(rc, cdf->cdf_pitch_lag, T_CDF_MID_PITCH_LAG);
-        i32 conIx = sx_rc_dec(rc, cdf->cdf_pitch_contour, T_CDF_MID_PITCH_CONTOUR);
-        i32 lag = 2 * SX_FS_KHZ + lagIx;   // SKP_Silk_decode_pitch.c:43-58 (8 kHz: stage-2 contours, above: stage-3 contours)
-        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_dec[i * SX_PITCH_CB_N + conIx];
-        c->PERIndex = sx_rc_dec(rc, cdf->cdf_ltp_per, T_CDF_MID_LTP_PER);
+        const i32 lag = 2 * SX_FS_KHZ + y->lagIx;   // SKP_Silk_decode_pitch.c:43-58 (8 kHz: stage-2 contours, above: stage-3 contours)
+        for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = lag + T_pitch_cb_dec[i * SX_PITCH_CB_N + y->conIx];
+        c->PERIndex = y->PERIndex;
         const i16* cbk = c->PERIndex == 0 ? T_ltp_vq0_Q14 : (c->PERIndex == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
-        const u16* gcdf = c->PERIndex == 0 ? cdf->cdf_ltp_gain0 : (c->PERIndex == 1 ? cdf->cdf_ltp_gain1 : cdf->cdf_ltp_gain2);
         for (int k = 0; k < SX_NB_SUBFR; k++) {
-            Ix = sx_rc_dec(rc, gcdf, T_cdf_mid_ltp_gain[c->PERIndex]);
+            const i32 Ix = y->LTPIx[k];
             for (int i = 0; i < SX_LTP_ORDER; i++) c->LTPCoef_Q14[k * SX_LTP_ORDER + i] = cbk[Ix * SX_LTP_ORDER + i];
         }
-        Ix = sx_rc_dec(rc, cdf->cdf_ltpscale, T_CDF_MID_LTPSCALE);
-        c->LTP_scale_Q14 = T_ltp_scales_Q14[Ix];
+        c->LTP_scale_Q14 = T_ltp_scales_Q14[y->LTPscaleIx];
     } else {
         for (int i = 0; i < SX_NB_SUBFR; i++) c->pitchL[i] = 0;
         for (int i = 0; i < SX_LTP_ORDER * SX_NB_SUBFR; i++) c->LTPCoef_Q14[i] = 0;
         c->PERIndex = 0;
         c->LTP_scale_Q14 = 0;
     }
-    SX_TRACE(4);
-    c->Seed = sx_rc_dec(rc, cdf->cdf_seed, T_CDF_MID_SEED);
-    SX_TRACE(5);
-    sx_decode_pulses(rc, c, q, cdf, tmp);
-    SX_TRACE(6);
-    lane_out[0] = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
-    lane_out[1] = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
+    c->Seed = y->Seed;
+    c->RateLevelIndex = y->RateLevelIndex;
+    lane_out[0] = y->vadFlag;
+    lane_out[1] = y->FrameTermination;
+    lane_out[2] = y->left;
+    lane_out[3] = y->error;
+}
 
-    i32 nBytesUsed;
-    sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytesUsed);
-    i32 left = rc->bufferLength - nBytesUsed;
-    lane_out[2] = left;
-    if (left < 0) rc->error = SX_RC_READ_BEYOND_BUFFER;
-    if (left == 0) sx_rc_check_after_decoding(rc);
-    lane_out[3] = rc->error;
-    SX_TRACE(7);
-    *rc_io = rc_local;
+// the two steps in a row for one description slot of the wave-per-stream decoder (a real call: two call sites per kernel)
+SX_FN void sx_decode_parameters(int nFramesDecoded, int first_frame_after_reset, SxDecDesc* md, i32* dbg, SxDecCtrl* c, SxRangeDec* rc_io,
+                                i16* q, int kDesp, int useMDIndex, const SxCdf* cdf, i32* lane_out, i32* nlsf_out, i32* tmp, SxFrameSyms* y) {
+    SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp); SX_IN_LDS(y);
+    i32 top = md->typeOffsetPrev;
+    sx_extract_parameters(nFramesDecoded, &top, dbg, rc_io, q, kDesp, useMDIndex, cdf, y, tmp);
+    sx_dequant_parameters(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
 }
 
 // SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
@@ -771,8 +848,10 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
 // One 20 ms low-band frame: SKP_Silk_SDK_Decode + SKP_Silk_decode_frame + AgoraSateDecodeTwoDesps.
 // rc[] persists across the two frames of a packet.  Returns 0, or a negative SILK error code
 // (SKP_Silk_errors.h) on a corrupt payload.
+// pre2: NULL = read the symbols off the range coder here (description md on lane md); else the records of the packet's description
+// slots from the extraction kernel, frame f of which holds this frame's symbols (the caller has checked that they can be used)
 SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
-                               i32 nB0, i32 nB1, int useMDIndex, i16* pOut) {
+                               i32 nB0, i32 nB1, int useMDIndex, i16* pOut, const SxExtracted* pre2 = 0, int f = 0) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(pOut);
     int ret = 0;
     SxDecCtrl* c = &w->ctrl;
@@ -825,17 +904,37 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             }
             wv_sync();
         }
+        if (pre2) {
+            // the symbols were read ahead (and do not depend on the bytes behind the description): stage them where the serial
+            // path would have put them
+            for (int d = 0; d < ndesc; d++) {
+                const i32* sy = (const i32*)&pre2[d].y[f];
+                i32* dy = (i32*)sx_dec_syms(w, d);
+                SX_PAR(i, (int)(sizeof(SxFrameSyms) / 4)) dy[i] = sy[i];
+                const i32* sq = (const i32*)&pre2[d].pulses[f][0];
+                i32* dq = (i32*)&w->u.parse.pulses[d][0];
+                SX_PAR(i, SX_FRAME / 2) dq[i] = sq[i];
+            }
+            wv_sync();
+        }
         // the two descriptions are independent range-coded streams: description md is parsed by lane md
         SX_PAR(md, ndesc) {
             SxRangeDec* r = &rc[SX_NLANES == 1 ? md : 0];
-            if (st->nFramesDecoded == 0) {
-                r->tail = tails[md];
-                if (md == 0) sx_rc_dec_init(r, payload, nB0);
-                else sx_rc_dec_init(r, payload + nB0, nB1);
+            if (pre2) {
+                sx_dequant_parameters(sx_dec_syms(w, md), st->nFramesDecoded, st->first_frame_after_reset, useMDIndex, &st->md[md], &w->u.parse.ctrl2[md],
+                                      w->u.parse.lane_out[md], &w->res_Q10[md * 2 * SX_LPC]);
+                w->u.parse.lane_len[md] = sx_dec_syms(w, md)->bufferLength;
+            } else {
+                if (st->nFramesDecoded == 0) {
+                    r->tail = tails[md];
+                    if (md == 0) sx_rc_dec_init(r, payload, nB0);
+                    else sx_rc_dec_init(r, payload + nB0, nB1);
+                }
+                sx_decode_parameters(st->nFramesDecoded, st->first_frame_after_reset, &st->md[md], st->dbg, &w->u.parse.ctrl2[md], r, w->u.parse.pulses[md],
+                                     md, useMDIndex, (const SxCdf*)&w->cdf, w->u.parse.lane_out[md], &w->res_Q10[md * 2 * SX_LPC],
+                                     &w->res_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)], sx_dec_syms(w, md));
+                w->u.parse.lane_len[md] = r->bufferLength;
             }
-            sx_decode_parameters(st, &w->u.parse.ctrl2[md], r, w->u.parse.pulses[md], md, useMDIndex, (const SxCdf*)&w->cdf, w->u.parse.lane_out[md],
-                                 &w->res_Q10[md * 2 * SX_LPC], &w->res_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)]);
-            w->u.parse.lane_len[md] = r->bufferLength;
         }
         wv_sync();
         SX_T(0)
@@ -1060,8 +1159,23 @@ SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
 //   lostflag 3: bits = MD2|HB,     nBytes0 = len(MD2)+8, nBytes1 = 0
 //   lostflag 1: packet lost (bits ignored)
 // Returns 0 / -1 / negative SILK code like the reference.
+// ext2: NULL, or the records of the packet's two description slots from the extraction kernel (batch path): used when the packet
+// is an ordinary one -- see sx_extracted_usable; otherwise the symbols are read here, serially, like without them.
+SX_HD bool sx_extracted_usable(const SxDecState* st, const SxExtracted* ext2, int lostflag) {
+    if (!ext2 || lostflag < 2) return false;
+    // the packet starts a new range-coder buffer (no frames left over from a payload that announced more than it carried)
+    if (SX_UNI(st->moreInternalDecoderFrames) != 0) return false;
+    const int ndesc = lostflag == 4 ? 2 : 1;
+    if (!SX_UNI(ext2[0].usable) || (ndesc > 1 && !SX_UNI(ext2[1].usable))) return false;
+    // ... and has the ordinary structure: frame 0 announces one more frame and leaves bytes for it, frame 1 is the last one
+    // (SKP_Silk_dec_API.c:125-150; nFramesDecoded is 1 / 2 at these points)
+    const SxExtracted* last = &ext2[ndesc - 1];
+    const bool more0 = SX_UNI(ext2[0].y[0].left) > 0 && SX_UNI(last->y[0].FrameTermination) == 1;
+    const bool more1 = SX_UNI(ext2[0].y[1].left) > 0 && SX_UNI(last->y[1].FrameTermination) == 1;
+    return more0 && !more1;
+}
 SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes1, int lostflag,
-                           int useMDIndex, i16* pcm_out) {
+                           int useMDIndex, i16* pcm_out, const SxExtracted* ext2 = 0) {
     SxDecState* st = &w->st;
     if (nBytes0 <= 0) return -1;
     const i32 hb_bytes = st->hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;     // (QMF_HB_FrameSize / BWE_FrameSize) * HB_BYTE
@@ -1086,7 +1200,8 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         rc[d].base_Q32 = m->rc_base_Q32; rc[d].range_Q16 = m->rc_range_Q16; rc[d].tail = m->rc_tail;
     }
     // the payload is read byte by byte by a serial coder: stage it in LDS
-    if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS) {
+    const SxExtracted* pre2 = sx_extracted_usable(st, ext2, lostflag) ? ext2 : 0;
+    if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS && !pre2) {
         SX_PAR(i, nBytes0) w->payload[i] = bits[i];
         bits = w->payload;
     }
@@ -1101,7 +1216,7 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     SX_PAR(i, SX_QMF_HIST) w->lo[i] = st->qmf_lo_hist[i];
     wv_sync();
     for (int f = 0; f < 2; f++) {
-        int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME]);
+        int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME], pre2, f);
         wv_sync();
 #if SX_NLANES == 1
         for (int d = 0; d < 2; d++) {
@@ -1128,4 +1243,65 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->u.hi[SX_BAND + i]; }
     wv_sync();
     return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------
+// Batch path, step 1: the symbols of ONE description slot of ONE packet, read ahead of the serial decoder by the extraction kernel
+// (one lane each: every description of every packet of the call at once).  The lane has the description's bytes and nothing else
+// -- not the stream's history -- so it decodes with the interval form of the range decoder (solo_rc.h, SxRangeDec2) and marks the
+// record usable only if both frames came out without a coder error and without depending on what lies behind the description.
+// ---------------------------------------------------------------------------------------------------
+#define SX_EXTRACT_PAY 128           // descriptions up to SX_EXTRACT_PAY - 4 bytes are staged in LDS; longer ones are read from HBM
+struct SxExtractLane {               // LDS, one lane (an odd number of dwords: the lanes of a wavefront sit at the same offset of
+    i32 tmp[2 * (SX_FRAME / 16)];    // their own copy most of the time)
+    i16 pulses[SX_FRAME];
+    u32 pay[SX_EXTRACT_PAY / 4];
+    i32 pad_[1 + (2 * (SX_FRAME / 16) + SX_FRAME / 2 + SX_EXTRACT_PAY / 4) % 2];
+};
+static_assert(sizeof(SxExtractLane) % 4 == 0 && (sizeof(SxExtractLane) / 4) % 2 == 1, "odd dword stride");
+
+// where description slot md of a packet handed over as (nBytes0, nBytes1, lostflag) lies (see sx_decode_packet); false: no such slot
+SX_HD bool sx_desc_span(int lostflag, i32 nBytes0, i32 nBytes1, int hb_joint, int md, i32* off, i32* len) {
+    if (lostflag < 2 || nBytes0 <= 0) return false;
+    const i32 hb_bytes = hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - hb_bytes;
+    const i32 nB1 = nBytes1 ? nBytes1 - hb_bytes : 0;
+    nB0 -= nB1;
+    if (md >= (lostflag == 4 ? 2 : 1)) return false;
+    *off = md == 0 ? 0 : nB0;
+    *len = md == 0 ? nB0 : nB1;
+    return true;
+}
+
+// src: the description's bytes inside the packet (HBM), len of them
+SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* cdf, SxExtractLane* L, SxExtracted* rec) {
+    rec->usable = 0;
+    if (len <= 0 || len > SX_MAX_ARITHM_BYTES) return;           // (the serial decoder reports what is wrong with it)
+    if (len <= SX_EXTRACT_PAY - 4) {
+        // aligned dwords from the packet, re-aligned, into the lane's LDS copy
+        const u32 a0 = (u32)((size_t)src & 3), sh8 = a0 * 8;
+        const u32* s4 = (const u32*)(src - a0);
+        const int ldw = (int)((a0 + (u32)len - 1) >> 2);          // last dword that holds a byte of the description
+        const int nd = (len + 3) >> 2;
+        u32 cur = s4[0];
+        for (int i = 0; i < nd; i++) {
+            const u32 nxt = s4[i + 1 <= ldw ? i + 1 : ldw];
+            L->pay[i] = sh8 ? ((cur >> sh8) | (nxt << (32 - sh8))) : cur;
+            cur = nxt;
+        }
+        src = (const u8*)&L->pay[0];
+    }
+    SxRangeDec2 r;
+    sx_rc_dec_init(&r, src, len);
+    i32 top = 0;
+    i32* dbg = 0;
+    for (int f = 0; f < 2; f++) {
+        SxFrameSyms y;
+        sx_extract_parameters(f, &top, dbg, &r, L->pulses, 0, useMDIndex, cdf, &y, L->tmp);
+        { const i32* sy = (const i32*)&y; i32* dy = (i32*)&rec->y[f]; for (int i = 0; i < (int)(sizeof(SxFrameSyms) / 4); i++) dy[i] = sy[i]; }
+        if (y.fs_bad || y.error) return;
+        { const i32* sq = (const i32*)&L->pulses[0]; i32* dq = (i32*)&rec->pulses[f][0]; for (int i = 0; i < SX_FRAME / 2; i++) dq[i] = sq[i]; }
+    }
+    rec->usable = r.ambiguous ? 0 : 1;
 }

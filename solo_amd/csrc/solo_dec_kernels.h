@@ -29,6 +29,34 @@ __device__ __forceinline__ void SX_K(solo_dec_leave)(SxDecWork* w, SxDecStream* 
     SX_PAR(i, (int)(sizeof(SxDecState) / 4)) dst[i] = src[i];
 }
 
+// One (bits, nbytes, recv) record of the batched API -> the reference's (pointer, nBytes[2], lostflag) calling convention.
+struct SxDecArgs { int lostflag, bad; i32 a0, a1, ptr_off; };
+SX_HD SxDecArgs sx_dec_map_record(i32 n0, i32 n1, int slot, int recv_mask, int hb_joint) {
+    // The lengths come from the network: a record that does not describe two descriptions inside its own slot
+    // (0 <= len(MD2)+HB <= total <= slot, MD2 carrying at least its high-band bytes) is never dereferenced; the packet is
+    // concealed as lost and the stream's status reports SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11) / _PAYLOAD_ERROR (-12).
+    const int hbb = hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    SxDecArgs r;
+    r.bad = 0;
+    if (n0 > slot) r.bad = -11;
+    else if (n0 > 0 && (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb))) r.bad = -12;
+    if (r.bad) { n0 = 0; n1 = 0; }
+    // DELIBERATE CONVENTION of the batched API (not reference behaviour): an EMPTY record (n0 <= 0, e.g. a DTX packet that
+    // was never sent) is concealed like a lost packet, i.e. decoded with lostflag = 1.  The reference library itself returns
+    // -1 for nBytes[0] <= 0 without touching its state (AGR_BWE_SDK_API.c:266) and its CLI then writes the previous output
+    // buffer again (test/dec_main.c:365-381); the legacy AGR_Sate_Decoder_Decode symbol of this library keeps that behaviour.
+    const int m = n0 <= 0 ? 0 : (recv_mask & 3);
+    // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
+    r.ptr_off = 0;
+    if (m == 3) { r.lostflag = 4; r.a0 = n0; r.a1 = n1; }
+    else if (m == 1) { r.lostflag = 2; r.a0 = n0 - n1; r.a1 = 0; }
+    else if (m == 2) { r.lostflag = 3; r.ptr_off = n0 - n1; r.a0 = n1; r.a1 = 0; }
+    else { r.lostflag = 1; r.a0 = n0 > 0 ? n0 : 16; r.a1 = n0 > 0 ? n1 : 0; }
+    if (r.lostflag == 2 && r.a0 <= 0) { r.lostflag = 1; r.a0 = 16; r.a1 = 0; r.ptr_off = 0; }          // nothing but the second description in the record
+    if (r.lostflag == 3 && r.a0 <= hbb) { r.lostflag = 1; r.a0 = 16; r.a1 = 0; r.ptr_off = 0; }
+    return r;
+}
+
 __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* states, const u8* __restrict__ bits,
                                                          const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                          int n_streams, int n_packets, int slot, int useMDIndex,
@@ -40,31 +68,10 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* s
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        const u8* b = bits + pk * (size_t)slot;
-        i32 n0 = nbytes[pk * 2 + 0], n1 = nbytes[pk * 2 + 1];
-        // The lengths come from the network: a record that does not describe two descriptions inside its own slot
-        // (0 <= len(MD2)+HB <= total <= slot, MD2 carrying at least its high-band bytes) is never dereferenced; the packet is
-        // concealed as lost and the stream's status reports SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11) / _PAYLOAD_ERROR (-12).
-        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
-        int bad = 0;
-        if (n0 > slot) bad = -11;
-        else if (n0 > 0 && (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb))) bad = -12;
-        if (bad) { n0 = 0; n1 = 0; }
-        // DELIBERATE CONVENTION of the batched API (not reference behaviour): an EMPTY record (n0 <= 0, e.g. a DTX packet that
-        // was never sent) is concealed like a lost packet, i.e. decoded with lostflag = 1.  The reference library itself returns
-        // -1 for nBytes[0] <= 0 without touching its state (AGR_BWE_SDK_API.c:266) and its CLI then writes the previous output
-        // buffer again (test/dec_main.c:365-381); the legacy AGR_Sate_Decoder_Decode symbol of this library keeps that behaviour.
-        const int m = n0 <= 0 ? 0 : (recv ? (recv[pk] & 3) : 3);
-        // receiver-side mapping of the reference harness (test/dec_main.c:255-378)
-        int lostflag;
-        i32 a0, a1;
-        const u8* ptr = b;
-        if (m == 3) { lostflag = 4; a0 = n0; a1 = n1; }
-        else if (m == 1) { lostflag = 2; a0 = n0 - n1; a1 = 0; }
-        else if (m == 2) { lostflag = 3; ptr = b + (n0 - n1); a0 = n1; a1 = 0; }
-        else { lostflag = 1; a0 = n0 > 0 ? n0 : 16; a1 = n0 > 0 ? n1 : 0; }
-        if (lostflag == 2 && a0 <= 0) { lostflag = 1; a0 = 16; a1 = 0; }          // nothing but the second description in the record
-        if (lostflag == 3 && a0 <= hbb) { lostflag = 1; a0 = 16; a1 = 0; }
+        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint);
+        const u8* ptr = bits + pk * (size_t)slot + a.ptr_off;
+        const int lostflag = a.lostflag, bad = a.bad;
+        const i32 a0 = a.a0, a1 = a.a1;
         i16* out = pcm + pk * SX_PACKET;
         int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
         if (ret == 0 && bad) ret = bad;
@@ -73,6 +80,75 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* s
     }
     SX_K(solo_dec_leave)(&w, &states[s]);
     if (status && SX_LANE == 0) status[s] = first_err;
+}
+
+// ---- batch path in two kernels -----------------------------------------------------------------------------------------------
+// Reading the symbols off the range coder is a serial chain per description: in the single kernel above it keeps 2 of 64 lanes
+// busy for ~45 % of the decoder's time.  But which symbol comes next depends only on symbols of the same packet, never on the
+// decoder's history, so the batch path reads ALL descriptions of ALL packets of a chunk at once, one LANE each
+// (solo_dec_extract_kernel, sx_extract_desc), and the decoder proper (one wavefront per stream, packets in order) starts from the
+// records: de-quantisation, synthesis, concealment, high band, QMF.  A record is only used for an ordinary packet
+// (sx_extracted_usable); anything else -- coder errors, a packet that announces more frames than it carries, symbols that depend
+// on the bytes behind the description -- is decoded serially as in the single kernel, with the exact history.
+#define SX_EXTRACT_LANES (SX_FS_KHZ == 8 ? 64 : 32)        // lanes per workgroup (LDS: ~0.5 KB per lane at 8 kHz, ~0.9 KB at 16 kHz)
+struct SxExtractWork {
+    SxCdfDec cdf;
+    SxExtractLane lane[SX_EXTRACT_LANES];
+};
+// recs: [(stream * pc + (p - p0)) * 2 + slot]; one lane per record
+__global__ void __launch_bounds__(SX_EXTRACT_LANES) SX_K(solo_dec_extract_kernel)(const SxDecStream* states, const u8* __restrict__ bits,
+                                                                                 const i16* __restrict__ nbytes, const u8* __restrict__ recv,
+                                                                                 int n_streams, int n_packets, int p0, int pc, int slot,
+                                                                                 int useMDIndex, SxExtracted* __restrict__ recs) {
+    __shared__ SxExtractWork w;
+    {
+        SxCdfDec* c = &w.cdf;
+#define X(type, name, n) for (int i = threadIdx.x; i < (n); i += SX_EXTRACT_LANES) c->name[i] = T_##name[i];
+        SX_CDF_LIST(X)
+#undef X
+    }
+    __syncthreads();
+    const size_t idx = (size_t)blockIdx.x * SX_EXTRACT_LANES + threadIdx.x;
+    if (idx >= (size_t)n_streams * (size_t)pc * 2) return;
+    const int md = (int)(idx & 1);
+    const size_t sp = idx >> 1;
+    const int s = (int)(sp / (size_t)pc), p = p0 + (int)(sp % (size_t)pc);
+    const size_t pk = (size_t)s * n_packets + p;
+    const int hb_joint = states[s].st.hb_joint;
+    const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, hb_joint);
+    SxExtracted* rec = &recs[idx];
+    i32 off = 0, len = 0;
+    if (!sx_desc_span(a.lostflag, a.a0, a.a1, hb_joint, md, &off, &len)) { rec->usable = 0; return; }
+    sx_extract_desc(bits + pk * (size_t)slot + a.ptr_off + off, len, useMDIndex, (const SxCdf*)&w.cdf, &w.lane[threadIdx.x], rec);
+}
+
+__global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream* states, const u8* __restrict__ bits,
+                                                            const i16* __restrict__ nbytes, const u8* __restrict__ recv,
+                                                            int n_streams, int n_packets, int p0, int pc, int slot, int useMDIndex,
+                                                            const SxExtracted* __restrict__ recs, i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+#ifdef SX_EXP_PAD
+    __shared__ volatile char exp_pad_[SX_EXP_PAD];
+    exp_pad_[threadIdx.x] = 0;
+#endif
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SX_K(solo_dec_enter)(&w, &states[s]);
+    i32 first_err = 0;
+    for (int p = p0; p < p0 + pc; p++) {
+        const size_t pk = (size_t)s * n_packets + p;
+        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint);
+        int ret = sx_decode_packet(&w, bits + pk * (size_t)slot + a.ptr_off, a.a0, a.a1, a.lostflag, useMDIndex, pcm + pk * SX_PACKET,
+                                   recs + ((size_t)s * pc + (size_t)(p - p0)) * 2);
+        if (ret == 0 && a.bad) ret = a.bad;
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+    }
+    SX_K(solo_dec_leave)(&w, &states[s]);
+    if (status && SX_LANE == 0) {
+        if (p0 == 0) status[s] = first_err;
+        else if (first_err != 0 && status[s] == 0) status[s] = first_err;
+    }
 }
 
 // Receiver front end: the two descriptions of a 40 ms packet arrive as separate network packets (MD1, and
@@ -154,6 +230,21 @@ static inline hipError_t SX_K(solo_dec_launch)(void* states, const uint8_t* bits
                        n_packets, slot, useMDIndex, pcm, status);
     return hipGetLastError();
 }
+static inline hipError_t SX_K(solo_dec_launch_extract)(const void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
+                                                       int n_packets, int p0, int pc, int slot, int useMDIndex, void* recs, hipStream_t s) {
+    const size_t lanes = (size_t)n_streams * (size_t)pc * 2;
+    hipLaunchKernelGGL(SX_K(solo_dec_extract_kernel), dim3((unsigned)((lanes + SX_EXTRACT_LANES - 1) / SX_EXTRACT_LANES)), dim3(SX_EXTRACT_LANES), 0, s,
+                       (const SxDecStream*)states, bits, nbytes, recv, n_streams, n_packets, p0, pc, slot, useMDIndex, (SxExtracted*)recs);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_dec_launch_synth)(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
+                                                     int n_packets, int p0, int pc, int slot, int useMDIndex, const void* recs,
+                                                     int16_t* pcm, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_dec_synth_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, bits, nbytes, recv, n_streams,
+                       n_packets, p0, pc, slot, useMDIndex, (const SxExtracted*)recs, pcm, status);
+    return hipGetLastError();
+}
+static inline size_t SX_K(solo_dec_extracted_bytes)() { return 2 * sizeof(SxExtracted); }      // per packet
 static inline hipError_t SX_K(solo_dec_launch_split)(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB,
                                                      const int16_t* lenB, int n_streams, int n_packets, int slot, int useMDIndex,
                                                      int16_t* pcm, int32_t* status, hipStream_t s) {

@@ -33,6 +33,10 @@ __global__ void __launch_bounds__(64, 5) SX_K(solo_enc_analysis_kernel)(SxEncStr
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
     __shared__ SxEncWork w;
+#ifdef SX_EXP_PAD
+    __shared__ volatile char exp_pad_[SX_EXP_PAD];
+    exp_pad_[threadIdx.x] = 0;
+#endif
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];

@@ -191,6 +191,135 @@ SX_HD void sx_rc_check_after_decoding(SxRangeDec* rc) {
 }
 
 // ---------------------------------------------------------------------------------------------------
+// decoder, interval form: the same decoder run for EVERY possible value of the four bytes that follow the description at once.
+// What those bytes are depends on the stream's history (see sx_rc_byte), which a decoder that works on the packets of a stream
+// IN PARALLEL (solo_dec.h, sx_extract_desc) does not have.  The decoder's base register is an increasing function of the
+// unknown bytes as long as the same symbols have been decoded, and every decision it takes is a threshold test on the base;
+// so it carries the base for the all-zeros and for the all-ones continuation and checks at every decision that both ends of
+// the interval fall on the same side.  If they always do, the decoded symbols are those of the reference decoder for ANY
+// history (every well-formed description: its own bytes pin the symbols down); if they do not, `ambiguous` is set and the
+// caller decodes that packet serially with the real history instead.
+// ---------------------------------------------------------------------------------------------------
+struct SxRangeDec2 {
+    const u8* buf;
+    i32 bufferLength, bufferIx;
+    u32 base_Q32;       // continuation 00 00 00 00
+    u32 base1_Q32;      // continuation FF FF FF FF
+    u32 range_Q16;
+    i32 error, ambiguous;
+};
+SX_HD void sx_rc_dec_init(SxRangeDec2* rc, const u8* buf, i32 len) {
+    rc->buf = buf;
+    rc->ambiguous = 0;
+    if (len > SX_MAX_ARITHM_BYTES || len < 0) { rc->error = SX_RC_DEC_PAYLOAD_TOO_LONG; rc->bufferLength = 0; return; }
+    rc->bufferLength = len;
+    rc->bufferIx = 0;
+    u32 b0 = 0, b1 = 0;
+    for (int k = 0; k < 4; k++) {
+        const bool in = k < len;
+        const u32 v = in ? (u32)buf[k] : 0u;
+        b0 = (b0 << 8) | v;
+        b1 = (b1 << 8) | (in ? v : 0xFFu);
+    }
+    rc->base_Q32 = b0;
+    rc->base1_Q32 = b1;
+    rc->range_Q16 = 0x0000FFFF;
+    rc->error = 0;
+}
+// the next byte into both bases (positions past the description: 00 / FF)
+#define SX_RC2_FEED()                                                                         \
+    {                                                                                         \
+        base_Q32 <<= 8; base1_Q32 <<= 8;                                                      \
+        if (bufferIx < rc->bufferLength) {                                                    \
+            const i32 pos_ = 4 + bufferIx++;                                                  \
+            const bool in_ = pos_ < rc->bufferLength;                                         \
+            const u32 v_ = in_ ? (u32)rc->buf[pos_] : 0u;                                     \
+            base_Q32 |= v_; base1_Q32 |= in_ ? v_ : 0xFFu;                                    \
+        }                                                                                     \
+    }
+#define SX_RC2_NORMALISE()                                                                    \
+    if (range_Q32 & 0xFF000000) {                                                             \
+        range_Q16 = range_Q32 >> 16;                                                          \
+    } else {                                                                                  \
+        if (range_Q32 & 0xFFFF0000) {                                                         \
+            range_Q16 = range_Q32 >> 8;                                                       \
+            if (((base_Q32 >> 24) != 0) != ((base1_Q32 >> 24) != 0)) rc->ambiguous = 1;       \
+            if (base_Q32 >> 24) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }         \
+        } else {                                                                              \
+            range_Q16 = range_Q32;                                                            \
+            if (((base_Q32 >> 16) != 0) != ((base1_Q32 >> 16) != 0)) rc->ambiguous = 1;       \
+            if (base_Q32 >> 16) { rc->error = SX_RC_NORMALIZATION_FAILED; return 0; }         \
+            SX_RC2_FEED()                                                                     \
+        }                                                                                     \
+        SX_RC2_FEED()                                                                         \
+    }                                                                                         \
+    if (range_Q16 == 0) { rc->error = SX_RC_ZERO_INTERVAL_WIDTH; return 0; }                  \
+    rc->base_Q32 = base_Q32; rc->base1_Q32 = base1_Q32;                                       \
+    rc->range_Q16 = range_Q16;                                                                \
+    rc->bufferIx = bufferIx;
+
+SX_HD i32 sx_rc_dec(SxRangeDec2* rc, const u16* prob, i32 probIx) {
+    u32 low_Q16 = 0, high_Q16, range_Q32;
+    u32 base_Q32 = rc->base_Q32, base1_Q32 = rc->base1_Q32, range_Q16 = rc->range_Q16;
+    i32 bufferIx = rc->bufferIx;
+    if (rc->error) return 0;
+    high_Q16 = prob[probIx];
+    if (range_Q16 * high_Q16 > base_Q32) {
+        SX_PLAIN_LOOP
+        for (;;) {
+            probIx--;
+            low_Q16 = prob[probIx];
+            if (range_Q16 * low_Q16 <= base_Q32) break;
+            high_Q16 = low_Q16;
+            if (high_Q16 == 0) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        }
+    } else {
+        SX_PLAIN_LOOP
+        for (;;) {
+            low_Q16 = high_Q16;
+            high_Q16 = prob[probIx + 1];
+            if (range_Q16 * high_Q16 > base_Q32) break;
+            probIx++;
+            if (high_Q16 == 0xFFFF) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }      // (the upper end is past the table as well)
+        }
+    }
+    if (!(range_Q16 * high_Q16 > base1_Q32)) rc->ambiguous = 1;        // the upper end of the interval decodes a later symbol
+    base_Q32 -= range_Q16 * low_Q16;
+    base1_Q32 -= range_Q16 * low_Q16;
+    range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+    SX_RC2_NORMALISE()
+    return probIx;
+}
+SX_HD i32 sx_rc_dec_bin(SxRangeDec2* rc, u32 p) {
+    u32 base_Q32 = rc->base_Q32, base1_Q32 = rc->base1_Q32, range_Q16 = rc->range_Q16, range_Q32, low_Q16, high_Q16;
+    i32 bufferIx = rc->bufferIx, sym;
+    if (rc->error) return 0;
+    if (range_Q16 * p > base_Q32) {
+        sym = 0; low_Q16 = 0; high_Q16 = p;
+    } else {
+        if (!(range_Q16 * 0xFFFFu > base_Q32)) { rc->error = SX_RC_CDF_OUT_OF_RANGE; return 0; }
+        sym = 1; low_Q16 = p; high_Q16 = 0xFFFFu;
+    }
+    if (!(range_Q16 * high_Q16 > base1_Q32)) rc->ambiguous = 1;
+    base_Q32 -= range_Q16 * low_Q16;
+    base1_Q32 -= range_Q16 * low_Q16;
+    range_Q32 = range_Q16 * (high_Q16 - low_Q16);
+    SX_RC2_NORMALISE()
+    return sym;
+}
+SX_HD void sx_rc_check_after_decoding(SxRangeDec2* rc) {      // (reads a byte of the description itself)
+    i32 nBytes;
+    i32 bits = sx_rc_length_bits(rc->bufferIx, rc->range_Q16, &nBytes);
+    if (nBytes - 1 >= rc->bufferLength) { rc->error = SX_RC_DECODER_CHECK_FAILED; return; }
+    if (bits & 7) {
+        i32 mask = 0xFF >> (bits & 7);
+        if (((i32)rc->buf[nBytes - 1] & mask) != mask) { rc->error = SX_RC_DECODER_CHECK_FAILED; return; }
+    }
+}
+#undef SX_RC2_NORMALISE
+#undef SX_RC2_FEED
+
+// ---------------------------------------------------------------------------------------------------
 // encoder
 // ---------------------------------------------------------------------------------------------------
 struct SxRangeEnc {

@@ -21,7 +21,7 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
 
 extern "C" {
 
-struct EmuDec { SxDecState st; SxDecWork w; SxDecShadow sh; int useMDIndex; };
+struct EmuDec { SxDecState st; SxDecWork w; SxDecShadow sh; int useMDIndex; SxExtractLane L; int two_step; };
 
 void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argument: joint_mode 1 (40 ms high-band frame)
     EmuDec* d = (EmuDec*)calloc(1, sizeof(EmuDec));
@@ -30,12 +30,28 @@ void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argume
     return d;
 }
 void emu_dec_destroy(void* h) { free(h); }
+// on: decode like the batch path's two kernels -- the packet's descriptions go through the history-free extraction step
+// (sx_extract_desc) first, the decoder proper then continues from its records where they are usable
+void emu_dec_set_split(void* h, int on) { ((EmuDec*)h)->two_step = on; }
+static int emu_usable_count = 0, emu_fallback_count = 0;
+int emu_dec_two_step_stats(int which) { return which ? emu_fallback_count : emu_usable_count; }
 int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int lostflag, int16_t* pcm) {
     EmuDec* d = (EmuDec*)h;
+    sx_cdf_load_dec(&d->w.cdf);
+    SxExtracted ext2[2];
+    if (d->two_step) {
+        memset(ext2, 0xA5, sizeof(ext2));                 // (whatever the decoder takes from a record must have been written by the extraction)
+        for (int md = 0; md < 2; md++) {                  // solo_dec_extract_kernel, one lane per description slot
+            ext2[md].usable = 0;
+            i32 off = 0, len = 0;
+            if (sx_desc_span(lostflag, nBytes0, nBytes1, d->st.hb_joint, md, &off, &len))
+                sx_extract_desc(bits + off, len, d->useMDIndex, (const SxCdf*)&d->w.cdf, &d->L, &ext2[md]);
+        }
+        if (lostflag >= 2) { if (sx_extracted_usable(&d->st, ext2, lostflag)) emu_usable_count++; else emu_fallback_count++; }
+    }
     d->w.st = d->st;                                      // the kernel keeps state + tables in LDS for a launch
     d->w.shadow = &d->sh;
-    sx_cdf_load_dec(&d->w.cdf);
-    int r = sx_decode_packet(&d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm);
+    int r = sx_decode_packet(&d->w, bits, nBytes0, nBytes1, lostflag, d->useMDIndex, pcm, d->two_step ? ext2 : 0);
     d->st = d->w.st;
     return r;
 }

@@ -123,10 +123,18 @@ def load_emu_wb():
 
 
 class EmuDecoder:
-    def __init__(self, use_md_index=0, wb=False):
+    # 1: decode like the batch path's two kernels (history-free symbol extraction per description -> records -> decoder);
+    # 0: the decoder reads its symbols itself.  tests/test_emu_decoder.py runs its cases in both.
+    SPLIT = int(os.environ.get("SOLO_EMU_DEC_SPLIT", "0"))
+
+    def __init__(self, use_md_index=0, wb=False, split=None):
         self.lib = load_emu_wb() if wb else load_emu()
         self.n = 1280 if wb else 640
         self.h = self.lib.emu_dec_create(use_md_index)
+        split = EmuDecoder.SPLIT if split is None else split
+        if split:
+            self.lib.emu_dec_set_split.argtypes = [C.c_void_p, C.c_int]
+            self.lib.emu_dec_set_split(self.h, split)
 
     def decode(self, payload, n0, n1, lostflag):
         buf = np.zeros(1100, np.uint8)

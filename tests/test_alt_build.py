@@ -27,3 +27,18 @@ def test_parity_suite_through_the_alternate_build():
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_decoder_suite_through_the_single_kernel_path():
+    """The batched decode call normally runs two kernels (history-free symbol extraction, one lane per description; then the decoder
+    proper); SOLO_DEC_SPLIT=0 keeps the single kernel that reads its symbols itself.  Both must give the reference's output: the decoder
+    tests (goldens, description loss, corrupted payloads, receiver) once more through the single-kernel path."""
+    env = dict(os.environ, SOLO_DEC_SPLIT="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(T.ROOT, "tests", "test_gpu_decoder.py"), os.path.join(T.ROOT, "tests", "test_pinned_corners.py"),
+                        os.path.join(T.ROOT, "tests", "test_gpu_receiver.py")],
+                       env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail

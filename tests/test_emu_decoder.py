@@ -1,9 +1,20 @@
 """Kernel SOURCE (solo_amd/csrc/solo_dec.h) compiled for the host (tests/emu, 1 lane) against the
 committed golden vectors -- runs without a GPU and without /root/reference."""
 import numpy as np
+import pytest
 
 import refcodec as R
 import solo_testlib as T
+
+
+@pytest.fixture(autouse=True, params=[0, 1], ids=["serial-parse", "extract-then-decode"])
+def _decoder_path(request):
+    """Every case runs through the decoder that reads its symbols itself and through the batch path's two steps: history-free
+    symbol extraction per description (solo_dec.h sx_extract_desc, interval-form range decoder) -> records -> decoder."""
+    old = T.EmuDecoder.SPLIT
+    T.EmuDecoder.SPLIT = request.param
+    yield
+    T.EmuDecoder.SPLIT = old
 
 
 def _decode_all(recs, pattern):
