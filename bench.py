@@ -39,6 +39,14 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
+# Runtime knob (read by the HIP runtime when it initialises, i.e. before the first torch.cuda / library call): the number of
+# hardware queues the process's HIP streams are spread over.  The encoder runs its three stages on three HIP streams, the decoder
+# its two on two more; with the runtime's default (4 queues) consecutive encode / decode calls that are enqueued without a host
+# synchronisation in between lose ~6 % (measured: 91.0 ms per step against 85.5 ms with 2 queues, 4096 streams x 50 packets; calls
+# that are synchronised one by one take the same time either way, and 1 queue serialises the encoder's pipeline: 132 ms).
+# Recorded in the JSON line (config.runtime_env); a value set by the caller wins.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 2.0       # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 PCM_BYTES = 1280.0             # 640 int16 samples per 40 ms packet
@@ -196,7 +204,8 @@ def main():
     st_d = torch.zeros((N,), dtype=torch.int32, device=dev)
     out = torch.zeros((N, P, 640), dtype=torch.int16, device=dev)
 
-    batch.set_timing(True)
+    # (per-kernel timing brackets -- HIP events with timestamps around every launch -- are switched on only for the few sampling
+    # steps AFTER the timed region: they cost several per cent of throughput)
     kms = {"analysis": [], "quantiser": [], "coding": [], "decode": []}
 
     # Optional serving shape (--overlap): consecutive encode calls are pipelined (solo_batch_set_async_join: the first analysis
@@ -253,6 +262,7 @@ def main():
     if overlap:
         batch.set_async_join(False)
         overlap = False
+    batch.set_timing(True)
     for _ in range(min(3, args.steps)):
         step()
         for name, v in batch.last_kernel_ms().items():
@@ -264,6 +274,7 @@ def main():
     kavg = {n: float(np.mean(v)) for n, v in kms.items()}
     dec_ms = kavg["decode"]
     # the encoder's kernels overlap each other (and, with --overlap, the decoder): encode alone is timed separately below
+    batch.set_timing(False)
     torch.cuda.synchronize()
     t1 = time.perf_counter()
     for _ in range(3):
@@ -286,17 +297,31 @@ def main():
         # is priced with the encode-only boundary bytes of the packets it handles per launch; the hand-over records between them are
         # implementation traffic
         alg = {"analysis": enc_alg, "quantiser": enc_alg, "coding": enc_alg, "decode": dec_alg}
-        kname = {"analysis": "solo_enc_analysis_kernel", "quantiser": "solo_nsq_kernel", "coding": "solo_enc_coding_kernel",
-                 "decode": "solo_decode_kernel"}
+        # the timed stages and the kernels behind them: the coding stage is two kernels on one HIP stream (range coder, lane per
+        # description; then high band + payload assembly), the decode call is two kernels on two streams (symbol extraction, lane per
+        # description; then the decoder proper, a chunk of packets behind) -- each stage is timed as a whole
+        split_dec = os.environ.get("SOLO_DEC_SPLIT", "1") != "0"
+        stage_kernels = {"analysis": ["solo_enc_analysis_kernel"], "quantiser": ["solo_nsq_kernel"],
+                         "coding": ["solo_enc_coding_kernel", "solo_enc_rc_kernel"],
+                         "decode": ["solo_dec_synth_kernel", "solo_dec_extract_kernel"] if split_dec else ["solo_decode_kernel"]}
+        kname = {n: v[0] for n, v in stage_kernels.items()}
         traffic = _profile_json("hbm_traffic.json") or {}
         insts = _profile_json("wave_instructions.json") or {}
         # the encoder kernels run as a pipeline over chunks of the step's packets: kavg = sum over the launches of a step
-        nl = {n: (enc_chunks if n != "decode" else 1) for n in kavg}
+        dec_chunk = int(os.environ.get("SOLO_DEC_CHUNK", "24"))       # (solo_api.hip: a first chunk of 4 packets, then chunks of this size)
+        if split_dec and dec_chunk > 0:
+            cp = min(P, dec_chunk)
+            c0 = 4 if P > 8 else cp
+            dec_chunks = 1 + (P - c0 + cp - 1) // cp
+        else:
+            dec_chunks = 1
+        nl = {n: (enc_chunks if n != "decode" else dec_chunks) for n in kavg}
 
         def tr_launch(n):
-            v = traffic.get(kname[n] + "_bytes_per_packet")
-            return None if v is None else int(v * packets_step / nl[n])
+            v = [traffic.get(k + "_bytes_per_packet") for k in stage_kernels[n]]
+            return None if any(x is None for x in v) else int(sum(v) * packets_step / nl[n])
         kernels = {kname[n]: {"launches_per_step": nl[n], "avg_launch_ms": round(kavg[n] / nl[n], 4),
+                              "kernels_of_the_stage": stage_kernels[n],
                               "packets_per_launch": packets_step // nl[n],
                               "algorithmic_bytes_per_launch": int(alg[n] * packets_step / nl[n]),
                               "achieved_GBps": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9, 4),
@@ -317,6 +342,7 @@ def main():
                                    ("BASELINE configs[4]: %d synthetic 16 kHz WB streams sharded evenly across %d x MI355X (%d per GPU), encode + "
                                     "decode per rank, RCCL gather only, 13.6 kbps, %d packets/stream/step" % (N * world, world, N, P)),
                        "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2),
+                       "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
                                     "(solo_batch_set_async_join, double-buffered bitstreams)" if args.overlap
                                     else "encode then decode on one stream")},
@@ -338,6 +364,7 @@ def main():
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 7)},
                          "note": "serial fixed-point recursions: instruction-issue / latency bound, not HBM bound -- see valu_issue"},
             "kernels": kernels,
+            "launches_per_step": {k: nl[n] for n, ks in stage_kernels.items() for k in ks},
         }
         peak_issue = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU
         if insts.get("valu_per_packet_round_trip"):

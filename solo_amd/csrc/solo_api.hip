@@ -84,7 +84,7 @@ struct solo_batch {
     void* d_nsq_ring;                // emission-ring scratch of the quantiser launches (one launch group of streams; frame-local data)
     // decoder pipeline: symbol extraction (stream sP) one chunk of packets ahead of the decoder proper (stream sS)
     hipStream_t sP, sS;
-    hipEvent_t evDFork, evDJoin, evP[2], evS[2];
+    hipEvent_t evDFork, evDJoin, evDJoin2, evP[2], evS[2];
     void* d_parsed[2];               // extraction records of the chunk being extracted / being decoded
     size_t parsed_bytes;             // size of each
     int dec_pipe_ready, dec_split, dec_chunk;
@@ -285,7 +285,7 @@ void solo_batch_destroy(solo_batch_t* b) {
     if (b->dec_pipe_ready && b->dec_split) {
         (void)hipStreamSynchronize(b->sP); (void)hipStreamSynchronize(b->sS);
         (void)hipStreamDestroy(b->sP); (void)hipStreamDestroy(b->sS);
-        (void)hipEventDestroy(b->evDFork); (void)hipEventDestroy(b->evDJoin);
+        (void)hipEventDestroy(b->evDFork); (void)hipEventDestroy(b->evDJoin); (void)hipEventDestroy(b->evDJoin2);
         for (int i = 0; i < 2; i++) { (void)hipEventDestroy(b->evP[i]); (void)hipEventDestroy(b->evS[i]); }
     }
     for (int i = 0; i < 2; i++) {
@@ -310,6 +310,7 @@ void solo_batch_destroy(solo_batch_t* b) {
     delete b;
 }
 
+#define SOLO_DEC_FIRST_CHUNK 4
 int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
                           int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
@@ -319,13 +320,14 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
         const char* e = getenv("SOLO_DEC_SPLIT");
         b->dec_split = e ? atoi(e) : 1;
         e = getenv("SOLO_DEC_CHUNK");
-        b->dec_chunk = e ? atoi(e) : 5;
+        b->dec_chunk = e ? atoi(e) : 24;
         if (b->dec_chunk <= 0) b->dec_chunk = 1 << 30;
         if (b->dec_split) {
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking));
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sS, hipStreamNonBlocking));
             SOLO_CHECK(hipEventCreateWithFlags(&b->evDFork, hipEventDisableTiming));
             SOLO_CHECK(hipEventCreateWithFlags(&b->evDJoin, hipEventDisableTiming));
+            SOLO_CHECK(hipEventCreateWithFlags(&b->evDJoin2, hipEventDisableTiming));
             for (int i = 0; i < 2; i++) {
                 SOLO_CHECK(hipEventCreateWithFlags(&b->evP[i], hipEventDisableTiming));
                 SOLO_CHECK(hipEventCreateWithFlags(&b->evS[i], hipEventDisableTiming));
@@ -345,8 +347,10 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // Two kernels: the symbols of every description of a chunk of packets are read off the range coder at once, one lane each; the
     // decoder proper (one wavefront per stream, packets in order) follows a chunk behind on a second stream; the records go through
     // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
+    // (a short first chunk -- its extraction has nothing to hide behind -- then long ones: every decoder launch reloads the stream states)
     const int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
-    const int nchunks = (n_packets + cp - 1) / cp;
+    const int c0 = n_packets > 2 * SOLO_DEC_FIRST_CHUNK ? SOLO_DEC_FIRST_CHUNK : cp;
+    const int nchunks = 1 + (n_packets - c0 + cp - 1) / cp;
     const size_t need = (size_t)b->n_streams * (size_t)cp * (b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes());
     if (need > b->parsed_bytes) {
         SOLO_CHECK(hipStreamSynchronize(st));
@@ -365,7 +369,7 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     SOLO_CHECK(hipStreamWaitEvent(b->sS, b->evDFork, 0));
     hipError_t lerr = hipSuccess;
     for (int c = 0; c < nchunks && lerr == hipSuccess; c++) {
-        const int p0 = c * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0, k = c & 1;
+        const int p0 = c == 0 ? 0 : c0 + (c - 1) * cp, pc = c == 0 ? c0 : ((p0 + cp <= n_packets) ? cp : n_packets - p0), k = c & 1;
         if (c >= 2) SOLO_CHECK(hipStreamWaitEvent(b->sP, b->evS[k], 0));
         lerr = (b->wb ? solo_wb_dec_launch_extract : solo_dec_launch_extract)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, p0, pc,
                                                                               b->slot, b->dec_ctrl.useMDIndex, b->d_parsed[k], b->sP);
@@ -380,8 +384,8 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // join both internal streams back into the caller's (also after a refused launch: nothing stays forked)
     (void)hipEventRecord(b->evDJoin, b->sP);
     (void)hipStreamWaitEvent(st, b->evDJoin, 0);
-    (void)hipEventRecord(b->evDJoin, b->sS);
-    (void)hipStreamWaitEvent(st, b->evDJoin, 0);
+    (void)hipEventRecord(b->evDJoin2, b->sS);
+    (void)hipStreamWaitEvent(st, b->evDJoin2, 0);
     if (tm) { (void)hipEventRecord(b->ev[5], st); b->ev_dec = 1; }
     SOLO_CHECK(lerr);
     return 0;

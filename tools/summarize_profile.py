@@ -45,7 +45,9 @@ lps = {}
 try:
     for line in open(os.path.join(src, "bench_trace.log")):
         if line.startswith("{") and '"kernels"' in line:
-            lps = {k: v.get("launches_per_step", 1) for k, v in json.loads(line)["kernels"].items()}
+            j = json.loads(line)
+            lps = {k: v.get("launches_per_step", 1) for k, v in j["kernels"].items()}
+            lps.update(j.get("launches_per_step", {}))
 except Exception:
     pass
 for k, e in out["kernels"].items():
