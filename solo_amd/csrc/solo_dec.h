@@ -892,13 +892,15 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             SxDecShadow* sh = w->shadow;
             const i32 len[2] = {nB0, ndesc > 1 ? nB1 : -1};
             const i32 off[2] = {0, nB0};
-            for (int d = 0; d < 2; d++) {
-                if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) {
-                    const u8* t = &sh->b[d][len[d]];
-                    tails[d] = (u32)t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+            if (!pre2) {
+                for (int d = 0; d < 2; d++) {
+                    if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) {
+                        const u8* t = &sh->b[d][len[d]];
+                        tails[d] = (u32)t[0] | ((u32)t[1] << 8) | ((u32)t[2] << 16) | ((u32)t[3] << 24);
+                    }
                 }
+                wv_sync();
             }
-            wv_sync();
             for (int d = 0; d < 2; d++) {
                 if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) { SX_PAR(i, len[d]) sh->b[d][i] = payload[off[d] + i]; }
             }
@@ -969,16 +971,19 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             used = len0 - st->nBytesLeft0;
             // inverse NSQ (decode_frame.c:166-264); the dither LCG is serial, regenerate it per lane
             const i32 seed0 = c->Seed;
+            i32 sd = sx_lcg_first(seed0);                 // iterate i + 1 of the dither LCG, for the lane's samples i
             if (desp_type == 2) {
                 SX_PAR(i, SX_FRAME) {
-                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
+                    const i32 dither = sd >> 31;
+                    sd = sx_lcg_next(sd);
                     i32 q_Q10 = sx_add(sx_shl(w->u.parse.pulses[0][i], 10), sx_shl(w->u.parse.pulses[1][i], 10));
                     q_Q10 = sx_add(offset_p1_Q10 + offset_p2_Q10, q_Q10);
                     st->exc_Q10[i] = (q_Q10 ^ dither) - dither;
                 }
             } else {
                 SX_PAR(i, SX_FRAME) {
-                    const i32 dither = sx_rand_skip(seed0, (u32)i + 1) >> 31;
+                    const i32 dither = sd >> 31;
+                    sd = sx_lcg_next(sd);
                     int first_half = (i % (SX_SUBFR << 1)) < SX_SUBFR;
                     int use_p1 = desp_type == 0 ? first_half : !first_half;
                     i32 q_Q10 = sx_add(use_p1 ? offset_p1_Q10 : offset_p2_Q10, sx_shl(w->u.parse.pulses[0][i], 10));
@@ -1188,6 +1193,10 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     // makes the NEXT call go on decoding the OLD buffer (SKP_Silk_dec_API.c:125-150, SKP_Silk_decode_frame.c:93-99): the coder
     // registers are therefore kept in the state record, and the old buffer is the shadow (SxDecShadow).
     SxRangeDec rc[2];
+    // (an ordinary packet whose symbols were read ahead: the serial coder is not used, and since such a packet ends without frames
+    // left over, the next packet re-initialises the coder's registers before it reads them)
+    const SxExtracted* pre2 = sx_extracted_usable(st, ext2, lostflag) ? ext2 : 0;
+    if (!pre2) {
 #if SX_NLANES == 1
     for (int d = 0; d < 2; d++) {
         const SxDecDesc* m = &st->md[d];
@@ -1199,8 +1208,8 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         rc[d].bufferLength = m->rc_bufferLength; rc[d].bufferIx = m->rc_bufferIx; rc[d].error = m->rc_error;
         rc[d].base_Q32 = m->rc_base_Q32; rc[d].range_Q16 = m->rc_range_Q16; rc[d].tail = m->rc_tail;
     }
+    }
     // the payload is read byte by byte by a serial coder: stage it in LDS
-    const SxExtracted* pre2 = sx_extracted_usable(st, ext2, lostflag) ? ext2 : 0;
     if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS && !pre2) {
         SX_PAR(i, nBytes0) w->payload[i] = bits[i];
         bits = w->payload;
@@ -1218,6 +1227,7 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     for (int f = 0; f < 2; f++) {
         int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME], pre2, f);
         wv_sync();
+        if (!pre2) {
 #if SX_NLANES == 1
         for (int d = 0; d < 2; d++) {
             SxDecDesc* m = &st->md[d];
@@ -1230,6 +1240,7 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
             m->rc_base_Q32 = rc[d].base_Q32; m->rc_range_Q16 = rc[d].range_Q16; m->rc_tail = rc[d].tail;
         }
         wv_sync();
+        }
         if (ret < 0) { st->last_error = ret; return ret; }
         if (f == 0) { SX_PAR(i, SX_FRAME) w->exc0_Q10[i] = st->exc_Q10[i]; }
         wv_sync();

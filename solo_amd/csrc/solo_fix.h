@@ -188,15 +188,29 @@ SX_HD i32 sx_inverse32_varQ(i32 b32, int Qres) {
 SX_HD i32 sx_rand(i32 seed) { return (i32)(907633515u + (u32)seed * 196314165u); }
 // n-th iterate of sx_rand (n >= 0) by square-and-multiply on the affine map x -> A x + C (mod 2^32): lets every lane of a
 // data-parallel loop regenerate "its" value of a serial LCG sequence
-SX_HD i32 sx_rand_skip(i32 seed, u32 n) {
+template <int BITS>
+SX_HD i32 sx_rand_skip_bits(i32 seed, u32 n) {      // n < 2^BITS
     u32 Ar = 1u, Cr = 0u, Ab = 196314165u, Cb = 907633515u;
 #pragma unroll
-    for (int bit = 0; bit < 9; bit++) {          // n < 512 (a 20 ms frame at 16 kHz has 320 samples)
+    for (int bit = 0; bit < BITS; bit++) {
         if (n & (1u << bit)) { Ar = Ab * Ar; Cr = Ab * Cr + Cb; }
         Cb = Ab * Cb + Cb;
         Ab = Ab * Ab;
     }
     return (i32)(Ar * (u32)seed + Cr);
+}
+SX_HD i32 sx_rand_skip(i32 seed, u32 n) { return sx_rand_skip_bits<9>(seed, n); }      // n < 512 (a 20 ms frame at 16 kHz has 320 samples)
+// A lane-strided loop over a serial LCG sequence (SX_PAR: i = lane, lane + NLANES, ...): the lane's first value by jump-ahead, the
+// following ones by the constant map "NLANES steps at once" (one multiply-add; compile-time constants)
+struct SxLcgMap { u32 A, C; };
+constexpr SxLcgMap sx_lcg_map(u32 n) {             // x -> A x + C = n applications of sx_rand
+    u32 Ar = 1u, Cr = 0u, Ab = 196314165u, Cb = 907633515u;
+    for (int bit = 0; bit < 32; bit++) {
+        if (n & (1u << bit)) { Ar = Ab * Ar; Cr = Ab * Cr + Cb; }
+        Cb = Ab * Cb + Cb;
+        Ab = Ab * Ab;
+    }
+    return SxLcgMap{Ar, Cr};
 }
 
 // ---- Speex-derived 16-bit helpers of the QMF (libBWE/AGR_BWE_fixed_generic.h:40-80) ---------------

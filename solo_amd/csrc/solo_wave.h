@@ -178,6 +178,9 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 
 // lane-strided parallel loop
 #define SX_PAR(i, n) for (int i = SX_LANE; i < (int)(n); i += SX_NLANES)
+// ... over a serial LCG sequence: sx_lcg_first(seed) = iterate SX_LANE + 1 of sx_rand, sx_lcg_next(v) = SX_NLANES iterates further
+SX_HD i32 sx_lcg_first(i32 seed) { return sx_rand_skip_bits<7>(seed, (u32)SX_LANE + 1u); }
+SX_HD i32 sx_lcg_next(i32 v) { constexpr SxLcgMap m = sx_lcg_map(SX_NLANES); return (i32)(m.A * (u32)v + m.C); }
 
 // wave-cooperative memcpy / memset / memmove helpers (element-wise, any POD type)
 template <typename T>
