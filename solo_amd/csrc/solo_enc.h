@@ -383,7 +383,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
 
 // SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
 // frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
-SX_FN void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame, SxNsqIn* in, SxFrameIdx* x) {
+SX_FN1 void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame, SxNsqIn* in, SxFrameIdx* x) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;

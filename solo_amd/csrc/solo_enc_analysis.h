@@ -82,7 +82,7 @@ SX_HD i32 sx_warped_gain(const i32* coefs_Q24, i32 lambda_Q16, int order) {
 }
 
 // limit_warped_coefs, noise_shape_analysis_FIX.c:52
-SX_FN void sx_limit_warped_coefs(i32* syn, i32* ana, i32 lambda_Q16, i32 limit_Q24, int order) {
+SX_FN1 void sx_limit_warped_coefs(i32* syn, i32* ana, i32 lambda_Q16, i32 limit_Q24, int order) {
     int ind = 0;
     i32 nom_Q16, den_Q24, gain_syn_Q16, gain_ana_Q16;
     lambda_Q16 = -lambda_Q16;
@@ -312,7 +312,7 @@ SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
     }
 
 // Schur recursion .. coefficient limiting of noise_shape_analysis_FIX.c:339-399 for the four subframes at once
-SX_FN void sx_shape_rows(SxShapeWork* sw, SxEncCtrl* c, i32 warping_Q16, i32 BWExp1_Q16, i32 BWExp2_Q16) {
+SX_FN1 void sx_shape_rows(SxShapeWork* sw, SxEncCtrl* c, i32 warping_Q16, i32 BWExp1_Q16, i32 BWExp2_Q16) {
     SX_IN_LDS(sw); SX_IN_LDS(c);
     const int s = SX_LANE >> 4, j = SX_LANE & 15;
     const i32* auto_corr = sw->corr[s];
@@ -428,7 +428,7 @@ SX_FN void sx_shape_rows(SxShapeWork* sw, SxEncCtrl* c, i32 warping_Q16, i32 BWE
 
 // SKP_Silk_noise_shape_analysis_FIX, noise_shape_analysis_FIX.c:137.
 // pitch_res = res_pitch + frame_length; x = x_buf + frame_length; x_windowed: 120-sample scratch (LDS)
-SX_FN void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, SxShapeWork* sw) {
+SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pitch_res, const i16* x, SxShapeWork* sw) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(pitch_res); SX_IN_LDS(x); SX_IN_LDS(sw);
     i32 tmp32;
     const i16* x_ptr = x - SX_LA_SHAPE;
@@ -635,7 +635,7 @@ struct SxPrefWork {                  // LDS scratch of the prefilter
     i32 vend[SX_SHAPE_ORDER + 1];
 };
 
-SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, SxPrefWork* pw) {
+SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, SxPrefWork* pw) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(xw); SX_IN_LDS(x); SX_IN_LDS(pw);
     i16* pf_sLTP_shp = pw->ring;
     const i32 lambda_Q16 = (i16)SX_WARPING_Q16;
@@ -824,7 +824,7 @@ SX_FN void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* 
 // LTP analysis
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_corrMatrix_FIX + corrVector_FIX, SKP_Silk_corrMatrix_FIX.c:35-152 (order 5, L = 40)
-SX_FN void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* XX, i32* rshifts, int x_odd) {
+SX_FN1 void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* XX, i32* rshifts, int x_odd) {
     SX_IN_LDS(x); SX_IN_LDS(XX);
     i32 energy, rshifts_local;
     sx_sum_sqr_shift(&energy, &rshifts_local, x, L + order - 1, x_odd);
@@ -878,7 +878,7 @@ SX_HD void sx_corr_vector(const i16* x, const i16* t, int L, int order, i32* Xt,
 }
 
 // SKP_Silk_solve_LDL_FIX and helpers, SKP_Silk_solve_LS_FIX.c:71-241 (M = 5)
-SX_FN void sx_solve_LDL(i32* A, int M, const i32* b, i32* x_Q16, i32* ws /* 50 words of LDS */) {
+SX_FN1 void sx_solve_LDL(i32* A, int M, const i32* b, i32* x_Q16, i32* ws /* 50 words of LDS */) {
     SX_IN_LDS(A); SX_IN_LDS(b); SX_IN_LDS(x_Q16); SX_IN_LDS(ws);
     i32 *L_Q16 = ws, *Y = ws + 25, *inv_D_Q36 = ws + 30, *inv_D_Q48 = ws + 35, *v_Q0 = ws + 40, *D_Q0 = ws + 45;
     int status = 1;
@@ -971,7 +971,7 @@ struct SxLtpWork {                   // LDS scratch of the LTP analysis: subfram
 };
 
 // SKP_Silk_find_LTP_FIX, SKP_Silk_find_LTP_FIX.c:39.  res_pitch: LPC residual buffer (336 samples)
-SX_FN void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15,
+SX_FN1 void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16* res_pitch, const i32* lag, const i32* Wght_Q15,
                        SxLtpWork* lw) {
     SX_IN_LDS(b_Q14); SX_IN_LDS(WLTP); SX_IN_LDS(LTPredCodGain_Q7); SX_IN_LDS(res_pitch); SX_IN_LDS(lag); SX_IN_LDS(Wght_Q15); SX_IN_LDS(lw);
     const int subfr_length = SX_SUBFR, mem_offset = SX_FRAME, HEAD = 2;
@@ -1118,7 +1118,7 @@ SX_HD i32 sx_vq_wmat_ec_one(const i16* in_Q14, const i32* W, const i16* row, i32
 
 // SKP_Silk_quant_LTP_gains_FIX, SKP_Silk_quant_LTP_gains_FIX.c:30 (lowComplexity = 0): all (codebook, subframe, entry)
 // rate-distortions at once (3 x 4 x up to 40 = 280 lanes' worth), then one lane per (codebook, subframe) picks the first minimum
-SX_FN void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8, i32* rd /* [3][4][40] LDS */,
+SX_FN1 void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8, i32* rd /* [3][4][40] LDS */,
                               i32* best /* [3][4][2] LDS */) {
     SX_IN_LDS(B_Q14); SX_IN_LDS(cbk_index); SX_IN_LDS(periodicity_index); SX_IN_LDS(W_Q18); SX_IN_LDS(rd); SX_IN_LDS(best);
     SX_PAR(t, 3 * 4 * 40) {
@@ -1768,7 +1768,7 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid*
 
 // SKP_Silk_find_LPC_FIX, SKP_Silk_find_LPC_FIX.c:32.  x: nb_subfr blocks of subfr_length samples (incl. `order` pre-samples)
 // LPC_res: scratch of 2*subfr_length samples (LDS)
-SX_FN void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q15, int useInterp, int order, const i16* x,
+SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q15, int useInterp, int order, const i16* x,
                        int subfr_length, i16* LPC_res, SxLpcWork* lw) {
     SX_IN_LDS(NLSF_Q15); SX_IN_LDS(interpIndex); SX_IN_LDS(prev_NLSFq_Q15); SX_IN_LDS(x); SX_IN_LDS(LPC_res); SX_IN_LDS(lw);
     i32* a_Q16 = lw->a_Q16;
@@ -1900,7 +1900,7 @@ SX_HD i64 wv_min_key(i64 k) {
 #endif
 
 // SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
-SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
+SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
                                i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
     SX_IN_LDS(w); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
     const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
@@ -2055,7 +2055,7 @@ SX_FN void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, co
 }
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
-SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
+SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w); SX_IN_LDS(pNLSF_Q15);
     i32 NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
     i32* pNLSFW_Q6 = w->W_Q6;
@@ -2105,7 +2105,7 @@ SX_FN void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvq
 }
 
 // SKP_Silk_residual_energy_FIX, SKP_Silk_residual_energy_FIX.c:32.  LPC_res: 100-sample scratch
-SX_FN void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][SX_MAX_LPC], const i32* gains, i16* LPC_res) {
+SX_FN1 void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][SX_MAX_LPC], const i32* gains, i16* LPC_res) {
     SX_IN_LDS(nrgs); SX_IN_LDS(nrgsQ); SX_IN_LDS(x); SX_IN_LDS(a_Q12); SX_IN_LDS(LPC_res);
     const int offset = SX_LPC + SX_SUBFR;
     const i16* x_ptr = x;
@@ -2144,7 +2144,7 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
 };
 
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
-SX_FN void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
+SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res_pitch); SX_IN_LDS(w);
     i32 *invGains_Q16 = w->invGains_Q16, *local_gains = w->local_gains, *Wght_Q15 = w->Wght_Q15;
     i32* NLSF_Q15 = w->NLSF_Q15;
@@ -2224,7 +2224,7 @@ SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditiona
 }
 
 // SKP_Silk_process_gains_FIX, SKP_Silk_process_gains_FIX.c:32
-SX_FN void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
+SX_FN1 void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
     SX_IN_LDS(st); SX_IN_LDS(c);
     if (c->sigtype == 0) {
         i32 s_Q16 = -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4));

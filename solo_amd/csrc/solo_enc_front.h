@@ -12,7 +12,7 @@
 //   y1[k] = sat( pshr15( sum_{j<32} a[j] * (int16)( x[2k+j-63] + x[2k-j] ) ) )
 //   y2[k] = sat( pshr15( sum_{j<32} (j even ? -1 : +1) * a[j] * ( x[2k+j-63] - x[2k-j] ) ) )
 // `tl` is a 63+640 sample scratch timeline (LDS).
-SX_FN void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16* hi) {
+SX_FN1 void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16* hi) {
     SX_IN_LDS(tl);
     SX_PAR(i, 63) tl[i] = hist->qmf_hist[i];
     SX_PAR(i, SX_PACKET) tl[63 + i] = (i16)(pcm[i] >> 1);
@@ -95,7 +95,7 @@ SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N
 }
 
 // SKP_Silk_VAD_GetSA_Q8 (+ GetNoiseLevels), SKP_Silk_VAD.c:75-318.  X is a 4 x 80 int16 scratch (LDS).
-SX_FN void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSNR_dB_Q7) {
+SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSNR_dB_Q7) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(X);
     SxVAD* v = &st->vad;
     i16* X0 = X, *X1 = X + 80, *X2 = X + 160, *X3 = X + 240;
@@ -187,7 +187,7 @@ SX_FN void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSN
 }
 
 // SKP_Silk_HP_variable_cutoff_FIX (HP_variable_cutoff_FIX.c:37) + SKP_Silk_biquad_alt (biquad_alt.c:38)
-SX_FN void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in) {
+SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(out);
     if (st->prev_sigtype == 0) {
         i32 pitch_freq_Hz_Q16 = sx_shl(SX_FS_KHZ * 1000, 16) / st->prevLag;
@@ -427,7 +427,7 @@ struct SxPitchWork {                 // LDS scratch of the pitch analysis
 
 // SKP_Silk_pitch_analysis_core, SKP_Silk_pitch_analysis_core.c:65, Fs = 8 kHz, complexity 2 (so the
 // third stage is skipped and the extended 11-entry stage-2 codebook is used).  Returns sigtype.
-SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagIndex, i32* contourIndex, i32* LTPCorr_Q15,
+SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagIndex, i32* contourIndex, i32* LTPCorr_Q15,
                                  i32 prevLag, i32 search_thres1_Q16, i32 search_thres2_Q15, SxPitchWork* w) {
     SX_IN_LDS(signal); SX_IN_LDS(pitch_out); SX_IN_LDS(lagIndex); SX_IN_LDS(contourIndex); SX_IN_LDS(LTPCorr_Q15); SX_IN_LDS(w);
     const int min_lag_4 = 8, max_lag_4 = 72, min_lag_8 = 16, max_lag_8 = 144, sf8 = 40;
@@ -789,7 +789,7 @@ SX_FN int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInde
 
 // SKP_Silk_find_pitch_lags_FIX, SKP_Silk_find_pitch_lags_FIX.c:32.  x = x_buf + frame_length.
 // res: 336 samples (LDS).  Wsig: 192 samples scratch.
-SX_FN void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i16* res, i16* Wsig, SxPitchWork* pw) {
+SX_FN1 void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i16* res, i16* Wsig, SxPitchWork* pw) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res); SX_IN_LDS(Wsig); SX_IN_LDS(pw);
     const int buf_len = SX_LA_PITCH + 2 * SX_FRAME;        // 336
     i32 auto_corr[SX_MAX_LPC + 1], A_Q24[SX_MAX_LPC], scale;

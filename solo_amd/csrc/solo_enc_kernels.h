@@ -28,8 +28,12 @@ __device__ __forceinline__ void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* 
     SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
 }
 
-// (waves-per-SIMD target 5 = at most 104 VGPRs: two of these waves share a SIMD with one quantiser wave of ~288 VGPRs)
-__global__ void __launch_bounds__(64, 5) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
+// waves-per-SIMD target of the analysis kernel = its register budget (5: <= 96 VGPRs, 4: <= 128).  LDS admits 14 - 16 of its
+// workgroups per CU, i.e. 4 - 5 per SIMD on the three SIMDs the quantiser's wave leaves.
+#ifndef SX_ANALYSIS_WAVES
+#define SX_ANALYSIS_WAVES 4
+#endif
+__global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
     __shared__ SxEncWork w;

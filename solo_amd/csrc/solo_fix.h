@@ -25,6 +25,14 @@
 #define SX_DEV
 #define SX_FN static
 #endif
+// stage functions with ONE call site.  Inlining them there (-DSX_INLINE_SINGLE) costs no code, but their private arrays then all
+// live in one frame (1008 B of scratch per lane instead of 380 along the deepest call chain) and the analysis kernel gets 14 % slower
+// (measured); so they stay real calls.
+#if defined(__HIPCC__) && defined(SX_INLINE_SINGLE)
+#define SX_FN1 __host__ __device__ __forceinline__
+#else
+#define SX_FN1 SX_FN
+#endif
 
 // address-space hints for generic pointer parameters of non-inlined stage functions: lets the compiler emit ds_* / global_*
 // instead of flat_* (LLVM InferAddressSpaces understands these assumes)

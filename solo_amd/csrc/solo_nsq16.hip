@@ -16,7 +16,13 @@
 #define SX_NSQ_WAVES 1
 #endif
 // ring: SX_NSQ_RING_CELLS(64) cells per workgroup (the emission ring of its sixteen streams, rows of 64 lanes = 1 KB)
-extern "C" __global__ void __launch_bounds__(64, SX_NSQ_WAVES) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
+// SX_NSQ_VGPR_CAP = n: the kernel may use 2 n of the SIMD's 512 registers (n architectural + n accumulation registers as spill space)
+#ifdef SX_NSQ_VGPR_CAP
+#define SX_NSQ_CAP_ATTR __attribute__((amdgpu_num_vgpr(SX_NSQ_VGPR_CAP)))
+#else
+#define SX_NSQ_CAP_ATTR
+#endif
+extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64, SX_NSQ_WAVES) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
                                                                  SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
                                                                  unsigned int* started, SxNsqCell* __restrict__ ring) {
     __shared__ SxNsqWork w[SX_PER_WAVE];
