@@ -119,8 +119,7 @@ struct SxDecCtrl {               // SKP_Silk_decoder_control, SKP_Silk_structs.h
     i32 Gains_Q16[SX_NB_SUBFR];
     i32 DeltaGains_Q16;
     i32 Seed;
-    i16 PredCoef_Q12[2][SX_MAX_LPC];
-    i16 LTPCoef_Q14[SX_LTP_ORDER * SX_NB_SUBFR];
+    i16 LTPCoef_Q14[SX_LTP_ORDER * SX_NB_SUBFR];    // (the prediction coefficients are not side information: SxDecWork::PredCoef_Q12)
     i32 LTP_scale_Q14;
     i32 PERIndex, RateLevelIndex, QuantOffsetType, sigtype, MDIndex, NLSFInterpCoef_Q2;
 };
@@ -143,6 +142,14 @@ struct alignas(16) SxExtracted {
     i16 pulses[2][SX_FRAME];
 };
 #define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
+// High band of a packet, decoded up front (side information) and synthesised next to the low band: see sx_hb_decode_side
+struct SxHbParams {
+    i32 lsp[2][SX_HB_LPC];          // quantised LSPs of the (up to) two high-band frames
+    i16 lpc[2][SX_HB_LPC];          // ... as prediction coefficients
+    i16 gain[2][4];                 // sub-frame gains (codebook values)
+    i32 S[SX_HB_LPC];               // synthesis filter state while the packet is being decoded (committed when the packet is done)
+    i32 piggy, frame, lost, pad_;   // piggy: the low-band synthesis of frame `frame` also runs the high-band filter (lane 1)
+};
 // Phases of a packet reuse the same LDS (the decoder's occupancy is LDS-bound): see the lifetimes in the comments
 struct SxDecWork {
     SxDecState st;                  // the stream's state: HBM record -> LDS at launch start, back at the end
@@ -150,6 +157,7 @@ struct SxDecWork {
     SxCdfDec cdf;                   // entropy-coding tables (loaded once per launch)
     u8 payload[SX_DEC_PAYLOAD_LDS + 4];
     SxDecCtrl ctrl;
+    i16 PredCoef_Q12[2][SX_MAX_LPC];    // prediction coefficients of the two frame halves (from the NLSF vectors of the description in use)
     // frame scratch, in turn: parse (NLSF vectors [0,40) + per-description pulse-decoder scratch [40,80)), NLSF->LPC
     // workspace [40,122), LPC residual of decode_core / concealment signal of the PLC, high-band side information + workspace
     i32 res_Q10[SX_FRAME];
@@ -167,7 +175,8 @@ struct SxDecWork {
         } syn;
         i16 hi[SX_QMF_HIST + SX_BAND];  // [history | packet] high band (high-band synthesis .. QMF)
     } u;
-    i32 exc0_Q10[SX_FRAME];         // low-band excitation of frame 0 (frame 1's is still in st.exc_Q10) -> high-band regeneration
+    SxHbParams hbp;
+    i16 hi_out[SX_BAND];            // high band of the packet as it is synthesised
     i16 lo[SX_QMF_HIST + SX_BAND];  // [history | packet] low band
 };
 
@@ -479,7 +488,7 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
     SX_PAR(i, SX_MAX_LPC) w->u.syn.sLPC_Q14[i] = st->sLPC_Q14[i];
     wv_sync();
     for (int k = 0; k < SX_NB_SUBFR; k++) {
-        const i16* A_Q12 = c->PredCoef_Q12[k >> 1];
+        const i16* A_Q12 = w->PredCoef_Q12[k >> 1];
         i16* B_Q14 = &c->LTPCoef_Q14[k * SX_LTP_ORDER];
         i32 Gain_Q16 = c->Gains_Q16[k];
         int sigtype = c->sigtype;
@@ -550,21 +559,59 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
             wv_sync();
         }
         // short-term prediction (decode_core.c:188-288), serial recursion: coefficients (pre-shifted for the high-word multiply)
-        // and the last SX_LPC outputs live in registers; slot r of the ring holds the sample of time t = r (mod SX_LPC)
+        // and the last SX_LPC outputs live in registers; slot r of the ring holds the sample of time t = r (mod SX_LPC).
+        // The high band's synthesis filter (AGR_BWE_LPC_synthesizer.c, sx_hb_lpc_synthesis) is the same kind of recursion over the
+        // same SX_SUBFR samples, fed with the excitation of this very subframe, and independent of the low band's: it runs in the
+        // SAME instruction stream on lane 1 (order SX_HB_LPC <= SX_LPC: its two / eight oldest ring slots meet zero coefficients),
+        // with its own input scaling, saturation and output; every other lane computes the low band (wave-uniform, as before).
         {
-            i32 a[SX_LPC], h[SX_LPC];
+            const SxHbParams* hp = &w->hbp;
+            const int piggy = hp->piggy;
+            const int hf = st->hb_joint ? 0 : hp->frame;                                   // high-band frame / its subframe under these samples
+            const int hk = st->hb_joint ? (hp->frame * 2 + (k >> 1)) : k;
+            const i32 hbGain_Q16 = sx_mul(-2867, (i32)hp->gain[hf][hk]);
+            i16* hb_out = &w->hi_out[hp->frame * SX_FRAME + k * SX_SUBFR];
+#if SX_NLANES == 1
+            for (int role = 0; role < (piggy ? 2 : 1); role++) {
+                const bool hbl = role == 1;
+#else
+            {
+                const bool hbl = piggy && SX_LANE == 1;
+#endif
+                i32 a[SX_LPC], h[SX_LPC];
 #pragma unroll
-            for (int j = 0; j < SX_LPC; j++) { a[j] = sx_pre16(A_Q12[j]); h[j] = w->u.syn.sLPC_Q14[SX_MAX_LPC - SX_LPC + j]; }
-            for (int i0 = 0; i0 < SX_SUBFR; i0 += SX_LPC) {
+                for (int j = 0; j < SX_LPC; j++) {
+                    const int jh = j - (SX_LPC - SX_HB_LPC);                                // ring slot j = time -SX_LPC + j
+                    const i32 al = sx_pre16(A_Q12[j]), hl = w->u.syn.sLPC_Q14[SX_MAX_LPC - SX_LPC + j];
+                    const i32 ah = j < SX_HB_LPC ? sx_pre16(hp->lpc[hf][j < SX_HB_LPC ? j : 0]) : 0;
+                    const i32 hh = jh >= 0 ? hp->S[jh >= 0 ? jh : 0] : 0;
+                    a[j] = hbl ? ah : al;
+                    h[j] = hbl ? hh : hl;
+                }
+                const i32* in = hbl ? pexc_Q10 : pres_Q10;
+                i16* out = hbl ? hb_out : pxq;
+                const bool hb_zero = hbl && hp->lost;                                      // high band lost: zero excitation (decode_frame_FIX.c:65)
+                for (int i0 = 0; i0 < SX_SUBFR; i0 += SX_LPC) {
 #pragma unroll
-                for (int u = 0; u < SX_LPC; u++) {
-                    i32 p = 0;
+                    for (int u = 0; u < SX_LPC; u++) {
+                        i32 p = 0;
 #pragma unroll
-                    for (int j = 0; j < SX_LPC; j++) p = sx_smlaw_pre(p, h[(u - 1 - j + 2 * SX_LPC) % SX_LPC], a[j]);
-                    i32 v = sx_add(pres_Q10[i0 + u], p);
-                    h[u] = sx_shl(v, 4);
-                    w->u.syn.sLPC_Q14[SX_MAX_LPC + i0 + u] = h[u];
-                    pxq[i0 + u] = (i16)sx_sat16(sx_rshift_round(sx_smulww(v, Gain_Q16), 10));
+                        for (int j = 0; j < SX_LPC; j++) p = sx_smlaw_pre(p, h[(u - 1 - j + 2 * SX_LPC) % SX_LPC], a[j]);
+                        const i32 x = hb_zero ? 0 : in[i0 + u];
+                        // low band: v = x + p, state v << 4, output sat16(round(v * gain >> 10));
+                        // high band: v = sat32(p + x * gain), state sat32(v << 4), output sat16(round(v >> 10))
+                        const i32 xs = hbl ? sx_smulww(hbGain_Q16, x) : x;
+                        const i32 v = hbl ? sx_add_sat32(p, xs) : sx_add(xs, p);
+                        const i32 hn = hbl ? sx_lshift_sat32(v, 4) : sx_shl(v, 4);
+                        const i32 o = hbl ? v : sx_smulww(v, Gain_Q16);
+                        h[u] = hn;
+                        if (!hbl) w->u.syn.sLPC_Q14[SX_MAX_LPC + i0 + u] = hn;
+                        out[i0 + u] = (i16)sx_sat16(sx_rshift_round(o, 10));
+                    }
+                }
+                if (hbl) {
+#pragma unroll
+                    for (int j = 0; j < SX_HB_LPC; j++) w->hbp.S[j] = h[SX_LPC - SX_HB_LPC + j];
                 }
             }
         }
@@ -584,7 +631,7 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
 }
 
 // SKP_Silk_PLC_update, SKP_Silk_PLC.c:75
-SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
+SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c, const i16* PredCoef1_Q12) {
     SxPLC* p = &st->plc;
     st->prev_sigtype = c->sigtype;
     i32 LTP_Gain_Q14 = 0;
@@ -612,7 +659,7 @@ SX_HD void sx_plc_update(SxDecState* st, SxDecCtrl* c) {
         p->pitchL_Q8 = sx_shl(sx_smulbb(SX_FS_KHZ, 18), 8);
         for (int i = 0; i < SX_LTP_ORDER; i++) p->LTPCoef_Q14[i] = 0;
     }
-    for (int i = 0; i < SX_LPC; i++) p->prevLPC_Q12[i] = c->PredCoef_Q12[1][i];
+    for (int i = 0; i < SX_LPC; i++) p->prevLPC_Q12[i] = PredCoef1_Q12[i];
     p->prevLTP_scale_Q14 = (i16)c->LTP_scale_Q14;
     for (int i = 0; i < SX_NB_SUBFR; i++) p->prevGain_Q16[i] = c->Gains_Q16[i];
 }
@@ -726,7 +773,7 @@ SX_HD void sx_plc(SxDecState* st, SxDecWork* w, i16* signal, int lost) {
         sx_plc_conceal(st, w, signal);
         st->lossCnt++;
     } else {
-        sx_plc_update(st, &w->ctrl);
+        sx_plc_update(st, &w->ctrl, w->PredCoef_Q12[1]);
     }
 }
 
@@ -998,16 +1045,16 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 const i32* nl = &w->res_Q10[(ndesc - 1) * 2 * SX_LPC];
                 const int interp = c->NLSFInterpCoef_Q2 < 4;
                 SX_PAR(v, 2) {
-                    if (v == 1) sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, &w->res_Q10[4 * SX_LPC]);
-                    else if (interp) sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1);
+                    if (v == 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, &w->res_Q10[4 * SX_LPC]);
+                    else if (interp) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1);
                 }
                 wv_sync();
                 if (!interp) {
-                    SX_PAR(i, SX_LPC) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
+                    SX_PAR(i, SX_LPC) w->PredCoef_Q12[0][i] = w->PredCoef_Q12[1][i];
                     wv_sync();
                 }
                 if (st->lossCnt) {
-                    SX_PAR(v, 2) sx_bwexpander(c->PredCoef_Q12[v], SX_LPC, 63570);
+                    SX_PAR(v, 2) sx_bwexpander(w->PredCoef_Q12[v], SX_LPC, 63570);
                     wv_sync();
                 }
             }
@@ -1072,66 +1119,81 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
     for (int j = 0; j < SX_HB_LPC; j++) S[j] = h[j];
 }
 
-// AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40, for both 20 ms frames of a packet.  The side information of
-// the two frames (LSP -> LPC conversion included) is decoded on two lanes; the synthesis and the state updates then run in
-// frame order.  `hb` = the 8 high-band bytes (ignored when lost); exc0 / exc1 = low-band excitation of frame 0 / 1.
-SX_FN void sx_hb_decode_packet(SxDecState* st, SxDecWork* w, const u8* hb, i16* OutHigh, const i32* exc0, const i32* exc1, int lostflag) {
-    SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(OutHigh); SX_IN_LDS(exc0); SX_IN_LDS(exc1);
-    i32* lsp = w->res_Q10;                       // [2][SX_HB_LPC]
-    i32* gains = &w->res_Q10[2 * SX_HB_LPC];     // [2][4]
-    i16* lpc = (i16*)&w->res_Q10[2 * SX_HB_LPC + 8];   // [2][SX_MAX_LPC]
-    i32* zero = w->exc0_Q10;                     // (frame 0's excitation copy is not used when the high band is lost)
+// AGR_Bwe_decode_frame_FIX, libBWE/AGR_BWE_decode_frame_FIX.c:40, for both 20 ms frames of a packet, in three steps:
+//   sx_hb_decode_side   before the low-band frames: the side information of the (up to) two high-band frames, LSP -> LPC conversion
+//                       included, on two lanes; nothing of the stream state changes
+//   (synthesis)         inside sx_decode_core, on lane 1 of the low band's own synthesis loop, subframe by subframe, from the
+//                       excitation of that subframe (hbp.piggy); packets whose low band is concealed instead of decoded have no
+//                       such loop and no excitation: sx_hb_finish runs the filter on zeros for them
+//   sx_hb_finish        after the low-band frames (not reached when the packet is abandoned, like the reference's high-band call):
+//                       commits the filter state, the loss / previous-frame bookkeeping in frame order, hands the band to the QMF
+// `hb` = the 8 high-band bytes (ignored when lost).
+SX_FN void sx_hb_decode_side(SxDecState* st, SxDecWork* w, const u8* hb, int lostflag) {
+    SX_IN_LDS(st); SX_IN_LDS(w);
+    SxHbParams* hp = &w->hbp;
     const int lost = (lostflag == 1 || lostflag == 2);
-    SX_T_BEGIN
-    if (lost) { SX_PAR(i, SX_SUBFR) zero[i] = 0; }
     const int nf = st->hb_joint ? 1 : 2;          // high-band frames per packet
-    const int sub_len = st->hb_joint ? 2 * SX_SUBFR : SX_SUBFR;   // BWE_SubFrameSize
     SX_PAR(f, nf) {
-        i32* l = &lsp[f * SX_HB_LPC];
+        i32* l = hp->lsp[f];
         if (lost) {
             for (int i = 0; i < SX_HB_LPC; i++) l[i] = st->HB_prev_NLSFq[i];
-            for (int k = 0; k < 4; k++) gains[f * 4 + k] = st->HB_prev_Gain;
+            for (int k = 0; k < 4; k++) hp->gain[f][k] = (i16)st->HB_prev_Gain;
         } else {
             int bitpos = f * 32;
             u32 idx = sx_hb_unpack(hb, &bitpos, 12);
             u32 idx1 = idx & 0xFF, idx2 = idx >> 8;
             for (int i = 0; i < SX_HB_LPC; i++) l[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i];
-            for (int k = 0; k < 4; k++) gains[f * 4 + k] = T_hb_gain_cb[sx_hb_unpack(hb, &bitpos, 5)];
+            for (int k = 0; k < 4; k++) hp->gain[f][k] = (i16)T_hb_gain_cb[sx_hb_unpack(hb, &bitpos, 5)];
         }
-        sx_nlsf2a_stable_ws(&lpc[f * SX_MAX_LPC], l, SX_HB_LPC, f == 0 ? &w->res_Q10[4 * SX_LPC] : w->u.ws1);   // same for all 4 subframes
+        sx_nlsf2a_stable_ws(hp->lpc[f], l, SX_HB_LPC, f == 0 ? &w->res_Q10[4 * SX_LPC] : w->u.ws1);   // same for all 4 subframes
     }
+    SX_PAR(i, SX_HB_LPC) hp->S[i] = st->HB_synth_state[i];
+    if (SX_LANE == 0) { hp->lost = lost; hp->piggy = 0; hp->frame = 0; }
     wv_sync();
-    SX_PAR(i, SX_QMF_HIST) w->u.hi[i] = st->qmf_hi_hist[i];      // (the high-band buffer shares its LDS with the workspace above)
-    wv_sync();
+}
+
+// piggy_done: both low-band frames were decoded (and the high band synthesised next to them)
+SX_FN void sx_hb_finish(SxDecState* st, SxDecWork* w, int lostflag, int piggy_done) {
+    SX_IN_LDS(st); SX_IN_LDS(w);
+    SxHbParams* hp = &w->hbp;
+    const int lost = (lostflag == 1 || lostflag == 2);
+    const int nf = st->hb_joint ? 1 : 2;
+    const int sub_len = st->hb_joint ? 2 * SX_SUBFR : SX_SUBFR;   // BWE_SubFrameSize
+    SX_T_BEGIN
+    if (!piggy_done) {
+        // the low band was concealed: the high band is lost with it, its filter runs on zero excitation (decode_frame_FIX.c:65)
+        i32* zero = w->res_Q10;
+        SX_PAR(i, SX_SUBFR) zero[i] = 0;
+        wv_sync();
+        for (int f = 0; f < nf; f++)
+            for (int k = 0; k < 4; k++)
+                for (int h = 0; h < sub_len; h += SX_SUBFR)
+                    sx_hb_lpc_synthesis(zero, hp->lpc[f], sx_mul(-2867, (i32)hp->gain[f][k]), hp->S, &w->hi_out[f * SX_FRAME + k * sub_len + h], SX_SUBFR);
+        wv_sync();
+    }
     SX_T(8)
     for (int f = 0; f < nf; f++) {
-        const i32* QHB_LSP = &lsp[f * SX_HB_LPC];
-        const i32* QGain = &gains[f * 4];
+        const i32* QHB_LSP = hp->lsp[f];
         if (lost) {
             st->hb_lossCnt++;
         } else {
             if (st->hb_first) {
                 for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
-                st->HB_prev_Gain = QGain[3];
+                st->HB_prev_Gain = hp->gain[f][3];
             }
             st->hb_lossCnt = 0;
         }
-        for (int k = 0; k < 4; k++) {
-            // excitation = low-band excitation of the samples under this subframe (zero when the high band is lost:
-            // decode_frame_FIX.c:65); sample n of the packet lives in exc0 for n < 160, in exc1 after
-            const int n0 = f * SX_FRAME + k * sub_len;
-            const i32* ex = lost ? zero : (n0 < SX_FRAME ? &exc0[n0] : &exc1[n0 - SX_FRAME]);
-            for (int h = 0; h < sub_len; h += SX_SUBFR)          // (zero[] is one 40-sample block: feed long subframes in halves)
-                sx_hb_lpc_synthesis(lost ? zero : ex + h, &lpc[f * SX_MAX_LPC], sx_mul(-2867, (i32)(i16)QGain[k]), st->HB_synth_state,
-                                    &OutHigh[n0 + h], SX_SUBFR);
-        }
         if (lostflag == 0 || lostflag == 4 || lostflag == 3) {
-            st->HB_prev_Gain = QGain[3];
+            st->HB_prev_Gain = hp->gain[f][3];
             for (int i = 0; i < SX_HB_LPC; i++) st->HB_prev_NLSFq[i] = QHB_LSP[i];
         }
         st->hb_first = 0;
-        wv_sync();
     }
+    wv_sync();
+    SX_PAR(i, SX_HB_LPC) st->HB_synth_state[i] = hp->S[i];
+    SX_PAR(i, SX_QMF_HIST) w->u.hi[i] = st->qmf_hi_hist[i];      // (the high-band buffer of the QMF shares its LDS with the frame scratch)
+    SX_PAR(i, SX_BAND) w->u.hi[SX_QMF_HIST + i] = w->hi_out[i];
+    wv_sync();
 }
 
 // AGR_Sate_qmf_synth, libBWE/AGR_BWE_qmf.c:86, as a direct polyphase form (wave-parallel):
@@ -1224,7 +1286,14 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
 #endif
     SX_PAR(i, SX_QMF_HIST) w->lo[i] = st->qmf_lo_hist[i];
     wv_sync();
+    sx_hb_decode_side(st, w, bits + hb_pos, lostflag);
+    int piggy_frames = 0;
     for (int f = 0; f < 2; f++) {
+        // a frame that is decoded (not concealed) runs the high band's synthesis filter next to its own (sx_decode_core)
+        w->hbp.frame = f;
+        w->hbp.piggy = lostflag != 1;
+        wv_sync();
+        if (lostflag != 1) piggy_frames++;
         int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME], pre2, f);
         wv_sync();
         if (!pre2) {
@@ -1242,12 +1311,9 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         wv_sync();
         }
         if (ret < 0) { st->last_error = ret; return ret; }
-        if (f == 0) { SX_PAR(i, SX_FRAME) w->exc0_Q10[i] = st->exc_Q10[i]; }
-        wv_sync();
     }
     SX_T_BEGIN
-    sx_hb_decode_packet(st, w, bits + hb_pos, &w->u.hi[SX_QMF_HIST], w->exc0_Q10, st->exc_Q10, lostflag);
-    wv_sync();
+    sx_hb_finish(st, w, lostflag, piggy_frames == 2);
     SX_T(6)
     sx_qmf_synth(w->lo, w->u.hi, pcm_out);
     SX_T(7)
