@@ -5,6 +5,7 @@
 // structs in HBM; the per-packet working set lives in LDS.  No host-side codec arithmetic exists in
 // this library: without a usable HIP device every entry point fails.
 #include <hip/hip_runtime.h>
+#include <vector>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -427,9 +428,31 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     if (!b->pipe_ready) {
         int lo = 0, hi = 0;
         (void)hipDeviceGetStreamPriorityRange(&lo, &hi);            // hi = numerically lowest = greatest priority
+        // SOLO_ENC_CUMASK = m > 0: spatial split -- the quantiser's stream runs on every m-th compute unit only (its one wave per
+        // stream group takes a whole SIMD: four of them fill a CU), the analysis / coding streams on all the others
+        const char* em = getenv("SOLO_ENC_CUMASK");
+        const int cu_mod = em ? atoi(em) : 0;
+        if (cu_mod > 1) {
+            hipDeviceProp_t prop;
+            int dev = 0;
+            SOLO_CHECK(hipGetDevice(&dev));
+            SOLO_CHECK(hipGetDeviceProperties(&prop, dev));
+            const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
+            const char* eo = getenv("SOLO_ENC_CUMASK_PHASE");
+            const int phase = eo ? atoi(eo) : 0;
+            std::vector<uint32_t> mq(nw, 0u), mo(nw, 0u);
+            for (int i = 0; i < ncu; i++) {
+                if (i % cu_mod == phase) mq[i >> 5] |= 1u << (i & 31);
+                else mo[i >> 5] |= 1u << (i & 31);
+            }
+            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sA, (uint32_t)nw, mo.data()));
+            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sB, (uint32_t)nw, mq.data()));
+            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sC, (uint32_t)nw, mo.data()));
+        } else {
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sA, hipStreamNonBlocking, lo));
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, lo));
+        }
         SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) {
             SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA[i], hipEventDisableTiming));
@@ -443,7 +466,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         const char* e = getenv("SOLO_ENC_CHUNK");
         b->chunk_packets = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_GATE");
-        b->gate = e ? atoi(e) : 1;
+        // residency gate (hold analysis chunk c + 1 until the quantiser launch of chunk c is resident): needed when the quantiser
+        // was 1024 workgroups that had to find room between 4096 analysis workgroups; with 256 quantiser workgroups it costs 3 %
+        // (measured 72.3 vs 69.9 ms per 204 800 packets), so it is off unless asked for
+        b->gate = e ? atoi(e) : 0;
         e = getenv("SOLO_ENC_GROUP");
         b->group_streams = e ? atoi(e) : 4096;
         {   // the quantiser launches of a call run one after the other on sB: one ring, sized for the largest launch group
@@ -514,12 +540,16 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
+            static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;     // timing experiments only: 1 = no quantiser, 2 = no coding (wrong output)
+            if (!(exp_skip & 1)) {
             if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->d_nsq_ring, b->sB)) != hipSuccess) goto launch_failed;
             b->started_target[c] += (unsigned int)ops->nsq_workgroups(ns);     // workgroups of this launch, counted once it is enqueued
+            }
             if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
             SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
             if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
+            if (!(exp_skip & 2))
             if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
             if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
             SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));

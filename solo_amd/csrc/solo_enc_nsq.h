@@ -844,12 +844,20 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     cell.Pred_Q16 = cExc16[ki][t];
                     cell.Shape_Q10 = cShp[ki][t];
                     cell.exc_Q10 = t == 0 ? cExc10[ki] : 0;
+#ifndef SX_EXP_NO_RING_STORE
                     SX_CELL(t, smpl_buf_idx, kk) = cell;
+#else
+                    if (cell.xqQ == 0x7F123456) SX_CELL(t, smpl_buf_idx, kk) = cell;      // (timing experiment: no ring traffic)
+#endif
                 }
                 {
                     SxNsqCell cr;
                     cr.xqQ = Seed[ki][0]; cr.Pred_Q16 = Seed[ki][1]; cr.Shape_Q10 = Seed[ki][2]; cr.exc_Q10 = 0;
+#ifndef SX_EXP_NO_RING_STORE
                     SX_CELL(SX_N_TRACKS, smpl_buf_idx, kk) = cr;
+#else
+                    if (cr.xqQ == 0x7F123456) SX_CELL(SX_N_TRACKS, smpl_buf_idx, kk) = cr;
+#endif
                 }
                 // the state's own slot now holds its newest ring entry
                 const u32 m = 3u << (2 * (smpl_buf_idx & 15));
