@@ -128,11 +128,12 @@ int32_t solo_batch_wait_encode(solo_batch_t *b, void *hip_stream, int32_t which)
 int32_t solo_batch_n_streams(const solo_batch_t *b);
 int32_t solo_batch_slot_bytes(const solo_batch_t *b);
 /* Name of the dominant kernel of the last encode / decode launch (for profiling tools). */
-/* Names of the device kernels: 0 = quantiser (dominant encode kernel), 1 = decode, 2 = encoder analysis, 3 = encoder coding. */
+/* Names of the device kernels behind the four timed stages: 0 = quantiser, 1 = decoder proper (batch path; symbol extraction is
+ * "solo_dec_extract_kernel"), 2 = encoder analysis, 3 = encoder high band + payload (the range coder is "solo_enc_rc_kernel"). */
 const char *solo_kernel_name(int32_t which);
 /* Benchmark aid: bracket every kernel of this handle with HIP events on its launch stream, and read the durations of
  * the most recent encode / decode call: ms4 = {analysis, quantiser, coding, decode} (-1 = not run yet).  solo_batch_encode
- * runs its three kernels as a pipeline over chunks of the call's packets (several launches per kernel, overlapping in
+ * runs its four kernels (three timed stages: the range coder is timed with the coding stage) as a pipeline over chunks of the call's packets (several launches per kernel, overlapping in
  * time on internal streams): the encoder entries are the SUM over the launches of that kernel, and
  * solo_batch_last_encode_chunks() is the number of launches per kernel of that call. */
 int32_t solo_batch_set_timing(solo_batch_t *b, int32_t on);

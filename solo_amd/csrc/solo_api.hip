@@ -160,7 +160,7 @@ extern "C" {
 
 const char* solo_version(void) { return "solo_mi355x 0.1 (gfx950)"; }
 
-const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : (which == 1 ? "solo_decode_kernel" : (which == 2 ? "solo_enc_analysis_kernel" : "solo_enc_coding_kernel")); }
+const char* solo_kernel_name(int32_t which) { return which == 0 ? "solo_nsq_kernel" : (which == 1 ? "solo_dec_synth_kernel" : (which == 2 ? "solo_enc_analysis_kernel" : "solo_enc_coding_kernel")); }
 
 int32_t solo_batch_n_streams(const solo_batch_t* b) { return b ? b->n_streams : 0; }
 
