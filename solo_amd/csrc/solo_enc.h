@@ -383,7 +383,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
 
 // SKP_Silk_encode_frame_FIX (SKP_Silk_encode_frame_FIX.c:33) up to and including the NSQ; the range coding of both
 // frames is deferred to the end of the packet (nothing in the analysis depends on it: DISABLE_BUF_RD)
-SX_FN1 void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame, SxNsqIn* in, SxFrameIdx* x) {
+SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn, int frame, SxNsqIn* in, SxFrameIdx* x) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
@@ -482,7 +482,7 @@ struct SxCodeIn {
 // Stage A of AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129): QMF split and the analysis chain of both 20 ms frames.
 // Nothing here depends on the quantiser's output (DISABLE_BUF_RD, SKP_Silk_define.h:53), so a whole launch of packets
 // can be analysed before any is quantised.
-SX_FN void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsqIn* in2, SxCodeIn* cin) {
+SX_FNW void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsqIn* in2, SxCodeIn* cin) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SX_T_BEGIN
@@ -500,7 +500,7 @@ SX_FN void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsqI
 // On the GPU the stage is two kernels: the range coder is a serial chain per description and runs LANE-per-description
 // (sx_code_description; 32 streams per wavefront, solo_enc_rc_kernel), the high-band encoder and the payload assembly run
 // wavefront-per-stream (sx_enc_stage_c_hb, sx_enc_stage_c_out; solo_enc_coding_kernel).  The host emulation calls the three in a row.
-SX_FN void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2) {
+SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2) {
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;

@@ -33,6 +33,13 @@
 #else
 #define SX_FN1 SX_FN
 #endif
+// the frame / packet level wrappers between a kernel and its stages: always inlined into the kernel (their callee-saved registers
+// would otherwise be saved and restored around every frame: ~100 B of scratch per lane and 2 x 24 scratch accesses per frame)
+#if defined(__HIPCC__) && !defined(SX_OUTLINE_WRAPPERS)
+#define SX_FNW __host__ __device__ __forceinline__
+#else
+#define SX_FNW SX_FN
+#endif
 
 // address-space hints for generic pointer parameters of non-inlined stage functions: lets the compiler emit ds_* / global_*
 // instead of flat_* (LLVM InferAddressSpaces understands these assumes)
