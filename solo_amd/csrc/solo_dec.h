@@ -139,7 +139,7 @@ struct alignas(16) SxExtracted {
     i32 usable;                      // both frames were read without a coder error and the symbols do not depend on the stream's history
     i32 pad_[3];
     SxFrameSyms y[2];
-    i16 pulses[2][SX_FRAME];
+    i8 pulses[2][SX_FRAME];
 };
 #define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
 // High band of a packet, decoded up front (side information) and synthesised next to the low band: see sx_hb_decode_side
@@ -230,34 +230,36 @@ SX_HD void sx_shell_split(i32* c1, i32* c2, RC* rc, i32 p, const u16* table, con
         *c2 = 0;
     }
 }
-template <typename RC>
-SX_HD void sx_shell_decoder(i16* q, RC* rc, i32 pulses4, const SxCdf* cdf) {
+template <typename RC, typename QT>
+SX_HD void sx_shell_decoder(QT* q, RC* rc, i32 pulses4, const SxCdf* cdf) {
     i32 p3[2], p2[4], p1[8], a, b;
     sx_shell_split(&p3[0], &p3[1], rc, pulses4, cdf->cdf_shell3, cdf);
     sx_shell_split(&p2[0], &p2[1], rc, p3[0], cdf->cdf_shell2, cdf);
     sx_shell_split(&p1[0], &p1[1], rc, p2[0], cdf->cdf_shell1, cdf);
-    sx_shell_split(&a, &b, rc, p1[0], cdf->cdf_shell0, cdf); q[0] = a; q[1] = b;
-    sx_shell_split(&a, &b, rc, p1[1], cdf->cdf_shell0, cdf); q[2] = a; q[3] = b;
+    sx_shell_split(&a, &b, rc, p1[0], cdf->cdf_shell0, cdf); q[0] = (QT)a; q[1] = (QT)b;
+    sx_shell_split(&a, &b, rc, p1[1], cdf->cdf_shell0, cdf); q[2] = (QT)a; q[3] = (QT)b;
     sx_shell_split(&p1[2], &p1[3], rc, p2[1], cdf->cdf_shell1, cdf);
-    sx_shell_split(&a, &b, rc, p1[2], cdf->cdf_shell0, cdf); q[4] = a; q[5] = b;
-    sx_shell_split(&a, &b, rc, p1[3], cdf->cdf_shell0, cdf); q[6] = a; q[7] = b;
+    sx_shell_split(&a, &b, rc, p1[2], cdf->cdf_shell0, cdf); q[4] = (QT)a; q[5] = (QT)b;
+    sx_shell_split(&a, &b, rc, p1[3], cdf->cdf_shell0, cdf); q[6] = (QT)a; q[7] = (QT)b;
     sx_shell_split(&p2[2], &p2[3], rc, p3[1], cdf->cdf_shell2, cdf);
     sx_shell_split(&p1[4], &p1[5], rc, p2[2], cdf->cdf_shell1, cdf);
-    sx_shell_split(&a, &b, rc, p1[4], cdf->cdf_shell0, cdf); q[8] = a; q[9] = b;
-    sx_shell_split(&a, &b, rc, p1[5], cdf->cdf_shell0, cdf); q[10] = a; q[11] = b;
+    sx_shell_split(&a, &b, rc, p1[4], cdf->cdf_shell0, cdf); q[8] = (QT)a; q[9] = (QT)b;
+    sx_shell_split(&a, &b, rc, p1[5], cdf->cdf_shell0, cdf); q[10] = (QT)a; q[11] = (QT)b;
     sx_shell_split(&p1[6], &p1[7], rc, p2[3], cdf->cdf_shell1, cdf);
-    sx_shell_split(&a, &b, rc, p1[6], cdf->cdf_shell0, cdf); q[12] = a; q[13] = b;
-    sx_shell_split(&a, &b, rc, p1[7], cdf->cdf_shell0, cdf); q[14] = a; q[15] = b;
+    sx_shell_split(&a, &b, rc, p1[6], cdf->cdf_shell0, cdf); q[12] = (QT)a; q[13] = (QT)b;
+    sx_shell_split(&a, &b, rc, p1[7], cdf->cdf_shell0, cdf); q[14] = (QT)a; q[15] = (QT)b;
 }
 
 // SKP_Silk_decode_pulses (SKP_Silk_decode_pulses.c:33) + SKP_Silk_decode_signs (code_signs.c:64).
 // tmp: 2 * SX_FRAME/16 words of per-description scratch (LDS)
-// returns the rate level index
-template <typename RC>
-SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, i16* q, const SxCdf* cdf, i32* tmp) {
+// returns the rate level index.  QT / TT: storage of the pulses / of the per-block scratch -- int16 / int32 in the decoder proper; the
+// extraction kernel keeps them in bytes (a lane's LDS row: what a well-formed stream holds always fits) and reports in *narrow
+// whether anything did not fit (the record is then not used)
+template <typename RC, typename QT, typename TT>
+SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, QT* q, const SxCdf* cdf, TT* tmp, i32* narrow) {
     SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
     const int iter = SX_FRAME / 16;
-    i32 *sum_pulses = tmp, *nLshifts = tmp + SX_FRAME / 16;
+    TT *sum_pulses = tmp, *nLshifts = tmp + SX_FRAME / 16;
     const i32 RateLevelIndex = sx_rc_dec(rc, &cdf->cdf_rate_levels[sigtype * 10], T_CDF_MID_RATE_LEVELS);
     const u16* cdf_ptr = &cdf->cdf_pulses_per_block[RateLevelIndex * 21];
     for (int i = 0; i < iter; i++) {
@@ -268,15 +270,16 @@ SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, i16* q, con
             sp = sx_rc_dec(rc, &cdf->cdf_pulses_per_block[9 * 21], T_CDF_MID_PULSES_PER_BLOCK);
             if (rc->error) break;   // (reference would spin on the zero returned after an error only until != 19; 0 != 19)
         }
-        nLshifts[i] = nl;
-        sum_pulses[i] = sp;
+        if (sizeof(TT) == 1 && nl > 7) *narrow = 1;
+        nLshifts[i] = (TT)nl;
+        sum_pulses[i] = (TT)sp;
     }
     const u32 p_lsb = cdf->cdf_lsb[1];
     for (int i = 0; i < iter; i++) {
         if (sum_pulses[i] > 0) {
             sx_shell_decoder(&q[i * 16], rc, sum_pulses[i], cdf);
         } else {
-            for (int k = 0; k < 16; k++) q[i * 16 + k] = 0;
+            for (int k = 0; k < 16; k++) q[i * 16 + k] = (QT)0;
         }
     }
     for (int i = 0; i < iter; i++) {
@@ -288,7 +291,8 @@ SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, i16* q, con
                     abs_q = sx_shl(abs_q, 1);
                     abs_q += sx_rc_dec_bin(rc, p_lsb);
                 }
-                q[i * 16 + k] = (i16)abs_q;
+                if (sizeof(QT) == 1 && abs_q > 127) *narrow = 1;
+                q[i * 16 + k] = (QT)abs_q;
             }
         }
     }
@@ -298,7 +302,7 @@ SX_HD i32 sx_decode_pulses(RC* rc, int sigtype, int QuantOffsetType, i16* q, con
         const i32 v = q[i];
         if (v > 0) {
             i32 data = sx_rc_dec_bin(rc, p_sign);
-            q[i] = (i16)(v * ((data << 1) - 1));
+            q[i] = (QT)(v * ((data << 1) - 1));
         }
     }
     return RateLevelIndex;
@@ -334,9 +338,9 @@ SX_HD void sx_nlsf_msvq_decode(i32* pNLSF_Q15, int sigtype, const i32* idx) {
 // later symbol reads as 0 either way, so the control block and the state come out the same.
 // typeOffsetPrev: signal type / offset symbol of the packet's previous frame (read when nFramesDecoded != 0, always written);
 // q / tmp: pulses and pulse-decoder scratch (LDS); dbg: first-failure trace record or NULL
-template <typename RC>
-SX_HD void sx_extract_parameters(int nFramesDecoded, i32* typeOffsetPrev, i32* dbg, RC* rc_io, i16* q, int kDesp, int useMDIndex, const SxCdf* cdf,
-                                 SxFrameSyms* y, i32* tmp) {
+template <typename RC, typename QT, typename TT>
+SX_HD void sx_extract_parameters(int nFramesDecoded, i32* typeOffsetPrev, i32* dbg, RC* rc_io, QT* q, int kDesp, int useMDIndex, const SxCdf* cdf,
+                                 SxFrameSyms* y, TT* tmp, i32* narrow) {
     SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(tmp);
     RC rc_local = *rc_io;
     RC* rc = &rc_local;
@@ -397,7 +401,7 @@ SX_HD void sx_extract_parameters(int nFramesDecoded, i32* typeOffsetPrev, i32* d
     SX_TRACE(4);
     y->Seed = sx_rc_dec(rc, cdf->cdf_seed, T_CDF_MID_SEED);
     SX_TRACE(5);
-    y->RateLevelIndex = sx_decode_pulses(rc, sigtype, QuantOffsetType, q, cdf, tmp);
+    y->RateLevelIndex = sx_decode_pulses(rc, sigtype, QuantOffsetType, q, cdf, tmp, narrow);
     SX_TRACE(6);
     y->vadFlag = sx_rc_dec(rc, cdf->cdf_vadflag, T_CDF_MID_VADFLAG);
     y->FrameTermination = sx_rc_dec(rc, cdf->cdf_frame_term, T_CDF_MID_FRAME_TERM);
@@ -470,8 +474,8 @@ SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int f
 SX_FN void sx_decode_parameters(int nFramesDecoded, int first_frame_after_reset, SxDecDesc* md, i32* dbg, SxDecCtrl* c, SxRangeDec* rc_io,
                                 i16* q, int kDesp, int useMDIndex, const SxCdf* cdf, i32* lane_out, i32* nlsf_out, i32* tmp, SxFrameSyms* y) {
     SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp); SX_IN_LDS(y);
-    i32 top = md->typeOffsetPrev;
-    sx_extract_parameters(nFramesDecoded, &top, dbg, rc_io, q, kDesp, useMDIndex, cdf, y, tmp);
+    i32 top = md->typeOffsetPrev, narrow = 0;
+    sx_extract_parameters(nFramesDecoded, &top, dbg, rc_io, q, kDesp, useMDIndex, cdf, y, tmp, &narrow);
     sx_dequant_parameters(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
 }
 
@@ -960,9 +964,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 const i32* sy = (const i32*)&pre2[d].y[f];
                 i32* dy = (i32*)sx_dec_syms(w, d);
                 SX_PAR(i, (int)(sizeof(SxFrameSyms) / 4)) dy[i] = sy[i];
-                const i32* sq = (const i32*)&pre2[d].pulses[f][0];
-                i32* dq = (i32*)&w->u.parse.pulses[d][0];
-                SX_PAR(i, SX_FRAME / 2) dq[i] = sq[i];
+                SX_PAR(i, SX_FRAME) w->u.parse.pulses[d][i] = (i16)pre2[d].pulses[f][i];
             }
             wv_sync();
         }
@@ -1329,14 +1331,12 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
 // -- not the stream's history -- so it decodes with the interval form of the range decoder (solo_rc.h, SxRangeDec2) and marks the
 // record usable only if both frames came out without a coder error and without depending on what lies behind the description.
 // ---------------------------------------------------------------------------------------------------
-#define SX_EXTRACT_PAY 128           // descriptions up to SX_EXTRACT_PAY - 4 bytes are staged in LDS; longer ones are read from HBM
-struct SxExtractLane {               // LDS, one lane (an odd number of dwords: the lanes of a wavefront sit at the same offset of
-    i32 tmp[2 * (SX_FRAME / 16)];    // their own copy most of the time)
-    i16 pulses[SX_FRAME];
-    u32 pay[SX_EXTRACT_PAY / 4];
-    i32 pad_[1 + (2 * (SX_FRAME / 16) + SX_FRAME / 2 + SX_EXTRACT_PAY / 4) % 2];
-};
-static_assert(sizeof(SxExtractLane) % 4 == 0 && (sizeof(SxExtractLane) / 4) % 2 == 1, "odd dword stride");
+// LDS row of one extraction lane: the per-block scratch and the pulses of one frame, in bytes; an odd number of dwords (the lanes
+// of a wavefront sit at the same offset of their own row most of the time)
+#define SX_EXTRACT_TMP (2 * (SX_FRAME / 16))
+#define SX_EXTRACT_ROW (4 * (((SX_EXTRACT_TMP + SX_FRAME + 3) / 4) | 1))
+struct SxExtractLane { u8 b[SX_EXTRACT_ROW]; };
+static_assert(SX_EXTRACT_TMP % 4 == 0 && (SX_EXTRACT_ROW / 4) % 2 == 1, "row layout");
 
 // where description slot md of a packet handed over as (nBytes0, nBytes1, lostflag) lies (see sx_decode_packet); false: no such slot
 SX_HD bool sx_desc_span(int lostflag, i32 nBytes0, i32 nBytes1, int hb_joint, int md, i32* off, i32* len) {
@@ -1351,34 +1351,21 @@ SX_HD bool sx_desc_span(int lostflag, i32 nBytes0, i32 nBytes1, int hb_joint, in
     return true;
 }
 
-// src: the description's bytes inside the packet (HBM), len of them
+// src: the description's bytes inside the packet (HBM), len of them (read in place: a serial coder touches every byte once, the
+// look-ups of the tables are what it waits for)
 SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* cdf, SxExtractLane* L, SxExtracted* rec) {
     rec->usable = 0;
     if (len <= 0 || len > SX_MAX_ARITHM_BYTES) return;           // (the serial decoder reports what is wrong with it)
-    if (len <= SX_EXTRACT_PAY - 4) {
-        // aligned dwords from the packet, re-aligned, into the lane's LDS copy
-        const u32 a0 = (u32)((size_t)src & 3), sh8 = a0 * 8;
-        const u32* s4 = (const u32*)(src - a0);
-        const int ldw = (int)((a0 + (u32)len - 1) >> 2);          // last dword that holds a byte of the description
-        const int nd = (len + 3) >> 2;
-        u32 cur = s4[0];
-        for (int i = 0; i < nd; i++) {
-            const u32 nxt = s4[i + 1 <= ldw ? i + 1 : ldw];
-            L->pay[i] = sh8 ? ((cur >> sh8) | (nxt << (32 - sh8))) : cur;
-            cur = nxt;
-        }
-        src = (const u8*)&L->pay[0];
-    }
     SxRangeDec2 r;
     sx_rc_dec_init(&r, src, len);
-    i32 top = 0;
+    i32 top = 0, narrow = 0;
     i32* dbg = 0;
     for (int f = 0; f < 2; f++) {
         SxFrameSyms y;
-        sx_extract_parameters(f, &top, dbg, &r, L->pulses, 0, useMDIndex, cdf, &y, L->tmp);
+        sx_extract_parameters(f, &top, dbg, &r, (i8*)&L->b[SX_EXTRACT_TMP], 0, useMDIndex, cdf, &y, &L->b[0], &narrow);
         { const i32* sy = (const i32*)&y; i32* dy = (i32*)&rec->y[f]; for (int i = 0; i < (int)(sizeof(SxFrameSyms) / 4); i++) dy[i] = sy[i]; }
-        if (y.fs_bad || y.error) return;
-        { const i32* sq = (const i32*)&L->pulses[0]; i32* dq = (i32*)&rec->pulses[f][0]; for (int i = 0; i < SX_FRAME / 2; i++) dq[i] = sq[i]; }
+        if (y.fs_bad || y.error || narrow) return;
+        { const i32* sq = (const i32*)&L->b[SX_EXTRACT_TMP]; i32* dq = (i32*)&rec->pulses[f][0]; for (int i = 0; i < SX_FRAME / 4; i++) dq[i] = sq[i]; }
     }
     rec->usable = r.ambiguous ? 0 : 1;
 }
