@@ -91,12 +91,15 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* s
 // (sx_extracted_usable); anything else -- coder errors, a packet that announces more frames than it carries, symbols that depend
 // on the bytes behind the description -- is decoded serially as in the single kernel, with the exact history.
 #define SX_EXTRACT_LANES (SX_FS_KHZ == 8 ? 64 : 32)        // lanes per workgroup (LDS: ~0.5 KB per lane at 8 kHz, ~0.9 KB at 16 kHz)
+#ifndef SX_EXTRACT_WAVES
+#define SX_EXTRACT_WAVES 4                                 // waves per SIMD the extraction kernel is compiled for (its register budget)
+#endif
 struct SxExtractWork {
     SxCdfDec cdf;
     SxExtractLane lane[SX_EXTRACT_LANES];
 };
 // recs: [(stream * pc + (p - p0)) * 2 + slot]; one lane per record
-__global__ void __launch_bounds__(SX_EXTRACT_LANES) SX_K(solo_dec_extract_kernel)(const SxDecStream* states, const u8* __restrict__ bits,
+__global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_dec_extract_kernel)(const SxDecStream* states, const u8* __restrict__ bits,
                                                                                  const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                                                  int n_streams, int n_packets, int p0, int pc, int slot,
                                                                                  int useMDIndex, SxExtracted* __restrict__ recs) {
