@@ -311,7 +311,7 @@ def main():
         dec_chunk = int(os.environ.get("SOLO_DEC_CHUNK", "24"))       # (solo_api.hip: a first chunk of 4 packets, then chunks of this size)
         if split_dec and dec_chunk > 0:
             cp = min(P, dec_chunk)
-            c0 = 4 if P > 8 else cp
+            c0 = 4 if (P > 8 and cp > 4) else cp
             dec_chunks = 1 + (P - c0 + cp - 1) // cp
         else:
             dec_chunks = 1

@@ -350,7 +350,7 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
     // (a short first chunk -- its extraction has nothing to hide behind -- then long ones: every decoder launch reloads the stream states)
     const int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
-    const int c0 = n_packets > 2 * SOLO_DEC_FIRST_CHUNK ? SOLO_DEC_FIRST_CHUNK : cp;
+    const int c0 = (n_packets > 2 * SOLO_DEC_FIRST_CHUNK && cp > SOLO_DEC_FIRST_CHUNK) ? SOLO_DEC_FIRST_CHUNK : cp;      // (never larger than the buffers: c0 <= cp)
     const int nchunks = 1 + (n_packets - c0 + cp - 1) / cp;
     const size_t need = (size_t)b->n_streams * (size_t)cp * (b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes());
     if (need > b->parsed_bytes) {

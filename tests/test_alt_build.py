@@ -42,3 +42,17 @@ def test_decoder_suite_through_the_single_kernel_path():
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+def test_decoder_suite_with_small_decode_chunks():
+    """The batched decode call works through its packets in chunks (symbol extraction a chunk ahead of the decoder proper; default
+    4 + 24 + 24 ...).  With SOLO_DEC_CHUNK=3 even short calls cross several chunk boundaries: same output required (stream state,
+    description shadow and the serial fall-back for unusual packets all carry over the boundaries)."""
+    env = dict(os.environ, SOLO_DEC_CHUNK="3")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(T.ROOT, "tests", "test_gpu_decoder.py"), os.path.join(T.ROOT, "tests", "test_pinned_corners.py")],
+                       env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
