@@ -594,28 +594,23 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 }
                 const i32* in = hbl ? pexc_Q10 : pres_Q10;
                 i16* out = hbl ? hb_out : pxq;
-                // One instruction stream for both roles, selects only.  The gain a role does not apply is 65536 ((65536 * y) >> 16 == y
-                // exactly); a lost high band has zero excitation (decode_frame_FIX.c:65): input gain 0; the low band's ring also goes
-                // to LDS (the next subframe starts from there), the high band's lane writes that store to a spare word instead.
-                const i32 gx = hbl ? (hp->lost ? 0 : hbGain_Q16) : 65536, go = hbl ? 65536 : Gain_Q16;
-                i32* ring = hbl ? &w->hbp.pad_ : &w->u.syn.sLPC_Q14[SX_MAX_LPC];
-                const int rmask = hbl ? 0 : -1;
+                const bool hb_zero = hbl && hp->lost;                                      // high band lost: zero excitation (decode_frame_FIX.c:65)
                 for (int i0 = 0; i0 < SX_SUBFR; i0 += SX_LPC) {
 #pragma unroll
                     for (int u = 0; u < SX_LPC; u++) {
                         i32 p = 0;
 #pragma unroll
                         for (int j = 0; j < SX_LPC; j++) p = sx_smlaw_pre(p, h[(u - 1 - j + 2 * SX_LPC) % SX_LPC], a[j]);
+                        const i32 x = hb_zero ? 0 : in[i0 + u];
                         // low band: v = x + p, state v << 4, output sat16(round(v * gain >> 10));
                         // high band: v = sat32(p + x * gain), state sat32(v << 4), output sat16(round(v >> 10))
-                        const i32 xs = sx_smulww(gx, in[i0 + u]);
-                        const i32 vw = sx_add(p, xs), vs = sx_add_sat32(p, xs);
-                        const i32 v = hbl ? vs : vw;
-                        const i32 hw = sx_shl(v, 4), hs = sx_lshift_sat32(v, 4);
-                        const i32 hn = hbl ? hs : hw;
+                        const i32 xs = hbl ? sx_smulww(hbGain_Q16, x) : x;
+                        const i32 v = hbl ? sx_add_sat32(p, xs) : sx_add(xs, p);
+                        const i32 hn = hbl ? sx_lshift_sat32(v, 4) : sx_shl(v, 4);
+                        const i32 o = hbl ? v : sx_smulww(v, Gain_Q16);
                         h[u] = hn;
-                        ring[(i0 + u) & rmask] = hn;
-                        out[i0 + u] = (i16)sx_sat16(sx_rshift_round(sx_smulww(go, v), 10));
+                        if (!hbl) w->u.syn.sLPC_Q14[SX_MAX_LPC + i0 + u] = hn;
+                        out[i0 + u] = (i16)sx_sat16(sx_rshift_round(o, 10));
                     }
                 }
                 if (hbl) {
