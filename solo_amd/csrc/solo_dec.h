@@ -575,6 +575,45 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
             const int hk = st->hb_joint ? (hp->frame * 2 + (k >> 1)) : k;
             const i32 hbGain_Q16 = sx_mul(-2867, (i32)hp->gain[hf][hk]);
             i16* hb_out = &w->hi_out[hp->frame * SX_FRAME + k * SX_SUBFR];
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+            // GPU form: ONE TAP PER LANE.  Lane (row, j) of the wavefront holds coefficient j and the output of time t - 1 - j of the
+            // row's filter: row 1 = the high band's, every other row a copy of the low band's.  A sample is then one high-word
+            // multiply, a sum over the 16-lane row (four DPP adds; the 32-bit sums wrap, so the order is free), the role's output
+            // arithmetic, and a one-lane shift of the row (DPP row_shr:1) -- instead of SX_LPC multiply-adds per filter in every lane.
+            {
+                const int row = SX_LANE >> 4, j = SX_LANE & 15;
+                const bool hbl = piggy && row == 1;
+                const i32 al = j < SX_LPC ? sx_pre16(A_Q12[j < SX_LPC ? j : 0]) : 0;
+                const i32 ah = j < SX_HB_LPC ? sx_pre16(hp->lpc[hf][j < SX_HB_LPC ? j : 0]) : 0;
+                const i32 hl = w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j];                    // (all 16 lanes carry true history; taps past the order meet zeros)
+                const i32 hh = j < SX_HB_LPC ? hp->S[SX_HB_LPC - 1 - (j < SX_HB_LPC ? j : 0)] : 0;
+                const i32 aj = hbl ? ah : al;
+                i32 hj = hbl ? hh : hl;
+                const i32* in = hbl ? pexc_Q10 : pres_Q10;
+                i16* out = hbl ? hb_out : pxq;
+                const bool hb_zero = hp->lost != 0;
+                for (int i = 0; i < SX_SUBFR; i++) {
+                    const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
+                    const i32 x = in[i];
+                    i32 hn, o;
+                    if (hbl) {
+                        const i32 v = sx_add_sat32(p, sx_smulww(hbGain_Q16, hb_zero ? 0 : x));
+                        hn = sx_lshift_sat32(v, 4);
+                        o = v;
+                    } else {
+                        const i32 v = sx_add(x, p);
+                        hn = sx_shl(v, 4);
+                        o = sx_smulww(v, Gain_Q16);
+                    }
+                    const i32 sh = __builtin_amdgcn_update_dpp(0, hj, 0x111, 0xF, 0xF, true);      // row_shr:1: lane j takes lane j - 1
+                    hj = j == 0 ? hn : sh;
+                    out[i] = (i16)sx_sat16(sx_rshift_round(o, 10));
+                }
+                wv_sync();
+                if (row == 0) w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j] = hj;                // the last SX_MAX_LPC outputs: the next subframe starts from them
+                if (hbl && j < SX_HB_LPC) w->hbp.S[SX_HB_LPC - 1 - j] = hj;
+            }
+#else
 #if SX_NLANES == 1
             for (int role = 0; role < (piggy ? 2 : 1); role++) {
                 const bool hbl = role == 1;
@@ -618,11 +657,12 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                     for (int j = 0; j < SX_HB_LPC; j++) w->hbp.S[j] = h[SX_LPC - SX_HB_LPC + j];
                 }
             }
-        }
-        wv_sync();
-        SX_PAR(i, SX_MAX_LPC) {
-            i32 t = w->u.syn.sLPC_Q14[SX_SUBFR + i];
-            w->u.syn.sLPC_Q14[i] = t;
+            wv_sync();
+            SX_PAR(i, SX_MAX_LPC) {
+                i32 t = w->u.syn.sLPC_Q14[SX_SUBFR + i];
+                w->u.syn.sLPC_Q14[i] = t;
+            }
+#endif
         }
         wv_sync();
         pexc_Q10 += SX_SUBFR;
