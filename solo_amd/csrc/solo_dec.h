@@ -479,6 +479,24 @@ SX_FN void sx_decode_parameters(int nFramesDecoded, int first_frame_after_reset,
     sx_dequant_parameters(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
 }
 
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+// All-pole recursion with ONE TAP PER LANE (see sx_decode_core): lane j of every 16-lane row holds the output of time t - 1 - j (hj)
+// and coefficient j, pre-shifted (aj; zero past the order).  step(i, p) turns the prediction p of sample i into the filter value v
+// (and stores whatever the caller wants of it); the new state sample is v << 4, saturating if SAT.  Returns the lane's final history.
+template <bool SAT, typename F>
+__device__ __forceinline__ i32 sx_iir_rows(i32 hj, const i32 aj, int n, F step) {
+    const int j = SX_LANE & 15;
+    for (int i = 0; i < n; i++) {
+        const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
+        const i32 v = step(i, p);
+        const i32 hn = SAT ? sx_lshift_sat32(v, 4) : sx_shl(v, 4);
+        const i32 sh = __builtin_amdgcn_update_dpp(0, hj, 0x111, 0xF, 0xF, true);          // row_shr:1
+        hj = j == 0 ? hn : sh;
+    }
+    return hj;
+}
+#endif
+
 // SKP_Silk_decode_core, SKP_Silk_decode_core.c:43.  exc_Q10 = st->exc_Q10; writes outBuf[160..320).
 SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(xq);
@@ -784,6 +802,21 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
     // LPC synthesis
     SX_PAR(i, SX_MAX_LPC) w->u.syn.sLPC_Q14[i] = st->sLPC_Q14[i];
     wv_sync();
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+    {   // one tap per lane (sx_iir_rows): the whole frame in one run, the last SX_MAX_LPC outputs go back to the state
+        const int j = SX_LANE & 15;
+        const i32 aj = j < SX_LPC ? sx_pre16(p->prevLPC_Q12[j < SX_LPC ? j : 0]) : 0;
+        const i32 hj = sx_iir_rows<false>(w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j], aj, SX_FRAME, [&](int i, i32 pr) {
+            const i32 v = sx_add(sig_Q10[i], pr);
+            sig_Q10[i] = v;
+            return v;
+        });
+        wv_sync();
+        if (SX_LANE < 16) w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j] = hj;
+        wv_sync();
+    }
+    (void)sig_ptr;
+#else
     sig_ptr = sig_Q10;
     for (int k = 0; k < SX_NB_SUBFR; k++) {
         for (int i = 0; i < SX_SUBFR; i++) {
@@ -799,6 +832,7 @@ SX_FN void sx_plc_conceal(SxDecState* st, SxDecWork* w, i16* signal) {
             w->u.syn.sLPC_Q14[i] = t;
         }
     }
+#endif
     SX_PAR(i, SX_MAX_LPC) st->sLPC_Q14[i] = w->u.syn.sLPC_Q14[i];
     SX_PAR(i, SX_FRAME) signal[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(sig_Q10[i], p->prevGain_Q16[SX_NB_SUBFR - 1]), 10));
     wv_sync();
@@ -926,9 +960,28 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
             CNG_sig[i] = (i16)sx_sat16(sx_rshift_round(sx_smulww(g->exc_buf_Q10[idx], g->smth_Gain_Q16), 10));
         }
         g->rand_seed = seed;
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+        {   // one tap per lane (sx_iir_rows); the coefficients go through the prediction-coefficient slot of the frame (free by now)
+            i16* LPC_buf = w->PredCoef_Q12[0];
+            sx_nlsf2a_stable(LPC_buf, g->smth_NLSF_Q15, SX_LPC);
+            wv_sync();
+            const int j = SX_LANE & 15;
+            const i32 aj = j < SX_LPC ? sx_pre16(LPC_buf[j < SX_LPC ? j : 0]) : 0;
+            const i32 h0 = j < SX_LPC ? g->synth_state[SX_LPC - 1 - (j < SX_LPC ? j : 0)] : 0;
+            const i32 hj = sx_iir_rows<true>(h0, aj, length, [&](int i, i32 pr) {
+                const i32 acc = sx_add_sat32(pr, sx_smulwb(1 << 26, CNG_sig[i]));
+                CNG_sig[i] = (i16)sx_sat16(sx_rshift_round(acc, 10));
+                return acc;
+            });
+            wv_sync();
+            if (SX_LANE < SX_LPC) g->synth_state[SX_LPC - 1 - j] = hj;
+            wv_sync();
+        }
+#else
         i16 LPC_buf[SX_MAX_LPC];
         sx_nlsf2a_stable(LPC_buf, g->smth_NLSF_Q15, SX_LPC);
         sx_lpc_synthesis_filter(CNG_sig, LPC_buf, 1 << 26, g->synth_state, CNG_sig, length, SX_LPC);
+#endif
         SX_PAR(i, length) signal[i] = (i16)sx_sat16((i32)signal[i] + (i32)CNG_sig[i]);
         wv_sync();
     } else {
@@ -1207,11 +1260,28 @@ SX_FN void sx_hb_finish(SxDecState* st, SxDecWork* w, int lostflag, int piggy_do
         i32* zero = w->res_Q10;
         SX_PAR(i, SX_SUBFR) zero[i] = 0;
         wv_sync();
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+        (void)sub_len;
+        for (int f = 0; f < nf; f++) {   // zero input: the gains do not matter; one tap per lane (sx_iir_rows), a whole high-band frame per run
+            const int j = SX_LANE & 15;
+            const i32 aj = j < SX_HB_LPC ? sx_pre16(hp->lpc[f][j < SX_HB_LPC ? j : 0]) : 0;
+            const i32 h0 = j < SX_HB_LPC ? hp->S[SX_HB_LPC - 1 - (j < SX_HB_LPC ? j : 0)] : 0;
+            i16* out = &w->hi_out[f * SX_FRAME];
+            const i32 hj = sx_iir_rows<true>(h0, aj, st->hb_joint ? 2 * SX_FRAME : SX_FRAME, [&](int i, i32 pr) {
+                out[i] = (i16)sx_sat16(sx_rshift_round(pr, 10));
+                return pr;
+            });
+            wv_sync();
+            if (SX_LANE < SX_HB_LPC) hp->S[SX_HB_LPC - 1 - j] = hj;
+            wv_sync();
+        }
+#else
         for (int f = 0; f < nf; f++)
             for (int k = 0; k < 4; k++)
                 for (int h = 0; h < sub_len; h += SX_SUBFR)
                     sx_hb_lpc_synthesis(zero, hp->lpc[f], sx_mul(-2867, (i32)hp->gain[f][k]), hp->S, &w->hi_out[f * SX_FRAME + k * sub_len + h], SX_SUBFR);
         wv_sync();
+#endif
     }
     SX_T(8)
     for (int f = 0; f < nf; f++) {
