@@ -32,11 +32,18 @@ else:
     b = solo_amd.SoloBatch(N, rate=24000, encoder=True, decoder=True, slot_bytes=512, samplerate=32000)
     x = torch.from_numpy(synth_batch(0, N, 2 * P, workers=16).reshape(N, P, 1280)).cuda()
 bits, nb, st = b.encode(x); out, st2 = b.decode(bits, nb); torch.cuda.synchronize()
+LOSS = float(os.environ.get("LOSS", "0"))          # probability that a description is lost (BASELINE config 4: 0.3), decode leg only
+recv = None
+if LOSS > 0:
+    rng = np.random.default_rng(4242)
+    m = (rng.random((N, P)) >= LOSS).astype(np.uint8) | ((rng.random((N, P)) >= LOSS).astype(np.uint8) << 1)
+    m[:, 0] = 3
+    recv = torch.from_numpy(m).cuda()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 R = 3
 te = td = 0.0
 for _ in range(R):
-    ev[0].record(); b.encode(x, bits, nb, st); ev[1].record(); b.decode(bits, nb, None, out, st2); ev[2].record(); torch.cuda.synchronize()
+    ev[0].record(); b.encode(x, bits, nb, st); ev[1].record(); b.decode(bits, nb, recv, out, st2); ev[2].record(); torch.cuda.synchronize()
     te += ev[0].elapsed_time(ev[1]); td += ev[1].elapsed_time(ev[2])
 print("%s parity enc=%s dec=%s | encode %.2f ms (%.0f pkt/s) decode %.2f ms (%.0f pkt/s) round trip %.0f pkt/s" % (
     os.environ.get("SOLO_LIB_OVERRIDE", "default"), ok, ok2, te / R, N * P * R / te * 1e3, td / R, N * P * R / td * 1e3, N * P * R / (te + td) * 1e3))
