@@ -1324,33 +1324,35 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
             i32 t1 = sx_add(sx_shl((i32)xr[n], hi ? QA - 16 : 17), a), t2 = sx_add(sx_shl((i32)xr[L - n - 1], hi ? QA - 16 : 17), b);
             t1 = sx_neg(t1); t2 = sx_neg(t2);
             if (hi) { t1 = sx_shl(t1, 32 - QA - rshifts); t2 = sx_shl(t2, 32 - QA - rshifts); }
-            // (b) column k: correlation rows and forward / backward correlations, all subframes
+            // (b) column k: correlation rows and forward / backward correlations.  Lane (row, k) adds the terms of ITS subframe (the
+            // row's own prediction errors t1 / t2 are already in its lanes), the four rows are then summed column by column
+            // (wrapping adds: the order is free), which leaves the same totals in every row
             {
-                i32 cf = Cf_k, cl = Cl_k, caf = CAf_k, cab = CAb_k;
-                for (int s = 0; s < nb_subfr; s++) {
-                    const i16* xs = x + s * L;
-                    const i32 T1 = __builtin_amdgcn_readlane(t1, s * 16), T2 = __builtin_amdgcn_readlane(t2, s * 16);
+                i32 dcf = 0, dcl = 0, dcaf = 0, dcab = 0;
+                if (row < nb_subfr) {
+                    const i16* xs = xr;
                     const int kk = sx_min(k, n);                       // columns past n only feed lanes that are never read
                     if (hi) {
                         const i32 x1 = sx_neg(sx_shl((i32)xs[n], 16 - rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], 16 - rshifts));
                         if (k < n) {
-                            cf = sx_smlawb(cf, x1, xs[n - k - 1]);
-                            cl = sx_smlawb(cl, x2, xs[L - n + k]);
+                            dcf = sx_smulwb(x1, xs[n - k - 1]);
+                            dcl = sx_smulwb(x2, xs[L - n + k]);
                         }
-                        caf = sx_smlawb(caf, T1, xs[n - kk]);
-                        cab = sx_smlawb(cab, T2, xs[L - n + kk - 1]);
+                        dcaf = sx_smulwb(t1, xs[n - kk]);
+                        dcab = sx_smulwb(t2, xs[L - n + kk - 1]);
                     } else {
                         const i32 x1 = sx_neg(sx_shl((i32)xs[n], -rshifts)), x2 = sx_neg(sx_shl((i32)xs[L - n - 1], -rshifts));
                         if (k < n) {
-                            cf = sx_add(cf, sx_mul(x1, xs[n - k - 1]));
-                            cl = sx_add(cl, sx_mul(x2, xs[L - n + k]));
+                            dcf = sx_mul(x1, xs[n - k - 1]);
+                            dcl = sx_mul(x2, xs[L - n + k]);
                         }
-                        caf = sx_smlaww(caf, T1, sx_shl((i32)xs[n - kk], -rshifts - 1));
-                        cab = sx_smlaww(cab, T2, sx_shl((i32)xs[L - n + kk - 1], -rshifts - 1));
+                        dcaf = sx_smulww(t1, sx_shl((i32)xs[n - kk], -rshifts - 1));
+                        dcab = sx_smulww(t2, sx_shl((i32)xs[L - n + kk - 1], -rshifts - 1));
                     }
                 }
-                if (k < n) { Cf_k = cf; Cl_k = cl; }
-                if (k <= n) { CAf_k = caf; CAb_k = cab; }
+                dcf = wv_col_sum(dcf); dcl = wv_col_sum(dcl); dcaf = wv_col_sum(dcaf); dcab = wv_col_sum(dcab);
+                if (k < n) { Cf_k = sx_add(Cf_k, dcf); Cl_k = sx_add(Cl_k, dcl); }
+                if (k <= n) { CAf_k = sx_add(CAf_k, dcaf); CAb_k = sx_add(CAb_k, dcab); }
             }
             // (c) reflection coefficient: numerator / denominator terms of column k < n
             i32 p1 = 0, p2 = 0, q3 = 0, q4 = 0;

@@ -64,6 +64,16 @@ SX_HD void wv_sync_lds() {
 #define SX_ROWS_COMBINE(v, OP)
 #endif
 SX_HD i32 wv_row_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) return v; }    // sum over each 16-lane row, in all of its lanes
+#if SX_NLANES == 64
+// sum over the four rows, column by column (lane j of every row gets v[j] + v[16 + j] + v[32 + j] + v[48 + j]): two gfx950 lane-swap
+// instructions (v_permlane32_swap: upper half of one operand <-> lower half of the other; v_permlane16_swap: odd rows <-> even rows)
+SX_HD i32 wv_col_sum(i32 v) {
+    auto a = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    const i32 s = sx_add((i32)a[0], (i32)a[1]);
+    auto b = __builtin_amdgcn_permlane16_swap(s, s, false, false);
+    return sx_add((i32)b[0], (i32)b[1]);
+}
+#endif
 SX_HD i32 wv_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) SX_ROWS_COMBINE(v, sx_add(v, t_)) return v; }
 SX_HD i32 wv_max(i32 v) { SX_ROW_REDUCE(v, (t_ > v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ > v ? t_ : v)) return v; }
 SX_HD i32 wv_min(i32 v) { SX_ROW_REDUCE(v, (t_ < v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ < v ? t_ : v)) return v; }
