@@ -140,6 +140,16 @@ struct alignas(16) SxExtracted {
     i32 pad_[3];
     SxFrameSyms y[2];
     i8 pulses[2][SX_FRAME];
+    // What needs nothing but this packet's bits, for the slot the decoder takes its coefficients from (the last description slot in
+    // use; it also carries the high-band bytes): NLSF -> prediction coefficients (stabilised) of each frame's own vector and of
+    // frame 1's interpolated one (frame 0's interpolates with the previous packet: left to the decoder), and the high band's side
+    // information (LSP vectors, their prediction coefficients, sub-frame gains).
+    i32 have_A, have_hb;
+    i16 A_final[2][SX_MAX_LPC];
+    i16 A_interp1[SX_MAX_LPC];
+    i32 hb_lsp[2][SX_HB_LPC];
+    i16 hb_lpc[2][SX_HB_LPC];
+    i16 hb_gain[2][4];
 };
 #define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
 // High band of a packet, decoded up front (side information) and synthesised next to the low band: see sx_hb_decode_side
@@ -1139,9 +1149,18 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                 // (decode_parameters.c:108-131); runs after the inverse NSQ because its second workspace reuses the pulses' LDS
                 const i32* nl = &w->res_Q10[(ndesc - 1) * 2 * SX_LPC];
                 const int interp = c->NLSFInterpCoef_Q2 < 4;
+                const SxExtracted* pa = (pre2 && SX_UNI(pre2[ndesc - 1].have_A)) ? &pre2[ndesc - 1] : 0;
+                if (pa) {
+                    // the conversions that need nothing but this packet's bits were done by the extraction kernel; frame 0's interpolated
+                    // vector (it interpolates with the previous packet's) is converted here, on one lane
+                    SX_PAR(i, SX_LPC) w->PredCoef_Q12[1][i] = pa->A_final[f][i];
+                    if (interp && f == 1) { SX_PAR(i, SX_LPC) w->PredCoef_Q12[0][i] = pa->A_interp1[i]; }
+                    if (interp && f == 0) { SX_PAR(v, 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1); }
+                } else {
                 SX_PAR(v, 2) {
                     if (v == 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, &w->res_Q10[4 * SX_LPC]);
                     else if (interp) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1);
+                }
                 }
                 wv_sync();
                 if (!interp) {
@@ -1223,11 +1242,16 @@ SX_HD void sx_hb_lpc_synthesis(const i32* in_Q10, const i16* A_Q12, i32 Gain_Q16
 //   sx_hb_finish        after the low-band frames (not reached when the packet is abandoned, like the reference's high-band call):
 //                       commits the filter state, the loss / previous-frame bookkeeping in frame order, hands the band to the QMF
 // `hb` = the 8 high-band bytes (ignored when lost).
-SX_FN void sx_hb_decode_side(SxDecState* st, SxDecWork* w, const u8* hb, int lostflag) {
+// pre: NULL, or the extraction record of the slot that carries the high-band bytes (side information already converted there)
+SX_FN void sx_hb_decode_side(SxDecState* st, SxDecWork* w, const u8* hb, int lostflag, const SxExtracted* pre) {
     SX_IN_LDS(st); SX_IN_LDS(w);
     SxHbParams* hp = &w->hbp;
     const int lost = (lostflag == 1 || lostflag == 2);
     const int nf = st->hb_joint ? 1 : 2;          // high-band frames per packet
+    if (pre && !lost && SX_UNI(pre->have_hb)) {
+        SX_PAR(i, nf * SX_HB_LPC) { (&hp->lsp[0][0])[i] = (&pre->hb_lsp[0][0])[i]; (&hp->lpc[0][0])[i] = (&pre->hb_lpc[0][0])[i]; }
+        SX_PAR(i, nf * 4) (&hp->gain[0][0])[i] = (&pre->hb_gain[0][0])[i];
+    } else
     SX_PAR(f, nf) {
         i32* l = hp->lsp[f];
         if (lost) {
@@ -1398,7 +1422,7 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
 #endif
     SX_PAR(i, SX_QMF_HIST) w->lo[i] = st->qmf_lo_hist[i];
     wv_sync();
-    sx_hb_decode_side(st, w, bits + hb_pos, lostflag);
+    sx_hb_decode_side(st, w, bits + hb_pos, lostflag, pre2 ? &pre2[lostflag == 4 ? 1 : 0] : 0);
     int piggy_frames = 0;
     for (int f = 0; f < 2; f++) {
         // a frame that is decoded (not concealed) runs the high band's synthesis filter next to its own (sx_decode_core)
@@ -1449,22 +1473,31 @@ struct SxExtractLane { u8 b[SX_EXTRACT_ROW]; };
 static_assert(SX_EXTRACT_TMP % 4 == 0 && (SX_EXTRACT_ROW / 4) % 2 == 1, "row layout");
 
 // where description slot md of a packet handed over as (nBytes0, nBytes1, lostflag) lies (see sx_decode_packet); false: no such slot
-SX_HD bool sx_desc_span(int lostflag, i32 nBytes0, i32 nBytes1, int hb_joint, int md, i32* off, i32* len) {
+// *sel: this is the slot the decoder takes its coefficients from; *hb_off: where the high-band bytes lie (-1: not in the packet)
+SX_HD bool sx_desc_span(int lostflag, i32 nBytes0, i32 nBytes1, int hb_joint, int md, i32* off, i32* len, int* sel = 0, i32* hb_off = 0) {
     if (lostflag < 2 || nBytes0 <= 0) return false;
     const i32 hb_bytes = hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - hb_bytes;
     const i32 nB1 = nBytes1 ? nBytes1 - hb_bytes : 0;
+    const i32 hb_pos = nB0;
     nB0 -= nB1;
-    if (md >= (lostflag == 4 ? 2 : 1)) return false;
+    const int ndesc = lostflag == 4 ? 2 : 1;
+    if (md >= ndesc) return false;
     *off = md == 0 ? 0 : nB0;
     *len = md == 0 ? nB0 : nB1;
+    if (sel) *sel = md == ndesc - 1;
+    if (hb_off) *hb_off = lostflag == 2 ? -1 : hb_pos;
     return true;
 }
 
 // src: the description's bytes inside the packet (HBM), len of them (read in place: a serial coder touches every byte once, the
 // look-ups of the tables are what it waits for)
-SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* cdf, SxExtractLane* L, SxExtracted* rec) {
+// sel: also convert the NLSF vectors; hb: the packet's high-band bytes or NULL (only looked at when sel)
+SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* cdf, SxExtractLane* L, SxExtracted* rec, int sel = 0,
+                           const u8* hb = 0, int hb_joint = 0) {
     rec->usable = 0;
+    rec->have_A = 0;
+    rec->have_hb = 0;
     if (len <= 0 || len > SX_MAX_ARITHM_BYTES) return;           // (the serial decoder reports what is wrong with it)
     SxRangeDec2 r;
     sx_rc_dec_init(&r, src, len);
@@ -1477,5 +1510,39 @@ SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* 
         if (y.fs_bad || y.error || narrow) return;
         { const i32* sq = (const i32*)&L->b[SX_EXTRACT_TMP]; i32* dq = (i32*)&rec->pulses[f][0]; for (int i = 0; i < SX_FRAME / 4; i++) dq[i] = sq[i]; }
     }
-    rec->usable = r.ambiguous ? 0 : 1;
+    if (r.ambiguous) return;
+    if (sel) {
+        // (private workspace: every lane of the wavefront is at the same place of its own copy, which is how scratch memory is laid out)
+        i32 ws[SX_NLSF2A_WS], nl[SX_LPC];
+        i16 a[SX_MAX_LPC];
+        for (int f = 0; f < 2; f++) {
+            for (int i = 0; i < SX_LPC; i++) nl[i] = rec->y[f].NLSF_Q15[i];
+            sx_nlsf2a_stable_ws(a, nl, SX_LPC, ws);
+            for (int i = 0; i < SX_LPC; i++) rec->A_final[f][i] = a[i];
+        }
+        if (rec->y[1].NLSFInterpCoef_Q2 < 4) {                   // frame 1 interpolates between the two vectors of this packet (sx_dequant_parameters)
+            const i32 coef = rec->y[1].NLSFInterpCoef_Q2;
+            for (int i = 0; i < SX_LPC; i++) {
+                const i32 prev = rec->y[0].NLSF_Q15[i];
+                nl[i] = prev + (sx_mul(coef, rec->y[1].NLSF_Q15[i] - prev) >> 2);
+            }
+            sx_nlsf2a_stable_ws(a, nl, SX_LPC, ws);
+            for (int i = 0; i < SX_LPC; i++) rec->A_interp1[i] = a[i];
+        }
+        rec->have_A = 1;
+        if (hb) {                                                // AGR_Bwe_decode_frame_FIX side information (sx_hb_decode_side)
+            const int nf = hb_joint ? 1 : 2;
+            for (int f = 0; f < nf; f++) {
+                int bitpos = f * 32;
+                const u32 idx = sx_hb_unpack(hb, &bitpos, 12);
+                const u32 idx1 = idx & 0xFF, idx2 = idx >> 8;
+                for (int i = 0; i < SX_HB_LPC; i++) { nl[i] = T_hb_lsp_cb1[idx1 * SX_HB_LPC + i] + T_hb_lsp_cb2[idx2 * SX_HB_LPC + i]; rec->hb_lsp[f][i] = nl[i]; }
+                for (int k = 0; k < 4; k++) rec->hb_gain[f][k] = (i16)T_hb_gain_cb[sx_hb_unpack(hb, &bitpos, 5)];
+                sx_nlsf2a_stable_ws(a, nl, SX_HB_LPC, ws);
+                for (int i = 0; i < SX_HB_LPC; i++) rec->hb_lpc[f][i] = a[i];
+            }
+            rec->have_hb = 1;
+        }
+    }
+    rec->usable = 1;
 }

@@ -120,9 +120,11 @@ __global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_
     const int hb_joint = states[s].st.hb_joint;
     const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, hb_joint);
     SxExtracted* rec = &recs[idx];
-    i32 off = 0, len = 0;
-    if (!sx_desc_span(a.lostflag, a.a0, a.a1, hb_joint, md, &off, &len)) { rec->usable = 0; return; }
-    sx_extract_desc(bits + pk * (size_t)slot + a.ptr_off + off, len, useMDIndex, (const SxCdf*)&w.cdf, &w.lane[threadIdx.x], rec);
+    i32 off = 0, len = 0, hb_off = -1;
+    int sel = 0;
+    if (!sx_desc_span(a.lostflag, a.a0, a.a1, hb_joint, md, &off, &len, &sel, &hb_off)) { rec->usable = 0; return; }
+    const u8* pkt = bits + pk * (size_t)slot + a.ptr_off;
+    sx_extract_desc(pkt + off, len, useMDIndex, (const SxCdf*)&w.cdf, &w.lane[threadIdx.x], rec, sel, hb_off >= 0 ? pkt + hb_off : 0, hb_joint);
 }
 
 __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream* states, const u8* __restrict__ bits,

@@ -43,9 +43,10 @@ int emu_dec_packet(void* h, const uint8_t* bits, int nBytes0, int nBytes1, int l
         memset(ext2, 0xA5, sizeof(ext2));                 // (whatever the decoder takes from a record must have been written by the extraction)
         for (int md = 0; md < 2; md++) {                  // solo_dec_extract_kernel, one lane per description slot
             ext2[md].usable = 0;
-            i32 off = 0, len = 0;
-            if (sx_desc_span(lostflag, nBytes0, nBytes1, d->st.hb_joint, md, &off, &len))
-                sx_extract_desc(bits + off, len, d->useMDIndex, (const SxCdf*)&d->w.cdf, &d->L, &ext2[md]);
+            i32 off = 0, len = 0, hb_off = -1;
+            int sel = 0;
+            if (sx_desc_span(lostflag, nBytes0, nBytes1, d->st.hb_joint, md, &off, &len, &sel, &hb_off))
+                sx_extract_desc(bits + off, len, d->useMDIndex, (const SxCdf*)&d->w.cdf, &d->L, &ext2[md], sel, hb_off >= 0 ? bits + hb_off : 0, d->st.hb_joint);
         }
         if (lostflag >= 2) { if (sx_extracted_usable(&d->st, ext2, lostflag)) emu_usable_count++; else emu_fallback_count++; }
     }
