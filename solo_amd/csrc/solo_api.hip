@@ -540,7 +540,11 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-            static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;     // timing experiments only: 1 = no quantiser, 2 = no coding (wrong output)
+#ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding -- wrong output
+            static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;
+#else
+            constexpr int exp_skip = 0;
+#endif
             if (!(exp_skip & 1)) {
             if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->d_nsq_ring, b->sB)) != hipSuccess) goto launch_failed;
             b->started_target[c] += (unsigned int)ops->nsq_workgroups(ns);     // workgroups of this launch, counted once it is enqueued
