@@ -63,7 +63,10 @@
 // instruction: for the bulk move of the survivors' registers, where latency is hidden by the number of them)
 SX_HD i32 sxq_sel(i32 v, i32 idx) {
     const i32 b0 = SXQ_DPP(v, 0x00), b1 = SXQ_DPP(v, 0x55), b2 = SXQ_DPP(v, 0xAA), b3 = SXQ_DPP(v, 0xFF);
-    return idx == 0 ? b0 : (idx == 1 ? b1 : (idx == 2 ? b2 : b3));
+    // (two levels of two-way selects on the index bits: a chain of ?: on idx == 0 / 1 / 2 is compiled into exec-mask branches)
+    const bool o_ = (idx & 1) != 0, h_ = (idx & 2) != 0;
+    const i32 lo_ = o_ ? b1 : b0, hi_ = o_ ? b3 : b2;
+    return h_ ? hi_ : lo_;
 }
 SX_HD i32 sxq_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & ~3u) | (u32)src)) << 2), v); }
 #define SXQ_GATHER(dst, src, idx) { (dst)[0] = sxq_sel((src)[0], (idx)[0]); }
@@ -120,7 +123,11 @@ struct alignas(16) SxNsqWork {       // LDS, per stream
 // part of the product is a multiple of 65536) -- one high-word multiply instead of a 64-bit product
 SX_HD i32 sx_mul_lambda(i32 x) { return sx_add(x, sx_smulw_pre(x, (i32)((u32)(SX_JOINT_LAMBDA - 65536) << 16))); }
 static_assert(SX_JOINT_LAMBDA - 65536 > 0 && SX_JOINT_LAMBDA - 65536 < 32768, "lambda split");
-SX_HD i32 sx_sel4(i32 a0, i32 a1, i32 a2, i32 a3, int i) { return i == 0 ? a0 : (i == 1 ? a1 : (i == 2 ? a2 : a3)); }
+SX_HD i32 sx_sel4(i32 a0, i32 a1, i32 a2, i32 a3, int i) {          // i in 0..3; selects on the index bits (no branches)
+    const bool o_ = (i & 1) != 0, h_ = (i & 2) != 0;
+    const i32 lo_ = o_ ? a1 : a0, hi_ = o_ ? a3 : a2;
+    return h_ ? hi_ : lo_;
+}
 
 // Agora_Silk_RDCx1, NSQ_del_dec.c:559: the two quantisation candidates of one side state.  The reference's three cases
 // (r < -1.5, r > 0.5, in between) differ in the two levels and in the sign of the rate term; written with selects so that the
@@ -701,9 +708,9 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 }
                 SX_FORK(kk) {
                     const int ki = SX_KI(kk);
-                    const i32 mis = (myRand[ki][0] != wr[ki][0] || myRand[ki][1] != wr[ki][1] || myRand[ki][2] != wr[ki][2]) ? 1 : 0;
+                    const i32 mis = ((myRand[ki][0] ^ wr[ki][0]) | (myRand[ki][1] ^ wr[ki][1]) | (myRand[ki][2] ^ wr[ki][2])) != 0 ? 1 : 0;
                     tq[ki] = mis;
-                    if (mis) { cRD[ki][0][0] = sx_add(cRD[ki][0][0], PEN); cRD[ki][0][1] = sx_add(cRD[ki][0][1], PEN); }
+                    { const i32 pen_ = mis ? PEN : 0; cRD[ki][0][0] = sx_add(cRD[ki][0][0], pen_); cRD[ki][0][1] = sx_add(cRD[ki][0][1], pen_); }
                     par[ki] = kk; csrc[ki] = kk; csel[ki] = 0;
                     c0[ki] = cRD[ki][0][0]; c1[ki] = cRD[ki][0][1];
                 }
@@ -716,7 +723,8 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     SXQ_GATHER(gq, par, mi2)                             // the state lane mi2 holds NOW (it may itself have been replaced)
                     SX_FORK(kk) {
                         const int ki = SX_KI(kk);
-                        if (mv2[ki] < mv[ki] && kk == mi[ki]) { par[ki] = gq[ki]; csrc[ki] = mi2[ki]; csel[ki] = 1; c0[ki] = mv2[ki]; }
+                        const bool rep_ = (mv2[ki] < mv[ki]) & (kk == mi[ki]);
+                        par[ki] = rep_ ? gq[ki] : par[ki]; csrc[ki] = rep_ ? mi2[ki] : csrc[ki]; csel[ki] = rep_ ? 1 : csel[ki]; c0[ki] = rep_ ? mv2[ki] : c0[ki];
                     }
                 } while (--RandSyncCtl > 0);
             }
