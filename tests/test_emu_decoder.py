@@ -51,6 +51,21 @@ def test_synthetic_streams_bernoulli_loss():
                 assert np.array_equal(x, z[key][s, p]), (key, s, p)
 
 
+def test_edge_family_goldens():
+    """The edge-signal fixture (tests/golden/edge28x12.npz) through the decoder with its description-loss mask: CRC-32 of every
+    packet the compiled reference decoded."""
+    import zlib
+    z = np.load(T.GOLDEN + "/edge28x12.npz")
+    N, P, _ = z["pcm"].shape
+    for i in range(N):
+        d = T.EmuDecoder()
+        for p in range(P):
+            n0, n1, m = int(z["nbytes"][i, p, 0]), int(z["nbytes"][i, p, 1]), int(z["recv"][i, p])
+            pl = z["bits"][i, p, :n0].tobytes()
+            x, ret = d.decode(pl, n0, n1, 1) if m == 0 else d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0 and zlib.crc32(x.tobytes()) == int(z["dec_crc"][i, p]), (i, p, m)
+
+
 def test_cold_start_leading_packets_lost():
     """Packets lost before anything was decoded: the reference decoder is still at its initial 24 kHz (create_init_destroy.c:41),
     emits zeros through the 24 -> 8 kHz resampler and fades the first decoded frame in with the 480-sample slope (decode_frame.c:303,

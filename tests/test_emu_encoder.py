@@ -41,6 +41,22 @@ def test_edge_signals_vs_compiled_reference():
             assert e.encode(x[p * 640:(p + 1) * 640]) == r.encode(x[p * 640:(p + 1) * 640]), (k, p)
 
 
+def test_edge_family_goldens():
+    """28 un-speech-like streams (two of every family of solo_amd.synth.edge_stream: silence with stray LSBs, full-scale noise,
+    square waves, DC, impulses, 90 dB ramps, clipping, bursts, high-band-only tones, Nyquist pattern, sub-audio sines, random walks):
+    the committed reference bitstreams (tests/golden/make_edge_golden.py), byte for byte."""
+    from solo_amd.synth import edge_stream
+    z = np.load(T.GOLDEN + "/edge28x12.npz")
+    N, P, _ = z["pcm"].shape
+    for i in range(N):
+        assert np.array_equal(edge_stream(i, P), z["pcm"][i]), i           # (the generator itself is pinned by the fixture)
+        e = T.EmuEncoder()
+        for p in range(P):
+            pl, n0, n1 = e.encode(z["pcm"][i, p])
+            assert (n0, n1) == tuple(int(v) for v in z["nbytes"][i, p]), (i, p)
+            assert pl == z["bits"][i, p, :n0].tobytes(), (i, p)
+
+
 def test_round_trip_through_emu_decoder():
     """encode -> decode with the emulated kernels reproduces the committed reference PCM"""
     z = np.load(T.GOLDEN + "/synth8x25.npz")

@@ -1,0 +1,58 @@
+#!/usr/bin/env python3
+"""Encoder + decoder host emulation (the kernel source compiled for the host, tests/emu) against the compiled reference
+(oracle/_ref, this container only) on the un-speech-like signal families of solo_amd.synth.edge_stream, several encoder
+configurations, random description loss.   python tools/debug/fuzz_encoder_emu.py [streams] [packets] [first_seed]"""
+import multiprocessing as mp, os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, p)
+import refcodec as R
+import solo_testlib as T
+from solo_amd.synth import edge_stream, EDGE_FAMILIES
+
+CFGS = [dict(rate=13600, joint=0, dtx=0, mdi=0), dict(rate=13600, joint=1, dtx=0, mdi=1), dict(rate=24000, joint=0, dtx=0, mdi=0),
+        dict(rate=13600, joint=0, dtx=1, mdi=0), dict(rate=10000, joint=0, dtx=0, mdi=0)]
+
+
+def one(args):
+    seed, P = args
+    cfg = CFGS[(seed // EDGE_FAMILIES) % len(CFGS)]
+    pcm = edge_stream(seed, P)
+    rng = np.random.default_rng(seed)
+    flags = cfg["mdi"] | (2 if cfg["joint"] else 0) | (4 if cfg["dtx"] else 0)          # flag word of the emulation: MD index, joint mode, DTX
+    e = T.EmuEncoder(cfg["rate"], flags)
+    r = R.RefEncoder("fix", rate=cfg["rate"], joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"])
+    T.EmuDecoder.SPLIT = seed & 1
+    de = T.EmuDecoder(flags & 3)
+    dr = R.RefDecoder("fix", joint=cfg["joint"], use_md_index=cfg["mdi"])
+    for p in range(P):
+        a, b = e.encode(pcm[p]), r.encode(pcm[p])
+        if a != b:
+            return (seed, p, "enc", cfg)
+        pl, n0, n1 = b
+        m = int(rng.integers(0, 4)) if p > 0 else 3
+        if n0 <= 0:
+            args_ = (b"", 16, 0, 1)                                   # DTX: nothing was sent, the receiver conceals
+        else:
+            args_ = (pl, n0, n1, 1) if m == 0 else R.map_loss(pl, n0, n1, not (m & 1), not (m & 2))
+        x, r1 = dr.decode(*args_)
+        y, r2 = de.decode(*args_)
+        if r1 != r2 or not np.array_equal(x, y):
+            return (seed, p, "dec", cfg, r1, r2)
+    return None
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 280
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+    s0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
+    with mp.get_context("fork").Pool(min(16, mp.cpu_count())) as pool:
+        res = pool.map(one, [(s0 + i, P) for i in range(N)], chunksize=2)
+    bad = [r for r in res if r]
+    print("EDGE FUZZ", "OK" if not bad else "MISMATCH", "%d streams x %d packets" % (N, P), bad[:12])
+    return 1 if bad else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

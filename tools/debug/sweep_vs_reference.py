@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Wide GPU-vs-compiled-reference sweep (needs oracle/_ref on the box): fresh random seeds, several configurations, every stream
 compared bit for bit -- encoder payloads, decoder PCM with description loss.  Not part of the test suite (minutes of CPU work on the
-box); run through gpurun after larger kernel changes:   python tools/debug/sweep_vs_reference.py [streams] [packets] [seed0]"""
+box); run through gpurun after larger kernel changes:   python tools/debug/sweep_vs_reference.py [streams] [packets] [seed0] [edge]
+(edge: the un-speech-like signal families of solo_amd.synth.edge_stream instead of the speech-like generator)"""
 import multiprocessing as mp, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 for p in (ROOT, os.path.join(ROOT, "oracle"), os.path.join(ROOT, "tests")):
@@ -11,8 +12,9 @@ import refcodec as R
 
 
 def ref_stream(args):
-    seed, P, cfg, recv = args
-    pcm = R.synth_stream(seed, P)
+    seed, P, cfg, recv, edge = args
+    from solo_amd.synth import edge_stream
+    pcm = edge_stream(seed, P) if edge else R.synth_stream(seed, P)
     e = R.RefEncoder("fix", rate=cfg["rate"], joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"])
     recs = [e.encode(pcm[p]) for p in range(P)]
     e.close()
@@ -34,13 +36,15 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 30
     seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 900000
+    edge = len(sys.argv) > 4 and sys.argv[4] == "edge"
+    from solo_amd.synth import edge_batch
     cfgs = [dict(rate=13600, joint=0, dtx=0, mdi=0, loss=0.3), dict(rate=13600, joint=1, dtx=0, mdi=1, loss=0.2),
             dict(rate=24000, joint=0, dtx=0, mdi=0, loss=0.1), dict(rate=13600, joint=0, dtx=1, mdi=0, loss=0.15)]
     bad = 0
     for ci, cfg in enumerate(cfgs):
         t0 = time.time()
         s0 = seed0 + ci * 100000
-        pcm = synth_batch(s0, N, P, workers=16)
+        pcm = edge_batch(s0, N, P) if edge else synth_batch(s0, N, P, workers=16)
         rng = np.random.default_rng(s0)
         recv = ((rng.random((N, P)) >= cfg["loss"]).astype(np.uint8) | ((rng.random((N, P)) >= cfg["loss"]).astype(np.uint8) << 1))
         b = solo_amd.SoloBatch(N, rate=cfg["rate"], encoder=True, decoder=True, slot_bytes=512, joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"])
@@ -49,17 +53,20 @@ def main():
         torch.cuda.synchronize()
         hb, hn, ho = bits.cpu().numpy(), nb.cpu().numpy(), out.cpu().numpy()
         with mp.get_context("fork").Pool(min(32, mp.cpu_count())) as pool:
-            ref = pool.map(ref_stream, [(s0 + i, P, cfg, [int(m) for m in recv[i]]) for i in range(N)], chunksize=4)
+            ref = pool.map(ref_stream, [(s0 + i, P, cfg, [int(m) for m in recv[i]], edge) for i in range(N)], chunksize=4)
         nbad = 0
+        first_bad = []
         for i, (recs, dec) in enumerate(ref):
             ok = all(hn[i, p, 0] == max(r[1], 0) * (1 if r[1] > 0 else 0) or (r[1] <= 0 and hn[i, p, 0] == 0) for p, r in enumerate(recs))
             ok = ok and all(hb[i, p, :r[1]].tobytes() == r[0] for p, r in enumerate(recs) if r[1] > 0 and hn[i, p, 0] == r[1])
             ok = ok and all(hn[i, p, 0] == r[1] and hn[i, p, 1] == r[2] for p, r in enumerate(recs) if r[1] > 0)
             ok = ok and np.array_equal(ho[i], dec)
             nbad += 0 if ok else 1
+            if not ok and len(first_bad) < 8:
+                first_bad.append(s0 + i)
         bad += nbad
         print("config %d %s: %d streams x %d packets, %d mismatching streams, status enc %d dec %d (%.0f s)" % (
-            ci, cfg, N, P, nbad, int(st.abs().max()), int(st2.abs().max()), time.time() - t0), flush=True)
+            ci, cfg, N, P, nbad, int(st.abs().max()), int(st2.abs().max()), time.time() - t0), first_bad if nbad else "", flush=True)
     print("SWEEP", "OK" if bad == 0 else "FAILED")
     return 1 if bad else 0
 
