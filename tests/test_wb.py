@@ -37,6 +37,24 @@ def test_wb_emulation_vs_goldens():
                 assert np.array_equal(x, z[key][s, p]), (key, s, p)
 
 
+@pytest.mark.parametrize("split", [0, 1])
+def test_wb_edge_family_goldens_emulation(split):
+    """Un-speech-like inputs in the 32 kHz mode (tests/golden/edge_wb13x8.npz, one stream per family of solo_amd.synth.edge_stream
+    except the full-scale square wave, on which the compiled reference overflows its stack at 32 kHz): encoder emulation against the
+    reference bitstreams, decoder emulation (both paths) against the CRC-32 of every packet the reference decoded under description loss."""
+    import zlib
+    z = np.load(T.GOLDEN + "/edge_wb13x8.npz")
+    N, P, _ = z["pcm"].shape
+    for i in range(N):
+        e, d = T.EmuEncoder(24000, 0, wb=True), T.EmuDecoder(0, wb=True, split=split)
+        for p in range(P):
+            pl, n0, n1 = e.encode(z["pcm"][i, p])
+            assert (n0, n1) == tuple(int(v) for v in z["nbytes"][i, p]) and pl == z["bits"][i, p, :n0].tobytes(), (i, p)
+            m = int(z["recv"][i, p])
+            x, ret = d.decode(pl, n0, n1, 1) if m == 0 else d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0 and zlib.crc32(x.tobytes()) == int(z["dec_crc"][i, p]), (i, p, m)
+
+
 @pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not built")
 @pytest.mark.parametrize("rate,joint", [(16000, 0), (24000, 0), (32000, 1), (40000, 0)])
 def test_wb_emulation_vs_reference(rate, joint):
