@@ -2,7 +2,7 @@
 """Long-running fuzz of the decoder's host emulation (the kernel source compiled for the host, tests/emu) against the compiled
 reference (oracle/_ref, this container only): bit errors, byte bursts, random description loss; both decode paths
 (single kernel / extraction + synthesis).  Same acceptance rule as tests/test_emu_decoder.py::test_corrupted_payloads_vs_reference.
-    python tools/debug/fuzz_decoder_emu.py [trials] [seed]"""
+    python tools/debug/fuzz_decoder_emu.py [trials] [seed] [wb]      (wb: the 32 kHz mode, tests/golden/wb4x20.npz)"""
 import os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -12,18 +12,22 @@ import refcodec as R
 
 trials = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1234
-z = np.load(T.GOLDEN + "/synth8x25.npz")
+wb = len(sys.argv) > 3 and sys.argv[3] == "wb"
+z = np.load(T.GOLDEN + ("/wb4x20.npz" if wb else "/synth8x25.npz"))
 bits, nb = z["bits"], z["nbytes"]
+NS, NP = nb.shape[0], nb.shape[1]
 rng = np.random.default_rng(seed)
 stats = dict(rejected=0, garbage=0, other_rate=0, packets=0)
 bad = []
 for trial in range(trials):
-    s = trial % 8
-    split = (trial >> 3) & 1
+    s = trial % NS
+    split = (trial // NS) & 1
     T.EmuDecoder.SPLIT = split
-    dr, de = R.RefDecoder(), T.EmuDecoder()
+    joint = 1 if (wb and s == 3) else 0                       # (stream 3 of the wide-band fixture was coded with joint_mode 1)
+    dr = R.RefDecoder("fix", joint=joint, samplerate=32000 if wb else 16000)
+    de = T.EmuDecoder(2 if joint else 0, wb=wb)
     p_hit = rng.choice([0.03, 0.1, 0.25])
-    for p in range(25):
+    for p in range(NP):
         n0, n1 = int(nb[s, p, 0]), int(nb[s, p, 1])
         pl = bytearray(bits[s, p, :n0].tobytes())
         hit = rng.random() < p_hit
