@@ -83,6 +83,7 @@ struct SxDecState {
     i32 prev_sigtype;
     i32 nBytesLeft0;
     i32 started;                 // 0 until the first received packet switched the decoder to 8 kHz
+    i32 HPState[2];              // output high-pass (runs from a packet's third frame on: only after a corrupted payload, sx_dec_hp_output)
     SxCNG cng;
     SxPLC plc;
     // high band + QMF (AGR_Sate_decoder_hb_state_FIX / AGR_Sate_HB_decoder_control_FIX)
@@ -213,6 +214,29 @@ SX_HD void sx_dec_state_init(SxDecState* st, int hb_joint = 0) {
     st->hb_first = 1;
     st->hb_joint = hb_joint;
     // CNG / PLC are (re)initialised on the first call because their fs_kHz field is 0
+    wv_sync();
+}
+
+// Output high-pass of the low-band decoder: SKP_Silk_decode_frame.c:381-383 applies SKP_Silk_biquad (SKP_Silk_biquad.c:43-72: second-order
+// section, state in Q13, the output rounded and then incremented by one) with the coefficients of the internal rate
+// (SKP_Silk_tables_other.c:72-81) once nFramesDecoded > 2.  With two frames per packet that only happens after a corrupted payload
+// whose termination symbol announced more frames than it carried: the following calls decode on in the old buffer as frames 3, 4, 5.
+// The state is zero at creation and never reset.  Serial on one lane: the case is rare.
+SX_HD void sx_dec_hp_output(i32* S, i16* x, int len) {
+    const i32 B0 = 8000, B1 = -16000, B2 = 8000;                                                    // MA part, Q13
+    const i32 A0_neg = SX_FS_KHZ == 8 ? 15885 : 16127, A1_neg = SX_FS_KHZ == 8 ? -7710 : -7940;    // negated AR part, Q13
+    SX_PAR(v, 1) {
+        i32 s0 = S[0], s1 = S[1];
+        for (int k = 0; k < len; k++) {
+            const i32 in = x[k];
+            const i32 o = sx_smlabb(s0, in, B0);
+            s0 = sx_add(sx_smlabb(s1, in, B1), sx_shl(sx_smulwb(o, A0_neg), 3));
+            s1 = sx_smlabb(sx_shl(sx_smulwb(o, A1_neg), 3), in, B2);
+            x[k] = (i16)sx_sat16(sx_rshift_round(o, 13) + 1);
+        }
+        S[0] = s0;
+        S[1] = s1;
+    }
     wv_sync();
 }
 
@@ -1190,7 +1214,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
     SX_T(4)
     sx_cng(st, w, pOut, SX_FRAME);
     SX_T(5)
-    // (output HP filter: guard nFramesDecoded > 2 can never hold with 2 frames per packet, decode_frame.c:381)
+    if (SX_UNI(st->nFramesDecoded) > 2) sx_dec_hp_output(st->HPState, pOut, SX_FRAME);      // (decode_frame.c:381: received or concealed frame alike)
     st->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
     // SKP_Silk_SDK_Decode bookkeeping, dec_API.c:125-150
     if (used) {

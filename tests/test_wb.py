@@ -38,6 +38,22 @@ def test_wb_emulation_vs_goldens():
 
 
 @pytest.mark.parametrize("split", [0, 1])
+def test_wb_more_frames_than_carried_emulation(split):
+    """The one known input on which the reference's output high-pass runs (SKP_Silk_decode_frame.c:381, nFramesDecoded > 2): a
+    corrupted description whose termination symbol announces more frames than the packet carries, so that the next packet's first
+    call decodes on in the OLD buffer as "frame 3" (tests/golden/make_more_frames_golden.py).  Six packets decode like the reference,
+    the seventh is rejected with the reference's code."""
+    z = np.load(T.GOLDEN + "/wb_more_frames.npz")
+    d = T.EmuDecoder(0, wb=True, split=split)
+    for p in range(z["recv"].shape[1]):
+        n0, n1, m = int(z["nbytes"][0, p, 0]), int(z["nbytes"][0, p, 1]), int(z["recv"][0, p])
+        x, ret = d.decode(*R.map_loss(z["bits"][0, p, :n0].tobytes(), n0, n1, not (m & 1), not (m & 2)))
+        assert ret == int(z["ret"][0, p]), (p, ret)
+        if ret == 0:
+            assert np.array_equal(x, z["dec"][0, p]), p
+
+
+@pytest.mark.parametrize("split", [0, 1])
 def test_wb_edge_family_goldens_emulation(split):
     """Un-speech-like inputs in the 32 kHz mode (tests/golden/edge_wb13x8.npz, one stream per family of solo_amd.synth.edge_stream
     except the full-scale square wave, on which the compiled reference overflows its stack at 32 kHz): encoder emulation against the
@@ -154,6 +170,22 @@ def test_wb_gpu_goldens(torch_cuda):
         assert np.array_equal(out, z[key][:3]), key
         out = _gpu_decode(torch_cuda, z["bits"][3:], z["nbytes"][3:], None if recv is None else recv[3:], joint=1)
         assert np.array_equal(out, z[key][3:]), key + " joint"
+
+
+@pytest.mark.gpu
+def test_wb_gpu_more_frames_than_carried(torch_cuda):
+    """tests/golden/wb_more_frames.npz on the GPU (see test_wb_more_frames_than_carried_emulation): the packets before the rejected
+    one equal the reference's PCM -- packet 5 through the output high-pass -- and the stream's status is the reference's code."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/wb_more_frames.npz")
+    P = z["recv"].shape[1]
+    b = solo_amd.SoloBatch(1, encoder=False, decoder=True, slot_bytes=z["bits"].shape[2], samplerate=32000)
+    out, st = b.decode(torch.from_numpy(np.ascontiguousarray(z["bits"])).to(b.device), torch.from_numpy(np.ascontiguousarray(z["nbytes"])).to(b.device),
+                       torch.from_numpy(np.ascontiguousarray(z["recv"])).to(b.device))
+    torch.cuda.synchronize()
+    assert int(st[0]) == int(z["ret"][0, P - 1])
+    assert np.array_equal(out.cpu().numpy()[0, :P - 1], z["dec"][0, :P - 1])
 
 
 @pytest.mark.gpu
