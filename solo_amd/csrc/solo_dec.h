@@ -44,6 +44,8 @@ struct SxDecDesc {               // SKP_Silk_md_decoder_state, SKP_Silk_structs.
     // packet: see sx_decode_packet
     i32 rc_bufferLength, rc_bufferIx, rc_error;
     u32 rc_base_Q32, rc_range_Q16, rc_tail;
+    i32 rc_stale;                // the slot's last description went through the batch path's records: only rc_bufferLength is current,
+                                 // the registers are rebuilt from the shadow buffer if they are ever needed (sx_decode_packet)
 };
 struct SxPLC {                   // SKP_Silk_PLC_struct, SKP_Silk_structs.h:268
     i32 pitchL_Q8;
@@ -108,6 +110,7 @@ struct SxDecState {
 // never staged in LDS: per packet the received description bytes are written once and eight bytes are read.
 struct SxDecShadow {
     u8 b[2][SX_MAX_ARITHM_BYTES + 8];
+    SxDecDesc keep[2];           // where sx_decode_packet parks a slot's state while it rebuilds the slot's coder registers
 };
 struct SxDecStream {             // one record per stream in HBM
     SxDecState st;
@@ -1107,6 +1110,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     r->tail = tails[md];
                     if (md == 0) sx_rc_dec_init(r, payload, nB0);
                     else sx_rc_dec_init(r, payload + nB0, nB1);
+                    st->md[md].rc_stale = 0;
                 }
                 sx_decode_parameters(st->nFramesDecoded, st->first_frame_after_reset, &st->md[md], st->dbg, &w->u.parse.ctrl2[md], r, w->u.parse.pulses[md],
                                      md, useMDIndex, (const SxCdf*)&w->cdf, w->u.parse.lane_out[md], &w->res_Q10[md * 2 * SX_LPC],
@@ -1431,6 +1435,31 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         rc[d].base_Q32 = m->rc_base_Q32; rc[d].range_Q16 = m->rc_range_Q16; rc[d].tail = m->rc_tail;
     }
     }
+    // A packet that went through the records left the coder registers of its slots behind (the next packet normally starts new
+    // buffers).  This call goes on in the OLD buffers (a corrupted payload announced more frames than it carried): rebuild the
+    // registers of such a slot the way the reference got them -- range_dec_init on the description (its bytes, and the four behind
+    // them, are still in the shadow buffer) and the symbol walk of its two frames; the slot's other state is put back afterwards.
+    if (!pre2 && SX_UNI(st->moreInternalDecoderFrames) != 0 && (SX_UNI(st->md[0].rc_stale) | SX_UNI(st->md[1].rc_stale)) != 0) {
+        SX_PAR(md, 2) {
+            SxDecDesc* m = &st->md[md];
+            if (m->rc_stale) {
+                SxDecDesc* keep = &w->shadow->keep[md];          // (HBM: a private copy would cost every lane of the kernel scratch memory)
+                *keep = *m;
+                SxRangeDec* r = &rc[SX_NLANES == 1 ? md : 0];
+                const u8* b = w->shadow->b[md];
+                const i32 len = m->rc_bufferLength;
+                r->tail = (u32)b[len] | ((u32)b[len + 1] << 8) | ((u32)b[len + 2] << 16) | ((u32)b[len + 3] << 24);
+                sx_rc_dec_init(r, b, len);
+                for (int f = 0; f < 2; f++)
+                    sx_decode_parameters(f, 0, m, (i32*)0, &w->u.parse.ctrl2[md], r, w->u.parse.pulses[md], md, useMDIndex, (const SxCdf*)&w->cdf,
+                                         w->u.parse.lane_out[md], &w->res_Q10[md * 2 * SX_LPC], &w->res_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)],
+                                         sx_dec_syms(w, md));
+                *m = *keep;
+                m->rc_stale = 0;          // (the registers themselves are stored from rc[] after every frame below)
+            }
+        }
+        wv_sync();
+    }
     // the payload is read byte by byte by a serial coder: stage it in LDS
     if (lostflag != 1 && nBytes0 <= SX_DEC_PAYLOAD_LDS && !pre2) {
         SX_PAR(i, nBytes0) w->payload[i] = bits[i];
@@ -1471,6 +1500,10 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         wv_sync();
         }
         if (ret < 0) { st->last_error = ret; return ret; }
+    }
+    if (pre2) {
+        SX_PAR(md, lostflag == 4 ? 2 : 1) { st->md[md].rc_stale = 1; st->md[md].rc_bufferLength = md == 0 ? nB0 : nB1; }
+        wv_sync();
     }
     SX_T_BEGIN
     sx_hb_finish(st, w, lostflag, piggy_frames == 2);

@@ -66,6 +66,22 @@ def test_edge_family_goldens():
             assert ret == 0 and zlib.crc32(x.tobytes()) == int(z["dec_crc"][i, p]), (i, p, m)
 
 
+def test_old_buffers_of_both_slots_after_a_record_path_packet():
+    """tests/golden/nb_stale_coder.npz (made by make_stale_coder_golden.py from fuzz trial 299538): a corrupted packet that announces
+    more frames than it carries makes a later two-description packet decode on in the old buffers of BOTH description slots; the
+    second slot's last description went through the batch path's records, which do not keep the coder registers -- the decoder
+    rebuilds them from the shadow buffer.  Thirteen packets decode like the reference, the fourteenth is rejected with its code."""
+    z = np.load(T.GOLDEN + "/nb_stale_coder.npz")
+    d = T.EmuDecoder()
+    for p in range(z["recv"].shape[1]):
+        n0, n1, m = int(z["nbytes"][0, p, 0]), int(z["nbytes"][0, p, 1]), int(z["recv"][0, p])
+        pl = z["bits"][0, p, :n0].tobytes()
+        x, ret = d.decode(pl, n0, n1, 1) if m == 0 else d.decode(*R.map_loss(pl, n0, n1, not (m & 1), not (m & 2)))
+        assert ret == int(z["ret"][0, p]), (p, ret)
+        if ret == 0:
+            assert np.array_equal(x, z["dec"][0, p]), p
+
+
 def test_cold_start_leading_packets_lost():
     """Packets lost before anything was decoded: the reference decoder is still at its initial 24 kHz (create_init_destroy.c:41),
     emits zeros through the 24 -> 8 kHz resampler and fades the first decoded frame in with the 480-sample slope (decode_frame.c:303,

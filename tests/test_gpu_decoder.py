@@ -36,6 +36,28 @@ def test_synthetic_goldens_clean_and_lossy(torch_cuda):
     assert np.array_equal(out, z["dec_loss"])
 
 
+def test_old_buffers_of_both_slots_after_a_record_path_packet(torch_cuda):
+    """tests/golden/nb_stale_coder.npz on the GPU (tests/test_emu_decoder.py has the story): the packets before the rejected one equal
+    the reference's PCM and the stream's status is the reference's return code, in one call and packet by packet."""
+    import solo_amd
+    torch = torch_cuda
+    z = np.load(T.GOLDEN + "/nb_stale_coder.npz")
+    bits, nb, recv = (np.ascontiguousarray(z[k]) for k in ("bits", "nbytes", "recv"))
+    P = recv.shape[1]
+    b = solo_amd.SoloBatch(1, encoder=False, decoder=True, slot_bytes=bits.shape[2])
+    out, st = b.decode(torch.from_numpy(bits).to(b.device), torch.from_numpy(nb).to(b.device), torch.from_numpy(recv).to(b.device))
+    torch.cuda.synchronize()
+    assert int(st[0]) == int(z["ret"][0, P - 1]) == -12
+    assert np.array_equal(out.cpu().numpy()[0, :P - 1], z["dec"][0, :P - 1])
+    b = solo_amd.SoloBatch(1, encoder=False, decoder=True, slot_bytes=bits.shape[2])
+    for p in range(P):
+        o, st = b.decode(torch.from_numpy(np.ascontiguousarray(bits[:, p:p + 1])).to(b.device), torch.from_numpy(np.ascontiguousarray(nb[:, p:p + 1])).to(b.device),
+                         torch.from_numpy(np.ascontiguousarray(recv[:, p:p + 1])).to(b.device))
+        assert int(st[0]) == int(z["ret"][0, p]), p
+        if p < P - 1:
+            assert np.array_equal(o.cpu().numpy()[0, 0], z["dec"][0, p]), p
+
+
 def test_cold_start_leading_packets_lost(torch_cuda):
     """Leading packets of a stream lost (decoder still at the reference's initial 24 kHz): zeros out, then the first decoded
     frame faded in with the 480-sample slope; one call and packet-by-packet calls."""

@@ -17,7 +17,8 @@ from solo_amd.synth import edge_stream, synth_stream
 P = 14
 
 
-def one(seed):
+def sequence(seed):
+    """-> (configuration, [(mapped decoder arguments (payload, nBytes0, nBytes1, lostflag), packet was corrupted)]) of trial `seed`"""
     rng = np.random.default_rng(0xDEC0DE00 + seed)
     wb = bool(rng.integers(0, 2))
     mdi, joint = int(rng.integers(0, 2)), int(rng.integers(0, 2))
@@ -28,10 +29,8 @@ def one(seed):
     enc = R.RefEncoder("fix", rate=rate, joint=joint, use_md_index=mdi, samplerate=fs)
     recs = [enc.encode(pcm[p]) for p in range(P)]
     split = int(rng.integers(0, 2))
-    dr = R.RefDecoder("fix", joint=joint, use_md_index=mdi, samplerate=fs)
-    de = T.EmuDecoder(mdi | (2 if joint else 0), wb=wb, split=split)
     p_hit = rng.choice([0.05, 0.15, 0.4])
-    hits = 0
+    seq = []
     for p, (pl, n0, n1) in enumerate(recs):
         if n0 <= 0 or n0 > 1000:
             break
@@ -53,16 +52,27 @@ def one(seed):
                 n1 = int(np.clip(n1 + rng.integers(-3, 4), (4 if joint else 8) + 1, n0 - 1))
         mode = int(rng.integers(0, 4)) if p > 0 else 0
         a = R.map_loss(bytes(pl), n0, n1, mode == 1, mode == 2) if mode != 3 else (bytes(pl), n0, n1, 1)
+        seq.append((a, bool(hit), (bytes(pl), n0, n1, {0: 3, 1: 2, 2: 1, 3: 0}[mode])))       # + the whole packet and its receive mask
+    return dict(wb=wb, mdi=mdi, joint=joint, rate=rate, split=split, fs=fs), seq
+
+
+def one(seed):
+    cfg, seq = sequence(seed)
+    wb, mdi, joint = cfg["wb"], cfg["mdi"], cfg["joint"]
+    dr = R.RefDecoder("fix", joint=joint, use_md_index=mdi, samplerate=cfg["fs"])
+    de = T.EmuDecoder(mdi | (2 if joint else 0), wb=wb, split=cfg["split"])
+    hits = 0
+    for p, (a, hit, _) in enumerate(seq):
         x, r1 = dr.decode(*a)
         y, r2 = de.decode(*a)
         if r1 == 0 and r2 == -12 and hit:
             return ("other_rate", hits)
         if r1 != r2:
-            return ("BAD", seed, p, "rc", r1, r2, dict(wb=wb, mdi=mdi, joint=joint, rate=rate, split=split))
+            return ("BAD", seed, p, "rc", r1, r2, cfg)
         if r1 < 0:
             return ("rejected", hits)
         if not np.array_equal(x, y):
-            return ("BAD", seed, p, "pcm", int(np.abs(x.astype(int) - y.astype(int)).max()), dict(wb=wb, mdi=mdi, joint=joint, rate=rate, split=split))
+            return ("BAD", seed, p, "pcm", int(np.abs(x.astype(int) - y.astype(int)).max()), cfg)
         hits += int(hit)
     return ("ok", hits)
 
