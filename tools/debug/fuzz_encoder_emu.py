@@ -2,7 +2,8 @@
 """Encoder + decoder host emulation (the kernel source compiled for the host, tests/emu) against the compiled reference
 (oracle/_ref, this container only) on the un-speech-like signal families of solo_amd.synth.edge_stream, several encoder
 configurations, random description loss.   python tools/debug/fuzz_encoder_emu.py [streams] [packets] [first_seed] [wb]
-(wb: the 32 kHz mode -- 1280-sample packets, 24 kbps, SILK wide band inside)"""
+(wb: the 32 kHz mode -- 1280-sample packets, 24 kbps, SILK wide band inside; random: speech-like streams at a random level under a
+random configuration -- sampling mode, rate, high-band framing, DTX, description index -- encoder only)"""
 import multiprocessing as mp, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -20,8 +21,33 @@ WB_CFGS = [dict(rate=24000, joint=0, dtx=0, mdi=0), dict(rate=24000, joint=1, dt
            dict(rate=18000, joint=0, dtx=1, mdi=0)]
 
 
+def one_random(seed, P):
+    """random configuration (sampling mode, rate, high-band framing, DTX, description index) on a speech-like stream at a random level"""
+    from solo_amd.synth import synth_stream
+    rng = np.random.default_rng(0xE0C0DE00 + seed)
+    wb = bool(rng.integers(0, 2))
+    joint, dtx, mdi = int(rng.integers(0, 2)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+    rate = int(rng.integers(15600, 48000)) if wb else int(rng.integers(5000, 40000))
+    gain = float(10.0 ** rng.uniform(-2.0, 0.45))
+    pcm = synth_stream(seed, 2 * P if wb else P).astype(np.float64) * gain
+    if dtx and rng.random() < 0.7:                                      # long near-silent stretches so that DTX engages
+        a0 = int(rng.integers(0, pcm.shape[0] // 2))
+        pcm[a0:a0 + int(rng.integers(8, 40))] *= 0.0005
+    pcm = np.clip(np.rint(pcm), -32768, 32767).astype(np.int16).reshape(P, 1280 if wb else 640)
+    flags = mdi | (2 if joint else 0) | (4 if dtx else 0)
+    e = T.EmuEncoder(rate, flags, wb=wb)
+    r = R.RefEncoder("fix", rate=rate, joint=joint, dtx=dtx, use_md_index=mdi, samplerate=32000 if wb else 16000)
+    for p in range(P):
+        a, b = e.encode(pcm[p]), r.encode(pcm[p])
+        if a != b:
+            return (seed, p, "enc", dict(wb=wb, rate=rate, joint=joint, dtx=dtx, mdi=mdi, gain=gain), a[1:], b[1:])
+    return None
+
+
 def one(args):
     seed, P, wb = args
+    if wb == "random":
+        return one_random(seed, P)
     if wb:
         return one_wb(seed, P)
     cfg = CFGS[(seed // EDGE_FAMILIES) % len(CFGS)]
@@ -114,7 +140,7 @@ def main():
     N = int(sys.argv[1]) if len(sys.argv) > 1 else 280
     P = int(sys.argv[2]) if len(sys.argv) > 2 else 20
     s0 = int(sys.argv[3]) if len(sys.argv) > 3 else 0
-    wb = len(sys.argv) > 4 and sys.argv[4] == "wb"
+    wb = (len(sys.argv) > 4 and sys.argv[4] == "wb") or (len(sys.argv) > 4 and sys.argv[4] == "random" and "random")
     res = run_isolated([(s0 + i, P, wb) for i in range(N)], min(16, mp.cpu_count()))
     crashed = [r[1] for r in res if r and r[0] == "crash"]
     bad = [r for r in res if r and r[0] != "crash"]
