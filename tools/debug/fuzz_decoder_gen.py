@@ -15,6 +15,7 @@ import solo_testlib as T
 from solo_amd.synth import edge_stream, synth_stream
 
 P = 14
+COLD = bool(os.environ.get("FUZZ_COLD"))          # FUZZ_COLD=1: the first seed % 4 packets of every stream are lost
 
 
 def sequence(seed):
@@ -51,6 +52,8 @@ def sequence(seed):
             else:                                              # the length record lies about where the second description starts
                 n1 = int(np.clip(n1 + rng.integers(-3, 4), (4 if joint else 8) + 1, n0 - 1))
         mode = int(rng.integers(0, 4)) if p > 0 else 0
+        if COLD and p < seed % 4:                               # leading packets never arrive: the decoder is still at its initial rate
+            mode = 3
         a = R.map_loss(bytes(pl), n0, n1, mode == 1, mode == 2) if mode != 3 else (bytes(pl), n0, n1, 1)
         seq.append((a, bool(hit), (bytes(pl), n0, n1, {0: 3, 1: 2, 2: 1, 3: 0}[mode])))       # + the whole packet and its receive mask
     return dict(wb=wb, mdi=mdi, joint=joint, rate=rate, split=split, fs=fs), seq
