@@ -1,31 +1,42 @@
 #!/usr/bin/env python3
 """Headline benchmark: 40 ms packets/s, encode + decode round trip.
 
-  python bench.py --gpus N --steps K --warmup W         (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
 
-One "step" = every stream of the batch encodes `--packets` consecutive 40 ms packets (AGR_Sate_Encoder_Encode semantics:
-QMF split, SILK analysis, 3-track delayed-decision NSQ, range coding of both descriptions, high band) and decodes them again
-(AGR_Sate_Decoder_Decode, both descriptions received, BWE resynthesis + QMF), through the C ABI of
-solo_amd/libsolo_mi355x.so.  Inputs are resident in HBM before the timed region; codec state stays in HBM between steps.
+N > 1 runs ONE RANK PER GPU.  Started under a launcher (the driver's `python -m torch.distributed.run --nproc-per-node N ... bench.py
+--gpus N`) it reads RANK / LOCAL_RANK / WORLD_SIZE; started plainly (`python bench.py --gpus N`) it launches the N ranks itself
+(solo_amd.dist.self_launch) -- and refuses with a non-zero exit code when fewer than N devices are visible.  WORLD_SIZE must equal
+--gpus in every case: a line can never report another job than the one that ran.
+
+One "step" = every stream of the batch encodes `--packets` consecutive 40 ms packets (AGR_Sate_Encoder_Encode semantics: QMF split,
+SILK analysis, 3-track delayed-decision NSQ, range coding of both descriptions, high band) and decodes them again
+(AGR_Sate_Decoder_Decode, both descriptions received, BWE resynthesis + QMF), through the C ABI of solo_amd/libsolo_mi355x.so.
+Inputs are resident in HBM before the timed region; codec state stays in HBM between steps.
 
   N = 1   BASELINE.json configs[2]: 4096 synthetic streams, round trip                     (the configuration `metric` is quoted on)
+          + two more timed legs in `extra`: configs[1] (the same 4096 streams, encode only) and configs[3] (8192 streams, decode
+          only, every description lost with probability 0.3, first packet kept: single-description decoding + concealment)
   N > 1   BASELINE.json configs[4]: 8192 streams PER GPU (65 536 on 8), encode + decode per rank, streams sharded contiguously
-          over the ranks with NO data-path collective; RCCL carries the barrier and ONE all_gather of the per-rank record
-          {packets, seconds, payload_bytes, payload_md5, pcm_md5}.  The line reports per-GPU and whole-node packets/s; a rank's
-          hashes equal those of a single-GPU run of the same global streams (`--first-stream r*8192 --streams 8192`).
+          over the ranks with NO data-path collective; RCCL carries the barriers, the max-over-ranks time and ONE all_gather of the
+          per-rank record {packets, seconds, payload_bytes, block hashes}.
 
 Prints ONE JSON line (rank 0):
-  value      whole-job packets/s = packets all ranks processed / max-over-ranks time of the K timed steps
-  roofline   SURVEY 8(d): the dominant kernel's ALGORITHMIC HBM bytes per launch -- what crosses the boundary: 1280 B PCM +
-             payload + 4 B of lengths per packet, nothing else -- / its average launch duration, measured live with HIP events
-             that the library records around every launch on the launch stream (solo_batch_set_timing), against 8 TB/s.
-             The kernel-to-kernel hand-over records and the per-stream state are implementation traffic: they show up in
-             `traffic` (PMC: 2 x FETCH_SIZE + WRITE_SIZE per launch, from profiles/hbm_traffic.json), not in `achieved`.
-  valu_issue the limiter that actually binds (serial fixed-point recursions): VALU wave-instructions per second of the whole
-             step (SQ_INSTS_VALU per packet from the rocprofv3 counter pass in profiles/, x measured packets/s) against the
-             chip's VALU issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)
-  cpu_baseline  the compiled reference (oracle/_ref, fixed-point tree) timed on the host cores this process may use (affinity and
-             cgroup quota respected), >= 10 s of work per worker
+  value          whole-job packets/s = packets all ranks processed / max-over-ranks time of the K timed steps
+  parity_checked the first step (freshly reset streams) of every rank is hashed per block of 4096 streams and compared with the
+                 hashes the COMPILED REFERENCE produced for the same streams (tests/golden/bench_blocks.json, made by
+                 tests/golden/make_bench_golden.py): true = every block of every rank equals the reference bit for bit
+  roofline       SURVEY 8(d): the dominant kernel's ALGORITHMIC HBM bytes per launch -- what crosses the boundary: 1280 B PCM +
+                 payload + 4 B of lengths per packet -- / its average launch duration, measured live with HIP events that the
+                 library records around every launch on the launch stream (solo_batch_set_timing), against 8 TB/s.  The
+                 kernel-to-kernel hand-over records and the per-stream state are implementation traffic: `traffic` (PMC: 2 x
+                 FETCH_SIZE + WRITE_SIZE per launch, profiles/hbm_traffic.json), not `achieved`.
+  valu_issue     the limiter that actually binds (serial fixed-point recursions): VALU wave-instructions per second of the whole
+                 step (SQ_INSTS_VALU per packet from the rocprofv3 counter pass in profiles/, x measured packets/s) against the
+                 chip's VALU issue peak (1024 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction)
+  profile_matches_head   the counter-derived fields (traffic, valu_issue) come from profiles/*.json; true when those were collected
+                 from the same kernel sources (solo_amd.kernel_source_hash) as the library that just ran
+  cpu_baseline   the compiled reference (oracle/_ref, fixed-point tree; -O3 like the reference's own Release build, and the -O2
+                 checker build beside it) on the host cores this process may use (affinity and cgroup quota respected)
 """
 import argparse
 import json
@@ -50,6 +61,15 @@ os.environ.setdefault("GPU_MAX_HW_QUEUES", "2")
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E, /opt/skills/guides/MI355X_MICROARCH.md
 N_SIMD, CLOCK_HZ, CYCLES_PER_VALU = 1024, 2.4e9, 2.0       # 256 CUs x 4 SIMD-32; a wave64 VALU instruction issues over 2 cycles
 PCM_BYTES = 1280.0             # 640 int16 samples per 40 ms packet
+LOSS_SEED, LOSS_P = 4242, 0.3  # configs[3]: Bernoulli description loss (also used by tests/golden/make_bench_golden.py)
+
+
+def loss_mask(n_streams, n_packets, p=LOSS_P, seed=LOSS_SEED):
+    """uint8 [N, P]: bit0 = MD1 received, bit1 = MD2 received; every description is lost with probability p, packet 0 is kept."""
+    rng = np.random.default_rng(seed)
+    m = (rng.random((n_streams, n_packets)) >= p).astype(np.uint8) | ((rng.random((n_streams, n_packets)) >= p).astype(np.uint8) << 1)
+    m[:, 0] = 3
+    return m
 
 
 # ---------------------------------------------------------------------------------------------------------------------
@@ -82,14 +102,14 @@ def effective_cores():
 def _cpu_worker_main(args):
     """One worker process: round-trips whole streams of the synthetic workload through the compiled reference encoder + decoder
     (both descriptions received) for `passes` passes over its streams.  Returns packets, wall and CPU seconds."""
-    widx, n_streams, P, passes, t_start = args
+    kind, widx, n_streams, P, passes, t_start = args
     sys.path.insert(0, os.path.join(HERE, "oracle"))
     import refcodec as R
     from solo_amd.synth import synth_stream
     pcm = [synth_stream(widx * n_streams + i, P) for i in range(n_streams)]
 
     def run(x):
-        e, d = R.RefEncoder("fix"), R.RefDecoder("fix")
+        e, d = R.RefEncoder(kind), R.RefDecoder(kind)
         for p in range(x.shape[0]):
             pl, n0, n1 = e.encode(x[p])
             d.decode(*R.map_loss(pl, n0, n1, False, False))
@@ -106,34 +126,47 @@ def _cpu_worker_main(args):
     return done, time.perf_counter() - w0, time.process_time() - c0
 
 
-def cpu_worker(target_seconds, packets_per_stream):
+def _cpu_leg(kind, cores, target_seconds, P):
     import multiprocessing as mp
+    S = 2
+    t = _cpu_worker_main((kind, 0, 1, min(P, 100), 1, 0.0))    # calibrate one pass on one core, then size every worker's job
+    per_packet = t[1] / t[0]
+    passes = max(1, int(math.ceil(target_seconds / (per_packet * P * S))))
+    with mp.get_context("fork").Pool(cores) as pool:
+        t_start = time.time() + 1.5 + 0.02 * cores
+        res = pool.map(_cpu_worker_main, [(kind, w, S, P, passes, t_start) for w in range(cores)], chunksize=1)
+    packets = sum(r[0] for r in res)
+    wall = max(r[1] for r in res)
+    cpu_s = [r[2] for r in res]
+    return {"value": round(packets / wall, 1), "per_core_packets_per_s": round(float(np.mean([r[0] / r[2] for r in res])), 1),
+            "worker_cpu_seconds": [round(min(cpu_s), 2), round(float(np.mean(cpu_s)), 2), round(max(cpu_s), 2)], "wall_seconds": round(wall, 2),
+            "packets": packets, "passes": passes, "streams_per_worker": S}
+
+
+def cpu_worker(target_seconds, packets_per_stream):
     sys.path.insert(0, os.path.join(HERE, "oracle"))
     import refcodec as R
     if not R.have_ref("fix"):
         print(json.dumps(None))
         return
     cores, info = effective_cores()
-    P, S = packets_per_stream, 2
-    # calibrate one pass on one core, then size every worker's job to ~target_seconds
-    t = _cpu_worker_main((0, 1, min(P, 100), 1, 0.0))
-    per_packet = t[1] / t[0]
-    passes = max(1, int(math.ceil(target_seconds / (per_packet * P * S))))
-    with mp.get_context("fork").Pool(cores) as pool:
-        t_start = time.time() + 1.5 + 0.02 * cores
-        res = pool.map(_cpu_worker_main, [(w, S, P, passes, t_start) for w in range(cores)], chunksize=1)
-    packets = sum(r[0] for r in res)
-    wall = max(r[1] for r in res)
-    cpu_s = [r[2] for r in res]
-    per_core = float(np.mean([r[0] / r[2] for r in res]))      # packets per CPU-second of a worker
-    print(json.dumps({
-        "value": round(packets / wall, 1), "unit": "40ms packets/s (encode+decode)", "cores": cores, "kind": "reference",
-        "per_core_packets_per_s": round(per_core, 1), "worker_cpu_seconds": [round(min(cpu_s), 2), round(float(np.mean(cpu_s)), 2), round(max(cpu_s), 2)],
-        "wall_seconds": round(wall, 2), "host": info,
-        "sample": "%d worker processes (= usable host CPUs: affinity %s, cgroup quota %s of %s hardware threads), each %d passes over %d "
-                  "streams x %d packets of the same synthetic workload through the compiled fixed-point reference "
-                  "(oracle/_ref/libsolo_ref_fix.so, gcc -O2): %d packets in %.1f s wall; worker_cpu_seconds = [min, mean, max]"
-                  % (cores, info["affinity"], info["cgroup_quota_cpus"], info["os_cpu_count"], passes, S, P, packets, wall)}))
+    P = packets_per_stream
+    have_o3 = R.have_ref("fix_O3")
+    main = _cpu_leg("fix_O3" if have_o3 else "fix", cores, target_seconds, P)
+    out = {"value": main["value"], "unit": "40ms packets/s (encode+decode)", "cores": cores, "kind": "reference",
+           "build": "gcc -O3 (oracle/_ref/libsolo_ref_fix_O3.so: the optimisation level of the reference's own CMake Release build)" if have_o3
+                    else "gcc -O2 (oracle/_ref/libsolo_ref_fix.so)",
+           "per_core_packets_per_s": main["per_core_packets_per_s"], "worker_cpu_seconds": main["worker_cpu_seconds"],
+           "wall_seconds": main["wall_seconds"], "host": info,
+           "sample": "%d worker processes (= usable host CPUs: affinity %s, cgroup quota %s of %s hardware threads), each %d passes over %d "
+                     "streams x %d packets of the same synthetic workload through the compiled fixed-point reference: %d packets in %.1f s wall; "
+                     "worker_cpu_seconds = [min, mean, max]" % (cores, info["affinity"], info["cgroup_quota_cpus"], info["os_cpu_count"],
+                                                                 main["passes"], main["streams_per_worker"], P, main["packets"], main["wall_seconds"])}
+    if have_o3:                                               # the -O2 build is the parity checker of the test suite: timed beside it
+        o2 = _cpu_leg("fix", cores, max(3.0, target_seconds / 2), P)
+        out["O2_build"] = {"value": o2["value"], "per_core_packets_per_s": o2["per_core_packets_per_s"], "wall_seconds": o2["wall_seconds"],
+                           "build": "gcc -O2 (oracle/_ref/libsolo_ref_fix.so, the checker)"}
+    print(json.dumps(out))
 
 
 def cpu_baseline(target_seconds, packets_per_stream):
@@ -155,7 +188,33 @@ def _profile_json(name):
         return None
 
 
-def main():
+def golden_blocks():
+    """tests/golden/bench_blocks.json: reference-generated hashes per block of 4096 streams (data, committed; see the script beside it)"""
+    try:
+        g = json.load(open(os.path.join(HERE, "tests", "golden", "bench_blocks.json")))
+        return g, {b["first_stream"]: b for b in g["blocks"]}
+    except Exception:
+        return None, {}
+
+
+def check_blocks(first_stream, hashes, gold, gmap, P, rate, slot, pcm_key="pcm_md5"):
+    """-> (checked: True / False / None, detail list).  None = nothing to compare with (no golden for these streams / this shape)."""
+    if not hashes or gold is None or P != gold["packets"] or rate != gold["rate_bps"] or slot != gold["slot_bytes"] or first_stream % gold["block_streams"]:
+        return None, []
+    det, ok, seen = [], True, 0
+    for i, h in enumerate(hashes):
+        g = gmap.get(first_stream + i * gold["block_streams"])
+        if g is None or g.get(pcm_key) is None:
+            det.append({"first_stream": first_stream + i * gold["block_streams"], "checked": None})
+            continue
+        seen += 1
+        good = (h["payload_md5"] == g["payload_md5"]) and (h["pcm_md5"] is None or h["pcm_md5"] == g[pcm_key])
+        ok = ok and good
+        det.append({"first_stream": g["first_stream"], "checked": bool(good), "payload_md5": h["payload_md5"], "pcm_md5": h["pcm_md5"]})
+    return (ok if seen == len(hashes) else (False if not ok else None)), det
+
+
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -164,45 +223,76 @@ def main():
     ap.add_argument("--first-stream", type=int, default=-1, help="global index of this process's first stream (default: rank * streams)")
     ap.add_argument("--packets", type=int, default=50, help="40 ms packets per stream per step (SURVEY 8(d): P >= 50 = 2 s of audio)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-hash", action="store_true", help="skip the payload / PCM md5 of the record (saves the device-to-host copy)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[3] legs (N = 1 only)")
+    ap.add_argument("--no-hash", action="store_true", help="skip the hashes of the first step (saves the device-to-host copies; parity_checked = null)")
     ap.add_argument("--overlap", action="store_true", help="decode of step k on a second stream beside the encode of step k+1")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU baseline: seconds of work per worker process")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: seconds of work per worker process")
     ap.add_argument("--cpu-packets-per-stream", type=int, default=400)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
-    args = ap.parse_args()
+    return ap.parse_args(argv)
+
+
+def timed_loop(fn, steps, warmup, barrier):
+    """W untimed calls, then exactly `steps` calls between two barrier + synchronize brackets -> seconds"""
+    for _ in range(warmup):
+        fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        fn()
+    barrier()
+    return time.perf_counter() - t0
+
+
+def main():
+    args = parse_args()
     if args.cpu_worker:
         cpu_worker(args.cpu_seconds, args.cpu_packets_per_stream)
         return
+    from solo_amd import dist as sdist
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    launched = "WORLD_SIZE" in os.environ
+    if args.gpus > 1 and not launched:
+        # plain `python bench.py --gpus N`: become the launcher of N ranks (never silently time one GPU)
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have < args.gpus:
+            raise SystemExit("bench.py --gpus %d: only %d HIP device(s) visible on this node" % (args.gpus, have))
+        sdist.self_launch(os.path.abspath(__file__), sys.argv[1:], args.gpus)          # execs; does not return
 
+    world, rank, local_rank = sdist.env_world()
+    sdist.check_world(args.gpus, world)
     import torch
     import solo_amd
 
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the codec has no CPU path")
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    from solo_amd import dist as sdist
+    if torch.cuda.device_count() < (local_rank + 1):
+        raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
+    dist = None
     if world > 1:
         torch.cuda.set_device(local_rank)
         dist = sdist.init("nccl", torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for N > 1"
     dev = torch.device("cuda", torch.cuda.current_device())
 
     N = args.streams if args.streams > 0 else (4096 if world == 1 else 8192)
-    P = args.packets
+    P, RATE, SLOT = args.packets, 13600, 512
     from solo_amd.synth import synth_batch
     first = args.first_stream if args.first_stream >= 0 else sdist.stream_range(rank, N)[0]
     ncpu, _ = effective_cores()
-    pcm = torch.from_numpy(synth_batch(first, N, P, workers=max(1, min(16, ncpu // max(1, min(world, 8)))))).to(dev)
-    batch = solo_amd.SoloBatch(N, rate=13600, encoder=True, decoder=True, slot_bytes=512)
-    bits = torch.zeros((N, P, 512), dtype=torch.uint8, device=dev)
+    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
+    pcm_host = synth_batch(first, N, P, workers=workers)
+    pcm = torch.from_numpy(pcm_host).to(dev)
+    batch = solo_amd.SoloBatch(N, rate=RATE, encoder=True, decoder=True, slot_bytes=SLOT)
+    bits = torch.zeros((N, P, SLOT), dtype=torch.uint8, device=dev)
     nb = torch.zeros((N, P, 2), dtype=torch.int16, device=dev)
     st_e = torch.zeros((N,), dtype=torch.int32, device=dev)
     st_d = torch.zeros((N,), dtype=torch.int32, device=dev)
     out = torch.zeros((N, P, 640), dtype=torch.int16, device=dev)
+    payload_acc = torch.zeros((1,), dtype=torch.int64, device=dev)      # payload bytes actually produced (summed on the device per step)
 
     # (per-kernel timing brackets -- HIP events with timestamps around every launch -- are switched on only for the few sampling
     # steps AFTER the timed region: they cost several per cent of throughput)
@@ -217,16 +307,18 @@ def main():
     if overlap:
         batch.set_async_join(True)
 
-    def step(k=None):
+    def step():
         if not overlap:
             batch.encode(pcm, bits, nb, st_e)
             batch.decode(bits, nb, None, out, st_d)
+            payload_acc.add_(nb[:, :, 0].sum(dtype=torch.int64))
             return
         j = step_no[0] & 1
         batch.encode(pcm, bits2[j], nb2[j], st_e)
         if step_no[0] > 0:                                # the previous step's packets: wait for THAT encode call, then decode
             batch.wait_encode(1)
             batch.decode(bits2[1 - j], nb2[1 - j], None, out, st_d)
+            payload_acc.add_(nb2[1 - j][:, :, 0].sum(dtype=torch.int64))
         step_no[0] += 1
 
     def drain():
@@ -234,6 +326,7 @@ def main():
             j = (step_no[0] - 1) & 1
             batch.wait_encode(0)
             batch.decode(bits2[j], nb2[j], None, out, st_d)
+            payload_acc.add_(nb2[j][:, :, 0].sum(dtype=torch.int64))
             step_no[0] = 0
 
     def barrier():
@@ -241,8 +334,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    # The first step after a reset is the one a single-GPU run of the same streams reproduces bit for bit: hash its outputs
-    # (outside the timed region).  Later steps continue the streams' state with the same input, so their bytes differ.
+    # The first step after a reset is the one the compiled reference reproduces bit for bit from the same input: hash its outputs
+    # per block of 4096 streams (outside the timed region).  Later steps continue the streams' state with the same input.
     step()
     drain()
     torch.cuda.synchronize()
@@ -252,12 +345,14 @@ def main():
         step()
     drain()
     barrier()
+    payload_acc.zero_()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        step(k)
+        step()
     drain()                                               # (the last step's decode: every packet is encoded AND decoded in the timed region)
     barrier()
     dt_local = time.perf_counter() - t0
+    payload_bytes_timed = int(payload_acc.item())
     # per-kernel durations: a few extra steps outside the timed region (reading the events synchronises the stream)
     if overlap:
         batch.set_async_join(False)
@@ -267,29 +362,68 @@ def main():
         step()
         for name, v in batch.last_kernel_ms().items():
             kms[name].append(v)
+    batch.set_timing(False)
     enc_chunks = max(1, batch.last_encode_chunks())
     dt = sdist.max_over_ranks(dt_local, dist, dev) if world > 1 else dt_local
-
     assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
     kavg = {n: float(np.mean(v)) for n, v in kms.items()}
-    dec_ms = kavg["decode"]
-    # the encoder's kernels overlap each other (and, with --overlap, the decoder): encode alone is timed separately below
-    batch.set_timing(False)
-    torch.cuda.synchronize()
-    t1 = time.perf_counter()
-    for _ in range(3):
-        batch.encode(pcm, bits, nb, st_e)
-    torch.cuda.synchronize()
-    enc_only_ms = (time.perf_counter() - t1) / 3 * 1e3
     packets_step = N * P
     value = world * packets_step * args.steps / dt
 
+    gold, gmap = golden_blocks()
+    hashes = None if args.no_hash else sdist.block_hashes(*first_step)
+    checked, detail = check_blocks(first, hashes, gold, gmap, P, RATE, SLOT)
+
+    # ---- extra legs (N = 1): BASELINE configs[1] and configs[3], each its own timed loop ------------------------------------
+    extra = {}
+    if world == 1 and not args.no_extra:
+        # configs[1]: the same 4096 streams, encode only
+        dt_e = timed_loop(lambda: batch.encode(pcm, bits, nb, st_e), args.steps, max(1, args.warmup), barrier)
+        assert int(st_e.abs().max()) == 0
+        extra["configs[1]"] = {"workload": "BASELINE configs[1]: %d synthetic 16 kHz WB streams, encode only, 13.6 kbps, %d packets/stream/step" % (N, P),
+                               "value": round(packets_step * args.steps / dt_e, 1), "unit": "40ms packets/s (encode)", "steps": args.steps,
+                               "warmup": max(1, args.warmup), "ms_per_step": round(dt_e / args.steps * 1e3, 3),
+                               "parity_checked": checked, "parity_note": "the payload hashes of the main leg's first step ARE this configuration's output"}
+        # configs[3]: 8192 streams, decode only, every description lost with probability 0.3 (seeded Bernoulli draws, packet 0 kept)
+        N8 = 8192
+        more = synth_batch(first + N, N8 - N, P, workers=workers) if N8 > N else None
+        pcm8 = torch.cat([pcm, torch.from_numpy(more).to(dev)]) if more is not None else pcm[:N8]
+        b8 = solo_amd.SoloBatch(N8, rate=RATE, encoder=True, decoder=True, slot_bytes=SLOT)
+        bits8, nb8, st8 = b8.encode(pcm8)
+        recv = torch.from_numpy(loss_mask(N8, P)).to(dev)
+        out8 = torch.zeros((N8, P, 640), dtype=torch.int16, device=dev)
+        st8d = torch.zeros((N8,), dtype=torch.int32, device=dev)
+        b8.decode(bits8, nb8, recv, out8, st8d)           # first decode of freshly reset decoders: the one the reference hashes describe
+        torch.cuda.synchronize()
+        assert int(st8.abs().max()) == 0 and int(st8d.abs().max()) == 0
+        chk8, det8 = (None, [])
+        if not args.no_hash:
+            h8 = sdist.block_hashes(nb8.cpu().numpy(), bits8.cpu().numpy(), out8.cpu().numpy())
+            chk8, det8 = check_blocks(first, h8, gold, gmap, P, RATE, SLOT, pcm_key="pcm_loss30_md5")
+        dt_d = timed_loop(lambda: b8.decode(bits8, nb8, recv, out8, st8d), args.steps, max(1, args.warmup), barrier)
+        assert int(st8d.abs().max()) == 0
+        m = recv.cpu().numpy()
+        extra["configs[3]"] = {"workload": "BASELINE configs[3]: %d streams decode only, descriptions lost independently with probability %.1f "
+                                           "(numpy default_rng(%d), packet 0 kept): single-description decoding + concealment, %d packets/stream/step" % (N8, LOSS_P, LOSS_SEED, P),
+                               "value": round(N8 * P * args.steps / dt_d, 1), "unit": "40ms packets/s (decode)", "steps": args.steps,
+                               "warmup": max(1, args.warmup), "ms_per_step": round(dt_d / args.steps * 1e3, 3),
+                               "packets_both_received": int((m == 3).sum()), "packets_one_description": int(((m == 1) | (m == 2)).sum()),
+                               "packets_lost": int((m == 0).sum()), "parity_checked": chk8, "parity_blocks": det8,
+                               "parity_note": "encoder payloads of the 8192 streams and the PCM of the first decode under this loss pattern, per block of "
+                                              "4096 streams, against the compiled reference (bench_blocks.json: payload_md5 / pcm_loss30_md5)"}
+        del b8, bits8, nb8, out8, pcm8, recv
+
     # ONE all_gather of the per-rank record (RCCL); no other collective besides the barriers and the max time
     record = sdist.result_record(rank, first, N, packets_step * args.steps, dt_local, *first_step)
-    record["payload_bytes"] = int(round(mean_payload * packets_step)) * args.steps
+    record["payload_bytes"] = payload_bytes_timed            # produced in the timed steps (device-side sum of nBytesOut[0])
+    record["parity_checked"] = checked
+    record["blocks"] = detail
+    record["device"] = torch.cuda.get_device_name(dev)
     records = sdist.gather_records(record, dist) if world > 1 else [record]
 
     if rank == 0:
+        all_checked = [r["parity_checked"] for r in records]
+        parity = (all(c is True for c in all_checked) if all(c is not None for c in all_checked) else (False if any(c is False for c in all_checked) else None))
         # ALGORITHMIC bytes per packet: what crosses the boundary, with the run's mean payload
         enc_alg = PCM_BYTES + mean_payload + 4.0
         dec_alg = mean_payload + 4.0 + PCM_BYTES
@@ -297,9 +431,6 @@ def main():
         # is priced with the encode-only boundary bytes of the packets it handles per launch; the hand-over records between them are
         # implementation traffic
         alg = {"analysis": enc_alg, "quantiser": enc_alg, "coding": enc_alg, "decode": dec_alg}
-        # the timed stages and the kernels behind them: the coding stage is two kernels on one HIP stream (range coder, lane per
-        # description; then high band + payload assembly), the decode call is two kernels on two streams (symbol extraction, lane per
-        # description; then the decoder proper, a chunk of packets behind) -- each stage is timed as a whole
         split_dec = os.environ.get("SOLO_DEC_SPLIT", "1") != "0"
         stage_kernels = {"analysis": ["solo_enc_analysis_kernel"], "quantiser": ["solo_nsq_kernel"],
                          "coding": ["solo_enc_coding_kernel", "solo_enc_rc_kernel"],
@@ -307,7 +438,9 @@ def main():
         kname = {n: v[0] for n, v in stage_kernels.items()}
         traffic = _profile_json("hbm_traffic.json") or {}
         insts = _profile_json("wave_instructions.json") or {}
-        # the encoder kernels run as a pipeline over chunks of the step's packets: kavg = sum over the launches of a step
+        src_hash = solo_amd.kernel_source_hash()
+        prof_hash = {"hbm_traffic.json": traffic.get("kernel_source_sha16"), "wave_instructions.json": insts.get("kernel_source_sha16")}
+        prof_ok = all(v == src_hash for v in prof_hash.values())
         dec_chunk = int(os.environ.get("SOLO_DEC_CHUNK", "24"))       # (solo_api.hip: a first chunk of 4 packets, then chunks of this size)
         if split_dec and dec_chunk > 0:
             cp = min(P, dec_chunk)
@@ -342,16 +475,20 @@ def main():
                                    ("BASELINE configs[4]: %d synthetic 16 kHz WB streams sharded evenly across %d x MI355X (%d per GPU), encode + "
                                     "decode per rank, RCCL gather only, 13.6 kbps, %d packets/stream/step" % (N * world, world, N, P)),
                        "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2),
+                       "launch": "torch.distributed.run, one rank per GPU" + (" (started by bench.py itself)" if os.environ.get("SOLO_SELF_LAUNCHED") else "") if world > 1 else "single process",
                        "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
                                     "(solo_batch_set_async_join, double-buffered bitstreams)" if args.overlap
                                     else "encode then decode on one stream")},
+            "parity_checked": parity,
+            "parity": {"what": "first step (freshly reset streams) hashed per block of 4096 streams: md5(nBytes || payload slots) and md5(decoded PCM), "
+                               "compared with the compiled reference's hashes of the same streams (tests/golden/bench_blocks.json)",
+                       "ranks": [{"rank": r["rank"], "first_stream": r["first_stream"], "checked": r["parity_checked"], "blocks": r["blocks"]} for r in records]},
             "realtime_streams": round(value / 25.0, 1),
             "per_gpu_packets_per_s": [r["packets_per_s"] for r in records],
             "whole_node_packets_per_s": round(value, 1),
-            "ranks": records,
-            "encode_only_packets_per_s": round(packets_step / (enc_only_ms * 1e-3), 1),
-            "decode_only_packets_per_s": round(packets_step / (dec_ms * 1e-3), 1),
+            "rccl_ranks": world if world > 1 else 0,
+            "ranks": [{k: v for k, v in r.items() if k != "blocks"} for r in records],
             "roofline": {"kernel": kname[dom], "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": tr_launch(dom),
                          "avg_launch_ms": round(kavg[dom] / nl[dom], 4), "launches_per_step": nl[dom],
@@ -359,13 +496,20 @@ def main():
                          "algorithmic_bytes_per_packet": round(alg[dom], 2),
                          "algorithmic_bytes_per_launch": int(alg_launch),
                          "formula": "achieved = packets_per_launch x (1280 + mean_payload + 4) B / avg_launch_ms; frac = achieved / 8 TB/s "
-                                    "(SURVEY 8(d); hand-over records and stream state count as traffic, not as algorithmic bytes)",
+                                    "(SURVEY 8(d); hand-over records and stream state count as traffic, not as algorithmic bytes).  Every encoder "
+                                    "stage in `kernels` is priced with the full encode boundary bytes of its packets (the stages are one pass over "
+                                    "a packet): their achieved_GBps are per stage, not additive",
                          "whole_step": {"algorithmic_bytes_per_packet": round(enc_alg + dec_alg, 2), "achieved": round(step_gbs, 4),
                                         "frac": round(step_gbs / HBM_PEAK_GBS, 7)},
                          "note": "serial fixed-point recursions: instruction-issue / latency bound, not HBM bound -- see valu_issue"},
             "kernels": kernels,
             "launches_per_step": {k: nl[n] for n, ks in stage_kernels.items() for k in ks},
+            "kernel_source_sha16": src_hash,
+            "profile_matches_head": prof_ok,
+            "profile_source": {"files": prof_hash, "git_head_of_profile": traffic.get("git_head"), "summary": insts.get("source")},
         }
+        if extra:
+            res["extra"] = extra
         peak_issue = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU
         if insts.get("valu_per_packet_round_trip"):
             v = insts["valu_per_packet_round_trip"] * (value / world)
@@ -373,7 +517,7 @@ def main():
                                  "unit": "G wave-instructions/s (VALU)", "frac": round(v / peak_issue, 4),
                                  "valu_wave_instructions_per_packet": insts.get("valu_per_packet"),
                                  "all_wave_instructions_per_packet": insts.get("all_per_packet"),
-                                 "source": insts.get("source"),
+                                 "source": insts.get("source"), "from_this_build": prof_ok,
                                  "note": "SQ_INSTS_VALU per packet of each kernel (rocprofv3 --pmc pass) x packets/s of this run, per GPU; "
                                          "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction"}
         if world == 1 and not args.no_cpu_baseline:
@@ -385,6 +529,8 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if checked is False:
+        raise SystemExit("bench.py: the first step does NOT equal the compiled reference's hashes (rank %d, first stream %d)" % (rank, first))
 
 
 if __name__ == "__main__":

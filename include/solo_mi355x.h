@@ -88,7 +88,8 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  * Streams keep their codec state in HBM inside the handle between calls (a call with n_packets = P
  * is identical to P calls with n_packets = 1).  Work is enqueued on `hip_stream` (a hipStream_t, may
  * be NULL for the default stream) and is asynchronous; no host synchronisation is performed.
- * Return value: 0 or a negative hipError_t.
+ * Return value: 0 or a negative hipError_t.  solo_batch_encode returns -1 for n_packets >= 148 000 (16 kHz) / 74 000 (32 kHz) per
+ * call -- split longer (offline) inputs over several calls; state carries over.
  * ---------------------------------------------------------------------------------------------- */
 typedef struct solo_batch solo_batch_t;
 

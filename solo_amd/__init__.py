@@ -41,6 +41,19 @@ class USER_Ctrl_dec(C.Structure):
 _lib = None
 
 
+def kernel_source_hash():
+    """sha256 (first 16 hex digits) over the kernel sources solo_amd/csrc/* in name order: identifies the BUILD a benchmark line or a
+    profile summary belongs to (the GPU box has no .git; profiles/*.json carry the same field, bench.py compares them)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(_HERE, "csrc")
+    for f in sorted(os.listdir(d)):
+        if f.endswith((".h", ".hip", ".inc")):
+            h.update(f.encode())
+            h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def load_library():
     """Loads libsolo_mi355x.so (raises if it has not been built: see __graft_entry__.build())."""
     global _lib

@@ -89,6 +89,7 @@ struct solo_batch {
     void* d_parsed[2];               // extraction records of the chunk being extracted / being decoded
     size_t parsed_bytes;             // size of each
     int dec_pipe_ready, dec_split, dec_chunk;
+    unsigned int dec_calls;          // two-kernel decode calls so far (evDJoin / evDJoin2 are recorded once > 0)
     void* d_rc_scratch;              // range-coder byte buffers of one coding launch (the launches of a call run in order on sC)
     size_t rc_scratch_bytes;
     void* d_enc_work;                // hand-over records of one launch: SxNsqIn[N][P][2] | SxNsqOut[N][P][2] | SxCodeIn[N][P]
@@ -232,6 +233,11 @@ int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
         }
     }
     if (b->have_dec) {
+        if (b->dec_pipe_ready && b->dec_split && b->dec_calls > 0) {
+            // like the encoder above: a decode call issued on another stream may still run on the internal streams
+            SOLO_CHECK(hipStreamWaitEvent(s, b->evDJoin, 0));
+            SOLO_CHECK(hipStreamWaitEvent(s, b->evDJoin2, 0));
+        }
         const int hbj = ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode);
         SOLO_CHECK(b->wb ? solo_wb_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s) : solo_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s));
     }
@@ -365,22 +371,30 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
         for (int i = 0; i < 2; i++) SOLO_CHECK(hipMalloc(&b->d_parsed[i], need));
         b->parsed_bytes = need;
     }
+    if (b->dec_calls > 0) {
+        // the previous decode call may have been issued on ANOTHER stream than this one: its kernels on sP / sS (and their use of
+        // d_parsed[]) must be done before this call's fork lets the internal streams run on
+        SOLO_CHECK(hipStreamWaitEvent(st, b->evDJoin, 0));
+        SOLO_CHECK(hipStreamWaitEvent(st, b->evDJoin2, 0));
+    }
     SOLO_CHECK(hipEventRecord(b->evDFork, st));
     SOLO_CHECK(hipStreamWaitEvent(b->sP, b->evDFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sS, b->evDFork, 0));
+    b->dec_calls++;
     hipError_t lerr = hipSuccess;
     for (int c = 0; c < nchunks && lerr == hipSuccess; c++) {
         const int p0 = c == 0 ? 0 : c0 + (c - 1) * cp, pc = c == 0 ? c0 : ((p0 + cp <= n_packets) ? cp : n_packets - p0), k = c & 1;
-        if (c >= 2) SOLO_CHECK(hipStreamWaitEvent(b->sP, b->evS[k], 0));
+        // (every failure inside the loop goes through the join block below: nothing of this call stays forked)
+        if (c >= 2 && (lerr = hipStreamWaitEvent(b->sP, b->evS[k], 0)) != hipSuccess) break;
         lerr = (b->wb ? solo_wb_dec_launch_extract : solo_dec_launch_extract)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, p0, pc,
                                                                               b->slot, b->dec_ctrl.useMDIndex, b->d_parsed[k], b->sP);
         if (lerr != hipSuccess) break;
-        SOLO_CHECK(hipEventRecord(b->evP[k], b->sP));
-        SOLO_CHECK(hipStreamWaitEvent(b->sS, b->evP[k], 0));
+        if ((lerr = hipEventRecord(b->evP[k], b->sP)) != hipSuccess) break;
+        if ((lerr = hipStreamWaitEvent(b->sS, b->evP[k], 0)) != hipSuccess) break;
         lerr = (b->wb ? solo_wb_dec_launch_synth : solo_dec_launch_synth)(b->d_dec_state, d_bits, d_nbytes, d_recv, b->n_streams, n_packets, p0, pc, b->slot,
                                                                           b->dec_ctrl.useMDIndex, b->d_parsed[k], d_pcm, d_status, b->sS);
         if (lerr != hipSuccess) break;
-        SOLO_CHECK(hipEventRecord(b->evS[k], b->sS));
+        if ((lerr = hipEventRecord(b->evS[k], b->sS)) != hipSuccess) break;
     }
     // join both internal streams back into the caller's (also after a refused launch: nothing stays forked)
     (void)hipEventRecord(b->evDJoin, b->sP);
@@ -408,6 +422,9 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t np = (size_t)b->n_streams * (size_t)n_packets;
     const solo_enc_ops* ops = b->eops;
+    // the quantiser addresses the hand-over records of its wavefront's sixteen streams with 32-bit offsets from a wave-uniform base
+    // (solo_nsq16.hip): 15 streams x 2 n_packets records must stay below 4 GiB (148 k narrow-band / 74 k wide-band packets per call)
+    if ((unsigned long long)15 * 2ull * (unsigned long long)n_packets * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
@@ -675,7 +692,7 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
         // lengths that do not describe bytes inside the caller's buffer are refused before anything is read (the reference would
         // read out of bounds): too long -> SKP_SILK_DEC_PAYLOAD_TOO_LARGE, inconsistent -> SKP_SILK_DEC_PAYLOAD_ERROR
         if (n0 > h->b->slot) { *nSamplesOut = (int16_t)ns; return -11; }
-        if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
+        if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb) || (lostflag == 4 && n0 < hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
         if (hipMemcpy(h->d_bits, bits, n0, hipMemcpyHostToDevice) != hipSuccess) return -1;
     }
     if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,

@@ -40,6 +40,9 @@ SX_HD SxDecArgs sx_dec_map_record(i32 n0, i32 n1, int slot, int recv_mask, int h
     r.bad = 0;
     if (n0 > slot) r.bad = -11;
     else if (n0 > 0 && (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb))) r.bad = -12;
+    // a record that is shorter than the high-band bytes every packet ends with cannot hold a first description + high band (recv
+    // bit 0) -- the reference would compute a negative low-band length from it (AGR_BWE_decode_frame_FIX.c:150-169)
+    else if (n0 > 0 && n0 < hbb && (recv_mask & 1)) r.bad = -12;
     if (r.bad) { n0 = 0; n1 = 0; }
     // DELIBERATE CONVENTION of the batched API (not reference behaviour): an EMPTY record (n0 <= 0, e.g. a DTX packet that
     // was never sent) is concealed like a lost packet, i.e. decoded with lostflag = 1.  The reference library itself returns

@@ -3,6 +3,7 @@
 torch.distributed (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests) is used only for: a barrier around the
 timed region, the max-over-ranks elapsed time, and one all_gather of per-rank result records."""
 import os
+import sys
 
 
 def env_world():
@@ -56,3 +57,59 @@ def result_record(rank, first_stream, n_streams, packets, seconds, nbytes, bits,
     if pcm is not None:
         rec["pcm_md5"] = hashlib.md5(pcm.tobytes()).hexdigest()
     return rec
+
+
+BLOCK_STREAMS = 4096
+
+
+def block_hashes(nbytes, bits, pcm, block=BLOCK_STREAMS):
+    """Hashes of ONE step from freshly reset streams, per aligned block of `block` streams (the unit tests/golden/bench_blocks.json
+    holds reference-generated hashes for): [{"payload_md5": md5(nbytes || bits), "pcm_md5": md5(pcm)}, ...].  Arrays as in
+    result_record; pcm may be None.  A stream count that is not a multiple of `block` gives None (nothing to compare with)."""
+    import hashlib
+    n = nbytes.shape[0]
+    if n % block:
+        return None
+    out = []
+    for b in range(n // block):
+        sl = slice(b * block, (b + 1) * block)
+        h = hashlib.md5()
+        h.update(nbytes[sl].tobytes())
+        h.update(bits[sl].tobytes())
+        out.append({"payload_md5": h.hexdigest(), "pcm_md5": hashlib.md5(pcm[sl].tobytes()).hexdigest() if pcm is not None else None})
+    return out
+
+
+def torchrun_command(script, argv, nproc, port=None):
+    """The command line that runs `script argv` as `nproc` ranks of one node (one process per GPU), the way the benchmark driver
+    does it: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P script argv."""
+    if port is None:
+        import socket
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(int(nproc)), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), script] + list(argv)
+
+
+def self_launch(script, argv, nproc, exec_=True, env=None, timeout=None):
+    """`python bench.py --gpus N` started WITHOUT a launcher: start the N ranks ourselves.  exec_=True replaces this process
+    (bench.py); exec_=False runs the launcher as a child and returns its CompletedProcess (tests)."""
+    cmd = torchrun_command(script, argv, nproc)
+    e = dict(os.environ if env is None else env)
+    e.setdefault("MASTER_ADDR", "127.0.0.1")
+    e["SOLO_SELF_LAUNCHED"] = "1"
+    if exec_:
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os.execve(sys.executable, cmd, e)
+    import subprocess
+    return subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=timeout)
+
+
+def check_world(requested_gpus, world):
+    """A run that was asked for N GPUs must BE N ranks: anything else would time a different job than the one it reports."""
+    if int(world) != int(requested_gpus):
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: start it as `python bench.py --gpus %d` (self-launching) or under "
+                         "`python -m torch.distributed.run --nnodes=1 --nproc-per-node %d ... bench.py --gpus %d`"
+                         % (requested_gpus, world, requested_gpus, requested_gpus, requested_gpus))

@@ -154,23 +154,6 @@ def test_many_streams_vs_compiled_reference(torch_cuda):
             assert bits[i, p, :n0].tobytes() == pl, (i, p)
 
 
-def test_use_md_index_and_rate(torch_cuda):
-    """useMDIndex = 1 and a second target rate against the host emulation of the same kernel source."""
-    import solo_amd
-    torch = torch_cuda
-    P = 8
-    pcm = np.stack([R.synth_stream(70 + i, P) for i in range(4)])
-    for rate, mdi in ((13600, 1), (24000, 0)):
-        b = solo_amd.SoloBatch(4, rate=rate, encoder=True, decoder=False, slot_bytes=512, use_md_index=mdi)
-        bits, nb = _gpu_encode(torch, pcm, batch=b)
-        for i in range(4):
-            e = T.EmuEncoder(rate, mdi)
-            for p in range(P):
-                pl, n0, n1 = e.encode(pcm[i, p])
-                assert (int(nb[i, p, 0]), int(nb[i, p, 1])) == (n0, n1), (rate, mdi, i, p)
-                assert bits[i, p, :n0].tobytes() == pl, (rate, mdi, i, p)
-
-
 def test_legacy_single_stream_api(torch_cuda):
     """AGR_Sate_Encoder_Init / _Encode / _Uninit driven exactly like test/enc_main.c does."""
     import ctypes as C

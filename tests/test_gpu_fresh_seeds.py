@@ -1,0 +1,138 @@
+"""Fresh-seed parity on every GPU test run: the seeds are derived from the hash of the kernel sources
+(solo_amd.kernel_source_hash), so every build of the kernels is checked on streams no earlier run has seen -- and the seed is printed,
+so a failure can be replayed with tools/debug/sweep_vs_reference.py / fuzz_decoder_gen.py.  Both tests compare the gfx950 library,
+through its C ABI, with the COMPILED REFERENCE running on the box's host cores (oracle/_ref travels with the snapshot).
+
+  * sweep: 1024 speech-like streams x 20 packets in four configurations (13.6 kbps / joint_mode 1 + useMDIndex / 24 kbps / DTX) and
+    256 un-speech-like `edge_stream`s x 20 packets in the same four: encoder payloads and lengths byte for byte, decoder PCM under
+    random description loss sample for sample;
+  * decoder fuzz: 2000 freshly generated streams (random rate, 16 / 32 kHz mode, description index on / off, both high-band framings,
+    speech-like and edge inputs) with corrupted packets (byte errors, bursts, bit flips, lying length records) under random description
+    loss, decoded packet by packet: accepted packets must give the reference's PCM, rejected ones its return code."""
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+import pytest
+
+import refcodec as R
+import solo_testlib as T
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not R.have_ref("fix"), reason="oracle/_ref not present")]
+sys.path.insert(0, os.path.join(T.ROOT, "tools", "debug"))
+
+
+def _seed():
+    import solo_amd
+    h = solo_amd.kernel_source_hash()
+    return h, 1000000 + (int(h[:6], 16) % 50000000)
+
+
+def test_fresh_seed_sweep_vs_compiled_reference():
+    import torch
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    import sweep_vs_reference as S
+    h, seed0 = _seed()
+    lines = []
+    bad = S.sweep(1024, 20, seed0, edge=False, log=lines.append)
+    bad += S.sweep(256, 20, seed0 + 7777, edge=True, log=lines.append)
+    print("kernel sources %s -> first seed %d\n%s" % (h, seed0, "\n".join(lines)))
+    assert bad == 0, "\n".join(lines)
+
+
+def _gen_and_ref(seed):
+    """one trial: generate + corrupt (reference encoder), decode with the reference decoder up to the first rejection"""
+    import fuzz_decoder_gen as F
+    cfg, seq = F.sequence(seed)
+    dr = R.RefDecoder("fix", joint=cfg["joint"], use_md_index=cfg["mdi"], samplerate=cfg["fs"])
+    out = []
+    for a, hit, _ in seq:
+        x, r1 = dr.decode(*a)
+        out.append((x, r1))
+        if r1 < 0:
+            break
+    dr.close()
+    return cfg, seq, out
+
+
+def _isolated_map(fn, items, workers):
+    """fn(item) in a forked child per item (the compiled reference aborts on some inputs -- e.g. full-scale square waves at 32 kHz
+    overflow its payload buffer, DESIGN.md section 5 -- and a pool would hang on a dead worker); crashed items give None"""
+    import pickle
+    results, active, nxt = [None] * len(items), {}, 0
+    while nxt < len(items) or active:
+        while nxt < len(items) and len(active) < workers:
+            r, w = os.pipe()
+            pid = os.fork()
+            if pid == 0:
+                os.close(r)
+                try:
+                    os.write(w, pickle.dumps(fn(items[nxt])))
+                finally:
+                    os._exit(0)
+            os.close(w)
+            active[pid] = (nxt, r)
+            nxt += 1
+        pid, status = os.wait()
+        if pid not in active:
+            continue
+        idx, r = active.pop(pid)
+        data = b""
+        while True:
+            chunk = os.read(r, 1 << 20)
+            if not chunk:
+                break
+            data += chunk
+        os.close(r)
+        if status == 0 and data:
+            results[idx] = pickle.loads(data)
+    return results
+
+
+def test_fresh_seed_decoder_fuzz_vs_compiled_reference():
+    import torch
+    import solo_amd
+    assert torch.cuda.is_available(), "GPU test run without a GPU"
+    h, seed0 = _seed()
+    NTR, S = 2000, 1024 + 64
+    done = _isolated_map(_gen_and_ref, list(range(seed0, seed0 + NTR)), min(32, mp.cpu_count()))
+    crashed = sum(1 for d in done if d is None)
+    trials = [(d[0], d[1]) if d is not None and len(d[1]) else None for d in done]
+    refs = [d[2] if d is not None else None for d in done]
+    groups = {}
+    for t, tr in enumerate(trials):
+        if tr is not None:
+            groups.setdefault((tr[0]["wb"], tr[0]["mdi"], tr[0]["joint"]), []).append(t)
+    kinds = {"ok": 0, "rejected": 0, "other_rate": 0}
+    accepted_corrupted = 0
+    for (wb, mdi, joint), members in sorted(groups.items()):
+        n, L = len(members), 1280 if wb else 640
+        P = max(len(trials[t][1]) for t in members)
+        bits = np.zeros((n, P, S), np.uint8); nb = np.zeros((n, P, 2), np.int16); recv = np.zeros((n, P), np.uint8)
+        for k, t in enumerate(members):
+            for p, (_, _, (pl, n0, n1, m)) in enumerate(trials[t][1]):
+                bits[k, p, :len(pl)] = np.frombuffer(pl, np.uint8); nb[k, p] = (n0, n1); recv[k, p] = m
+        d = solo_amd.SoloBatch(n, encoder=False, decoder=True, slot_bytes=S, use_md_index=mdi, joint=joint, samplerate=32000 if wb else 16000)
+        dev = d.device
+        got = np.zeros((n, P, L), np.int16); rets = np.zeros((n, P), np.int32)
+        for p in range(P):                                   # one call per packet: every packet's return code is seen
+            pcm, st = d.decode(torch.from_numpy(np.ascontiguousarray(bits[:, p:p + 1])).to(dev), torch.from_numpy(np.ascontiguousarray(nb[:, p:p + 1])).to(dev),
+                               torch.from_numpy(np.ascontiguousarray(recv[:, p:p + 1])).to(dev))
+            got[:, p] = pcm.cpu().numpy()[:, 0]; rets[:, p] = st.cpu().numpy()
+        d.close()
+        for k, t in enumerate(members):
+            cfg, seq = trials[t]
+            res = "ok"
+            for p, (x, r1) in enumerate(refs[t]):
+                r2, hit = int(rets[k, p]), seq[p][1]
+                if r1 == 0 and r2 == -12 and hit:            # a corrupted rate index that claims another internal rate (one rate per handle)
+                    res = "other_rate"; break
+                assert r1 == r2, ("return code", seed0 + t, p, r1, r2, cfg)
+                if r1 < 0:
+                    res = "rejected"; break
+                assert np.array_equal(x, got[k, p]), ("pcm", seed0 + t, p, cfg)
+                accepted_corrupted += int(hit)
+            kinds[res] += 1
+    print("kernel sources %s -> first seed %d: %s, accepted corrupted packets %d, reference crashed on %d inputs" % (h, seed0, kinds, accepted_corrupted, crashed))
+    assert kinds["ok"] + kinds["rejected"] >= NTR * 0.85 and accepted_corrupted >= 500 and crashed <= NTR * 0.1, (kinds, accepted_corrupted, crashed)

@@ -50,7 +50,7 @@ def _scenario(torch, mdi, seed, fs=16000):
 
 
 @pytest.mark.parametrize("mdi,fs", [(0, 16000), (1, 16000), (1, 32000)])
-def test_split_arrivals_equal_masked_decode(torch_cuda, mdi, fs):
+def test_split_arrivals_vs_compiled_reference_and_masked_decode(torch_cuda, mdi, fs):
     import solo_amd
     torch = torch_cuda
     hb, hn, recv, dA, lA, dB, lB = _scenario(torch, mdi, 11 + mdi, fs)
@@ -65,15 +65,17 @@ def test_split_arrivals_equal_masked_decode(torch_cuda, mdi, fs):
     assert int(st.abs().max()) == 0 and int(st2.abs().max()) == 0
     assert np.array_equal(got.cpu().numpy(), want.cpu().numpy())
     assert len({int(m) for m in recv.ravel()}) == 4
-    if mdi:                                                       # the masked decode itself, against the host emulation
-        w = want.cpu().numpy()
-        for i in range(0, N, 6):
-            d = T.EmuDecoder(use_md_index=1, wb=fs == 32000)
-            for p in range(P):
-                n0, n1 = int(hn[i, p, 0]), int(hn[i, p, 1])
-                m = int(recv[i, p])
-                out, ret = d.decode(*R.map_loss(hb[i, p, :n0].tobytes(), n0, n1, not (m & 1), not (m & 2)))
-                assert ret == 0 and np.array_equal(out, w[i, p]), (i, p, m)
+    # both against the COMPILED REFERENCE decoder fed the correctly ordered (ptr, nBytes, lostflag) call of test/dec_main.c:255-378
+    # (incl. the 32 kHz mode, which tests/test_pinned_corners.py does not cover)
+    assert R.have_ref("fix"), "oracle/_ref did not travel with the snapshot"
+    w = got.cpu().numpy()
+    for i in range(N):
+        d = R.RefDecoder("fix", use_md_index=mdi, samplerate=fs)
+        for p in range(P):
+            n0, n1 = int(hn[i, p, 0]), int(hn[i, p, 1])
+            m = int(recv[i, p])
+            out, ret = d.decode(*R.map_loss(hb[i, p, :n0].tobytes(), n0, n1, not (m & 1), not (m & 2)))
+            assert ret == 0 and np.array_equal(out, w[i, p]), (i, p, m)
 
 
 def test_oversized_split_packet_is_rejected(torch_cuda):

@@ -30,16 +30,14 @@ def ref_stream(args):
     return recs, np.stack(out)
 
 
-def main():
+CFGS = [dict(rate=13600, joint=0, dtx=0, mdi=0, loss=0.3), dict(rate=13600, joint=1, dtx=0, mdi=1, loss=0.2),
+        dict(rate=24000, joint=0, dtx=0, mdi=0, loss=0.1), dict(rate=13600, joint=0, dtx=1, mdi=0, loss=0.15)]
+
+
+def sweep(N, P, seed0, edge=False, cfgs=CFGS, log=print):
+    """-> number of streams (over all configurations) whose encoder payloads or decoder PCM differ from the compiled reference"""
     import torch, solo_amd
-    from solo_amd.synth import synth_batch
-    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
-    P = int(sys.argv[2]) if len(sys.argv) > 2 else 30
-    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 900000
-    edge = len(sys.argv) > 4 and sys.argv[4] == "edge"
-    from solo_amd.synth import edge_batch
-    cfgs = [dict(rate=13600, joint=0, dtx=0, mdi=0, loss=0.3), dict(rate=13600, joint=1, dtx=0, mdi=1, loss=0.2),
-            dict(rate=24000, joint=0, dtx=0, mdi=0, loss=0.1), dict(rate=13600, joint=0, dtx=1, mdi=0, loss=0.15)]
+    from solo_amd.synth import synth_batch, edge_batch
     bad = 0
     for ci, cfg in enumerate(cfgs):
         t0 = time.time()
@@ -65,8 +63,18 @@ def main():
             if not ok and len(first_bad) < 8:
                 first_bad.append(s0 + i)
         bad += nbad
-        print("config %d %s: %d streams x %d packets, %d mismatching streams, status enc %d dec %d (%.0f s)" % (
-            ci, cfg, N, P, nbad, int(st.abs().max()), int(st2.abs().max()), time.time() - t0), first_bad if nbad else "", flush=True)
+        log("config %d %s: %d streams x %d packets (%s, first seed %d), %d mismatching streams, status enc %d dec %d (%.0f s) %s" % (
+            ci, cfg, N, P, "edge" if edge else "speech-like", s0, nbad, int(st.abs().max()), int(st2.abs().max()), time.time() - t0, first_bad if nbad else ""))
+        b.close()
+    return bad
+
+
+def main():
+    N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+    P = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+    seed0 = int(sys.argv[3]) if len(sys.argv) > 3 else 900000
+    edge = len(sys.argv) > 4 and sys.argv[4] == "edge"
+    bad = sweep(N, P, seed0, edge, log=lambda s: print(s, flush=True))
     print("SWEEP", "OK" if bad == 0 else "FAILED")
     return 1 if bad else 0
 
