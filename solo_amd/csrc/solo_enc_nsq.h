@@ -177,6 +177,11 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 // Lane-strided read-modify-write / copy loops over HBM arrays with SX_MLP independent loads in flight per lane (written as "all
 // loads, then all stores": the compiler cannot reorder a load over a store to the same array by itself, and one dependent
 // round trip per element is what the subframe prologue would otherwise spend its time on)
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SX_LAMBDA_INLINE __attribute__((always_inline))
+#else
+#define SX_LAMBDA_INLINE
+#endif
 #define SX_MLP 8
 SX_HD void sx_scale_q16(i32* p, int n, i32 gain_adj_Q16) {       // p[i] = SMULWW(gain_adj, p[i]), i < n
     for (int base = SX_LANE; base < n; base += SX_MLP * SX_NLANES) {
@@ -291,9 +296,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     i32 dith[SX_NK], myRand[SX_NK][SX_N_TRACKS];
     i32 cRD[SX_NK][SX_N_TRACKS][2], cQ0[SX_NK][SX_N_TRACKS][2], cQ10[SX_NK][SX_N_TRACKS][2];
     i32 curL[SX_NK][SX_N_TRACKS][SX_LTP_ORDER], curS[SX_NK][SX_N_TRACKS][3];      // long-term prediction / harmonic shaping taps of the sample
-    // own-slot cells of the ring position the sample emits / tests (pf: track cells, pfR: random states), and those of the NEXT
-    // sample: the ring is a delay line in HBM, its reads are issued two samples before they are used (see the rotation in phase F)
-    SxNsqCell pf[SX_NK][SX_N_TRACKS], pfR[SX_NK], nx[SX_NK][SX_N_TRACKS], nxR[SX_NK];
+    // The ring is a delay line in HBM; its reads are issued TWO samples before they are used.  Two register sets take turns: even
+    // samples consume set A (qA: own-slot track cells of the ring position the sample emits, rA: its random states) and refill it
+    // with the cells sample i + 2 will need, odd samples do the same with set B.  The sample loop is written two samples per
+    // iteration so that no set is ever copied into another at the loop's back edge: such a copy would wait for loads issued a few
+    // hundred instructions earlier in the same sample (round 2's single rotating queue did).
+    SxNsqCell qA[SX_NK][SX_N_TRACKS], rA[SX_NK], qB[SX_NK][SX_N_TRACKS], rB[SX_NK];
     // scratch of the joint decision
     i32 jv[SX_NK], mv[SX_NK], mi[SX_NK], mv2[SX_NK], mi2[SX_NK], tq[SX_NK], par[SX_NK], csrc[SX_NK], csel[SX_NK], c0[SX_NK], c1[SX_NK], nrep[SX_NK];
     i32 gq[SX_NK];
@@ -314,10 +322,10 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             for (int j = 0; j < SX_LTP_ORDER; j++) curL[a][t][j] = 0;
 #pragma unroll
             for (int j = 0; j < 3; j++) curS[a][t][j] = 0;
-            pf[a][t].xqQ = pf[a][t].Pred_Q16 = pf[a][t].Shape_Q10 = pf[a][t].exc_Q10 = 0;
-            pfR[a] = pf[a][t];
-            nx[a][t] = pf[a][t];
-            nxR[a] = pf[a][t];
+            qA[a][t].xqQ = qA[a][t].Pred_Q16 = qA[a][t].Shape_Q10 = qA[a][t].exc_Q10 = 0;
+            rA[a] = qA[a][t];
+            qB[a][t] = qA[a][t];
+            rB[a] = qA[a][t];
         }
     }
 
@@ -351,9 +359,9 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         const int ki = SX_KI(kk);
         const int l0 = (SX_DD_MASK + decisionDelay) & SX_DD_MASK;
 #pragma unroll
-        for (int t = 0; t < SX_N_TRACKS; t++) { pf[ki][t] = SX_CELL(t, l0, kk); nx[ki][t] = SX_CELL(t, (l0 - 1) & SX_DD_MASK, kk); }
-        pfR[ki] = SX_CELL(SX_N_TRACKS, l0, kk);
-        nxR[ki] = SX_CELL(SX_N_TRACKS, (l0 - 1) & SX_DD_MASK, kk);
+        for (int t = 0; t < SX_N_TRACKS; t++) { qA[ki][t] = SX_CELL(t, l0, kk); qB[ki][t] = SX_CELL(t, (l0 - 1) & SX_DD_MASK, kk); }
+        rA[ki] = SX_CELL(SX_N_TRACKS, l0, kk);
+        rB[ki] = SX_CELL(SX_N_TRACKS, (l0 - 1) & SX_DD_MASK, kk);
     }
     int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
     int subfr = 0;
@@ -543,10 +551,26 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         }
         wv_sync();
         SX_TA(1)
-        for (int i = 0; i < SX_SUBFR; i++) {
+        // one sample of the trellis; qf / qr: the register set (A or B) that holds the ring cells this sample consumes
+        auto sample_step = [&](const int i, SxNsqCell (&qf)[SX_NK][SX_N_TRACKS], SxNsqCell (&qr)[SX_NK]) SX_LAMBDA_INLINE {
             const bool emitted = subfr > 0 || i >= decisionDelay;
             const int smpl_new = (smpl_buf_idx - 1) & SX_DD_MASK;                  // ring position this sample writes
             const int last_smple_idx = (smpl_new + decisionDelay) & SX_DD_MASK;    // ring position this sample emits
+            // The sample takes the cells it will emit / test out of its register set (em, er) and at once refills the set with the
+            // cells sample i + 2 consumes: a whole sample's work (and the other set's turn) lies between a request and its first
+            // use, and the requests stand in front of this sample's stores (vector memory operations complete in order).  The
+            // requested cells were written decisionDelay - 2 >= 11 samples ago.
+            SxNsqCell em[SX_NK][SX_N_TRACKS], er[SX_NK];
+            SX_FORK(kk) {
+                const int ki = SX_KI(kk);
+#pragma unroll
+                for (int t = 0; t < SX_N_TRACKS; t++) {
+                    em[ki][t] = qf[ki][t];
+                    qf[ki][t] = SX_CELL(t, (last_smple_idx - 2) & SX_DD_MASK, kk);
+                }
+                er[ki] = qr[ki];
+                qr[ki] = SX_CELL(SX_N_TRACKS, (last_smple_idx - 2) & SX_DD_MASK, kk);
+            }
             // phase A: predictions, shaping, residual, dither -- the three tracks of the lane's state
             SX_FORK(kk) {
                 const int ki = SX_KI(kk);
@@ -691,11 +715,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 {
                     const bool written = k * SX_SUBFR + i >= decisionDelay;
                     SX_FORK(kk) { gq[SX_KI(kk)] = SX_LIN_SLOT(linLo[SX_KI(kk)], linHi[SX_KI(kk)], last_smple_idx); }
-                    SX_FORK(kk) { tq[SX_KI(kk)] = pfR[SX_KI(kk)].xqQ; }
+                    SX_FORK(kk) { tq[SX_KI(kk)] = er[SX_KI(kk)].xqQ; }
                     SXQ_GATHER(c0, tq, gq)
-                    SX_FORK(kk) { myRand[SX_KI(kk)][0] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = pfR[SX_KI(kk)].Pred_Q16; }
+                    SX_FORK(kk) { myRand[SX_KI(kk)][0] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = er[SX_KI(kk)].Pred_Q16; }
                     SXQ_GATHER(c0, tq, gq)
-                    SX_FORK(kk) { myRand[SX_KI(kk)][1] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = pfR[SX_KI(kk)].Shape_Q10; }
+                    SX_FORK(kk) { myRand[SX_KI(kk)][1] = written ? c0[SX_KI(kk)] : 0; tq[SX_KI(kk)] = er[SX_KI(kk)].Shape_Q10; }
                     SXQ_GATHER(c0, tq, gq)
                     SX_FORK(kk) { myRand[SX_KI(kk)][2] = written ? c0[SX_KI(kk)] : 0; }
                 }
@@ -800,20 +824,6 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
             // that owns the winner's slot of the emitted ring position holds the three cells in its prefetch registers.
             SXQ_ARGMIN(jv, mv, mi)
-            // The ring's read queue moves on BEFORE this sample's stores are issued: vector memory operations complete in order, so the
-            // only wait of the sample (for the cells requested one sample ago) then has nothing younger than a sample in front of it.
-            SxNsqCell em[SX_NK][SX_N_TRACKS];
-            SX_FORK(kk) {
-                const int ki = SX_KI(kk);
-#pragma unroll
-                for (int t = 0; t < SX_N_TRACKS; t++) {
-                    em[ki][t] = pf[ki][t];
-                    pf[ki][t] = nx[ki][t];
-                    nx[ki][t] = SX_CELL(t, (last_smple_idx - 2) & SX_DD_MASK, kk);
-                }
-                pfR[ki] = nxR[ki];
-                nxR[ki] = SX_CELL(SX_N_TRACKS, (last_smple_idx - 2) & SX_DD_MASK, kk);
-            }
             if (emitted) {
                 SXQ_GATHER(tq, linLo, mi)
                 SXQ_GATHER(gq, linHi, mi)
@@ -874,6 +884,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             }
             wv_sync_lds();
             SX_TA(8)
+        };
+        static_assert(SX_SUBFR % 2 == 0, "two samples per iteration");
+        for (int i = 0; i < SX_SUBFR; i += 2) {
+            sample_step(i, qA, rA);
+            sample_step(i + 1, qB, rB);
         }
         sLTP_shp_buf_idx += SX_SUBFR;
         sLTP_buf_idx += SX_SUBFR;
