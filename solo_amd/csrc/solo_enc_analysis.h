@@ -631,8 +631,9 @@ struct SxPrefWork {                  // LDS scratch of the prefilter
     i16 ring[SX_LTP_BUF];            // staged harmonic-shaping ring (pf_sLTP_shp)
     i32 o[2][SX_SHAPE_ORDER][2];     // (section output, running sum) in flight between neighbouring lanes, double buffered
     i16 st_res[SX_FRAME + 1];        // short-term residual of the frame; [0] = last sample of the previous frame
-    i32 x_filt_Q12[SX_FRAME];
+    alignas(16) i32 x_filt_Q12[SX_FRAME];
     i32 vend[SX_SHAPE_ORDER + 1];
+    i32 lf_end[2];                   // final (sLF_AR, sLF_MA) of the low-frequency recursion (GPU build: it runs on one lane)
 };
 
 SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16* x, SxPrefWork* pw) {
@@ -739,23 +740,37 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
     const int buf_idx0 = SX_UNI(st->pf_sLTP_shp_buf_idx);
     i32 ma[3] = {0, 0, 0};
     {
-        i32 xf[3];
+        // the recursion runs on the vector unit of one lane (SX_VEC, see sx_allpass2_lanes): three high-word multiplies and five
+        // adds / shifts per sample, x_filt read four samples at a time and replaced in place by sLF_MA
+        if (SX_LANE == 0) {
+            i32 ar = sLF_AR, mq = sLF_MA;
+            SX_VEC(ar); SX_VEC(mq);
+            SxV4i* xq = (SxV4i*)pw->x_filt_Q12;
 #pragma unroll
-        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; xf[j] = i < SX_FRAME ? pw->x_filt_Q12[i] : 0; }
+            for (int k = 0; k < SX_NB_SUBFR; k++) {
+                i32 tilt = sx_pre16(c->Tilt_Q14[k]), lfb = sx_pre16(c->LF_shp_Q14[k]), lft = (i32)((u32)c->LF_shp_Q14[k] & 0xFFFF0000u);
+                SX_VEC(tilt); SX_VEC(lfb); SX_VEC(lft);
+                for (int n4 = k * (SX_SUBFR / 4); n4 < (k + 1) * (SX_SUBFR / 4); n4++) {
+                    SxV4i v = xq[n4];
 #pragma unroll
-        for (int cc = 0; cc < 3; cc++) {
-            const int nend = sx_min(SX_FRAME, 64 * (cc + 1));
-            for (int n = 64 * cc; n < nend; n++) {
-                const int k = n / SX_SUBFR;
-                const i32 Tilt_Q14 = SX_UNI(c->Tilt_Q14[k]), LF_shp_Q14 = SX_UNI(c->LF_shp_Q14[k]);
-                const i32 xv = SX_RDLANE(xf[cc], n & 63);
-                const i32 n_Tilt_Q10 = sx_smulwb(sLF_AR, Tilt_Q14);
-                const i32 n_LF_Q10 = sx_smlawb(sx_smulwt(sLF_AR, LF_shp_Q14), sLF_MA, LF_shp_Q14);
-                sLF_AR = sx_sub(xv, sx_shl(n_Tilt_Q10, 2));
-                sLF_MA = sx_sub(sLF_AR, sx_shl(n_LF_Q10, 2));
-                SX_WRLANE(ma[cc], n & 63, sLF_MA);
+                    for (int u = 0; u < 4; u++) {
+                        const i32 n_Tilt_Q10 = sx_smulw_pre(ar, tilt);
+                        const i32 n_LF_Q10 = sx_add(sx_smulw_pre(ar, lft), sx_smulw_pre(mq, lfb));
+                        ar = sx_sub(v.v[u], sx_shl(n_Tilt_Q10, 2));
+                        mq = sx_sub(ar, sx_shl(n_LF_Q10, 2));
+                        v.v[u] = mq;
+                    }
+                    xq[n4] = v;
+                }
             }
+            pw->lf_end[0] = ar;
+            pw->lf_end[1] = mq;
         }
+        wv_sync();
+        sLF_AR = SX_UNI(pw->lf_end[0]);
+        sLF_MA = SX_UNI(pw->lf_end[1]);
+#pragma unroll
+        for (int j = 0; j < 3; j++) { const int i = SX_LANE + 64 * j; ma[j] = i < SX_FRAME ? pw->x_filt_Q12[i] : 0; }
     }
 #pragma unroll
     for (int j = 0; j < 3; j++) {

@@ -36,10 +36,63 @@ SX_FN1 void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16
     wv_sync();
 }
 
+struct alignas(16) SxV4i { i32 v[4]; };        // 16-byte LDS moves
+#ifdef SX_LANE_STREAM
+// Serial recursions cost the wave one instruction slot per operation whichever unit executes them, but the scalar unit issues
+// only one instruction per four cycles PER SIMD for all of its waves together (the vector unit: two): wave-uniform sample
+// recursions left to the scalar unit are the dearest instructions of the analysis kernel (tools/debug/mb_issue.hip,
+// DESIGN.md section 4).  SX_VEC(x) pins a value to a vector register and hides its uniformity from the compiler, so the
+// arithmetic that depends on it is emitted for the vector unit.
+#define SX_VEC(x) asm volatile("" : "+v"(x))
+// Two first-order all-pass chains side by side -- the structure of SKP_Silk_ana_filt_bank_1 (ana_filt_bank_1.c:45) and of
+// SKP_Silk_resampler_down2 (resampler_down2.c:41): lane 0 runs the chain of the EVEN input samples, X = Y + (Y * cA >> 16),
+// lane 1 that of the ODD ones, X = Y * cB >> 16; per pair of samples the two chain outputs are exchanged inside the lane pair
+// (DPP) and lane 0 stores the low band sat16(rshift_round(o1 + o0, 11)), lane 1 the high band sat16(rshift_round(o1 - o0, 11))
+// (a caller that has no use for it passes a dump area).  S: the two chain states (null = zero state, not written back).  `in` may alias outL (in-place decimation):
+// every block of four pairs is read before any of its outputs is stored, and outputs trail the inputs.
+SX_HD void sx_allpass2_lanes(const i16* in, int npairs, i32* S, i32 cA, i32 cB, i16* outL, i16* outH) {
+    if (SX_LANE < 2) {
+        const int l = SX_LANE;
+        i32 s = S ? S[l] : 0;
+        i32 cpre = sx_pre16(l ? cB : cA);
+        SX_VEC(cpre);
+        const i32 mask = l ? 0 : -1;
+        const i16* ip = in + l;                       // the lane's samples: in[2k + l]
+        i16* op = l ? outH : outL;
+        i32 x[4], xn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xn[u] = ip[2 * u];
+        for (int k = 0; k < npairs; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = xn[u];
+            if (k + 4 < npairs) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) xn[u] = ip[2 * (k + 4 + u)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const i32 in32 = sx_shl(x[u], 10);
+                const i32 Y = sx_sub(in32, s);
+                const i32 X = sx_add(sx_smulw_pre(Y, cpre), Y & mask);
+                const i32 o = sx_add(s, X);
+                s = sx_add(in32, X);
+                const i32 p = SX_DPP_(o, 0xB1);       // the other chain's output (quad_perm [1,0,3,2])
+                const i32 v = l ? sx_sub(o, p) : sx_add(p, o);
+                op[k + u] = (i16)sx_sat16(sx_rshift_round(v, 11));
+            }
+        }
+        if (S) S[l] = s;
+    }
+    wv_sync();
+}
+#endif
+
 // SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
 SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
     const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
 #ifdef SX_LANE_STREAM
+    sx_allpass2_lanes(in, N >> 1, S, A21, A20, outL, outH);
+#elif 0
     // N <= 64 * SX_FCH samples in (a frame), half as many out per band (in may alias outL: everything is read before anything is stored)
     i32 r[SX_FCH], oL[(SX_FCH + 1) / 2], oH[(SX_FCH + 1) / 2];
 #pragma unroll
@@ -187,8 +240,10 @@ SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pS
 }
 
 // SKP_Silk_HP_variable_cutoff_FIX (HP_variable_cutoff_FIX.c:37) + SKP_Silk_biquad_alt (biquad_alt.c:38)
-SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(out);
+// scratch: SX_HP_SCRATCH_WORDS words of LDS (GPU build: the input-only terms of the biquad for the whole frame)
+#define SX_HP_SCRATCH_WORDS (4 * (SX_FRAME + 1))     // (+1: the recursion requests entry k + 1 while it works on entry k)
+SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const i16* in, i32* scratch) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(out); SX_IN_LDS(scratch);
     if (st->prev_sigtype == 0) {
         i32 pitch_freq_Hz_Q16 = sx_shl(SX_FS_KHZ * 1000, 16) / st->prevLag;
         i32 pitch_freq_log_Q7 = sx_lin2log(pitch_freq_Hz_Q16) - (16 << 7);
@@ -218,6 +273,49 @@ SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const 
     B0 = SX_UNI(B0); B1 = SX_UNI(B1); B2 = SX_UNI(B2);
     i32 S0 = SX_UNI(st->In_HP_State[0]), S1 = SX_UNI(st->In_HP_State[1]);
 #ifdef SX_LANE_STREAM
+    // The three products with the input sample feed nothing back: they are formed for the whole frame at once, lane-parallel.
+    // What remains of the recursion per sample -- the two products with the new output and their rounding -- runs on the vector
+    // unit of ONE lane (SX_VEC: see sx_allpass2_lanes), reading its input terms 16 bytes at a time and storing the output sample.
+    {
+        SxV4i* bx = (SxV4i*)scratch;
+        const i32 b0p = B0, b1p = B1, b2p = B2;
+        SX_PAR(k, SX_FRAME) {
+            const i32 xs = sx_pre16(in[k]);              // smulwb(B, x) = (B * (x << 16)) >> 32
+            SxV4i v;
+            v.v[0] = sx_smulw_pre(b0p, xs); v.v[1] = sx_smulw_pre(b1p, xs); v.v[2] = sx_smulw_pre(b2p, xs); v.v[3] = 0;
+            bx[k] = v;
+        }
+        wv_sync();
+        if (SX_LANE == 0) {
+            i32 s0 = S0, s1 = S1;
+            i32 a0l = sx_pre16(A0_L), a0u = sx_pre16(A0_U), a1l = sx_pre16(A1_L), a1u = sx_pre16(A1_U);
+            SX_VEC(s0); SX_VEC(s1); SX_VEC(a0l); SX_VEC(a0u); SX_VEC(a1l); SX_VEC(a1u);
+            SxV4i cur = bx[0];
+#pragma unroll 4
+            for (int k = 0; k < SX_FRAME; k++) {
+                const SxV4i t = cur;
+                cur = bx[k + 1];
+                const i32 out32_Q14 = sx_shl(sx_add(s0, t.v[0]), 2);
+                // (SX_VEC on each high word: the compiler would otherwise fuse the rounding shift into a 64-bit product -- low word,
+                // unsigned high word and sign corrections -- three times the instructions of v_mul_hi_i32 + shift)
+                i32 m0 = sx_smulw_pre(out32_Q14, a0l), m1 = sx_smulw_pre(out32_Q14, a1l), u0 = sx_smulw_pre(out32_Q14, a0u), u1 = sx_smulw_pre(out32_Q14, a1u);
+                SX_VEC(m0); SX_VEC(m1); SX_VEC(u0); SX_VEC(u1);
+                i32 n0 = sx_add(s1, sx_rshift_round(m0, 14));
+                n0 = sx_add(n0, u0);
+                n0 = sx_add(n0, t.v[1]);
+                i32 n1 = sx_rshift_round(m1, 14);
+                n1 = sx_add(n1, u1);
+                n1 = sx_add(n1, t.v[2]);
+                s0 = n0; s1 = n1;
+                out[k] = (i16)sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14);
+            }
+            st->In_HP_State[0] = s0;
+            st->In_HP_State[1] = s1;
+        }
+        wv_sync();
+        return;
+    }
+#elif 0
     i32 r[SX_FCH], o[SX_FCH];
 #pragma unroll
     for (int j = 0; j < SX_FCH; j++) { const int i = SX_LANE + 64 * j; r[j] = i < SX_FRAME ? (i32)in[i] : 0; o[j] = 0; }
@@ -350,10 +448,15 @@ SX_HD void sx_k2a(i32* A_Q24, const i16* rc_Q15, int order) {
 
 // SKP_Silk_resampler_down2, SKP_Silk_resampler_down2.c:41 (zero initial state, serial)
 #define SX_DOWN2_MAXIN (40 * SX_FS_KHZ)      // the longest input: the pitch analysis buffer, 40 ms at the internal rate
-SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen) {
+// dump: inLen / 2 samples of LDS that may be overwritten (GPU build: the unused high band of the all-pass pair lands there)
+SX_HD void sx_down2_zero_state(i16* out, const i16* in, int inLen, i16* dump) {
+#ifdef SX_LANE_STREAM
+    sx_allpass2_lanes(in, inLen >> 1, (i32*)0, T_down2_c1[0], T_down2_c0[0], out, dump);
+    return;
+#endif
     i32 S0 = 0, S1 = 0;
     const i32 c0 = SX_UNI(T_down2_c0[0]), c1 = SX_UNI(T_down2_c1[0]);
-#ifdef SX_LANE_STREAM
+#if 0
     // inLen <= SX_DOWN2_MAXIN samples in (lane registers), half as many out
     i32 r[SX_DOWN2_MAXIN / 64], o[(SX_DOWN2_MAXIN / 2 + 63) / 64];
 #pragma unroll
@@ -436,10 +539,10 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
     SX_PAR(i, 320) w->sig8[i] = signal[i];
     wv_sync();
 #else
-    sx_down2_zero_state(w->sig8, signal, 640);      // 16 -> 8 kHz (pitch_analysis_core.c:127-129)
+    sx_down2_zero_state(w->sig8, signal, 640, (i16*)w->tmp32);      // 16 -> 8 kHz (pitch_analysis_core.c:127-129)
     wv_sync();
 #endif
-    sx_down2_zero_state(w->sig4, w->sig8, 320);
+    sx_down2_zero_state(w->sig4, w->sig8, 320, (i16*)w->tmp32);
 #if SX_NLANES == 1
     for (int i = 159; i > 0; i--) w->sig4[i] = (i16)sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]);
 #else
