@@ -5,6 +5,7 @@
 //   libBWE/AGR_BWE_bits.c:77, libSATECodec/SKP_Silk_enc_API.c:104-275, SKP_Silk_encode_frame_FIX.c:33,
 //   SKP_Silk_encode_parameters.c:33, SKP_Silk_encode_pulses.c:55, SKP_Silk_shell_coder.c:84, SKP_Silk_code_signs.c:40
 #pragma once
+#include <stddef.h>
 #include "solo_enc_analysis.h"
 #include "solo_enc_nsq.h"
 #include "solo_cdf.h"
@@ -289,7 +290,8 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q, &hw->lpc.u.grid);
     wv_sync();
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
-    sx_nlsf_weights_laroia(weight, NLSF_Q15, SX_HB_LPC);
+    if (SX_LANE == 0) sx_nlsf_weights_laroia(SX_VPTR(weight), SX_VPTR(NLSF_Q15), SX_HB_LPC);      // (one lane, vector unit: SX_VPTR)
+    wv_sync();
     int idx1 = 0;
     {
         i32 my_best = SX_I32_MAX;
@@ -328,7 +330,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     const i32 hb_lsp_idx = (idx2 << 8) + idx1;
     i16* A_Q12 = hw->A_Q12;
-    sx_nlsf2a_stable_ws(A_Q12, NLSF_Q15, SX_HB_LPC, hw->ws);
+    if (SX_LANE == 0) sx_nlsf2a_stable_ws(SX_VPTR(A_Q12), SX_VPTR(NLSF_Q15), SX_HB_LPC, SX_VPTR(hw->ws));
     wv_sync();
     u32 word = (u32)hb_lsp_idx << 20;
     // the four blocks of N / 4 samples are filtered from zero state (the reference calls the filter once per block)
@@ -418,6 +420,8 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     wv_sync();
     SX_ENC_TAP(3, st, w, w->xfw);
     SX_T(4)
+    static_assert(offsetof(SxFrontWork, Wsig) == offsetof(SxFrontWork, res_pitch) + sizeof(f->res_pitch) && offsetof(SxFrontWork, res_pitch) % 4 == 0,
+                  "res_pitch and Wsig are one scratch area for the NLSF quantiser");
     sx_find_pred_coefs(st, c, f->x_buf, f->res_pitch, &f->u.pred);
     wv_sync();
     SX_ENC_TAP(4, st, w, w->xfw);

@@ -1889,10 +1889,17 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
     i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
     i32 NLSF0[SX_MAX_LPC], W0_Q6[SX_MAX_LPC];
     i32 ws[2][SX_NLSF2A_WS];
+    i32 Res_Q15[16 * SX_LPC];
+};
+// ... and the part of it that lives OUTSIDE the prediction analysis' union: in the residual / window buffers of the front end
+// (SxFrontWork::res_pitch, ::Wsig), which nothing reads between the long-term prediction analysis and the next frame.  (The
+// analysis kernel's LDS decides how many of its workgroups fit on a compute unit beside the quantiser's: 16 x 8.6 KB do, 16 x
+// 9.6 KB did not -- the last two of a CU's 16 streams then ran as a second round)
+struct SxMsvqAux {
+    i32 Res_new_Q15[16 * SX_LPC];
     i32 Rate_Q5[16], Rate_new_Q5[16];
     i32 TempIndices[16];
     u8 Path[16 * SX_NLSF_STAGES], Path_new[16 * SX_NLSF_STAGES];
-    i32 Res_Q15[16 * SX_LPC], Res_new_Q15[16 * SX_LPC];
 };
 
 #if SX_NLANES != 1
@@ -1918,8 +1925,8 @@ SX_HD i64 wv_min_key(i64 k) {
 
 // SKP_Silk_NLSF_MSVQ_encode_FIX, SKP_Silk_NLSF_MSVQ_encode_FIX.c:33 (16 survivors, 6 stages, order 10)
 SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, const i32* prev_q_Q15, const i32* pW_Q6,
-                               i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w) {
-    SX_IN_LDS(w); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
+                               i32 mu_Q15, i32 mu_fluc_red_Q16, int deactivate_fluc_red, SxMsvqWork* w, SxMsvqAux* x) {
+    SX_IN_LDS(w); SX_IN_LDS(x); SX_IN_LDS(NLSFIndices); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(prev_q_Q15); SX_IN_LDS(pW_Q6);   // pW_Q6 = w->W_Q6
     const i32 nvec0[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, nvec1[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
     const i32* nvec = w->nvec;
     const int nStages = SX_NLSF_STAGES, S = SX_MSVQ_SURVIVORS;
@@ -1938,7 +1945,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
     }
     const i16* cb = w->cb;
     const i16* rates = w->rates;
-    SX_PAR(i, S) w->Rate_Q5[i] = 0;
+    SX_PAR(i, S) x->Rate_Q5[i] = 0;
     SX_PAR(i, SX_LPC) w->Res_Q15[i] = pNLSF_Q15[i];
     wv_sync();
     int prev_survivors = 1, cur_survivors = 0;
@@ -1961,7 +1968,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                 i32 diff = in[m] - cv[m];
                 sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
             }
-            w->RateDist_Q18[t] = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
+            w->RateDist_Q18[t] = sx_smlabb(sum_error, x->Rate_Q5[n] + rts[i], mu_Q15);
             w->taken[t] = 0;
         }
         // SKP_Silk_insertion_sort_increasing (the cur_survivors best of `total`, value ascending, first index wins ties)
@@ -1972,7 +1979,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                 if (!w->taken[t] && (v < bv || (v == bv && t < bi))) { bv = v; bi = t; }
             }
             w->Sorted_Q18[r] = bv;
-            w->TempIndices[r] = bi;
+            x->TempIndices[r] = bi;
             w->taken[bi] = 1;
         }
         for (int r = 0; r < cur_survivors; r++) w->RateDist_Q18[r] = w->Sorted_Q18[r];
@@ -1995,7 +2002,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                     i32 diff = in[m] - cv[m];
                     sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
                 }
-                const i32 rd = sx_smlabb(sum_error, w->Rate_Q5[n] + rts[i], mu_Q15);
+                const i32 rd = sx_smlabb(sum_error, x->Rate_Q5[n] + rts[i], mu_Q15);
                 const i64 key = (i64)(((u64)(u32)rd << 32) | (u32)t);
                 if (j == 0) k0 = key; else if (j == 1) k1 = key; else if (j == 2) k2 = key; else k3 = key;
             }
@@ -2014,7 +2021,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         }
         if (SX_LANE < cur_survivors) {
             w->RateDist_Q18[SX_LANE] = mine_v;
-            w->TempIndices[SX_LANE] = mine_i;
+            x->TempIndices[SX_LANE] = mine_i;
         }
 #endif
         wv_sync();
@@ -2026,21 +2033,21 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         // (a row of SX_MSVQ_ROW lanes per survivor: SX_LPC residual entries, the rate, up to nStages - 1 inherited path entries, the new one)
         SX_PAR(ki, cur_survivors * SX_MSVQ_ROW) {
             const int k = ki / SX_MSVQ_ROW, i = ki % SX_MSVQ_ROW;
-            int input_index = 0, cb_index = w->TempIndices[k];
+            int input_index = 0, cb_index = x->TempIndices[k];
             if (s > 0) {
                 input_index = cb_index / K;
                 cb_index = cb_index - input_index * K;
             }
-            if (i < SX_LPC) w->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
-            if (i == SX_LPC) w->Rate_new_Q5[k] = w->Rate_Q5[input_index] + rts[cb_index];
-            if (i > SX_LPC && i - SX_LPC - 1 < s) w->Path_new[k * nStages + (i - SX_LPC - 1)] = w->Path[input_index * nStages + (i - SX_LPC - 1)];
-            if (i == SX_MSVQ_ROW - 1) w->Path_new[k * nStages + s] = (u8)cb_index;
+            if (i < SX_LPC) x->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
+            if (i == SX_LPC) x->Rate_new_Q5[k] = x->Rate_Q5[input_index] + rts[cb_index];
+            if (i > SX_LPC && i - SX_LPC - 1 < s) x->Path_new[k * nStages + (i - SX_LPC - 1)] = x->Path[input_index * nStages + (i - SX_LPC - 1)];
+            if (i == SX_MSVQ_ROW - 1) x->Path_new[k * nStages + s] = (u8)cb_index;
         }
         wv_sync();
         if (s < nStages - 1) {
-            SX_PAR(i, cur_survivors * SX_LPC) w->Res_Q15[i] = w->Res_new_Q15[i];
-            SX_PAR(i, cur_survivors) w->Rate_Q5[i] = w->Rate_new_Q5[i];
-            SX_PAR(i, cur_survivors * nStages) w->Path[i] = w->Path_new[i];
+            SX_PAR(i, cur_survivors * SX_LPC) w->Res_Q15[i] = x->Res_new_Q15[i];
+            SX_PAR(i, cur_survivors) x->Rate_Q5[i] = x->Rate_new_Q5[i];
+            SX_PAR(i, cur_survivors * nStages) x->Path[i] = x->Path_new[i];
             wv_sync();
         }
         prev_survivors = cur_survivors;
@@ -2052,7 +2059,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
         SX_PAR(sv, cur_survivors) {
             i32* out = &w->Res_Q15[sv * SX_LPC];
-            sx_nlsf_msvq_decode_cb(out, &w->Path_new[sv * nStages], cb, nvec, w->ndelta);
+            sx_nlsf_msvq_decode_cb(out, &x->Path_new[sv * nStages], cb, nvec, w->ndelta);
             i32 wsse_Q20 = 0;
             for (int i = 0; i < SX_LPC; i++) {
                 i32 se = out[i] - prev_q_Q15[i];
@@ -2065,15 +2072,15 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         if (bv < bestRateDist_Q20) { bestRateDist_Q20 = bv; bestIndex = bi; }
         wv_sync();
     }
-    SX_PAR(i, nStages) NLSFIndices[i] = w->Path_new[bestIndex * nStages + i];
+    SX_PAR(i, nStages) NLSFIndices[i] = x->Path_new[bestIndex * nStages + i];
     wv_sync();
     sx_nlsf_msvq_decode_cb(pNLSF_Q15, NLSFIndices, cb, nvec, w->ndelta);
     wv_sync();
 }
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
-SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w); SX_IN_LDS(pNLSF_Q15);
+SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w, SxMsvqAux* aux) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(w); SX_IN_LDS(pNLSF_Q15); SX_IN_LDS(aux);
     i32 NLSF_mu_Q15, NLSF_mu_fluc_red_Q16;
     i32* pNLSFW_Q6 = w->W_Q6;
     if (c->sigtype == 0) {
@@ -2086,16 +2093,13 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
     NLSF_mu_Q15 = sx_max(NLSF_mu_Q15, 1);
     const int doInterpolate = c->NLSFInterpCoef_Q2 < 4;     // useInterpolatedNLSFs == 1
     const i32 interp_Q2 = c->NLSFInterpCoef_Q2;
-    // Laroia weights of the target and (if interpolating) of the interpolated vector: one vector per lane
-    SX_PAR(v, 2) {
-        if (v == 0) {
-            sx_nlsf_weights_laroia(pNLSFW_Q6, pNLSF_Q15, SX_LPC);
-        } else if (doInterpolate) {
-            for (int i = 0; i < SX_LPC; i++)
-                w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
-            sx_nlsf_weights_laroia(w->W0_Q6, w->NLSF0, SX_LPC);
-        }
+    // Laroia weights of the target and (if interpolating) of the interpolated vector: one vector per lane, both lanes in step
+    // (the same instructions on per-lane pointers; written as two branches the two would run one after the other, as scalar code)
+    if (doInterpolate) {
+        SX_PAR(i, SX_LPC) w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
+        wv_sync();
     }
+    SX_PAR(v, doInterpolate ? 2 : 1) sx_nlsf_weights_laroia(v ? w->W0_Q6 : pNLSFW_Q6, v ? w->NLSF0 : pNLSF_Q15, SX_LPC);
     wv_sync();
     if (doInterpolate) {
         const i32 i_sqr_Q15 = sx_shl(sx_smulbb(interp_Q2, interp_Q2), 11);
@@ -2103,16 +2107,14 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
     }
     wv_sync();
     sx_nlsf_msvq_encode(c->NLSFIndices, pNLSF_Q15, c->sigtype, st->prev_NLSFq_Q15, pNLSFW_Q6, NLSF_mu_Q15, NLSF_mu_fluc_red_Q16,
-                        st->first_frame_after_reset, w);
-    // quantised NLSFs -> LPC for the two frame halves: half v on lane v
+                        st->first_frame_after_reset, w, aux);
+    // quantised NLSFs -> LPC for the two frame halves: half v on lane v, both lanes in step
+    if (doInterpolate) {
+        SX_PAR(i, SX_LPC) w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
+        wv_sync();
+    }
     SX_PAR(v, 2) {
-        if (v == 1) {
-            sx_nlsf2a_stable_ws(c->PredCoef_Q12[1], pNLSF_Q15, SX_LPC, w->ws[1]);
-        } else if (doInterpolate) {
-            for (int i = 0; i < SX_LPC; i++)
-                w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
-            sx_nlsf2a_stable_ws(c->PredCoef_Q12[0], w->NLSF0, SX_LPC, w->ws[0]);
-        }
+        if (v == 1 || doInterpolate) sx_nlsf2a_stable_ws(c->PredCoef_Q12[v], v ? pNLSF_Q15 : w->NLSF0, SX_LPC, w->ws[v]);
     }
     wv_sync();
     if (!doInterpolate) {
@@ -2161,7 +2163,9 @@ struct SxPredWork {                   // LDS scratch of find_pred_coefs
 };
 
 // SKP_Silk_find_pred_coefs_FIX, SKP_Silk_find_pred_coefs_FIX.c:31
-SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, const i16* res_pitch, SxPredWork* w) {
+// res_pitch: the LPC residual of the pitch analysis (read by the long-term prediction analysis), followed by SX_PITCH_LPC_WIN more
+// samples of dead scratch (SxFrontWork::Wsig): the NLSF quantiser's survivor tables are kept there afterwards (SxMsvqAux)
+SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i16* res_pitch, SxPredWork* w) {
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(x_buf); SX_IN_LDS(res_pitch); SX_IN_LDS(w);
     i32 *invGains_Q16 = w->invGains_Q16, *local_gains = w->local_gains, *Wght_Q15 = w->Wght_Q15;
     i32* NLSF_Q15 = w->NLSF_Q15;
@@ -2197,7 +2201,9 @@ SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, c
     sx_find_LPC(NLSF_Q15, &c->NLSFInterpCoef_Q2, st->prev_NLSFq_Q15, 1 - st->first_frame_after_reset, SX_LPC, w->LPC_in_pre,
                 SX_SUBFR + SX_LPC, w->LPC_res, &w->u.lpc);
     SX_T(17)
-    sx_process_NLSFs(st, c, NLSF_Q15, &w->u.msvq);
+    static_assert(sizeof(SxMsvqAux) <= sizeof(i16) * (2 * SX_FRAME + SX_LA_PITCH + SX_PITCH_LPC_WIN), "survivor tables exceed res_pitch + Wsig");
+    wv_sync();                                   // (the last readers of res_pitch are done)
+    sx_process_NLSFs(st, c, NLSF_Q15, &w->u.msvq, (SxMsvqAux*)(void*)res_pitch);
     SX_T(19)
     sx_residual_energy(c->ResNrg, c->ResNrgQ, w->LPC_in_pre, c->PredCoef_Q12, local_gains, w->LPC_res);
     SX_T(20)
@@ -2243,6 +2249,7 @@ SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditiona
 // SKP_Silk_process_gains_FIX, SKP_Silk_process_gains_FIX.c:32
 SX_FN1 void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
     SX_IN_LDS(st); SX_IN_LDS(c);
+    st = SX_VPTR(st); c = SX_VPTR(c);            // wave-uniform scalar stage: on the vector unit (SX_VPTR)
     if (c->sigtype == 0) {
         i32 s_Q16 = -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4));
         for (int k = 0; k < 4; k++) c->Gains_Q16[k] = sx_smlawb(c->Gains_Q16[k], c->Gains_Q16[k], s_Q16);

@@ -15,23 +15,31 @@ __global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* st
 //   A  solo_enc_analysis_kernel  one wavefront per stream: QMF split + analysis chain of every frame of the launch
 //   B  solo_nsq_kernel           four streams per wavefront (solo_nsq16.hip): the delayed-decision quantiser
 //   C  solo_enc_coding_kernel    one wavefront per stream: high-band encoder, range coding, payload assembly
-__device__ __forceinline__ void SX_K(solo_enc_enter)(SxEncWork* w, const SxEncStream* rec) {
+#ifdef SX_OUTLINE_WRAPPERS
+#define SX_ENTER_FN static __device__ __attribute__((noinline))
+#else
+#define SX_ENTER_FN __device__ __forceinline__
+#endif
+SX_ENTER_FN void SX_K(solo_enc_enter)(SxEncWork* w, const SxEncStream* rec) {
     const i32* src = (const i32*)&rec->core;
     i32* dst = (i32*)&w->st;
     SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
     wv_sync();
 }
-__device__ __forceinline__ void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
+SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
     wv_sync();
     const i32* src = (const i32*)&w->st;
     i32* dst = (i32*)&rec->core;
     SX_PAR(i, (int)(sizeof(SxEncState) / 4)) dst[i] = src[i];
 }
 
-// waves-per-SIMD target of the analysis kernel = its register budget (5: <= 96 VGPRs, 4: <= 128).  LDS admits 14 - 16 of its
-// workgroups per CU, i.e. 4 - 5 per SIMD on the three SIMDs the quantiser's wave leaves.
+// waves-per-SIMD target of the analysis kernel = its register budget (5: <= 96 VGPRs, 4: <= 128).  All 16 analysis workgroups
+// of a compute unit (4096 streams / 256 CUs) must be resident BESIDE the quantiser's workgroup, or the last ones run as a second
+// round that costs a whole single-wave latency (round 2: 12 resident, 1.24 ms per launch; 16 resident: 0.9 ms, DESIGN.md
+// section 4): 5 waves on each of the three SIMDs the quantiser leaves + one beside the quantiser's wave (its register cap,
+// solo_nsq16.hip), and 16 x 8.6 KB of LDS + the quantiser's 23 KB <= 160 KB.
 #ifndef SX_ANALYSIS_WAVES
-#define SX_ANALYSIS_WAVES 4
+#define SX_ANALYSIS_WAVES 5
 #endif
 __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
@@ -43,6 +51,12 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
 #endif
     const int s = blockIdx.x;
     if (s >= n_streams) return;
+#ifdef SX_EXP_STAGGER     // timing experiment: the waves that share a SIMD start a fraction of a frame apart
+    {
+        const int q = (blockIdx.x >> SX_EXP_STAGGER_SHIFT) & 3;
+        for (int i = 0; i < q * SX_EXP_STAGGER; i++) __builtin_amdgcn_s_sleep(127);
+    }
+#endif
     SxEncStream* rec = &states[s];
     SX_K(solo_enc_enter)(&w, rec);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets

@@ -16,7 +16,12 @@
 #define SX_NSQ_WAVES 1
 #endif
 // ring: SX_NSQ_RING_CELLS(64) cells per workgroup (the emission ring of its sixteen streams, rows of 64 lanes = 1 KB)
-// SX_NSQ_VGPR_CAP = n: the kernel may use 2 n of the SIMD's 512 registers (n architectural + n accumulation registers as spill space)
+// SX_NSQ_VGPR_CAP = n: the kernel may use 2 n of the SIMD's 512 registers (n accumulation registers as spill space on top of the
+// 256 architectural ones).  176 -> 352 registers: the sample loop still has no scratch access (it has at 160), and 160 registers
+// of the quantiser's SIMD are left for one wave of the analysis kernel (96), see solo_enc_kernels.h.
+#ifndef SX_NSQ_VGPR_CAP
+#define SX_NSQ_VGPR_CAP 176
+#endif
 #ifdef SX_NSQ_VGPR_CAP
 #define SX_NSQ_CAP_ATTR __attribute__((amdgpu_num_vgpr(SX_NSQ_VGPR_CAP)))
 #else

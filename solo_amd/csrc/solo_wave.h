@@ -177,6 +177,17 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 #define SX_UNI(x) ((i32)(x))
 #endif
 
+// SX_VPTR(p): the same pointer, but opaque to the compiler's uniformity analysis (an offset of zero that lives in a vector
+// register).  Wave-uniform straight-line arithmetic on values loaded through it is emitted for the VECTOR unit instead of the
+// scalar unit: one wave pays one issue slot per instruction either way, but the scalar unit takes one instruction per four cycles
+// per SIMD for all of its waves together, the vector unit two (tools/debug/mb_issue.hip).
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+SX_HD int sx_vzero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
+#define SX_VPTR(p) ((p) + sx_vzero())
+#else
+#define SX_VPTR(p) (p)
+#endif
+
 // Serial recursions over a block of samples (IIR sections that cannot be re-cut over the lanes) read and write their samples
 // through lane registers instead of LDS: sample i lives in lane (i & 63) of register (i >> 6); the scalar loop fetches it with
 // v_readlane and deposits results with a lane-select, so no LDS round trip sits on the recursion's critical path.
