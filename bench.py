@@ -441,10 +441,11 @@ def main():
         src_hash = solo_amd.kernel_source_hash()
         prof_hash = {"hbm_traffic.json": traffic.get("kernel_source_sha16"), "wave_instructions.json": insts.get("kernel_source_sha16")}
         prof_ok = all(v == src_hash for v in prof_hash.values())
-        dec_chunk = int(os.environ.get("SOLO_DEC_CHUNK", "24"))       # (solo_api.hip: a first chunk of 4 packets, then chunks of this size)
+        dec_chunk = int(os.environ.get("SOLO_DEC_CHUNK", "64"))       # (solo_api.hip: one chunk up to 64 packets)
+        dec_first = int(os.environ.get("SOLO_DEC_FIRST_CHUNK", "64"))
         if split_dec and dec_chunk > 0:
             cp = min(P, dec_chunk)
-            c0 = 4 if (P > 8 and cp > 4) else cp
+            c0 = dec_first if (P > 2 * dec_first and cp > dec_first) else cp
             dec_chunks = 1 + (P - c0 + cp - 1) // cp
         else:
             dec_chunks = 1
@@ -476,7 +477,7 @@ def main():
                                     "decode per rank, RCCL gather only, 13.6 kbps, %d packets/stream/step" % (N * world, world, N, P)),
                        "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2),
                        "launch": "torch.distributed.run, one rank per GPU" + (" (started by bench.py itself)" if os.environ.get("SOLO_SELF_LAUNCHED") else "") if world > 1 else "single process",
-                       "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
+                       "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_DEC_FIRST_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
                                     "(solo_batch_set_async_join, double-buffered bitstreams)" if args.overlap
                                     else "encode then decode on one stream")},

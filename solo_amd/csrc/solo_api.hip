@@ -88,7 +88,8 @@ struct solo_batch {
     hipEvent_t evDFork, evDJoin, evDJoin2, evP[2], evS[2];
     void* d_parsed[2];               // extraction records of the chunk being extracted / being decoded
     size_t parsed_bytes;             // size of each
-    int dec_pipe_ready, dec_split, dec_chunk;
+    int parsed_two;                  // both buffers have that size (a call of one chunk needs only the first)
+    int dec_pipe_ready, dec_split, dec_chunk, dec_first;
     unsigned int dec_calls;          // two-kernel decode calls so far (evDJoin / evDJoin2 are recorded once > 0)
     void* d_rc_scratch;              // range-coder byte buffers of one coding launch (the launches of a call run in order on sC)
     size_t rc_scratch_bytes;
@@ -317,7 +318,14 @@ void solo_batch_destroy(solo_batch_t* b) {
     delete b;
 }
 
-#define SOLO_DEC_FIRST_CHUNK 4
+// Chunks of the two-kernel decoder.  The extraction of chunk c + 1 was meant to hide behind the synthesis of chunk c, but the two
+// kernels never share a compute unit (the synthesis kernel's 16 workgroups take all of its LDS and registers), so every chunk
+// boundary only costs: a synthesis launch reloads and stores 4096 stream states, and its last workgroups run in a thinly populated
+// tail.  Measured (4096 streams x 50 packets): chunks of 24 packets after a first one of 4: 9.0 ms; 6 + 44: 7.7 ms; ONE chunk:
+// 7.4 ms (8192 streams, 30 % description loss: 17.5 / 16.2 / 16.0 ms).  So a call is one chunk up to 64 packets (the extraction
+// records of a chunk are 1952 B per packet: 512 MB for 4096 streams x 64 packets), longer calls are cut into chunks of 64.
+#define SOLO_DEC_FIRST_CHUNK 64
+#define SOLO_DEC_CHUNK_DEFAULT 64
 int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
                           int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
@@ -327,8 +335,11 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
         const char* e = getenv("SOLO_DEC_SPLIT");
         b->dec_split = e ? atoi(e) : 1;
         e = getenv("SOLO_DEC_CHUNK");
-        b->dec_chunk = e ? atoi(e) : 24;
+        b->dec_chunk = e ? atoi(e) : SOLO_DEC_CHUNK_DEFAULT;
         if (b->dec_chunk <= 0) b->dec_chunk = 1 << 30;
+        e = getenv("SOLO_DEC_FIRST_CHUNK");
+        b->dec_first = e ? atoi(e) : SOLO_DEC_FIRST_CHUNK;
+        if (b->dec_first <= 0) b->dec_first = SOLO_DEC_FIRST_CHUNK;
         if (b->dec_split) {
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking));
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sS, hipStreamNonBlocking));
@@ -356,10 +367,10 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
     // (a short first chunk -- its extraction has nothing to hide behind -- then long ones: every decoder launch reloads the stream states)
     const int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
-    const int c0 = (n_packets > 2 * SOLO_DEC_FIRST_CHUNK && cp > SOLO_DEC_FIRST_CHUNK) ? SOLO_DEC_FIRST_CHUNK : cp;      // (never larger than the buffers: c0 <= cp)
+    const int c0 = (n_packets > 2 * b->dec_first && cp > b->dec_first) ? b->dec_first : cp;      // (never larger than the buffers: c0 <= cp)
     const int nchunks = 1 + (n_packets - c0 + cp - 1) / cp;
     const size_t need = (size_t)b->n_streams * (size_t)cp * (b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes());
-    if (need > b->parsed_bytes) {
+    if (need > b->parsed_bytes || (nchunks > 1 && !b->parsed_two)) {
         SOLO_CHECK(hipStreamSynchronize(st));
         (void)hipStreamSynchronize(b->sP);
         (void)hipStreamSynchronize(b->sS);
@@ -368,8 +379,9 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
             b->d_parsed[i] = NULL;
         }
         b->parsed_bytes = 0;
-        for (int i = 0; i < 2; i++) SOLO_CHECK(hipMalloc(&b->d_parsed[i], need));
+        for (int i = 0; i < 2; i++) SOLO_CHECK(hipMalloc(&b->d_parsed[i], i == 0 || nchunks > 1 ? need : 256));     // (one chunk: one buffer)
         b->parsed_bytes = need;
+        b->parsed_two = nchunks > 1;
     }
     if (b->dec_calls > 0) {
         // the previous decode call may have been issued on ANOTHER stream than this one: its kernels on sP / sS (and their use of

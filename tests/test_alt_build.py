@@ -46,10 +46,11 @@ def test_decoder_suite_through_the_single_kernel_path():
 
 @pytest.mark.gpu
 def test_decoder_suite_with_small_decode_chunks():
-    """The batched decode call works through its packets in chunks (symbol extraction a chunk ahead of the decoder proper; default
-    4 + 24 + 24 ...).  With SOLO_DEC_CHUNK=3 even short calls cross several chunk boundaries: same output required (stream state,
-    description shadow and the serial fall-back for unusual packets all carry over the boundaries)."""
-    env = dict(os.environ, SOLO_DEC_CHUNK="3")
+    """The batched decode call works through its packets in chunks (symbol extraction, then the decoder proper, per chunk; by
+    default a call of up to 64 packets is ONE chunk).  With SOLO_DEC_CHUNK=3 and a first chunk of 2 even short calls cross several
+    chunk boundaries: same output required (stream state, description shadow and the serial fall-back for unusual packets all
+    carry over the boundaries; the two record buffers alternate)."""
+    env = dict(os.environ, SOLO_DEC_CHUNK="3", SOLO_DEC_FIRST_CHUNK="2")
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
                         os.path.join(T.ROOT, "tests", "test_gpu_decoder.py"), os.path.join(T.ROOT, "tests", "test_pinned_corners.py")],
                        env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
