@@ -10,7 +10,7 @@ ROOT=$(pwd)
 OUT=$ROOT/gpurun_out/prof
 mkdir -p "$OUT"
 export TMPDIR=/tmp
-CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+CMD="python $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra"
 PASSES=${*:-trace fetch write sq inst lane}
 cd /tmp
 for p in $PASSES; do

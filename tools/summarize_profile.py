@@ -12,8 +12,17 @@ import sys
 
 src, dst = sys.argv[1], sys.argv[2]
 packets_step = int(sys.argv[3]) if len(sys.argv) > 3 else 204800
-out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline`",
-       "packets_per_step": packets_step, "kernels": {}}
+import subprocess
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import solo_amd
+try:
+    git_head = subprocess.check_output(["git", "-C", ROOT, "rev-parse", "HEAD"], text=True).strip()
+    git_dirty = bool(subprocess.check_output(["git", "-C", ROOT, "status", "--porcelain", "--", "solo_amd/csrc"], text=True).strip())
+except Exception:
+    git_head, git_dirty = None, None
+out = {"source": "rocprofv3 --kernel-trace --stats / --pmc (separate passes) over `python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra`",
+       "packets_per_step": packets_step, "kernel_source_sha16": None, "git_head": git_head, "git_kernel_sources_modified_since_head": git_dirty, "kernels": {}}
 st = os.path.join(src, "trace", "r01_kernel_stats.csv")
 lines = []
 for r in csv.DictReader(open(st)):
@@ -48,6 +57,8 @@ try:
             j = json.loads(line)
             lps = {k: v.get("launches_per_step", 1) for k, v in j["kernels"].items()}
             lps.update(j.get("launches_per_step", {}))
+            out["kernel_source_sha16"] = j.get("kernel_source_sha16")      # the build that was profiled (bench.py prints it)
+            out["bench_line_of_the_trace_pass"] = {k: j.get(k) for k in ("value", "ms_per_step", "parity_checked")}
 except Exception:
     pass
 for k, e in out["kernels"].items():
@@ -72,14 +83,17 @@ for k, e in out["kernels"].items():
 os.makedirs(os.path.dirname(dst) or ".", exist_ok=True)
 json.dump(out, open(dst + "_summary.json", "w"), indent=1)
 open(dst + "_kernel_stats.csv", "w").write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n" + "\n".join(lines) + "\n")
+if out["kernel_source_sha16"] != solo_amd.kernel_source_hash():
+    print("WARNING: the profiled build (%s) is not the kernel source of this tree (%s)" % (out["kernel_source_sha16"], solo_amd.kernel_source_hash()))
 tr = {"note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per 40 ms packet and kernel; see "
-              + os.path.basename(dst) + "_summary.json"}
+              + os.path.basename(dst) + "_summary.json", "kernel_source_sha16": out["kernel_source_sha16"], "git_head": git_head}
 for k, e in out["kernels"].items():
     if "hbm_bytes_per_packet_corrected" in e:
         tr[k + "_bytes_per_packet"] = e["hbm_bytes_per_packet_corrected"]
 json.dump(tr, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
 # VALU / all wave-instructions per packet (bench.py's valu_issue block reads this)
-wi = {"source": os.path.basename(dst) + "_summary.json (rocprofv3 --pmc SQ_INSTS_* pass)", "valu_per_packet": {}, "all_per_packet": {}}
+wi = {"source": os.path.basename(dst) + "_summary.json (rocprofv3 --pmc SQ_INSTS_* pass)", "kernel_source_sha16": out["kernel_source_sha16"], "git_head": git_head,
+      "valu_per_packet": {}, "all_per_packet": {}}
 for k, e in out["kernels"].items():
     w = e.get("wave_instructions_per_packet")
     if w and "gate" not in k:
