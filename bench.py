@@ -225,7 +225,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the configs[1] / configs[3] legs (N = 1 only)")
     ap.add_argument("--no-hash", action="store_true", help="skip the hashes of the first step (saves the device-to-host copies; parity_checked = null)")
-    ap.add_argument("--overlap", action="store_true", help="decode of step k on a second stream beside the encode of step k+1")
+    ap.add_argument("--no-overlap", action="store_true", help="strictly sequential schedule: every step's decode finishes before the next step's encode is issued "
+                                                             "(default: the decode of step k is issued after the encode of step k+1, see config.schedule)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="CPU baseline: seconds of work per worker process")
     ap.add_argument("--cpu-packets-per-stream", type=int, default=400)
     ap.add_argument("--cpu-worker", action="store_true", help=argparse.SUPPRESS)
@@ -298,10 +299,10 @@ def main():
     # steps AFTER the timed region: they cost several per cent of throughput)
     kms = {"analysis": [], "quantiser": [], "coding": [], "decode": []}
 
-    # Optional serving shape (--overlap): consecutive encode calls are pipelined (solo_batch_set_async_join: the first analysis
+    # Default schedule (off with --no-overlap): consecutive encode calls are pipelined (solo_batch_set_async_join: the first analysis
     # chunk of step k + 1 starts while the last quantiser / coding chunks of step k still run) and the decode of step k is issued
     # after the encode of step k + 1; the bitstream buffers are double-buffered.  Default: encode then decode, one stream.
-    overlap = args.overlap
+    overlap = not args.no_overlap
     bits2, nb2 = [bits, torch.zeros_like(bits) if overlap else bits], [nb, torch.zeros_like(nb) if overlap else nb]
     step_no = [0]
     if overlap:
@@ -376,6 +377,15 @@ def main():
 
     # ---- extra legs (N = 1): BASELINE configs[1] and configs[3], each its own timed loop ------------------------------------
     extra = {}
+    if world == 1 and not args.no_extra and not args.no_overlap:
+        # the same round trip with the strictly sequential schedule (decode of a step done before the next encode is issued)
+        def seq_step():
+            batch.encode(pcm, bits, nb, st_e)
+            batch.decode(bits, nb, None, out, st_d)
+        ns = max(2, min(5, args.steps))
+        dt_s = timed_loop(seq_step, ns, 1, barrier)
+        extra["sequential_schedule"] = {"workload": "the headline round trip, encode then decode on one stream (--no-overlap)", "steps": ns, "warmup": 1,
+                                        "value": round(packets_step * ns / dt_s, 1), "unit": "40ms packets/s (encode+decode)", "ms_per_step": round(dt_s / ns * 1e3, 3)}
     if world == 1 and not args.no_extra:
         # configs[1]: the same 4096 streams, encode only
         dt_e = timed_loop(lambda: batch.encode(pcm, bits, nb, st_e), args.steps, max(1, args.warmup), barrier)
@@ -479,7 +489,7 @@ def main():
                        "launch": "torch.distributed.run, one rank per GPU" + (" (started by bench.py itself)" if os.environ.get("SOLO_SELF_LAUNCHED") else "") if world > 1 else "single process",
                        "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_DEC_FIRST_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
-                                    "(solo_batch_set_async_join, double-buffered bitstreams)" if args.overlap
+                                    "(solo_batch_set_async_join, double-buffered bitstreams); every packet is encoded AND decoded inside the timed region" if not args.no_overlap
                                     else "encode then decode on one stream")},
             "parity_checked": parity,
             "parity": {"what": "first step (freshly reset streams) hashed per block of 4096 streams: md5(nBytes || payload slots) and md5(decoded PCM), "

@@ -500,7 +500,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         // (measured 72.3 vs 69.9 ms per 204 800 packets), so it is off unless asked for
         b->gate = e ? atoi(e) : 0;
         e = getenv("SOLO_ENC_GROUP");
-        b->group_streams = e ? atoi(e) : 4096;
+        b->group_streams = e ? atoi(e) : 8192;        // (8192 streams: one group of 8192 takes 120 ms per 50 packets, two of 4096 take 134 ms)
         {   // the quantiser launches of a call run one after the other on sB: one ring, sized for the largest launch group
             const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
             SOLO_CHECK(hipMalloc(&b->d_nsq_ring, ops->nsq_ring_bytes(gs)));
@@ -539,9 +539,9 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
-    // Streams beyond one full round of workgroups (4096 = 16 analysis workgroups x 256 CUs, 1024 quantiser waves = one per SIMD) are
-    // processed group after group: measured 2.04 M packets/s at 4096 streams per launch against 1.80 M at 8192 and 1.70 M at 16384.
-    // All per-stream arrays are stream-major, so a group is the same launch on offset pointers.
+    // Streams beyond 8192 (SOLO_ENC_GROUP) are processed group after group; all per-stream arrays are stream-major, so a group is the
+    // same launch on offset pointers.  (Round 1 measured groups of 4096 as the fastest shape; since the analysis kernel's workgroups
+    // all fit beside the quantiser's -- round 3 -- 8192 streams in one group are 11 % faster than two groups of 4096.)
     const int G = b->group_streams > 0 ? b->group_streams : b->n_streams;
     const int ngroups = (b->n_streams + G - 1) / G;
     const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
