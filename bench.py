@@ -423,6 +423,28 @@ def main():
                                               "4096 streams, against the compiled reference (bench_blocks.json: payload_md5 / pcm_loss30_md5)"}
         del b8, bits8, nb8, out8, pcm8, recv
 
+    if world == 1 and not args.no_extra and P % 2 == 0:
+        # the 32 kHz mode (`samplerate = 32000`: 1280-sample packets, SILK wide band inside, 24 kbps): the same input
+        # samples taken as 32 kHz audio, P / 2 packets per stream per step, sequential encode then decode
+        bw = solo_amd.SoloBatch(N, rate=24000, encoder=True, decoder=True, slot_bytes=SLOT, samplerate=32000)
+        Pw = P // 2
+        xw = pcm.view(N, Pw, 1280)
+        bits_w = torch.zeros((N, Pw, SLOT), dtype=torch.uint8, device=dev); nb_w = torch.zeros((N, Pw, 2), dtype=torch.int16, device=dev)
+        out_w = torch.zeros((N, Pw, 1280), dtype=torch.int16, device=dev)
+        st_we = torch.zeros((N,), dtype=torch.int32, device=dev); st_wd = torch.zeros((N,), dtype=torch.int32, device=dev)
+
+        def wb_step():
+            bw.encode(xw, bits_w, nb_w, st_we)
+            bw.decode(bits_w, nb_w, None, out_w, st_wd)
+        nw = max(2, min(5, args.steps))
+        dt_w = timed_loop(wb_step, nw, 1, barrier)
+        assert int(st_we.abs().max()) == 0 and int(st_wd.abs().max()) == 0
+        extra["samplerate_32000"] = {"workload": "%d streams in the 32 kHz mode (1280-sample 40 ms packets, SILK wide band + 8-16 kHz high band, 24 kbps), encode then decode, "
+                                                 "%d packets/stream/step" % (N, Pw), "value": round(N * Pw * nw / dt_w, 1), "unit": "40ms packets/s (encode+decode, 32 kHz)",
+                                     "steps": nw, "warmup": 1, "ms_per_step": round(dt_w / nw * 1e3, 3), "mean_payload_bytes": round(float(nb_w[:, :, 0].float().mean().item()), 2),
+                                     "parity_checked": None, "parity_note": "bit-exactness of the 32 kHz mode is covered by tests/test_wb.py (goldens + compiled reference), not by a hash of this batch"}
+        del bw, bits_w, nb_w, out_w
+
     # ONE all_gather of the per-rank record (RCCL); no other collective besides the barriers and the max time
     record = sdist.result_record(rank, first, N, packets_step * args.steps, dt_local, *first_step)
     record["payload_bytes"] = payload_bytes_timed            # produced in the timed steps (device-side sum of nBytesOut[0])
