@@ -625,21 +625,25 @@ int32_t solo_batch_encode(solo_batch_t*, const int16_t*, int32_t, uint8_t*, int1
 // ---- the reference's six entry points: a batch of one stream, staged through device buffers ----------
 struct solo_single {
     solo_batch* b;
+    // One device block and one pinned host block of the same layout: [status 16 B][pcm 2 x 1280 B][nbytes 16 B][bits: slot bytes].
+    // A call is one host-to-device copy, the kernels, one device-to-host copy and ONE synchronisation (round 2 made three synchronous
+    // copies per call: 0.26 ms per decoded packet against 0.024 ms of the reference on a host core, tools/legacy_api_cost.py).
+    uint8_t* d_blk;
+    uint8_t* h_blk;
     int16_t* d_pcm;
     uint8_t* d_bits;
     int16_t* d_nbytes;
-    uint8_t* d_recv;
     int32_t* d_status;
     int is_enc;
 };
+#define SOLO_SINGLE_PCM_OFF 16
+#define SOLO_SINGLE_NB_OFF (16 + 2 * SX_PACKET * 2)
+#define SOLO_SINGLE_BITS_OFF (SOLO_SINGLE_NB_OFF + 16)
 
 static void single_free(solo_single* h) {
     if (!h) return;
-    if (h->d_pcm) (void)hipFree(h->d_pcm);
-    if (h->d_bits) (void)hipFree(h->d_bits);
-    if (h->d_nbytes) (void)hipFree(h->d_nbytes);
-    if (h->d_recv) (void)hipFree(h->d_recv);
-    if (h->d_status) (void)hipFree(h->d_status);
+    if (h->d_blk) (void)hipFree(h->d_blk);
+    if (h->h_blk) (void)hipHostFree(h->h_blk);
     solo_batch_destroy(h->b);
     free(h);
 }
@@ -649,12 +653,17 @@ static solo_single* single_new(const USER_Ctrl_enc* e, const USER_Ctrl_dec* d) {
     if (!h) return NULL;
     h->is_enc = e != NULL;
     h->b = solo_batch_create(1, e, d, 1024 + 64);   // MAX_FRAME_BYTES of the reference harness + slack
-    if (!h->b || hipMalloc((void**)&h->d_pcm, 2 * SX_PACKET * 2) != hipSuccess || hipMalloc((void**)&h->d_bits, h->b->slot) != hipSuccess ||
-        hipMalloc((void**)&h->d_nbytes, 4) != hipSuccess || hipMalloc((void**)&h->d_recv, 4) != hipSuccess ||
-        hipMalloc((void**)&h->d_status, 4) != hipSuccess) {
+    const size_t blk = h->b ? (size_t)SOLO_SINGLE_BITS_OFF + (size_t)h->b->slot : 0;
+    if (!h->b || hipMalloc((void**)&h->d_blk, blk) != hipSuccess || hipHostMalloc((void**)&h->h_blk, blk, hipHostMallocDefault) != hipSuccess ||
+        hipMemset(h->d_blk, 0, blk) != hipSuccess) {
         single_free(h);
         return NULL;
     }
+    memset(h->h_blk, 0, blk);
+    h->d_status = (int32_t*)h->d_blk;
+    h->d_pcm = (int16_t*)(h->d_blk + SOLO_SINGLE_PCM_OFF);
+    h->d_nbytes = (int16_t*)(h->d_blk + SOLO_SINGLE_NB_OFF);
+    h->d_bits = h->d_blk + SOLO_SINGLE_BITS_OFF;
     return h;
 }
 
@@ -667,15 +676,21 @@ void* AGR_Sate_Encoder_Init(USER_Ctrl_enc* enc_Ctrl) {
 int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int32_t bufSize, int16_t* nBytesOut) {
     solo_single* h = (solo_single*)st;
     if (!h || !h->is_enc) return -1;
-    if (hipMemcpy(h->d_pcm, pcm, h->b->eops->packet_samples * 2, hipMemcpyHostToDevice) != hipSuccess) return -1;      // JC1_FrameSize samples
+    const size_t pcm_bytes = (size_t)h->b->eops->packet_samples * 2;                                             // JC1_FrameSize samples
+    memcpy(h->h_blk + SOLO_SINGLE_PCM_OFF, pcm, pcm_bytes);
+    if (hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
+    // lengths + the whole payload slot in one copy (a payload is at most a few hundred bytes; the slot 1088)
+    if (hipMemcpyAsync(h->h_blk + SOLO_SINGLE_NB_OFF, h->d_blk + SOLO_SINGLE_NB_OFF, 16 + (size_t)h->b->slot, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int16_t nb[2];
-    if (hipMemcpy(nb, h->d_nbytes, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    memcpy(nb, h->h_blk + SOLO_SINGLE_NB_OFF, 4);
     int32_t n = nb[0];
     if (n == 0 && h->b->enc_ctrl.dtx_enable)                                 // DTX packet: the reference still returns the high-band bytes
         n = ctrl_hb_joint(h->b->enc_ctrl.joint_enable, h->b->enc_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     if (n > bufSize) n = bufSize;                                            // AGR_Sate_bits_write truncates to max_nbytes
-    if (n > 0 && hipMemcpy(bits, h->d_bits, n, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n > h->b->slot) n = h->b->slot;
+    if (n > 0) memcpy(bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n);
     nBytesOut[0] = nb[0];
     nBytesOut[1] = nb[1];
     return n;
@@ -705,12 +720,16 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
         // read out of bounds): too long -> SKP_SILK_DEC_PAYLOAD_TOO_LARGE, inconsistent -> SKP_SILK_DEC_PAYLOAD_ERROR
         if (n0 > h->b->slot) { *nSamplesOut = (int16_t)ns; return -11; }
         if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb) || (lostflag == 4 && n0 < hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
-        if (hipMemcpy(h->d_bits, bits, n0, hipMemcpyHostToDevice) != hipSuccess) return -1;
+        memcpy(h->h_blk + SOLO_SINGLE_BITS_OFF, bits, (size_t)n0);
+        if (hipMemcpyAsync(h->d_bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n0, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     }
     if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,
                                                                   h->d_status, (hipStream_t)0) != hipSuccess) return -1;
+    // status + decoded packet in one copy, one synchronisation
+    if (hipMemcpyAsync(h->h_blk, h->d_blk, SOLO_SINGLE_PCM_OFF + (size_t)ns * 2, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int32_t ret = 0;
-    if (hipMemcpy(&ret, h->d_status, 4, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    memcpy(&ret, h->h_blk, 4);
     // the reference rewrites the caller's nBytes[] with the low-band lengths (AGR_BWE_decode_frame_FIX.c:150-169)
     int32_t nb0 = (lostflag == 2) ? n0 : n0 - hbb;
     int32_t nb1 = n1 ? n1 - hbb : 0;
@@ -720,7 +739,7 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
     // untouched (the reference leaves whatever its aborted synthesis produced there, which is not defined by its inputs)
     *nSamplesOut = (int16_t)ns;
     if (ret < 0) return ret;
-    if (hipMemcpy(pcm, h->d_pcm, ns * 2, hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    memcpy(pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, (size_t)ns * 2);
     return 0;
 }
 
@@ -754,6 +773,15 @@ int32_t solo_debug_prof(unsigned long long* out32, int32_t reset) {
     if (reset) {
         unsigned long long z[32] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_prof), z, sizeof(z)) != hipSuccess) return -1;
+    }
+    return 0;
+}
+// ... and the histogram of the analysis waves' lifetimes (4 SIMDs x 64 bins of 50 us)
+int32_t solo_debug_hist(unsigned long long* out256, int32_t reset) {
+    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_sx_hist), 256 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (reset) {
+        unsigned long long z[256] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_hist), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
 }

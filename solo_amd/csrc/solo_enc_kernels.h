@@ -41,6 +41,9 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 #ifndef SX_ANALYSIS_WAVES
 #define SX_ANALYSIS_WAVES 5
 #endif
+#ifndef SX_ANALYSIS_PRIO
+#define SX_ANALYSIS_PRIO 3
+#endif
 __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
@@ -51,6 +54,9 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
 #endif
     const int s = blockIdx.x;
     if (s >= n_streams) return;
+    // the same issue priority as the quantiser's wave (solo_nsq16.hip): with the quantiser above the analysis waves the encoder is
+    // 0.5 % slower, below them 18 % (the quantiser starves); the range coder / coding kernels of older chunks stay at 0
+    __builtin_amdgcn_s_setprio(SX_ANALYSIS_PRIO);
 #ifdef SX_EXP_STAGGER     // timing experiment: the waves that share a SIMD start a fraction of a frame apart
     {
         const int q = (blockIdx.x >> SX_EXP_STAGGER_SHIFT) & 3;
@@ -58,6 +64,9 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
     }
 #endif
     SxEncStream* rec = &states[s];
+#if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    const unsigned long long hist_t0_ = wall_clock64();
+#endif
     SX_K(solo_enc_enter)(&w, rec);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
         const size_t pk = (size_t)s * n_packets + p;
@@ -65,6 +74,14 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
         wv_sync();
     }
     SX_K(solo_enc_leave)(&w, rec);
+#if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
+    if (threadIdx.x == 0) {     // histogram of the waves' lifetimes in 50 us bins (100 MHz clock), per SIMD of the CU: g_sx_hist[simd][bin]
+        unsigned hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const unsigned long long dt = wall_clock64() - hist_t0_;
+        const unsigned bin = (unsigned)(dt / 5000u);
+        atomicAdd(&g_sx_hist[(hw >> 4) & 3][bin < 63 ? bin : 63], 1ull);
+    }
+#endif
 }
 
 // Entropy coding, LANE per description: lane l of workgroup g codes description (l & 1) of stream 32 g + (l >> 1).  The coder is a

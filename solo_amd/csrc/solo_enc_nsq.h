@@ -83,11 +83,15 @@ SX_HD i32 sxq_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((
 
 // phase timer of the quantiser (debug builds with -DSX_PROF): per-lane register accumulators, flushed once per frame
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SX_TA_BEGIN unsigned long long ta_acc_[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter();
+#define SX_TA_BEGIN unsigned long long ta_acc_[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter(); \
+    const unsigned long long ta_core0_ = ta_last_, ta_real0_ = wall_clock64();      /* slots 30 / 31: shader-clock and 100 MHz ticks of the whole frame */
 #define SX_TA(id) { const unsigned long long t_ = __builtin_readcyclecounter(); ta_acc_[id] += t_ - ta_last_; ta_last_ = t_; }
-#define SX_TA_END if (threadIdx.x == 0) { for (int q_ = 0; q_ < 14; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]); }
+#define SX_TA_END if (threadIdx.x == 0) { for (int q_ = 0; q_ < 14; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]);                  \
+        atomicAdd(&g_sx_prof[30], __builtin_readcyclecounter() - ta_core0_); atomicAdd(&g_sx_prof[31], wall_clock64() - ta_real0_); }
 #define SX_TA_COUNT(id, n) ta_acc_[id] += (n);
+#define SX_TA_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* attribution only: the wait for the ring cells, apart from the stores after it */
 #else
+#define SX_TA_WAIT_VM
 #define SX_TA_BEGIN
 #define SX_TA(id)
 #define SX_TA_COUNT(id, n)
@@ -291,7 +295,10 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     // the sample loop's own ring traffic (every cell is written once and read once, a decision delay later) with the non-temporal
     // cache policy: 32 MB of ring per 4096 streams otherwise sweep everything else -- the stream histories the subframe prologues
     // wait for -- out of the 32 MB of L2 (measured: 61.3 -> 59.95 ms per 204 800 packets; -DSX_RING_TEMPORAL: the default policy)
-#if defined(__HIP_DEVICE_COMPILE__) && !defined(SX_RING_TEMPORAL)
+#if defined(SX_EXP_NO_RING_LOAD)
+#define SX_CELL_LD(dst_, t_, pos_, slot_) { i32 z_ = 0; SX_OPAQUE(z_); (dst_).xqQ = z_; (dst_).Pred_Q16 = z_; (dst_).Shape_Q10 = z_; (dst_).exc_Q10 = z_; }   /* (timing experiment) */
+#define SX_CELL_ST(t_, pos_, slot_, src_) SX_CELL(t_, pos_, slot_) = (src_);
+#elif defined(__HIP_DEVICE_COMPILE__) && !defined(SX_RING_TEMPORAL)
     typedef int sx_v4i_ __attribute__((ext_vector_type(4)));
     typedef int sx_v3i_ __attribute__((ext_vector_type(3)));
     // (only the centre track's cells carry a fourth word: the other rows move twelve bytes -- a 16-byte load whose last word is
@@ -592,6 +599,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 er[ki] = qr[ki];
                 SX_CELL_LD(qr[ki], SX_N_TRACKS, (last_smple_idx - 2) & SX_DD_MASK, kk)
             }
+            SX_TA(12)
             // phase A: predictions, shaping, residual, dither -- the three tracks of the lane's state
             SX_FORK(kk) {
                 const int ki = SX_KI(kk);
@@ -845,6 +853,9 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
             // that owns the winner's slot of the emitted ring position holds the three cells in its prefetch registers.
             SXQ_ARGMIN(jv, mv, mi)
+            SX_TA(10)
+            SX_TA_WAIT_VM
+            SX_TA(11)
             if (emitted) {
                 SXQ_GATHER(tq, linLo, mi)
                 SXQ_GATHER(gq, linHi, mi)
@@ -857,8 +868,15 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                         for (int t = 0; t < SX_N_TRACKS; t++) {
                             const i32 pv = crossed ? sx_smulww(gadjT[t], em[ki][t].Pred_Q16) : em[ki][t].Pred_Q16;
                             const i32 sv = crossed ? sx_smulww(gadjT[t], em[ki][t].Shape_Q10) : em[ki][t].Shape_Q10;
+#ifndef SX_EXP_NO_EMIT
                             SX_NSQ_EMIT_OUT(t, em[ki][t], pos, sv)
                             SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = pv;
+#else
+                            if (em[ki][t].xqQ == 0x7F123456) {             // (timing experiment: no emission stores)
+                                SX_NSQ_EMIT_OUT(t, em[ki][t], pos, sv)
+                                SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = pv;
+                            }
+#endif
                             const int D = lagT[t] - decisionDelay - (SX_LTP_ORDER / 2 + 1);
                             if ((unsigned)(i + D + 5) < (unsigned)SX_TAPL_N) w->tapL[t][i + D + 5] = pv;
                             if ((unsigned)(i + D + 4) < (unsigned)SX_TAPS_N) w->tapS[t][i + D + 4] = sv;

@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include "solo_enc_nsq.h"
 
+#ifndef SX_NSQ_PRIO
+#define SX_NSQ_PRIO 3
+#endif
 #ifndef SX_NSQ_WAVES
 #define SX_NSQ_WAVES 1
 #endif
@@ -36,7 +39,7 @@ extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64, SX_NSQ_WAVES) S
     if (started && threadIdx.x == 0) atomicAdd(started, 1u);     // lets the host-side pipeline start the next analysis chunk once this kernel is resident
     if (s >= n_streams) return;
     // a latency-bound wave that shares its SIMD with the analysis / coding kernels of neighbouring chunks: issue first
-    __builtin_amdgcn_s_setprio(3);
+    __builtin_amdgcn_s_setprio(SX_NSQ_PRIO);
     // wave-uniform bases + 32-bit lane offsets (solo_enc_nsq.h): the states / records of the wavefront's sixteen streams
     char* Pu = (char*)&states[(size_t)blockIdx.x * SX_PER_WAVE];
     const u32 pOff = (u32)g * (u32)sizeof(SxEncStream) + (u32)offsetof(SxEncStream, nsq);

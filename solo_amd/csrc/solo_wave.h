@@ -225,6 +225,7 @@ SX_HD void wv_move_down(T* dst, const T* src, int n) {
 // optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
 #if defined(SX_PROF) && defined(__HIPCC__)
 static __device__ unsigned long long g_sx_prof[32];
+static __device__ unsigned long long g_sx_hist[4][64];
 #endif
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();
