@@ -99,6 +99,7 @@ struct solo_batch {
     hipEvent_t ev[6];                // decode: 4|D|5  (0..3: unused since the encoder is pipelined)
     int ev_ready, ev_enc, ev_dec;
     // encoder pipeline: the packets of a call go through analysis -> quantiser -> coding in chunks on three streams
+    int achunk;                      // analysis launches cover achunk chunks (env SOLO_ENC_ACHUNK, default 1)
     int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
     hipStream_t sA, sB, sC;
     hipEvent_t evFork, evJoinA[2], evJoinC[2], evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS], evC[SOLO_MAX_CHUNKS];
@@ -494,6 +495,8 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         }
         const char* e = getenv("SOLO_ENC_CHUNK");
         b->chunk_packets = e ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_ACHUNK");
+        b->achunk = (e && atoi(e) > 0) ? atoi(e) : 1;
         e = getenv("SOLO_ENC_GATE");
         // residency gate (hold analysis chunk c + 1 until the quantiser launch of chunk c is resident): needed when the quantiser
         // was 1024 workgroups that had to find room between 4096 analysis workgroups; with 256 quantiser workgroups it costs 3 %
@@ -545,7 +548,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const int G = b->group_streams > 0 ? b->group_streams : b->n_streams;
     const int ngroups = (b->n_streams + G - 1) / G;
     const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
-    int idx = 0;
+    int idx = 0, a_slot = 0;
     hipError_t lerr = hipSuccess;
     for (int g = 0; g < ngroups; g++) {
         const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
@@ -563,11 +566,19 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             const int p0 = cc * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
             if (ngroups == 1 && cc < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
             if (idx > 0 && b->gate) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
-            if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-            if ((lerr = ops->analysis(g_states, g_pcm, ns, n_packets, p0, pc, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
-            if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
-            SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
-            SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
+            // SOLO_ENC_ACHUNK = a > 1: one analysis launch covers a chunks (the stream state is loaded and stored once per launch);
+            // the quantiser / coding launches of those chunks stay chunk-wise and wait for that one launch
+            if (cc % b->achunk == 0) {
+                if (ngroups == 1) for (int q = 1; q < b->achunk && cc + q < nchunks && cc + q < b->evC_valid; q++)
+                    SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[(idx + q) % SOLO_MAX_CHUNKS], 0));
+                const int pa = (p0 + b->achunk * cp <= n_packets) ? b->achunk * cp : n_packets - p0;
+                if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
+                if ((lerr = ops->analysis(g_states, g_pcm, ns, n_packets, p0, pa, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
+                if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
+                SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
+                a_slot = c;
+            } else if (tm) { (void)hipEventRecord(b->tev[0][c][0], b->sA); (void)hipEventRecord(b->tev[0][c][1], b->sA); }
+            SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[a_slot], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
 #ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding -- wrong output
             static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;

@@ -398,6 +398,7 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     SX_PAR(i, SX_FRAME + SX_LA_SHAPE) f->x_buf[i] = hist->x_buf[i];
     SX_PAR(i, SX_FRAME) f->res_pitch[i] = pIn[i];          // res_pitch doubles as the staging buffer of the raw input
     wv_sync();
+    SX_STRETCH_LATENCY();
     sx_vad(st, c, f->res_pitch, f->Wsig, &SNR_dB_Q7);
     wv_sync();
     static_assert(sizeof(f->u) >= SX_HP_SCRATCH_WORDS * sizeof(i32), "the pitch work area doubles as the high-pass filter's scratch");
@@ -484,6 +485,9 @@ struct SxCodeIn {
     i16 hi[SX_BAND];                 // high band of the packet (QMF output) for the BWE encoder
 };
 
+#ifndef SX_EXP_ANALYSIS_FRAMES
+#define SX_EXP_ANALYSIS_FRAMES 2      // (timing experiments: 1 = only the first frame of a packet is analysed -- wrong output)
+#endif
 // Stage A of AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129): QMF split and the analysis chain of both 20 ms frames.
 // Nothing here depends on the quantiser's output (DISABLE_BUF_RD, SKP_Silk_define.h:53), so a whole launch of packets
 // can be analysed before any is quantised.
@@ -491,10 +495,11 @@ SX_FNW void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsq
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SX_T_BEGIN
+    SX_STRETCH_DENSE();
     sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, cin->hi);
     wv_sync();
     SX_T(0)
-    for (int frame = 0; frame < 2; frame++) {
+    for (int frame = 0; frame < SX_EXP_ANALYSIS_FRAMES; frame++) {
         sx_enc_analyse_frame(rec, w, hist->lo + frame * SX_FRAME, frame, &in2[frame], &cin->idx[frame]);
         wv_sync();
     }

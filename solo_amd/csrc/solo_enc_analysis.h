@@ -2180,6 +2180,7 @@ SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
         local_gains[i] = (1 << 16) / invGains_Q16[i];
     }
     wv_sync();
+    SX_STRETCH_DENSE();
     if (c->sigtype == 0) {
         sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15, &w->u.ltp);
         sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_Q8, w->u.vq.rd, w->u.vq.best);
@@ -2203,9 +2204,12 @@ SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     SX_T(17)
     static_assert(sizeof(SxMsvqAux) <= sizeof(i16) * (2 * SX_FRAME + SX_LA_PITCH + SX_PITCH_LPC_WIN), "survivor tables exceed res_pitch + Wsig");
     wv_sync();                                   // (the last readers of res_pitch are done)
+    SX_STRETCH_LATENCY();
     sx_process_NLSFs(st, c, NLSF_Q15, &w->u.msvq, (SxMsvqAux*)(void*)res_pitch);
     SX_T(19)
+    SX_STRETCH_DENSE();
     sx_residual_energy(c->ResNrg, c->ResNrgQ, w->LPC_in_pre, c->PredCoef_Q12, local_gains, w->LPC_res);
+    SX_STRETCH_LATENCY();
     SX_T(20)
     for (int i = 0; i < SX_LPC; i++) st->prev_NLSFq_Q15[i] = NLSF_Q15[i];
 }

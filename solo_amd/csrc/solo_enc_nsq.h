@@ -83,10 +83,10 @@ SX_HD i32 sxq_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((
 
 // phase timer of the quantiser (debug builds with -DSX_PROF): per-lane register accumulators, flushed once per frame
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
-#define SX_TA_BEGIN unsigned long long ta_acc_[14] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter(); \
+#define SX_TA_BEGIN unsigned long long ta_acc_[20] = {0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0}; unsigned long long ta_last_ = __builtin_readcyclecounter(); \
     const unsigned long long ta_core0_ = ta_last_, ta_real0_ = wall_clock64();      /* slots 30 / 31: shader-clock and 100 MHz ticks of the whole frame */
 #define SX_TA(id) { const unsigned long long t_ = __builtin_readcyclecounter(); ta_acc_[id] += t_ - ta_last_; ta_last_ = t_; }
-#define SX_TA_END if (threadIdx.x == 0) { for (int q_ = 0; q_ < 14; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]);                  \
+#define SX_TA_END if (threadIdx.x == 0) { for (int q_ = 0; q_ < 20; q_++) atomicAdd(&g_sx_prof[q_], ta_acc_[q_]);                  \
         atomicAdd(&g_sx_prof[30], __builtin_readcyclecounter() - ta_core0_); atomicAdd(&g_sx_prof[31], wall_clock64() - ta_real0_); }
 #define SX_TA_COUNT(id, n) ta_acc_[id] += (n);
 #define SX_TA_WAIT_VM asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       /* attribution only: the wait for the ring cells, apart from the stores after it */
@@ -120,6 +120,13 @@ struct alignas(16) SxNsqWork {       // LDS, per stream
     i32 tapL[SX_N_TRACKS][SX_TAPL_N];                     // long-term prediction history (sLTP_Q16)
     i32 tapS[SX_N_TRACKS][SX_TAPS_N];                     // shaping history (sLTP_shp_Q10)
     i16 x[SX_FRAME];                 // prefiltered input of the frame (staged from the hand-over record)
+    // Gain-adjustment factors of the last eight subframe starts, per track: [0, 4) the previous frame's, [4, 8) this frame's
+    // (65536 where the gain did not change), and this frame's pitch lags.  The reference rescales its history arrays at every
+    // subframe start (SKP_Silk_nsq_del_dec_scale_states); here the histories in HBM are written ONCE, unscaled, and a history entry
+    // receives the factors of the subframe starts that lie between its own subframe and the one that stages it when it is staged
+    // into a tap window: no read-modify-write pass over the histories, no memory round trips for it in the subframe prologue.
+    i32 gfac[SX_N_TRACKS][2 * SX_NB_SUBFR];
+    i32 lagk[SX_NB_SUBFR];
 #if SX_NLANES == 1
     SxNsqCell ring_emu[SX_NSQ_RING_CELLS(4)];             // host emulation: the emission ring of the one stream
 #endif
@@ -189,60 +196,6 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 #define SX_LAMBDA_INLINE
 #endif
 #define SX_MLP 8
-SX_HD void sx_scale_q16(i32* p, int n, i32 gain_adj_Q16) {       // p[i] = SMULWW(gain_adj, p[i]), i < n
-    for (int base = SX_LANE; base < n; base += SX_MLP * SX_NLANES) {
-        i32 v[SX_MLP];
-#pragma unroll
-        for (int u = 0; u < SX_MLP; u++) { const int i = base + u * SX_NLANES; v[u] = i < n ? p[i] : 0; }
-#pragma unroll
-        for (int u = 0; u < SX_MLP; u++) { const int i = base + u * SX_NLANES; if (i < n) p[i] = sx_smulww(gain_adj_Q16, v[u]); }
-    }
-}
-// SKP_Silk_nsq_del_dec_scale_states for the HBM histories of the three tracks at once: the SX_FRAME newest shaping-history entries
-// (16-byte aligned rows) and, unless the prediction history was just re-whitened, its newest m entries; ch[t]: the gain of track t changed.
-// All loads of a pass are issued before the first store.
-SX_HD void sx_scale_histories(SxNsqGlobal* g, int shp_first, int pred_first, int m, const i32* gadj, const bool* ch) {
-#if SX_NLANES == 1
-    for (int t = 0; t < SX_N_TRACKS; t++) {
-        if (!ch[t]) continue;
-        for (int i = 0; i < SX_FRAME; i++) g->shp[t][shp_first + i] = sx_smulww(gadj[t], g->shp[t][shp_first + i]);
-        for (int i = 0; i < m; i++) g->sLTP_Q16[t][pred_first + i] = sx_smulww(gadj[t], g->sLTP_Q16[t][pred_first + i]);
-    }
-#else
-    // one track at a time: ten 16-byte loads + up to sixteen dword loads per lane in flight (the quantiser's own state fills most of
-    // the register file; larger batches spill)
-#pragma unroll
-    for (int t = 0; t < SX_N_TRACKS; t++) {
-        if (!ch[t]) continue;
-        constexpr int NV = SX_FRAME / 4, PER = (NV + SX_NLANES - 1) / SX_NLANES;
-        SxV4 v[PER];
-        SxV4* q = (SxV4*)&g->shp[t][shp_first];
-        i32 vl[16];
-#pragma unroll
-        for (int u = 0; u < PER; u++) { const int i = SX_LANE + u * SX_NLANES; if (i < NV) v[u] = q[i]; }
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int i = SX_LANE + u * SX_NLANES; if (i < m) vl[u] = g->sLTP_Q16[t][pred_first + i]; }
-#pragma unroll
-        for (int u = 0; u < PER; u++) {
-            const int i = SX_LANE + u * SX_NLANES;
-            if (i < NV) {
-#pragma unroll
-                for (int e = 0; e < 4; e++) v[u].v[e] = sx_smulww(gadj[t], v[u].v[e]);
-                q[i] = v[u];
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 16; u++) { const int i = SX_LANE + u * SX_NLANES; if (i < m) g->sLTP_Q16[t][pred_first + i] = sx_smulww(gadj[t], vl[u]); }
-        for (int base = SX_LANE + 16 * SX_NLANES; base < m; base += 8 * SX_NLANES) {       // (pitch lags above 62 samples)
-            i32 w8[8];
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = base + u * SX_NLANES; if (i < m) w8[u] = g->sLTP_Q16[t][pred_first + i]; }
-#pragma unroll
-            for (int u = 0; u < 8; u++) { const int i = base + u * SX_NLANES; if (i < m) g->sLTP_Q16[t][pred_first + i] = sx_smulww(gadj[t], w8[u]); }
-        }
-    }
-#endif
-}
 SX_HD void sx_copy_v4(SxV4* dst, const SxV4* src, int n) {       // n 16-byte elements, dst below src
     for (int base = SX_LANE; base < n; base += SX_MLP * SX_NLANES) {
         SxV4 v[SX_MLP];
@@ -364,6 +317,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         i32* xd = (i32*)w->x;
 #pragma unroll 8
         SX_PAR(i, SX_FRAME / 2) xd[i] = xs[i];
+        SX_PAR(i, SX_N_TRACKS * SX_NB_SUBFR) {
+            const int t = i / SX_NB_SUBFR, kq = i - t * SX_NB_SUBFR;
+            w->gfac[t][kq] = P->nsq[t].gadjPrev[kq];
+            w->gfac[t][SX_NB_SUBFR + kq] = 65536;
+        }
+        SX_PAR(i, SX_NB_SUBFR) w->lagk[i] = c->pitchL[i];
         SX_FORK(k) {
             const int ki = SX_KI(k);
             Seed2[ki] = SeedInit2[ki] = (k + c->Seed) & 3;
@@ -393,6 +352,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     }
     int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
     int subfr = 0;
+    int rewhite_k = 0;                                          // the subframe whose start last re-whitened the prediction history
 
     // MD gain split (md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1401-1417)
     const i32 inv_gain_p1_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
@@ -412,15 +372,33 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         else SX_AT(i8, Ou, oQ + (u32)(((t_)-1) * SX_FRAME + (pos_))) = (i8)((cell_).xqQ >> 16);                              \
         SX_AT(i16, Pu, pXq + (u32)((t_) * 2 * SX_FRAME + SX_FRAME + (pos_)) * 2u) = (i16)(cell_).xqQ;                        \
         SX_AT(i32, Pu, pShp + (u32)((t_) * (2 * SX_FRAME + 8) + SX_FRAME + (pos_)) * 4u) = (shape_);                         \
+        SX_NSQ_EMIT_PREV(t_, cell_, pos_, shape_)                                                                            \
     }
+    // The two histories that the reference shifts down by a frame when the frame ends (the quantised signal and the shaping history)
+    // get every emitted sample twice: at its place in the current-frame half and at the same place of the previous-frame half, which
+    // is what the shift would copy there (the entries are written once and never modified: the gain factors are applied when they are
+    // staged).  No reader of this frame reaches the overwritten entries any more: a window / re-whitening run of subframe k starts at
+    // FRAME + k SUBFR - lag - 12 at the earliest, > k SUBFR, and the entries below k SUBFR - decisionDelay are the ones rewritten.
+#ifndef SX_NSQ_SHIFT_COPY
+#define SX_NSQ_EMIT_PREV(t_, cell_, pos_, shape_)                                                                            \
+        SX_AT(i16, Pu, pXq + (u32)((t_) * 2 * SX_FRAME + (pos_)) * 2u) = (i16)(cell_).xqQ;                                   \
+        SX_AT(i32, Pu, pShp + (u32)((t_) * (2 * SX_FRAME + 8) + (pos_)) * 4u) = (shape_);
+#else
+#define SX_NSQ_EMIT_PREV(t_, cell_, pos_, shape_)
+#endif
 
     for (int k = 0; k < SX_NB_SUBFR; k++) {
-        const i16* A_Q12 = c->PredCoef_Q12[(k >> 1) | (1 - LSF_interpolation_flag)];
-        const i16* B_Q14 = &c->LTPCoef_Q14[k * SX_LTP_ORDER];
-        const i16* AR_shp_Q13 = &c->AR2_Q13[k * SX_SHAPE_ORDER];
-        i32 HarmShapeFIRPacked_Q14 = c->HarmShapeGain_Q14[k] >> 2;
-        HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[k] >> 1, 16);
-        const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k], Gain_Q16 = c->Gains_Q16[k];
+#ifdef SX_EXP_COEF_K0            // (timing experiments only: every subframe reads subframe 0's coefficients -- cache hits)
+        const int kx = 0;
+#else
+        const int kx = k;
+#endif
+        const i16* A_Q12 = c->PredCoef_Q12[(kx >> 1) | (1 - LSF_interpolation_flag)];
+        const i16* B_Q14 = &c->LTPCoef_Q14[kx * SX_LTP_ORDER];
+        const i16* AR_shp_Q13 = &c->AR2_Q13[kx * SX_SHAPE_ORDER];
+        i32 HarmShapeFIRPacked_Q14 = c->HarmShapeGain_Q14[kx] >> 2;
+        HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[kx] >> 1, 16);
+        const i32 Tilt_Q14 = c->Tilt_Q14[kx], LF_shp_Q14 = c->LF_shp_Q14[kx], Gain_Q16 = c->Gains_Q16[kx];
         // filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form; the same for the
         // three tracks and the four states of the stream
         i32 Apre[SX_LPC], ARpre[SX_SHAPE_ORDER], Bpre[SX_LTP_ORDER];
@@ -442,6 +420,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         for (int j = 0; j < SX_LTP_ORDER; j++) SX_OPAQUE(Bpre[j]);
         SX_OPAQUE(Tilt_pre); SX_OPAQUE(LFb_pre); SX_OPAQUE(LFt_pre); SX_OPAQUE(Hb_pre); SX_OPAQUE(Ht_pre);
         int rewhite = 0;
+        SX_TA(13)
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
         inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
         i32 inv_gain_Q32 = sx_shl(inv_gain_Q16, 16);                    // scale_states, NSQ_del_dec.c:1611-1616
@@ -482,6 +461,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     }
                     wv_sync();
                 }
+                SX_TA(14)
                 // re-whiten the quantised signal with the new LPC (SKP_Silk_MA_Prediction from a zero state)
                 const int lag = lagT[0];
                 const int start_idx = SX_FRAME - lag - SX_LPC - SX_LTP_ORDER / 2;
@@ -492,7 +472,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 i32 Ac[SX_LPC];
 #pragma unroll
                 for (int j = 0; j < SX_LPC; j++) Ac[j] = A_Q12[j];
+#ifdef SX_EXP_SKIP_REWHITE
+                for (int t = 0; t < 0; t++) {
+#else
                 for (int t = 0; t < SX_N_TRACKS; t++) {
+#endif
                     const i16* in = &P->xq[t][start_idx + k * SX_SUBFR];
                     i32 h[SX_LPC];                                     // h[j] = in[n - 1 - j], zero before the start (zero initial state)
 #pragma unroll
@@ -504,8 +488,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                         for (int j = 0; j < SX_LPC; j++) acc = sx_smlabb(acc, h[j], Ac[j]);
                         const i32 xin = in[n];
                         i32 o = sx_rshift_round(sx_sub(sx_shl(xin, 12), acc), 12);
-                        // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[])
-                        g->sLTP_Q16[t][start_idx + n] = sx_smulwb(inv_gain_Q32, sx_sat16(o));
+                        // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[]) -- and into
+                        // this subframe's tap window, which covers [FRAME - lag - 2, FRAME) of it
+                        const i32 rw = sx_smulwb(inv_gain_Q32, sx_sat16(o));
+                        g->sLTP_Q16[t][start_idx + n] = rw;
+                        const int wi = n - SX_LPC;                            // = (start_idx + n) - (FRAME - lag - LTP_ORDER / 2)
+                        if ((unsigned)wi < (unsigned)SX_TAPL_N) w->tapL[t][wi] = rw;
 #pragma unroll
                         for (int j = SX_LPC - 1; j > 0; j--) h[j] = h[j - 1];
                         h[0] = xin;
@@ -513,9 +501,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 }
                 sLTP_buf_idx = SX_FRAME;
                 rewhite = 1;
-                wv_sync();
+                rewhite_k = k;
+                SX_TA(15)
             }
         }
+        SX_TA(13)
         // SKP_Silk_nsq_del_dec_scale_states (NSQ_del_dec.c:1593).  The ring cells are NOT rescaled here: gadjT[] is applied to the
         // cells of the previous subframe when (and if) they are emitted.
         i32 gadjT[SX_N_TRACKS];
@@ -541,10 +531,17 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 }
                 prevInv[t] = inv_gain_Q16;
             }
-            const int m = rewhite ? 0 : c->pitchL[k] + SX_LTP_ORDER / 2;
-            sx_scale_histories(g, sLTP_shp_buf_idx - SX_FRAME, sLTP_buf_idx - m, m, gadjT, gch);
-            wv_sync();
+            // (the histories in HBM are not rescaled: the factors are recorded and applied when history entries are staged, below)
+            SX_FORK(kk) {
+                if (kk == 0) {
+#pragma unroll
+                    for (int t = 0; t < SX_N_TRACKS; t++) w->gfac[t][SX_NB_SUBFR + k] = gadjT[t];
+                }
+            }
+            (void)gch;
+            wv_sync();                                    // factors visible; the emission stores of the previous subframe have landed
         }
+        SX_TA(16)
 
         // ---- the per-sample trellis (SKP_Silk_md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1341) ----
         const int odd = subfr & 1;
@@ -562,17 +559,55 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         }
         {
             constexpr int NL = (SX_TAPL_N + SX_NLANES - 1) / SX_NLANES, NS = (SX_TAPS_N + SX_NLANES - 1) / SX_NLANES;
+            // A history entry is stored once, unscaled.  What the reference's rescaling passes would have done to it by now is applied
+            // here, in the reference's order (every smulww rounds): the factor of subframe start j for every j between the entry's own
+            // subframe and this one -- shaping history: the newest SX_FRAME entries are rescaled at every start, so all of them
+            // (an entry that a tap can reach is at most four subframes old); prediction history: only the newest lag_j + 2 entries
+            // are, and only at starts that did not re-whiten it.
 #pragma unroll
             for (int t = 0; t < SX_N_TRACKS; t++) {               // per track: all loads of the lane first, then the LDS writes
                 i32 vl[NL], vs[NS];
-                const i32* srcL = &g->sLTP_Q16[t][pred_base - lagT[t] - SX_LTP_ORDER / 2];     // tap j of iteration i sits at srcL[i - j + 4]
-                const i32* srcS = &g->shp[t][shp_base - lagT[t] - 1];                          // tap j of iteration i sits at srcS[i - j + 2]
+                const int iL0 = pred_base - lagT[t] - SX_LTP_ORDER / 2, iS0 = shp_base - lagT[t] - 1;
+                const i32* srcL = &g->sLTP_Q16[t][iL0];                                        // tap j of iteration i sits at srcL[i - j + 4]
+                const i32* srcS = &g->shp[t][iS0];                                             // tap j of iteration i sits at srcS[i - j + 2]
+                const bool stageL = voiced && !rewhite;          // (a re-whitening start has just written its window itself)
 #pragma unroll
-                for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; vl[u] = (voiced && n < SX_TAPL_N) ? srcL[n] : 0; }
+                for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; vl[u] = (stageL && n < SX_TAPL_N) ? srcL[n] : 0; }
 #pragma unroll
                 for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; vs[u] = (lagC > 0 && n < SX_TAPS_N) ? srcS[n] : 0; }
+                if (stageL) {
 #pragma unroll
-                for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = vl[u]; }
+                    for (int u = 0; u < NL; u++) {
+                        const int n = SX_LANE + u * SX_NLANES, idx = iL0 + n;
+                        const int ep = idx < SX_FRAME ? rewhite_k : rewhite_k + (idx - SX_FRAME) / SX_SUBFR;      // the entry's own subframe
+#pragma unroll
+                        for (int j = 1; j < SX_NB_SUBFR; j++) {
+                            const bool ap = (j > rewhite_k) & (j <= k) & (j > ep) & (idx >= SX_FRAME + SX_SUBFR * (j - rewhite_k) - (w->lagk[j] + SX_LTP_ORDER / 2));
+                            const i32 sc = sx_smulww(w->gfac[t][SX_NB_SUBFR + j], vl[u]);
+                            vl[u] = ap ? sc : vl[u];
+                        }
+                    }
+                }
+                if (lagC > 0) {
+#pragma unroll
+                    for (int u = 0; u < NS; u++) {
+                        const int n = SX_LANE + u * SX_NLANES, idx = iS0 + n;
+                        const int r = idx / SX_SUBFR - SX_NB_SUBFR;                    // the entry's subframe relative to this frame: -4 .. 3
+#pragma unroll
+                        for (int d = SX_NB_SUBFR - 1; d >= 0; d--) {                   // subframe starts k - 3 .. k, in time order
+                            const int j = k - d;
+                            const i32 sc = sx_smulww(w->gfac[t][SX_NB_SUBFR + j], vs[u]);
+                            vs[u] = (j > r) ? sc : vs[u];
+                        }
+                    }
+                }
+                if (stageL) {
+#pragma unroll
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = vl[u]; }
+                } else if (!voiced) {
+#pragma unroll
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = 0; }
+                }
 #pragma unroll
                 for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPS_N) w->tapS[t][n] = vs[u]; }
             }
@@ -868,15 +903,10 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                         for (int t = 0; t < SX_N_TRACKS; t++) {
                             const i32 pv = crossed ? sx_smulww(gadjT[t], em[ki][t].Pred_Q16) : em[ki][t].Pred_Q16;
                             const i32 sv = crossed ? sx_smulww(gadjT[t], em[ki][t].Shape_Q10) : em[ki][t].Shape_Q10;
-#ifndef SX_EXP_NO_EMIT
-                            SX_NSQ_EMIT_OUT(t, em[ki][t], pos, sv)
-                            SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = pv;
-#else
-                            if (em[ki][t].xqQ == 0x7F123456) {             // (timing experiment: no emission stores)
-                                SX_NSQ_EMIT_OUT(t, em[ki][t], pos, sv)
-                                SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = pv;
-                            }
-#endif
+                            // (HBM gets the cell as it is -- it belongs to the previous subframe, this start's factor reaches it when
+                            // it is staged --, this subframe's windows get it with the factor applied)
+                            SX_NSQ_EMIT_OUT(t, em[ki][t], pos, em[ki][t].Shape_Q10)
+                            SX_AT(i32, Pu, pLtp + (u32)(t * 2 * SX_FRAME + pred_base + i - decisionDelay) * 4u) = em[ki][t].Pred_Q16;
                             const int D = lagT[t] - decisionDelay - (SX_LTP_ORDER / 2 + 1);
                             if ((unsigned)(i + D + 5) < (unsigned)SX_TAPL_N) w->tapL[t][i + D + 5] = pv;
                             if ((unsigned)(i + D + 4) < (unsigned)SX_TAPS_N) w->tapS[t][i + D + 4] = sv;
@@ -979,21 +1009,26 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 n->sLF_AR_shp_Q12 = LF_AR[ki][t];
                 n->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
                 n->prev_inv_gain_Q16 = prevInv[t];
+#pragma unroll
+                for (int kq = 0; kq < SX_NB_SUBFR; kq++) n->gadjPrev[kq] = w->gfac[t][SX_NB_SUBFR + kq];
             }
         }
     }
     wv_sync();
     // the current frame becomes the history of the next one (16-byte moves; the upper half keeps its values: the reference's
     // memcpy does the same)
+#ifdef SX_NSQ_SHIFT_COPY          // (the reference's way: a copy pass when the frame ends; the default writes both halves at emission)
 #pragma unroll
     for (int t = 0; t < SX_N_TRACKS; t++) {
         sx_copy_v4((SxV4*)&g->shp[t][0], (const SxV4*)&g->shp[t][SX_FRAME], SX_FRAME / 4);
         sx_copy_v4((SxV4*)&P->xq[t][0], (const SxV4*)&P->xq[t][SX_FRAME], SX_FRAME / 8);
     }
+#endif
     wv_sync();
     SX_TA(9)
     SX_TA_END
 #undef SX_NSQ_EMIT_OUT
+#undef SX_NSQ_EMIT_PREV
 #undef SX_CELL
 #undef SX_CELL_LD
 #undef SX_CELL_ST

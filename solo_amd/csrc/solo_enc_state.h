@@ -39,6 +39,8 @@ struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:4
     i32 sLF_AR_shp_Q12;
     i32 lagPrev;
     i32 prev_inv_gain_Q16;
+    i32 gadjPrev[SX_NB_SUBFR];       // gain-adjustment factors of the previous frame's four subframe starts (65536 = none): the history
+                                     // arrays are stored unscaled, the factors are applied when history is staged (solo_enc_nsq.h)
 };
 
 // Compact per-stream encoder state: loaded into LDS when a launch starts, written back when it ends.
@@ -164,7 +166,10 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
         st->vad.NrgRatioSmth_Q8[b] = 100 * 256;
     }
     st->vad.counter = 15;
-    for (int t = 0; t < SX_N_TRACKS; t++) rec->nsq.nsq[t].prev_inv_gain_Q16 = 65536;
+    for (int t = 0; t < SX_N_TRACKS; t++) {
+        rec->nsq.nsq[t].prev_inv_gain_Q16 = 65536;
+        for (int k = 0; k < SX_NB_SUBFR; k++) rec->nsq.nsq[t].gadjPrev[k] = 65536;
+    }
     // setup_fs_FIX (control_codec_FIX.c:232): only the CENTRE nsq state gets lagPrev = 100
     st->prevLag = 100;
     st->prev_sigtype = 1;

@@ -12,6 +12,9 @@
 #include <hip/hip_runtime.h>
 #include "solo_enc_nsq.h"
 
+#ifndef SX_EXP_NSQ_FRAMES
+#define SX_EXP_NSQ_FRAMES 2          // (timing experiments: 1 = only the first frame of a packet is quantised -- wrong output)
+#endif
 #ifndef SX_NSQ_PRIO
 #define SX_NSQ_PRIO 3
 #endif
@@ -46,7 +49,7 @@ extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64, SX_NSQ_WAVES) S
     const u32 rec_stride = (u32)n_packets * 2u;                     // hand-over records between consecutive streams
     SxNsqCell* rgu = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS(64);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
-        for (int f = 0; f < 2; f++) {
+        for (int f = 0; f < SX_EXP_NSQ_FRAMES; f++) {
             const size_t r0 = ((size_t)blockIdx.x * SX_PER_WAVE * n_packets + p) * 2 + f;       // record of the wavefront's first stream
             sx_nsq_del_dec(Pu, pOff, &in[r0 + (size_t)g * rec_stride], (char*)&out[r0], (u32)g * rec_stride * (u32)sizeof(SxNsqOut), &w[g], rgu,
                            (u32)(g * SX_GROUP), 64);

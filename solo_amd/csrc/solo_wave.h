@@ -222,6 +222,26 @@ SX_HD void wv_move_down(T* dst, const T* src, int n) {
     }
 }
 
+// Issue priority of the wave inside its SIMD.  The arbiter serves the waves of a SIMD in a fixed order: a wave that runs a dense chain
+// of dependent vector instructions has one ready almost every time the vector unit frees up and keeps the unit; the occasional vector
+// instruction of a wave in a latency-bound stretch (address arithmetic between LDS / memory round trips, lane-serial recursions) then
+// waits for the dense stretch to END, so that one wave's waiting time does not hide the others' arithmetic (tools/debug/mb_overlap.hip:
+// two waves alternating 1200 cycles of dependent v_mul_hi / v_add with 1200 cycles of dependent LDS reads take 3350 cycles per round,
+// 2460 when the LDS stretch raises its priority).  The stages of the analysis chain therefore say which kind they are.
+#if defined(__HIP_DEVICE_COMPILE__)
+#ifndef SX_PRIO_LAT
+#define SX_PRIO_LAT 3
+#endif
+#ifndef SX_PRIO_DENSE
+#define SX_PRIO_DENSE 3
+#endif
+#define SX_STRETCH_LATENCY() __builtin_amdgcn_s_setprio(SX_PRIO_LAT)
+#define SX_STRETCH_DENSE() __builtin_amdgcn_s_setprio(SX_PRIO_DENSE)
+#else
+#define SX_STRETCH_LATENCY()
+#define SX_STRETCH_DENSE()
+#endif
+
 // optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
 #if defined(SX_PROF) && defined(__HIPCC__)
 static __device__ unsigned long long g_sx_prof[32];

@@ -7,9 +7,10 @@ import torch, solo_amd
 from solo_amd.synth import synth_batch
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 P = int(sys.argv[2]) if len(sys.argv) > 2 else 10
-NAMES = {1: "setup / subframe prologue / frame end", 2: "A predict+shape+residual (3 tracks)", 3: "B+C candidates (in-lane)", 4: "E judge: winner, expiry",
+NAMES = {1: "frame setup + prologue: tap windows to LDS + frame end", 2: "A predict+shape+residual (3 tracks)", 3: "B+C candidates (in-lane)", 4: "E judge: winner, expiry",
          5: "E replace-worst-by-best rounds (index registers)", 6: "survivor gather (bpermute)", 7: "F emit (stores)", 8: "G update + tap rotation", 9: "frame epilogue",
-         10: "D undo + joint winner", 11: "wait for the ring cells of this sample (vmcnt 0)", 12: "ring refill requests (4 loads)"}
+         10: "D undo + joint winner", 11: "wait for the ring cells of this sample (vmcnt 0)", 12: "ring refill requests (4 loads)",
+         13: "prologue: coefficients, gains", 14: "prologue: flush of the winner's lineage (k = 2)", 15: "prologue: re-whitening", 16: "prologue: history rescaling"}
 b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
 pcm = torch.from_numpy(synth_batch(0, N, P)).cuda()
 b.encode(pcm); torch.cuda.synchronize()

@@ -23,6 +23,7 @@ for p in $PASSES; do
     inst)  ARGS="--pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES" ;;
     lane)  ARGS="--pmc SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_WAVE_CYCLES" ;;
     icache) ARGS="--pmc SQC_ICACHE_REQ SQC_ICACHE_HITS SQC_ICACHE_MISSES SQC_ICACHE_MISSES_DUPLICATE SQ_IFETCH SQ_INSTS_BRANCH" ;;
+    lds)   ARGS="--pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_INSTS_VALU_INT32 SQ_INSTS_VALU_INT64 GRBM_GUI_ACTIVE" ;;
     scalar) ARGS="--pmc SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_SMEM SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_WAVE_CYCLES" ;;
     *) echo "unknown pass $p"; continue ;;
   esac
