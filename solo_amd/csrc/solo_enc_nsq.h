@@ -113,7 +113,7 @@ struct alignas(16) SxNsqCell {
 #define SX_NSQ_RING_ROWS (SX_N_TRACKS + 1)                   // per ring position: one row of cells per track + one row of random states
 #define SX_NSQ_RING_CELLS(stride) (SX_NSQ_RING_ROWS * SX_DD_DELAY * (stride))      // cells of one ring with `stride` lanes per row
 
-struct alignas(16) SxNsqWork {       // LDS, per stream
+struct alignas(16) SxNsqWorkBody {   // LDS, per stream
     // Tap windows of the current subframe, per track: the history entries the subframe's taps can reach, staged from HBM when the
     // subframe starts; a sample emitted during the subframe is also written to its place in the window.  Tap j of iteration i is
     // then ONE LDS read at a fixed place: tapL[i - j + 4] / tapS[i - j + 2].
@@ -131,6 +131,21 @@ struct alignas(16) SxNsqWork {       // LDS, per stream
     SxNsqCell ring_emu[SX_NSQ_RING_CELLS(4)];             // host emulation: the emission ring of the one stream
 #endif
 };
+// The sixteen streams of a wavefront read the same member of their own SxNsqWork in one LDS instruction (the four lanes of a stream the
+// same word): conflict-free when the stride between the records, in words, is 4 x an odd number modulo the 64 banks (16 records -> 16
+// different groups of 4 banks).  A stride of 368 words (48 mod 64) put the sixteen streams on FOUR banks: 21 % of the quantiser's LDS
+// cycles were bank conflicts (SQ_LDS_BANK_CONFLICT, profiles/r03_bench_v2 before the padding).
+constexpr int sx_nsq_work_pad_words(int body_words) {
+    int pad = 0;
+    while ((body_words + pad) % 4 != 0 || ((body_words + pad) % 64) % 8 != 4) pad++;
+    return pad;
+}
+#if SX_NLANES == 1
+struct alignas(16) SxNsqWork : SxNsqWorkBody {};
+#else
+struct alignas(16) SxNsqWork : SxNsqWorkBody { i32 pad_[sx_nsq_work_pad_words((int)(sizeof(SxNsqWorkBody) / 4))]; };
+static_assert(((sizeof(SxNsqWork) / 4) % 64) % 8 == 4 && sizeof(SxNsqWork) % 16 == 0, "LDS stride of the per-stream records");
+#endif
 
 // SMULWW(x, INTERNAL_JOINT_LAMBDA) = (x * 90000) >> 16 with 90000 = 65536 + 24464: x + SMULWB(x, 24464), exactly (the first
 // part of the product is a multiple of 65536) -- one high-word multiply instead of a 64-bit product

@@ -32,7 +32,7 @@ for r in csv.DictReader(open(st)):
                                                         "min_ms": float(r["MinNs"]) / 1e6, "max_ms": float(r["MaxNs"]) / 1e6,
                                                         "percent": float(r["Percentage"])}
     lines.append(",".join([name[:60], r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"]]))
-for d in ("fetch", "write", "sq", "inst", "lane"):
+for d in ("fetch", "write", "sq", "inst", "lane", "lds"):
     f = os.path.join(src, d, "r01_counter_collection.csv")
     if not os.path.exists(f):
         continue
