@@ -1876,6 +1876,12 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
 // ---------------------------------------------------------------------------------------------------
 // NLSF MSVQ
 // ---------------------------------------------------------------------------------------------------
+// 16 kHz internal rate: the codebooks are 7.3 KB (216 vectors of 16) and would be most of the analysis kernel's LDS; they are read
+// from the tables where they lie instead (the same few KB for every stream: cache hits), which takes the workgroup from 16.0 to
+// 12 KB = two resident rounds of a compute unit's sixteen streams beside the quantiser instead of three
+#ifndef SX_MSVQ_CB_IN_LDS
+#define SX_MSVQ_CB_IN_LDS (SX_FS_KHZ == 8)
+#endif
 struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 vectors per later stage; 64 in stage 0)
 #if SX_NLANES == 1
     i32 RateDist_Q18[256];
@@ -1884,7 +1890,9 @@ struct SxMsvqWork {                   // LDS scratch (16 survivors x up to 16 ve
     i32 RateDist_Q18[16];
 #endif
     i32 Sorted_Q18[16];
+#if SX_MSVQ_CB_IN_LDS
     i16 cb[SX_NLSF_CB_MAXVEC * SX_LPC], rates[SX_NLSF_CB_MAXVEC];   // the signal type's codebook and rate table, staged from HBM once per frame
+#endif
     i32 ndelta[SX_LPC + 2], nvec[SX_NLSF_STAGES];
     i32 W_Q6[SX_MAX_LPC];             // NLSF weights (read by every lane of the rate-distortion search)
     i32 NLSF0[SX_MAX_LPC], W0_Q6[SX_MAX_LPC];
@@ -1931,20 +1939,27 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
     const i32* nvec = w->nvec;
     const int nStages = SX_NLSF_STAGES, S = SX_MSVQ_SURVIVORS;
     {   // stage the codebook of this signal type in LDS (32-bit words, coalesced)
+        const i32* gnd = sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15;
+#if SX_MSVQ_CB_IN_LDS
         const u32* gcb = (const u32*)(sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15);
         const u32* grt = (const u32*)(sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5);
-        const i32* gnd = sigtype == 0 ? T_nlsf_cb0_ndelta_min_Q15 : T_nlsf_cb1_ndelta_min_Q15;
         const int nv = sigtype == 0 ? SX_NLSF_CB0_NVEC_TOTAL : SX_NLSF_CB1_NVEC_TOTAL;
         u32* lcb = (u32*)w->cb;
         u32* lrt = (u32*)w->rates;
         SX_PAR(i, nv * SX_LPC / 2) lcb[i] = gcb[i];
         SX_PAR(i, nv / 2) lrt[i] = grt[i];
+#endif
         SX_PAR(i, SX_LPC + 1) w->ndelta[i] = gnd[i];
         SX_PAR(i, SX_NLSF_STAGES) w->nvec[i] = sigtype == 0 ? nvec0[i] : nvec1[i];
         wv_sync();
     }
+#if SX_MSVQ_CB_IN_LDS
     const i16* cb = w->cb;
     const i16* rates = w->rates;
+#else
+    const i16* cb = (const i16*)(sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15);
+    const i16* rates = (const i16*)(sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5);
+#endif
     SX_PAR(i, S) x->Rate_Q5[i] = 0;
     SX_PAR(i, SX_LPC) w->Res_Q15[i] = pNLSF_Q15[i];
     wv_sync();
