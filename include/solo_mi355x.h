@@ -116,6 +116,23 @@ int32_t solo_batch_decode(solo_batch_t *b, const uint8_t *d_bits, const int16_t 
 int32_t solo_batch_decode_split(solo_batch_t *b, const uint8_t *d_descA, const int16_t *d_lenA, const uint8_t *d_descB,
                                 const int16_t *d_lenB, int32_t slot_bytes, int32_t n_packets, int16_t *d_pcm,
                                 int32_t *d_status, void *hip_stream);
+/* Receiver staging ring: the "cache queue" of README.md:52-58 (imag/solo_neteq.png) kept in device memory for all streams of the
+ * handle.  solo_recv_create: queue of `depth` sequence numbers per stream (1..4096), `slot_bytes` per description (<= 32767), every
+ * stream's play-out position at `first_seq` (>= 0); calling it again empties the queue.  solo_recv_insert files n arrivals in any
+ * order: stream, sequence number of the 40 ms packet, desc = 0 (MD1) / 1 (MD2 || HB) when the transport knows which description it
+ * carries, -1 when it does not (the library reads the index the description carries as its first coded symbol: needs
+ * useMDIndex = 1), payload = d_payload[offset .. offset + len).  An arrival for a packet that has been played, that lies `depth` or
+ * more ahead, whose slot is taken (a second copy) or whose fields are out of range is dropped and counted.  solo_recv_decode decodes the
+ * next n_packets (<= depth) sequence numbers of EVERY stream from what has arrived by then (the merge and the (ptr, nBytes, lostflag)
+ * mapping of solo_batch_decode_split; nothing arrived = concealment), frees those entries and advances the play-out positions.
+ * d_pcm int16 [N][n_packets][packet samples], d_status int32 [N] or NULL.  Calls on one handle must be ordered (same stream, or
+ * events).  solo_recv_stats copies {inserted, late, ahead, duplicate, bad, 0, 0, 0} to HOST memory (synchronises the stream). */
+typedef struct { int32_t stream, seq, desc, offset, len; } solo_arrival_t;
+int32_t solo_recv_create(solo_batch_t *b, int32_t depth, int32_t slot_bytes, int32_t first_seq, void *hip_stream);
+int32_t solo_recv_insert(solo_batch_t *b, const solo_arrival_t *d_arrivals, int32_t n_arrivals, const uint8_t *d_payload,
+                         int64_t payload_bytes, void *hip_stream);
+int32_t solo_recv_decode(solo_batch_t *b, int32_t n_packets, int16_t *d_pcm, int32_t *d_status, void *hip_stream);
+int32_t solo_recv_stats(solo_batch_t *b, uint32_t *out8, void *hip_stream);
 /* Pipelining consecutive encode calls: with on = 1 solo_batch_encode returns without making `hip_stream` wait for the handle's
  * internal streams, so the next encode call starts while the tail of this one still runs (the caller passes different output
  * buffers to calls in flight).  Before consuming the outputs of an encode call on some stream, call

@@ -24,6 +24,7 @@ ABI_SYMBOLS = [
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
     "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split", "solo_batch_set_async_join",
     "solo_batch_wait_encode", "solo_debug_l0", "solo_debug_sum_sqr_shift",
+    "solo_recv_create", "solo_recv_insert", "solo_recv_decode", "solo_recv_stats",
 ]
 
 
@@ -81,6 +82,14 @@ def load_library():
     lib.solo_batch_decode_split.restype = C.c_int32
     lib.solo_batch_decode_split.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p,
                                             C.c_void_p, C.c_void_p]
+    lib.solo_recv_create.restype = C.c_int32
+    lib.solo_recv_create.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+    lib.solo_recv_insert.restype = C.c_int32
+    lib.solo_recv_insert.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.solo_recv_decode.restype = C.c_int32
+    lib.solo_recv_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.solo_recv_stats.restype = C.c_int32
+    lib.solo_recv_stats.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.solo_batch_set_async_join.restype = C.c_int32
     lib.solo_batch_set_async_join.argtypes = [C.c_void_p, C.c_int32]
     lib.solo_batch_wait_encode.restype = C.c_int32
@@ -227,6 +236,42 @@ class SoloBatch:
         if r:
             raise RuntimeError("solo_batch_decode_split -> %d" % r)
         return pcm, status
+
+    # ---- receiver staging ring (solo_recv_*: the reference README's "cache queue", sequence-indexed) ----
+    RECV_STATS = ("inserted", "late", "ahead", "duplicate", "bad")
+
+    def recv_create(self, depth, slot_bytes=256, first_seq=0):
+        r = self.lib.solo_recv_create(self.h, depth, slot_bytes, first_seq, self._stream())
+        if r:
+            raise RuntimeError("solo_recv_create -> %d" % r)
+
+    def recv_insert(self, arrivals, payload):
+        """arrivals: int32 [n,5] (stream, seq, desc, offset, len) on the device; payload: uint8 [bytes] on the device."""
+        t = self.torch
+        assert arrivals.is_cuda and arrivals.dtype == t.int32 and arrivals.is_contiguous() and arrivals.dim() == 2 and arrivals.shape[1] == 5
+        assert payload.is_cuda and payload.dtype == t.uint8 and payload.is_contiguous()
+        r = self.lib.solo_recv_insert(self.h, arrivals.data_ptr(), arrivals.shape[0], payload.data_ptr(), payload.numel(), self._stream())
+        if r:
+            raise RuntimeError("solo_recv_insert -> %d" % r)
+
+    def recv_decode(self, n_packets=1, pcm=None, status=None):
+        """Decode the next n_packets sequence numbers of every stream from what has arrived -> pcm int16 [N,n_packets,samples]."""
+        t = self.torch
+        if pcm is None:
+            pcm = t.zeros((self.n_streams, n_packets, self.packet_samples), dtype=t.int16, device=self.device)
+        if status is None:
+            status = t.zeros((self.n_streams,), dtype=t.int32, device=self.device)
+        r = self.lib.solo_recv_decode(self.h, n_packets, pcm.data_ptr(), status.data_ptr(), self._stream())
+        if r:
+            raise RuntimeError("solo_recv_decode -> %d" % r)
+        return pcm, status
+
+    def recv_stats(self):
+        out = (C.c_uint32 * 8)()
+        r = self.lib.solo_recv_stats(self.h, out, self._stream())
+        if r:
+            raise RuntimeError("solo_recv_stats -> %d" % r)
+        return dict(zip(self.RECV_STATS, list(out)[:5]))
 
     def close(self):
         if getattr(self, "h", None):

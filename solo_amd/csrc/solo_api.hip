@@ -60,6 +60,8 @@ hipError_t solo_wb_dec_launch_split(void* states, const uint8_t* descA, const in
                                     int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
 hipError_t solo_wb_dec_launch_raw(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm, int32_t* status,
                                   hipStream_t s);
+hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* lens, int32_t* play, int n_streams, int n_packets, int depth, int slot,
+                                   int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s);
 }
 
 #ifdef SOLO_WITH_ENCODER
@@ -114,6 +116,12 @@ struct solo_batch {
     int group_streams;               // env SOLO_ENC_GROUP (default 4096): streams per launch group of the encoder pipeline (0 = all)
     int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
     void* d_dec_state;               // SxDecState[n_streams] of the build that matches `wb`
+    // receiver staging ring (solo_recv.h): payload [N][D][2][slot] | length words [N][D] | play-out positions [N] | statistics
+    uint8_t* d_recv_ring;
+    uint32_t* d_recv_lens;
+    int32_t* d_recv_play;
+    uint32_t* d_recv_stats;
+    int32_t recv_depth, recv_slot;
     int wb;                          // decoder control asked for samplerate 32000: 1280-sample packets, SILK at 16 kHz
 };
 
@@ -289,8 +297,10 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
     return b;
 }
 
+static void solo_recv_free(solo_batch_t* b);
 void solo_batch_destroy(solo_batch_t* b) {
     if (!b) return;
+    solo_recv_free(b);
     if (b->dec_pipe_ready && b->dec_split) {
         (void)hipStreamSynchronize(b->sP); (void)hipStreamSynchronize(b->sS);
         (void)hipStreamDestroy(b->sP); (void)hipStreamDestroy(b->sS);
@@ -425,6 +435,54 @@ int32_t solo_batch_decode_split(solo_batch_t* b, const uint8_t* d_descA, const i
     if (!b || !b->have_dec || !d_descA || !d_lenA || !d_descB || !d_lenB || !d_pcm || n_packets <= 0 || slot_bytes <= 0) return -1;
     SOLO_CHECK((b->wb ? solo_wb_dec_launch_split : solo_dec_launch_split)(b->d_dec_state, d_descA, d_lenA, d_descB, d_lenB, b->n_streams, n_packets,
                                                                           slot_bytes, b->dec_ctrl.useMDIndex, d_pcm, d_status, (hipStream_t)hip_stream));
+    return 0;
+}
+
+// ---- receiver staging ring (solo_recv.h) ---------------------------------------------------------------------------------------
+static void solo_recv_free(solo_batch_t* b) {
+    if (b->d_recv_ring) (void)hipFree(b->d_recv_ring);
+    if (b->d_recv_lens) (void)hipFree(b->d_recv_lens);
+    if (b->d_recv_play) (void)hipFree(b->d_recv_play);
+    if (b->d_recv_stats) (void)hipFree(b->d_recv_stats);
+    b->d_recv_ring = NULL; b->d_recv_lens = NULL; b->d_recv_play = NULL; b->d_recv_stats = NULL;
+    b->recv_depth = b->recv_slot = 0;
+}
+int32_t solo_recv_create(solo_batch_t* b, int32_t depth, int32_t slot_bytes, int32_t first_seq, void* hip_stream) {
+    if (!b || !b->have_dec || depth <= 0 || depth > 4096 || slot_bytes <= 0 || slot_bytes > 0x7FFF || first_seq < 0) return -1;
+    hipStream_t st = (hipStream_t)hip_stream;
+    if (depth != b->recv_depth || slot_bytes != b->recv_slot) {
+        SOLO_CHECK(hipStreamSynchronize(st));
+        solo_recv_free(b);
+        const size_t ne = (size_t)b->n_streams * (size_t)depth;
+        hipError_t e = hipMalloc((void**)&b->d_recv_ring, ne * 2 * (size_t)slot_bytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_recv_lens, ne * sizeof(uint32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_recv_play, (size_t)b->n_streams * sizeof(int32_t));
+        if (e == hipSuccess) e = hipMalloc((void**)&b->d_recv_stats, SX_RECV_NSTATS * sizeof(uint32_t));
+        if (e != hipSuccess) { solo_recv_free(b); return -(int32_t)e; }
+        b->recv_depth = depth; b->recv_slot = slot_bytes;
+    }
+    SOLO_CHECK(solo_recv_launch_reset(b->d_recv_lens, b->d_recv_play, b->d_recv_stats, b->n_streams, depth, first_seq, st));
+    return 0;
+}
+int32_t solo_recv_insert(solo_batch_t* b, const solo_arrival_t* d_arrivals, int32_t n_arrivals, const uint8_t* d_payload, int64_t payload_bytes,
+                         void* hip_stream) {
+    if (!b || !b->d_recv_ring || n_arrivals < 0 || (n_arrivals > 0 && (!d_arrivals || !d_payload)) || payload_bytes < 0) return -1;
+    if (n_arrivals == 0) return 0;
+    SOLO_CHECK(solo_recv_launch_insert(d_arrivals, n_arrivals, d_payload, (long long)payload_bytes, b->n_streams, b->recv_depth, b->recv_slot, b->dec_ctrl.useMDIndex,
+                                       b->d_recv_ring, b->d_recv_lens, b->d_recv_play, b->d_recv_stats, (hipStream_t)hip_stream));
+    return 0;
+}
+int32_t solo_recv_decode(solo_batch_t* b, int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
+    if (!b || !b->d_recv_ring || !d_pcm || n_packets <= 0 || n_packets > b->recv_depth) return -1;
+    SOLO_CHECK((b->wb ? solo_wb_dec_launch_ring : solo_dec_launch_ring)(b->d_dec_state, b->d_recv_ring, b->d_recv_lens, b->d_recv_play, b->n_streams, n_packets,
+                                                                        b->recv_depth, b->recv_slot, b->dec_ctrl.useMDIndex, d_pcm, d_status,
+                                                                        (hipStream_t)hip_stream));
+    return 0;
+}
+int32_t solo_recv_stats(solo_batch_t* b, uint32_t* out8, void* hip_stream) {
+    if (!b || !b->d_recv_ring || !out8) return -1;
+    SOLO_CHECK(hipMemcpyAsync(out8, b->d_recv_stats, SX_RECV_NSTATS * sizeof(uint32_t), hipMemcpyDeviceToHost, (hipStream_t)hip_stream));
+    SOLO_CHECK(hipStreamSynchronize((hipStream_t)hip_stream));
     return 0;
 }
 

@@ -31,6 +31,10 @@ hipError_t solo_wb_dec_launch_split(void* states, const uint8_t* descA, const in
                                     int n_packets, int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
     return solo_dec_launch_split_wb(states, descA, lenA, descB, lenB, n_streams, n_packets, slot, useMDIndex, pcm, status, s);
 }
+hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* lens, int32_t* play, int n_streams, int n_packets, int depth, int slot,
+                                   int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
+    return solo_dec_launch_ring_wb(states, ring, lens, play, n_streams, n_packets, depth, slot, useMDIndex, pcm, status, s);
+}
 hipError_t solo_wb_dec_launch_raw(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm, int32_t* status,
                                   hipStream_t s) {
     return solo_dec_launch_raw_wb(state, bits, n0, n1, lostflag, useMDIndex, pcm, status, s);

@@ -3,6 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "solo_dec.h"
+#include "solo_recv.h"
 
 __global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecStream* states, int n_streams, int hb_joint) {
     const int s = blockIdx.x;
@@ -166,6 +167,36 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
 // (two copies of the same description count once); with useMDIndex = 0 slot A is MD1 and slot B is MD2 || HB.  The kernel then
 // builds the (ptr, nBytes, lostflag) triple of test/dec_main.c:255-378 and decodes.  Packets above the LDS staging size
 // (252 B; 13.6 kbps packets are ~80 B) are rejected with SKP_SILK_DEC_PAYLOAD_TOO_LARGE (-11).
+// one packet of the receiver front end: what lies in the two arrival slots -> (ptr, nBytes, lostflag) -> the decoder
+__device__ __forceinline__ int SX_K(sx_decode_split_packet)(SxDecWork& w, const u8* pa, i32 la, const u8* pb, i32 lb, int slot, int useMDIndex, i16* out) {
+    if (la < 0 || la > slot) la = 0;
+    if (lb < 0 || lb > slot) lb = 0;
+    const u8 *p1 = pa, *p2 = pb;
+    i32 l1 = la, l2 = lb;
+    if (useMDIndex == 1) {
+        int ia = -1, ib = -1;
+        if (la > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
+        if (lb > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
+        p1 = pa; l1 = 0; p2 = pb; l2 = 0;
+        if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
+        if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
+    }
+    const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
+    if (l1 + l2 > SX_DEC_PAYLOAD_LDS) return -11;
+    wv_sync();
+    SX_PAR(i, l1) w.payload[i] = p1[i];
+    SX_PAR(i, l2) w.payload[l1 + i] = p2[i];
+    wv_sync();
+    int lostflag;
+    i32 a0, a1;
+    if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
+    else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
+    else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
+    else { lostflag = 1; a0 = hbb + 1; a1 = 0; }
+    return sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
+}
+
 __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecStream* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
                                                                const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
                                                                int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
@@ -176,45 +207,67 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecStr
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        const u8* pa = descA + pk * (size_t)slot;
-        const u8* pb = descB + pk * (size_t)slot;
-        i32 la = lenA[pk], lb = lenB[pk];
-        if (la < 0 || la > slot) la = 0;
-        if (lb < 0 || lb > slot) lb = 0;
-        const u8 *p1 = pa, *p2 = pb;
-        i32 l1 = la, l2 = lb;
-        if (useMDIndex == 1) {
-            int ia = -1, ib = -1;
-            if (la > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pa, sx_min(la, SX_MAX_ARITHM_BYTES)); ia = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ia = -1; }
-            if (lb > 0) { SxRangeDec r; r.error = 0; r.tail = 0; sx_rc_dec_init(&r, pb, sx_min(lb, SX_MAX_ARITHM_BYTES)); ib = sx_rc_dec(&r, w.cdf.cdf_mdindex, T_CDF_MID_MDINDEX); if (r.error) ib = -1; }
-            p1 = pa; l1 = 0; p2 = pb; l2 = 0;
-            if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
-            if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
-        }
-        const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
-        if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
-        i16* out = pcm + pk * SX_PACKET;
-        int ret;
-        if (l1 + l2 > SX_DEC_PAYLOAD_LDS) {
-            ret = -11;
-        } else {
-            wv_sync();
-            SX_PAR(i, l1) w.payload[i] = p1[i];
-            SX_PAR(i, l2) w.payload[l1 + i] = p2[i];
-            wv_sync();
-            int lostflag;
-            i32 a0, a1;
-            if (l1 > 0 && l2 > 0) { lostflag = 4; a0 = l1 + l2; a1 = l2; }
-            else if (l1 > 0) { lostflag = 2; a0 = l1; a1 = 0; }
-            else if (l2 > 0) { lostflag = 3; a0 = l2; a1 = 0; }
-            else { lostflag = 1; a0 = hbb + 1; a1 = 0; }
-            ret = sx_decode_packet(&w, w.payload, a0, a1, lostflag, useMDIndex, out);
-        }
+        const int ret = SX_K(sx_decode_split_packet)(w, descA + pk * (size_t)slot, lenA[pk], descB + pk * (size_t)slot, lenB[pk], slot, useMDIndex,
+                                                     pcm + pk * SX_PACKET);
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
     SX_K(solo_dec_leave)(&w, &states[s]);
     if (status && SX_LANE == 0) status[s] = first_err;
+}
+
+// ---- receiver staging ring (solo_recv.h): arrivals filed by sequence number, decoded when their turn comes -----------------------
+// one wavefront files one arrival
+__global__ void __launch_bounds__(64) SX_K(solo_recv_insert_kernel)(const SxRecvArrival* __restrict__ arr, int n_arr, const u8* __restrict__ payload,
+                                                               long long payload_bytes, int n_streams, int depth, int slot, int useMDIndex, u8* ring,
+                                                               u32* lens, const i32* __restrict__ play, u32* stats) {
+    const int a = blockIdx.x;
+    if (a >= n_arr) return;
+    const SxRecvArrival r = arr[a];
+    int sl = -1;
+    int verdict = sx_recv_file(&r, payload, payload_bytes, n_streams, depth, slot, useMDIndex, play, lens, SX_LANE == 0, &sl);
+    if (verdict == SX_RECV_INSERTED) {
+        sl = wv_bcast(sl, 0);
+        if (sl < 0) verdict = SX_RECV_DUP;
+    }
+    const size_t e = sl >= 0 ? sx_recv_entry(r.stream, r.seq, depth) : 0;
+    if (SX_LANE == 0) atomicAdd(&stats[verdict], 1u);
+    if (sl >= 0) {
+        u8* dst = ring + (e * 2 + (size_t)sl) * (size_t)slot;
+        const u8* src = payload + r.offset;
+        SX_PAR(i, r.len) dst[i] = src[i];
+    }
+}
+__global__ void __launch_bounds__(64) SX_K(solo_recv_reset_kernel)(u32* lens, i32* play, u32* stats, int n_streams, int depth, i32 first_seq) {
+    const size_t i = (size_t)blockIdx.x * 64 + threadIdx.x;
+    if (i < (size_t)n_streams * (size_t)depth) lens[i] = 0;
+    if (i < (size_t)n_streams) play[i] = first_seq;
+    if (i < SX_RECV_NSTATS) stats[i] = 0;
+}
+// the next n_packets sequence numbers of every stream: merge what has arrived (as the split kernel does), decode, free the entries
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_ring_kernel)(SxDecStream* states, const u8* ring, u32* lens, i32* play, int n_streams, int n_packets,
+                                                              int depth, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
+    __shared__ SxDecWork w;
+    const int s = blockIdx.x;
+    if (s >= n_streams) return;
+    SX_K(solo_dec_enter)(&w, &states[s]);
+    i32 first_err = 0;
+    const i32 play0 = play[s];
+    for (int p = 0; p < n_packets; p++) {
+        const size_t e = sx_recv_entry(s, play0 + p, depth);
+        const u32 lw = lens[e];
+        const u8* pa = ring + e * 2 * (size_t)slot;
+        const int ret = SX_K(sx_decode_split_packet)(w, pa, (i32)(lw & 0xFFFFu), pa + slot, (i32)(lw >> 16), slot, useMDIndex,
+                                                     pcm + ((size_t)s * n_packets + p) * SX_PACKET);
+        if (ret < 0 && first_err == 0) first_err = ret;
+        wv_sync();
+        if (SX_LANE == 0) lens[e] = 0;
+    }
+    SX_K(solo_dec_leave)(&w, &states[s]);
+    if (SX_LANE == 0) {
+        play[s] = play0 + n_packets;
+        if (status) status[s] = first_err;
+    }
 }
 
 // single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
@@ -258,6 +311,25 @@ static inline hipError_t SX_K(solo_dec_launch_split)(void* states, const uint8_t
                                                      int16_t* pcm, int32_t* status, hipStream_t s) {
     hipLaunchKernelGGL(SX_K(solo_decode_split_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, descA, lenA, descB, lenB,
                        n_streams, n_packets, slot, useMDIndex, pcm, status);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_recv_launch_reset)(uint32_t* lens, int32_t* play, uint32_t* stats, int n_streams, int depth, int32_t first_seq, hipStream_t s) {
+    size_t n = (size_t)n_streams * (size_t)depth;
+    if (n < SX_RECV_NSTATS) n = SX_RECV_NSTATS;
+    hipLaunchKernelGGL(SX_K(solo_recv_reset_kernel), dim3((unsigned)((n + 63) / 64)), dim3(64), 0, s, lens, play, stats, n_streams, depth, first_seq);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_recv_launch_insert)(const void* arrivals, int n_arr, const uint8_t* payload, long long payload_bytes, int n_streams, int depth,
+                                                       int slot, int useMDIndex, uint8_t* ring, uint32_t* lens, const int32_t* play, uint32_t* stats,
+                                                       hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_recv_insert_kernel), dim3(n_arr), dim3(64), 0, s, (const SxRecvArrival*)arrivals, n_arr, payload, payload_bytes, n_streams,
+                       depth, slot, useMDIndex, ring, lens, play, stats);
+    return hipGetLastError();
+}
+static inline hipError_t SX_K(solo_dec_launch_ring)(void* states, const uint8_t* ring, uint32_t* lens, int32_t* play, int n_streams, int n_packets, int depth,
+                                                    int slot, int useMDIndex, int16_t* pcm, int32_t* status, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_decode_ring_kernel), dim3(n_streams), dim3(64), 0, s, (SxDecStream*)states, ring, lens, play, n_streams, n_packets, depth,
+                       slot, useMDIndex, pcm, status);
     return hipGetLastError();
 }
 static inline hipError_t SX_K(solo_dec_launch_raw)(void* state, const uint8_t* bits, int n0, int n1, int lostflag, int useMDIndex, int16_t* pcm,

@@ -15,6 +15,7 @@ static void emu_tap(int stage, const SxEncState* st, const SxEncWork* w, const i
 #endif
 #include "../../solo_amd/csrc/solo_dec.h"
 #include "../../solo_amd/csrc/solo_l0_probe.h"
+#include "../../solo_amd/csrc/solo_recv.h"
 #ifndef EMU_DEC_ONLY
 #include "../../solo_amd/csrc/solo_enc.h"
 #endif
@@ -64,6 +65,18 @@ void emu_sum_sqr_shift(const int16_t* x, int len, int odd_start, int32_t* energy
 int emu_sizeof_dec_state() { return (int)sizeof(SxDecState); }
 int emu_sizeof_dec_work() { return (int)sizeof(SxDecWork); }
 int emu_packet_samples() { return SX_PACKET; }
+
+// receiver staging ring: the bookkeeping of solo_recv_insert_kernel (window check, slot claim), one arrival after the other
+void emu_recv_file(const int32_t* arrivals, int n, int n_streams, int depth, int slot, const uint8_t* payload, long long payload_bytes, int useMDIndex,
+                   const int32_t* play, uint32_t* lens, int32_t* verdict, int32_t* slot_out) {
+    for (int a = 0; a < n; a++) {
+        SxRecvArrival r = {arrivals[5 * a], arrivals[5 * a + 1], arrivals[5 * a + 2], arrivals[5 * a + 3], arrivals[5 * a + 4]};
+        int sl = -1;
+        int v = sx_recv_file(&r, payload, payload_bytes, n_streams, depth, slot, useMDIndex, play, lens, 1, &sl);
+        if (v == SX_RECV_INSERTED && sl < 0) v = SX_RECV_DUP;
+        verdict[a] = v; slot_out[a] = sl;
+    }
+}
 
 }  // extern "C"
 
