@@ -44,7 +44,8 @@ _lib = None
 
 def kernel_source_hash():
     """sha256 (first 16 hex digits) over the kernel sources solo_amd/csrc/* in name order: identifies the BUILD a benchmark line or a
-    profile summary belongs to (the GPU box has no .git; profiles/*.json carry the same field, bench.py compares them)."""
+    profile summary belongs to (the GPU box has no .git; profiles/*.json carry the same field, bench.py compares them).  Build
+    flags from solo_amd/build_flags.txt count as source."""
     import hashlib
     h = hashlib.sha256()
     d = os.path.join(_HERE, "csrc")
@@ -52,7 +53,20 @@ def kernel_source_hash():
         if f.endswith((".h", ".hip", ".inc")):
             h.update(f.encode())
             h.update(open(os.path.join(d, f), "rb").read())
+    flags = build_flags()
+    if flags:                       # (an empty / absent flags file leaves the hash of the sources alone)
+        h.update(" ".join(flags).encode())
     return h.hexdigest()[:16]
+
+
+def build_flags():
+    """Extra -D options the library is built with (solo_amd/build_flags.txt, one per line, '#' comments): part of a build's identity
+    together with the sources, so that a profile taken from a flag variant is attributed to it (__graft_entry__.build() reads the
+    same file)."""
+    p = os.path.join(_HERE, "build_flags.txt")
+    if not os.path.exists(p):
+        return []
+    return [l.strip() for l in open(p) if l.strip() and not l.strip().startswith("#")]
 
 
 def load_library():

@@ -140,7 +140,11 @@ constexpr int sx_nsq_work_pad_words(int body_words) {
     while ((body_words + pad) % 4 != 0 || ((body_words + pad) % 64) % 8 != 4) pad++;
     return pad;
 }
-#if SX_NLANES == 1
+// (-DSX_NSQ_WORK_PAD=0: the unpadded records, for A/B timing of the two layouts)
+#ifndef SX_NSQ_WORK_PAD
+#define SX_NSQ_WORK_PAD 1
+#endif
+#if SX_NLANES == 1 || !SX_NSQ_WORK_PAD
 struct alignas(16) SxNsqWork : SxNsqWorkBody {};
 #else
 struct alignas(16) SxNsqWork : SxNsqWorkBody { i32 pad_[sx_nsq_work_pad_words((int)(sizeof(SxNsqWorkBody) / 4))]; };

@@ -1,0 +1,58 @@
+#!/bin/bash
+# The one gpurun call that closes a round (GPU minutes are scarce, so the steps are ordered by what only this call can produce):
+#   gpurun --timeout 900 -- 'bash tools/gpu_round_end.sh'
+# 1. A/B of build-flag variants under build/ against the in-tree library (tools/quick_bench.py: parity against the goldens + timing);
+#    a variant that is bit-exact and >= 1.5 % faster on the encoder is adopted for the rest of the call: its flags go to
+#    solo_amd/build_flags.txt (part of the build's identity, solo_amd.kernel_source_hash()) and to gpurun_out/build_flags.txt, from
+#    where the container copies them and rebuilds the same library.
+# 2. the GPU tests of what is new this round; 3. rocprofv3 trace + instruction + traffic passes; 4. the driver's bench command;
+# 5. the remaining counter passes; 6. the whole GPU suite.
+set -u
+ROOT=$(pwd)
+OUT=$ROOT/gpurun_out
+mkdir -p "$OUT"
+export TMPDIR=/tmp
+T0=$(date +%s)
+log() { echo "[$(( $(date +%s) - T0 )) s] $*" | tee -a "$OUT/run.log"; }
+: > "$OUT/run.log"
+python -c "import torch; print(torch.cuda.get_device_name(0))" > "$OUT/dev.log" 2>&1
+log "torch imported: $(tail -1 "$OUT/dev.log")"
+
+# ---- 1. build-flag variants:  build/libsolo_<name>.so built with the flags in build/libsolo_<name>.flags
+: > "$OUT/ab.log"
+VARIANTS=$(ls build/libsolo_*.flags 2>/dev/null | sed 's/\.flags$//')
+if [ -n "$VARIANTS" ]; then
+  for round in 1 2; do
+    for lib in solo_amd/libsolo_mi355x $VARIANTS; do
+      SOLO_LIB_OVERRIDE=$ROOT/$lib.so timeout 150 python tools/quick_bench.py 4096 10 2>&1 | grep -v amdgpu.ids >> "$OUT/ab.log"
+    done
+  done
+  python tools/pick_variant.py "$OUT/ab.log" > "$OUT/ab_choice.txt" 2>&1
+  CH=$(tail -1 "$OUT/ab_choice.txt")
+  log "A/B: $CH"
+  if [ -f "$ROOT/$CH.flags" ]; then
+    cp "$ROOT/$CH.flags" solo_amd/build_flags.txt
+    cp "$ROOT/$CH.flags" "$OUT/build_flags.txt"
+    cp "$ROOT/$CH.so" solo_amd/libsolo_mi355x.so
+  fi
+fi
+
+# ---- 2. what is new this round
+timeout 300 python -m pytest tests/test_recv_ring.py tests/test_wb.py tests/test_pinned_corners.py -m gpu -x -q > "$OUT/gputest_new.log" 2>&1
+log "new GPU tests: rc=$? $(tail -1 "$OUT/gputest_new.log")"
+
+# ---- 3. profile, first half
+bash tools/profile_gpu.sh trace inst fetch write > "$OUT/profile1.log" 2>&1
+log "profile passes 1: $(tr '\n' ' ' < "$OUT/profile1.log" | cut -c1-200)"
+
+# ---- 4. the driver's bench command
+timeout 400 python bench.py > "$OUT/bench.json" 2> "$OUT/bench.err"
+log "bench: rc=$? $(cut -c1-160 "$OUT/bench.json" | tail -1)"
+
+# ---- 5. profile, second half
+bash tools/profile_gpu.sh sq lane lds > "$OUT/profile2.log" 2>&1
+log "profile passes 2: $(tr '\n' ' ' < "$OUT/profile2.log" | cut -c1-200)"
+
+# ---- 6. the whole GPU suite
+timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/gputest.log" 2>&1
+log "GPU suite: rc=$? $(tail -1 "$OUT/gputest.log")"
