@@ -56,3 +56,11 @@ log "profile passes 2: $(tr '\n' ' ' < "$OUT/profile2.log" | cut -c1-200)"
 # ---- 6. the whole GPU suite
 timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/gputest.log" 2>&1
 log "GPU suite: rc=$? $(tail -1 "$OUT/gputest.log")"
+
+# ---- 7. section / phase timers of the profiling build (build/libsolo_prof.so = the same sources with -DSX_PROF), if there is time left
+if [ -f build/libsolo_prof.so ]; then
+  { SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_sections.py 4096 10
+    SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_nsq.py 4096 10
+    SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_dec.py 4096 10; } > "$OUT/prof_sections.log" 2>&1
+  log "section timers: $(grep -c cycles "$OUT/prof_sections.log") lines"
+fi
