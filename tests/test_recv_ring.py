@@ -86,6 +86,46 @@ def test_emu_filing_rules_against_model(mdi):
     assert int((lens != 0).sum()) == sum(1 for v in model_lens.values() if v[0] or v[1])
 
 
+@need_ref
+def test_emu_unknown_description_with_damaged_payloads():
+    """desc = -1 on payloads that are not descriptions (random bytes, bit errors, one-byte payloads): the index is whatever the range
+    decoder makes of the first symbol -- 0 or 1 files the arrival in that slot, a coder error counts it as bad; nothing else may
+    happen (no other verdict, no length word touched for a bad one), and an undamaged description is still recognised afterwards."""
+    lib = T.load_emu()
+    lib.emu_recv_file.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p, C.c_void_p,
+                                  C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(99)
+    enc = R.RefEncoder("fix", rate=13600, use_md_index=1)
+    pl, n0, n1 = enc.encode(R.synth_stream(3, 1)[0])
+    good = [np.frombuffer(pl[:n0 - n1], np.uint8), np.frombuffer(pl[n0 - n1:n0], np.uint8)]
+    N, D, SLOT = 600, 1, 200
+    blobs, arr, off = [], [], 0
+    for i in range(N - 2):
+        kind = i % 3
+        if kind == 0:
+            x = rng.integers(0, 256, int(rng.integers(1, 120)), dtype=np.uint8)
+        elif kind == 1:
+            x = good[i & 1].copy(); x[int(rng.integers(0, 3))] ^= np.uint8(1 << int(rng.integers(0, 8)))
+        else:
+            x = good[i & 1][:int(rng.integers(1, 4))].copy()
+        blobs.append(x); arr.append((i, 0, -1, off, x.size)); off += x.size
+    for d in (0, 1):
+        blobs.append(good[d]); arr.append((N - 2 + d, 0, -1, off, good[d].size)); off += good[d].size
+    payload = np.concatenate(blobs)
+    arr = np.array(arr, np.int32)
+    play = np.zeros(N, np.int32); lens = np.zeros((N, D), np.uint32)
+    verdict = np.zeros(N, np.int32); slots = np.zeros(N, np.int32)
+    lib.emu_recv_file(arr.ctypes.data, N, N, D, SLOT, payload.ctypes.data, payload.size, 1, play.ctypes.data, lens.ctypes.data, verdict.ctypes.data,
+                      slots.ctypes.data)
+    assert set(verdict.tolist()) <= {INSERTED, BAD}
+    for i in range(N):
+        if verdict[i] == INSERTED:
+            assert slots[i] in (0, 1) and int(lens[i, 0]) == int(arr[i, 4]) << (16 * int(slots[i]))
+        else:
+            assert slots[i] == -1 and lens[i, 0] == 0
+    assert verdict[N - 2] == INSERTED and slots[N - 2] == 0 and verdict[N - 1] == INSERTED and slots[N - 1] == 1
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # GPU
 # ---------------------------------------------------------------------------------------------------------------------
