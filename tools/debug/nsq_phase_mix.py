@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Static instruction mix of the quantiser's sample step, phase by phase: compiles solo_nsq16.hip with -DSX_PROF (the phase timer reads
 the cycle counter at every phase boundary: s_memtime) and counts the instructions between consecutive reads of the FIRST of the two
-samples of the loop body.  With the cycles per phase of tools/prof_nsq.py (pass its output file) it prints cycles per instruction.
+samples of the loop body.  (The timer reads do not stop the instruction scheduler: arithmetic of one phase may sit on the other side of a
+read -- the first line, "ring refill requests", is mostly filter arithmetic of phase A; the loop total is exact.)  With the cycles per phase of tools/prof_nsq.py (pass its output file) it prints cycles per instruction.
     python tools/debug/nsq_phase_mix.py [gpurun_out/prof_sections.log]           (no GPU needed for the counts)"""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
