@@ -7,7 +7,16 @@
 #pragma once
 #include <stddef.h>
 #include "solo_enc_analysis.h"
+// the quantiser: one lane per (track, state), a 16-lane row per stream (solo_enc_nsq_row.h); -DSX_NSQ_QUAD: round 3's form, one
+// lane per state carrying the three tracks (solo_enc_nsq.h; kept for A/B timing)
+#ifdef SX_NSQ_QUAD
 #include "solo_enc_nsq.h"
+#define SX_NSQ_EMU_STRIDE 4
+#else
+#include "solo_enc_nsq_row.h"
+typedef SxRowWork SxNsqWork;
+#define SX_NSQ_EMU_STRIDE 12
+#endif
 #include "solo_cdf.h"
 
 // what the parameter coder needs of one frame (kept from both frames until the packet is assembled)
@@ -593,7 +602,7 @@ SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, SxCodeIn* cin, const 
     sx_enc_stage_a(rec, w, pcm, rec->nsq_in, cin);
     wv_sync();
     for (int frame = 0; frame < 2; frame++) {
-        sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, 4);
+        sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, SX_NSQ_EMU_STRIDE);
         wv_sync();
     }
     return sx_enc_stage_c(rec, w, cin, rec->nsq_out, bits, buf_size, nBytesOut);

@@ -1,0 +1,946 @@
+// solo_enc_nsq_row.h -- the SOLO multiple-description noise-shaping quantiser: three coupled delayed-decision
+// trellises (centre, MD1, MD2), 4 states each, quantising one 20 ms frame.  Row E6 of SURVEY.md section 8(a).
+// Reference: JC1_SDK_SRC_ARM/src/libSATECodec/SKP_Silk_NSQ_del_dec.c:148-1694 and Agora_SILK_func.c:7-160.
+//
+// Mapping (MI355X): ONE LANE = ONE DELAYED-DECISION STATE OF ONE TRACK.  A stream is one 16-lane DPP row: lane = 4 * track + state,
+// tracks 0 (centre), 1 (MD1), 2 (MD2); the row's last quad is spare (it runs along on copies of the centre's data and never
+// stores).  A 64-lane wavefront quantises FOUR streams; 4096 streams = 1024 wavefronts = one per SIMD of the chip.
+//  * The per-sample dependent chain of a wavefront is the work of ONE track: the three tracks' prediction / shaping filters,
+//    survivor moves, emissions and updates -- which the reference (and the round-3 kernel: one lane = one state of all three
+//    tracks) executes one after the other -- are the same instructions on different lanes.
+//  * What the tracks of a state tell each other per sample crosses the row with DPP row shifts (bank-masked, so one instruction
+//    delivers a quad's value to another quad): the centre residual that the sides split (1 value), the side candidates the
+//    centre combines (8), the centre's choice (1 packed word), the joint costs (sums over the row's quads by row rotations), the
+//    expiry flags (or over the quads), the survivor plan (1 packed word).  No LDS exchange, no barrier.
+//  * What the states of a track tell each other stays inside a quad: arg-min / arg-max butterflies (DPP quad_perm), quad
+//    broadcasts + selects for single values on the decision's critical path, ds_bpermute for the bulk move of the survivors'
+//    registers (37 per sample; latency hidden by their number).
+//  * The reference's replace-worst-by-best loop (up to three rounds of struct copies, Agora_Silk_JudgeWinner) is first played on
+//    three small index registers (parent state / candidate source / candidate number), then every filter register is moved once.
+//  * The second candidate's decoder simulation (Agora_Silk_UndoPred_And_Shap) is evaluated after the decision, for the one
+//    candidate a lane keeps, instead of for both candidates of every state before it.
+//  * The 32-deep decision-delay histories are not copied when a survivor replaces a state: every (time, slot) cell is stored
+//    once and each state carries a 64-bit "lineage" word (2 bits per ring position = which slot holds its ancestor's sample).
+//    One 16-byte cell per lane and sample (quantised sample, pulse / centre excitation, prediction and shaping history, random
+//    state) in an HBM ring laid out [position][lane]: ONE dwordx4 store and ONE dwordx4 prefetch per sample.
+//  * The reference rescales all ring cells whenever the subframe gain changes; a cell crosses at most one such boundary before
+//    it is emitted (decision delay <= 32 < subframe length), so the factor is applied to the one emitted cell instead.
+// The same source compiles for the host (tests/emu, SX_NLANES == 1): lane-private variables become arrays over the twelve live
+// lanes of a row and the exchanges become array reads.
+#pragma once
+#include <stddef.h>
+#include "solo_enc_state.h"
+
+#define SX_JOINT_LAMBDA 90000        // INTERNAL_JOINT_LAMBDA, SKP_Silk_define.h:48 (LARS_LAMBDA_AGR == 0)
+#define SX_DD_MASK (SX_DD_DELAY - 1)
+
+// ---- the lanes of a stream ---------------------------------------------------------------------------------------------------
+#if SX_NLANES == 1
+#define RW_NL 12
+#define RW_FORK(l) for (int l = 0; l < 12; l++)
+#define RW_LI(l) (l)
+#else
+#define RW_NL 1
+#define RW_FORK(l) for (int l = SX_LANE, once_ = 1; once_; once_ = 0)
+#define RW_LI(l) 0
+#endif
+#define RW_T(l) ((l) >> 2)                       // track of lane l (3: the spare quad of the GPU's row)
+#define RW_K(l) ((l) & 3)                        // delayed-decision state
+#define RW_TT(l) (RW_T(l) > 2 ? 0 : RW_T(l))     // track whose data the lane reads (the spare quad shadows the centre)
+#define RW_LIVE(l) (RW_T(l) < 3)
+// a value every lane of the stream holds identically, as a scalar for the stream's control flow
+#define RW_UNI(arr) ((arr)[0])
+
+// Exchanges.  They stand OUTSIDE the RW_FORK loops (host: they walk the lanes themselves).
+//  inside a quad (the four states of one track):
+//   RWK_GATHER(dst, src, idx)    dst[l] = src[quad(l) + idx[l]]
+//   RWK_ARGMIN / RWK_ARGMAX(val, mv, mi)   extreme of val over the quad and the LOWEST state index holding it, in every lane
+//   RWK_SUM(val, out)
+//   RWK_PERM(LV, idx)            LV(l) = LV(quad(l) + idx[l]) for an lvalue macro LV(lane)
+//  across the quads of a row (the tracks of one state):
+//   RWT_FROM(dst, src, T)        dst[l] = src[4 T + state(l)]                    (every lane receives track T's value)
+//   RWT_TO0(dst, src, T)         the same, but only the centre's lanes receive (the other lanes keep dst)
+//   RWT_SUM(dst, src) / RWT_OR   dst[l] = sum / or over the three tracks of src[4 t + state(l)]
+#if SX_NLANES == 1
+#define RWK_GATHER(dst, src, idx) { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = (src)[q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[(q_ & ~3) | (idx)[q_]]; }
+#define RWK_ARG_(val, mv, mi, CMP) { for (int b_ = 0; b_ < 12; b_ += 4) { i32 bv_ = (val)[b_]; int bi_ = 0;                         \
+        for (int q_ = 1; q_ < 4; q_++) if ((val)[b_ + q_] CMP bv_) { bv_ = (val)[b_ + q_]; bi_ = q_; }                                \
+        for (int q_ = 0; q_ < 4; q_++) { (mv)[b_ + q_] = bv_; (mi)[b_ + q_] = bi_; } } }
+#define RWK_ARGMIN(val, mv, mi) RWK_ARG_(val, mv, mi, <)
+#define RWK_ARGMAX(val, mv, mi) RWK_ARG_(val, mv, mi, >)
+#define RWK_SUM(val, out) { for (int b_ = 0; b_ < 12; b_ += 4) { const i32 s_ = sx_add(sx_add((val)[b_], (val)[b_ + 1]), sx_add((val)[b_ + 2], (val)[b_ + 3])); \
+        for (int q_ = 0; q_ < 4; q_++) (out)[b_ + q_] = s_; } }
+#define RWK_PERM(LV, idx) { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = LV(q_); for (int q_ = 0; q_ < 12; q_++) LV(q_) = o_[(q_ & ~3) | (idx)[q_]]; }
+#define RWT_FROM(dst, src, T) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = (src)[4 * (T) + q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
+#define RWT_TO0(dst, src, T) { for (int q_ = 0; q_ < 4; q_++) (dst)[q_] = (src)[4 * (T) + q_]; }
+#define RWT_SUM(dst, src) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = sx_add(sx_add((src)[q_], (src)[4 + q_]), (src)[8 + q_]); for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
+#define RWT_OR(dst, src) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = (src)[q_] | (src)[4 + q_] | (src)[8 + q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
+#else
+#define RW_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
+// the lanes of bank (= quad of every row) `bank` take the value of the lane `ctrl` names, all other lanes keep `old`
+#define RW_DPP_BANK(old, v, ctrl, bank) __builtin_amdgcn_update_dpp((old), (v), (ctrl), 0xf, 1 << (bank), false)
+#define RW_SHR(n) (0x110 + (n))      // row_shr:n  lane i <- lane i - n
+#define RW_SHL(n) (0x100 + (n))      // row_shl:n  lane i <- lane i + n
+#define RW_ROR(n) (0x120 + (n))      // row_ror:n  lane i <- lane (i - n) mod 16
+// value of state idx (0..3, may differ from lane to lane) of the own quad.  Two forms: four quad broadcasts + selects (seven VALU
+// instructions, no LDS round trip: for the few values on the decision's critical path) and ds_bpermute (one LDS-crossbar
+// instruction: for the bulk move of the survivors' registers, where latency is hidden by the number of them)
+SX_HD i32 rwk_sel(i32 v, i32 idx) {
+    const i32 b0 = RW_DPP(v, 0x00), b1 = RW_DPP(v, 0x55), b2 = RW_DPP(v, 0xAA), b3 = RW_DPP(v, 0xFF);
+    // (two levels of two-way selects on the index bits: a chain of ?: on idx == 0 / 1 / 2 is compiled into exec-mask branches)
+    const bool o_ = (idx & 1) != 0, h_ = (idx & 2) != 0;
+    const i32 lo_ = o_ ? b1 : b0, hi_ = o_ ? b3 : b2;
+    return h_ ? hi_ : lo_;
+}
+SX_HD i32 rwk_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & ~3u) | (u32)src)) << 2), v); }
+#define RWK_GATHER(dst, src, idx) { (dst)[0] = rwk_sel((src)[0], (idx)[0]); }
+#define RWK_ARG_STEP_(CTRL, CMP) { const i32 tv_ = RW_DPP(bv_, CTRL), ti_ = RW_DPP(bi_, CTRL); \
+                                   const bool take_ = (tv_ CMP bv_) | ((tv_ == bv_) & (ti_ < bi_)); bv_ = take_ ? tv_ : bv_; bi_ = take_ ? ti_ : bi_; }
+#define RWK_ARG_(val, mv, mi, CMP) { i32 bv_ = (val)[0], bi_ = (i32)(threadIdx.x & 3u); RWK_ARG_STEP_(0xB1, CMP) RWK_ARG_STEP_(0x4E, CMP) (mv)[0] = bv_; (mi)[0] = bi_; }
+#define RWK_ARGMIN(val, mv, mi) RWK_ARG_(val, mv, mi, <)
+#define RWK_ARGMAX(val, mv, mi) RWK_ARG_(val, mv, mi, >)
+#define RWK_SUM(val, out) { i32 s_ = (val)[0]; s_ = sx_add(s_, RW_DPP(s_, 0xB1)); s_ = sx_add(s_, RW_DPP(s_, 0x4E)); (out)[0] = s_; }
+#define RWK_PERM(LV, idx) { LV(0) = rwk_from(LV(0), (idx)[0]); }
+SX_HD i32 rwt_from0(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHR(4), 1); d = RW_DPP_BANK(d, v, RW_SHR(8), 2); return RW_DPP_BANK(d, v, RW_SHR(12), 3); }
+SX_HD i32 rwt_from1(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHL(4), 0); d = RW_DPP_BANK(d, v, RW_SHR(4), 2); return RW_DPP_BANK(d, v, RW_SHR(8), 3); }
+SX_HD i32 rwt_from2(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHL(8), 0); d = RW_DPP_BANK(d, v, RW_SHL(4), 1); return RW_DPP_BANK(d, v, RW_SHR(4), 3); }
+#define RWT_FROM(dst, src, T) { (dst)[0] = (T) == 0 ? rwt_from0((src)[0]) : ((T) == 1 ? rwt_from1((src)[0]) : rwt_from2((src)[0])); }
+#define RWT_TO0(dst, src, T) { (dst)[0] = RW_DPP_BANK((dst)[0], (src)[0], RW_SHL(4 * (T)), 0); }
+// (the spare quad contributes nothing; every quad of the row, the spare one included, receives the result)
+#define RWT_SUM(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
+        (dst)[0] = sx_add(sx_add(v_, RW_DPP(v_, RW_ROR(4))), sx_add(RW_DPP(v_, RW_ROR(8)), RW_DPP(v_, RW_ROR(12)))); }
+#define RWT_OR(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
+        (dst)[0] = (v_ | RW_DPP(v_, RW_ROR(4))) | (RW_DPP(v_, RW_ROR(8)) | RW_DPP(v_, RW_ROR(12))); }
+#endif
+
+// One cell of the emission ring: what ONE state slot of ONE track wrote at ONE ring position.  16 bytes, written / prefetched as
+// one dwordx4 per lane.  The quantised sample is already scaled and saturated with the gain of the subframe that wrote it
+// (the reference keeps Xq_Q10 and a ring of gains and combines them when the sample is emitted).
+//   w0  bits 0..15: quantised output sample (int16); bits 16..31: X bits 0..15
+//   w1  bits 0..25: LPC excitation Q10 (only its low 26 bits reach the prediction history: the reference stores it << 6);
+//       bits 26..31: X bits 16..21
+//   w2  shaping history sample Q10
+//   w3  random state of the slot after this sample
+// X = what the track hands to the coder for the sample: the pulse (side tracks) / the excitation Q10 (centre: the high band's gain
+// reference; |excitation| < 2^18), as a 22-bit signed number.
+struct alignas(16) SxRowCell { i32 w0, w1, w2, w3; };
+SX_HD i32 rw_cell_x(const SxRowCell& c) { return (i32)((u32)sx_shl(c.w1 >> 26, 16) | ((u32)c.w0 >> 16)); }
+SX_HD i32 rw_cell_xq(const SxRowCell& c) { return (i32)(i16)c.w0; }
+SX_HD i32 rw_cell_pred_Q16(const SxRowCell& c) { return sx_shl(c.w1, 6); }
+
+#define SX_TAPL_N (SX_SUBFR + SX_LTP_ORDER - 1)              // history entries the five prediction taps of one subframe can reach
+#define SX_TAPS_N (SX_SUBFR + 2)                             // ... the three shaping taps
+struct alignas(16) SxRowWorkBody {   // LDS, per stream
+    // Tap windows of the current subframe, per track: the history entries the subframe's taps can reach, staged from HBM when the
+    // subframe starts; a sample emitted during the subframe is also written to its place in the window.  Tap j of iteration i is
+    // then ONE LDS read at a fixed place: tapL[i - j + 4] / tapS[i - j + 2].
+    i32 tapL[SX_N_TRACKS][SX_TAPL_N];                     // long-term prediction history (sLTP_Q16)
+    i32 tapS[SX_N_TRACKS][SX_TAPS_N];                     // shaping history (sLTP_shp_Q10)
+    i32 xsc[SX_SUBFR];                                    // the subframe's input, scaled by its inverse gain (Q10)
+    // Gain-adjustment factors of the last eight subframe starts, per track: [0, 4) the previous frame's, [4, 8) this frame's
+    // (65536 where the gain did not change), and this frame's pitch lags.  The reference rescales its history arrays at every
+    // subframe start (SKP_Silk_nsq_del_dec_scale_states); here the histories in HBM are written ONCE, unscaled, and a history entry
+    // receives the factors of the subframe starts that lie between its own subframe and the one that stages it when it is staged
+    // into a tap window: no read-modify-write pass over the histories, no memory round trips for it in the subframe prologue.
+    i32 gfac[SX_N_TRACKS][2 * SX_NB_SUBFR];
+    i32 lagk[SX_NB_SUBFR];
+#if SX_NLANES == 1
+    SxRowCell ring_emu[SX_DD_DELAY * 12];                 // host emulation: the emission ring of the one stream
+#endif
+};
+// The four streams of a wavefront read the same member of their own record in one LDS instruction (a quad the same word, the three
+// tracks of a stream three rows of a window): conflict-free when the twelve words fall into twelve different banks.
+constexpr bool rw_stride_ok(int stride, int rowL, int rowS) {
+    for (int pass = 0; pass < 2; pass++) {
+        const int row = pass ? rowS : rowL;
+        bool used[64] = {};
+        for (int s = 0; s < 4; s++)
+            for (int t = 0; t < 3; t++) {
+                const int b = (s * stride + t * row) % 64;
+                if (used[b]) return false;
+                used[b] = true;
+            }
+    }
+    return true;
+}
+constexpr int rw_work_pad_words(int body_words) {
+    int pad = 0;
+    while ((body_words + pad) % 4 != 0 || !rw_stride_ok(body_words + pad, SX_TAPL_N, SX_TAPS_N)) pad++;
+    return pad;
+}
+#if SX_NLANES == 1
+struct alignas(16) SxRowWork : SxRowWorkBody {};
+#else
+struct alignas(16) SxRowWork : SxRowWorkBody { i32 pad_[rw_work_pad_words((int)(sizeof(SxRowWorkBody) / 4))]; };
+static_assert(rw_stride_ok((int)(sizeof(SxRowWork) / 4), SX_TAPL_N, SX_TAPS_N) && sizeof(SxRowWork) % 16 == 0, "LDS stride of the per-stream records");
+#endif
+
+// SMULWW(x, INTERNAL_JOINT_LAMBDA) = (x * 90000) >> 16 with 90000 = 65536 + 24464: x + SMULWB(x, 24464), exactly (the first
+// part of the product is a multiple of 65536) -- one high-word multiply instead of a 64-bit product
+SX_HD i32 sx_mul_lambda(i32 x) { return sx_add(x, sx_smulw_pre(x, (i32)((u32)(SX_JOINT_LAMBDA - 65536) << 16))); }
+static_assert(SX_JOINT_LAMBDA - 65536 > 0 && SX_JOINT_LAMBDA - 65536 < 32768, "lambda split");
+SX_HD i32 sx_sel4(i32 a0, i32 a1, i32 a2, i32 a3, int i) {          // i in 0..3; selects on the index bits (no branches)
+    const bool o_ = (i & 1) != 0, h_ = (i & 2) != 0;
+    const i32 lo_ = o_ ? a1 : a0, hi_ = o_ ? a3 : a2;
+    return h_ ? hi_ : lo_;
+}
+
+// Agora_Silk_RDCx1, NSQ_del_dec.c:559: the two quantisation candidates of one side state.  The reference's three cases
+// (r < -1.5, r > 0.5, in between) differ in the two levels and in the sign of the rate term; written with selects so that the
+// lanes of a wavefront never diverge here.
+SX_HD void sx_nsq_rdcx1(i32 RD_prev, i32 r_Q10, i32 r_p_Q10, i32 inv_of_delta_Q16, i32 Lambda_Q10, i32 offset_Q10,
+                        i32* cRD, i32* cQ0, i32* cQ10, i32* cRdInd) {
+    r_p_Q10 = sx_smulww(inv_of_delta_Q16, r_p_Q10);
+    r_Q10 = sx_sub(r_Q10, offset_Q10);
+    r_p_Q10 = sx_sub(r_p_Q10, offset_Q10);
+    r_Q10 = sx_limit(r_Q10, -(64 << 10), 64 << 10);
+    const bool lo = r_Q10 < -1536, hi = r_Q10 > 512;
+    const i32 rq = sx_shl(sx_rshift_round(r_Q10, 10), 10);
+    const i32 q1 = (lo | hi) ? rq : -1024;
+    const i32 q2 = lo ? sx_add(rq, 1024) : (hi ? sx_sub(rq, 1024) : 0);
+    const i32 e1 = sx_sub(r_p_Q10, q1), e2 = sx_sub(r_p_Q10, q2);
+    const i32 a1 = sx_add(q1, offset_Q10), a2 = sx_add(q2, offset_Q10);
+    const i32 rd1 = sx_smlabb(sx_mul(hi ? a1 : sx_neg(a1), Lambda_Q10), e1, e1) >> 10;      // rate term negated unless r > 0.5
+    const i32 rd2 = sx_smlabb(sx_mul(lo ? sx_neg(a2) : a2, Lambda_Q10), e2, e2) >> 10;      // rate term negated only if r < -1.5
+    const bool first = rd1 < rd2;              // candidate 1 takes slot 0
+    cRD[0] = sx_add(RD_prev, first ? rd1 : rd2);
+    cRD[1] = sx_add(RD_prev, first ? rd2 : rd1);
+    cQ0[0] = (i8)((first ? q1 : q2) >> 10);
+    cQ0[1] = (i8)((first ? q2 : q1) >> 10);
+    cQ10[0] = sx_add(offset_Q10, first ? q1 : q2);
+    cQ10[1] = sx_add(offset_Q10, first ? q2 : q1);
+    cRdInd[0] = first ? rd1 : rd2;
+    cRdInd[1] = first ? rd2 : rd1;
+}
+
+SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambda_Q10) {
+    const i32 e = sx_sub(r_temp_Q10, q_Q10);
+    const i32 a = sx_add(q_Q10, offset_Q10);
+    return sx_smlabb(sx_mul(q_Q10 < 0 ? sx_neg(a) : a, Lambda_Q10), e, e) >> 10;
+}
+
+// SX_OPAQUE(x): hides how a value was computed from the optimiser (an empty asm that "modifies" the register).  Used on the
+// pre-shifted filter coefficients: knowing that the low 16 bits are zero, LLVM rewrites (a * (b << 16)) >> 32 as a 64-bit a * b >> 16,
+// five instructions instead of one v_mul_hi_i32.  SX_SCHED_FENCE: the instruction scheduler does not move code across it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SX_OPAQUE(x) asm volatile("" : "+v"(x))
+#define SX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
+#define SX_LAMBDA_INLINE __attribute__((always_inline))
+#else
+#define SX_OPAQUE(x)
+#define SX_SCHED_FENCE()
+#define SX_LAMBDA_INLINE
+#endif
+
+// (the quantiser kernel has exactly one call site: inlined there, so that no callee-saved registers go through scratch)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_GROUP)
+#define SX_NSQ_FN __device__ __forceinline__
+#else
+#define SX_NSQ_FN SX_FN
+#endif
+// SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  c->xfw: prefiltered input; out->q: pulses of MD1 / MD2, out->r: centre excitation Q10.
+// Addressing: the stores of the sample loop (ring cells, emitted samples) are written as  wave-uniform base + 32-bit lane offset,
+// so that the base stays in scalar registers and no 64-bit per-lane pointers have to be kept alive across the loop:
+//   Pu + pOff    the stream's SxNsqPersist,      Ou + oOff   its SxNsqOut of this frame,
+//   ringu        the emission ring of the wavefront's streams, cell (position, lane of the row) at index position * rstride + rlane + lane
+#define SX_AT(T, ubase, off) (*(T*)((char*)(ubase) + (size_t)(u32)(off)))
+SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u32 oOff, SxRowWork* w, SxRowCell* ringu, u32 rlane, int rstride) {
+    SX_IN_LDS(w);
+    SxNsqPersist* P = (SxNsqPersist*)(Pu + pOff);
+    SxNsqOut* out = (SxNsqOut*)(Ou + oOff);
+    SxNsqGlobal* g = &P->g;
+    const int voiced = c->sigtype == 0;
+    const i32 offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
+    int lagC = P->nsq[0].lagPrev;                              // the centre's lag: governs the decision delay and the shaping taps of all tracks
+    int smpl_buf_idx = 0;
+    int decisionDelay = sx_min(SX_DD_DELAY, SX_SUBFR);
+    if (voiced) {
+        for (int k = 0; k < SX_NB_SUBFR; k++) decisionDelay = sx_min(decisionDelay, c->pitchL[k] - SX_LTP_ORDER / 2 - 1);
+    } else if (lagC > 0) {
+        decisionDelay = sx_min(decisionDelay, lagC - SX_LTP_ORDER / 2 - 1);
+    }
+    const int LSF_interpolation_flag = c->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
+    const i32 Lambda_Q10 = c->Lambda_Q10;
+#define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)((pos_) * rstride) + rlane + (u32)(lane_)) * (u32)sizeof(SxRowCell))
+    // the sample loop's own ring traffic (every cell is written once and read once, a decision delay later) with the non-temporal
+    // cache policy: 32 MB of ring per 4096 streams otherwise sweep everything else -- the stream histories the subframe prologues
+    // wait for -- out of the 32 MB of L2
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(SX_RING_TEMPORAL)
+    typedef int rw_v4i_ __attribute__((ext_vector_type(4)));
+#define RW_CELL_LD(dst_, pos_, lane_) { const rw_v4i_ v_ = __builtin_nontemporal_load((const rw_v4i_*)&RW_CELL(pos_, lane_)); \
+        (dst_).w0 = v_.x; (dst_).w1 = v_.y; (dst_).w2 = v_.z; (dst_).w3 = v_.w; }
+#define RW_CELL_ST(pos_, lane_, src_) { rw_v4i_ v_; v_.x = (src_).w0; v_.y = (src_).w1; v_.z = (src_).w2; v_.w = (src_).w3; \
+        __builtin_nontemporal_store(v_, (rw_v4i_*)&RW_CELL(pos_, lane_)); }
+#else
+#define RW_CELL_LD(dst_, pos_, lane_) (dst_) = RW_CELL(pos_, lane_);
+#define RW_CELL_ST(pos_, lane_, src_) RW_CELL(pos_, lane_) = (src_);
+#endif
+
+    // ---- lane-private state: one delayed-decision state of one track (registers on the GPU) ----
+    i32 sAR2[RW_NL][SX_SHAPE_ORDER], sLPC[RW_NL][SX_LPC];        // sLPC[0] = newest quantised sample (Q14)
+    i32 LF_AR[RW_NL], Seed[RW_NL], RD[RW_NL], lastShp[RW_NL];
+    i32 Seed2[RW_NL], SeedInit2[RW_NL], linLo[RW_NL], linHi[RW_NL];          // per state: identical in the three tracks' lanes
+    i32 lagT[RW_NL], prevInv[RW_NL], gadj[RW_NL];                            // per track
+    // byte offsets of the lane's track inside the stream's records
+    u32 pNsq[RW_NL], pXq[RW_NL], pShp[RW_NL], pLtp[RW_NL], oX[RW_NL];
+    // per sample
+    i32 LTP_pred[RW_NL], LPC_pred[RW_NL], n_AR[RW_NL], n_LF[RW_NL], rD[RW_NL], rC[RW_NL], dith[RW_NL];
+    i32 cRD[RW_NL][2], cQ0[RW_NL][2], cQ10[RW_NL][2], sRdInd[RW_NL][2];
+    i32 p1q0[RW_NL], p1q1[RW_NL], p1r0[RW_NL], p1r1[RW_NL], p2q0[RW_NL], p2q1[RW_NL], p2r0[RW_NL], p2r1[RW_NL];
+    // The ring is a delay line in HBM; its reads are issued TWO samples before they are used.  Two register sets take turns: even
+    // samples consume set A (the own-slot cell of the ring position the sample emits) and refill it with the cell sample i + 2
+    // will need, odd samples do the same with set B.  The sample loop is written two samples per iteration so that no set is
+    // ever copied into another at the loop's back edge: such a copy would wait for loads issued a few hundred instructions
+    // earlier in the same sample.
+    SxRowCell qA[RW_NL], qB[RW_NL];
+    // scratch of the joint decision
+    i32 jv[RW_NL], mv[RW_NL], mi[RW_NL], mv2[RW_NL], mi2[RW_NL], tq[RW_NL], tq2[RW_NL], par[RW_NL], csrc[RW_NL], csel[RW_NL], c0[RW_NL], c1[RW_NL], nrep[RW_NL];
+    i32 gq[RW_NL], myRand[RW_NL];
+#pragma unroll
+    for (int a = 0; a < RW_NL; a++) {
+        Seed2[a] = SeedInit2[a] = linLo[a] = linHi[a] = dith[a] = lagT[a] = prevInv[a] = 0;
+        gadj[a] = 65536;
+        pNsq[a] = pXq[a] = pShp[a] = pLtp[a] = oX[a] = 0u;
+        jv[a] = mv[a] = mi[a] = mv2[a] = mi2[a] = tq[a] = tq2[a] = par[a] = csrc[a] = csel[a] = c0[a] = c1[a] = nrep[a] = gq[a] = myRand[a] = 0;
+        p1q0[a] = p1q1[a] = p1r0[a] = p1r1[a] = p2q0[a] = p2q1[a] = p2r0[a] = p2r1[a] = 0;
+#pragma unroll
+        for (int j = 0; j < SX_SHAPE_ORDER; j++) sAR2[a][j] = 0;
+#pragma unroll
+        for (int j = 0; j < SX_LPC; j++) sLPC[a][j] = 0;
+        LF_AR[a] = Seed[a] = RD[a] = lastShp[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = rC[a] = 0;
+#pragma unroll
+        for (int j = 0; j < 2; j++) cRD[a][j] = cQ0[a][j] = cQ10[a][j] = sRdInd[a][j] = 0;
+        qA[a].w0 = qA[a].w1 = qA[a].w2 = qA[a].w3 = 0;
+        qB[a] = qA[a];
+    }
+
+    // Agora_Silk_Init_DelDecState (NSQ_del_dec.c:148): every track starts from the same seed.  Only the random-state history is
+    // ever read before it is written (the expiry test of the first decisionDelay samples of a frame): those reads give zero, see phase E.
+    {
+        SX_PAR(i, SX_N_TRACKS * SX_NB_SUBFR) {
+            const int t = i / SX_NB_SUBFR, kq = i - t * SX_NB_SUBFR;
+            w->gfac[t][kq] = P->nsq[t].gadjPrev[kq];
+            w->gfac[t][SX_NB_SUBFR + kq] = 65536;
+        }
+        SX_PAR(i, SX_NB_SUBFR) w->lagk[i] = c->pitchL[i];
+        RW_FORK(l) {
+            const int li = RW_LI(l), tt = RW_TT(l), k = RW_K(l), t = RW_T(l);
+            pNsq[li] = pOff + (u32)(offsetof(SxNsqPersist, nsq) + (size_t)tt * sizeof(SxNSQ));
+            pXq[li] = pOff + (u32)(offsetof(SxNsqPersist, xq) + (size_t)tt * 2 * SX_FRAME * sizeof(i16));
+            pShp[li] = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, shp) + (size_t)tt * (2 * SX_FRAME + 8) * sizeof(i32));
+            pLtp[li] = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, sLTP_Q16) + (size_t)tt * 2 * SX_FRAME * sizeof(i32));
+            oX[li] = t == 0 ? oOff + (u32)offsetof(SxNsqOut, r) : oOff + (u32)(offsetof(SxNsqOut, q) + (size_t)(tt - 1) * SX_FRAME);
+            const SxNSQ* n = &SX_AT(SxNSQ, Pu, pNsq[li]);
+            lagT[li] = n->lagPrev;
+            prevInv[li] = n->prev_inv_gain_Q16;
+            Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
+            linLo[li] = linHi[li] = k * 0x55555555;                  // slot k at every ring position
+            Seed[li] = (k + c->Seed) & 3;
+            RD[li] = 0;
+            LF_AR[li] = n->sLF_AR_shp_Q12;
+            lastShp[li] = SX_AT(i32, Pu, pShp[li] + (u32)(SX_FRAME - 1) * 4u);       // the reference seeds ring position 0 of every state with it
+#pragma unroll
+            for (int i = 0; i < SX_LPC; i++) sLPC[li][i] = n->sLPC_Q14[SX_MAX_LPC - 1 - i];
+#pragma unroll
+            for (int i = 0; i < SX_SHAPE_ORDER; i++) sAR2[li][i] = n->sAR2_Q14[i];
+        }
+        wv_sync();
+    }
+    RW_FORK(l) {       // prime the ring's read queue: the cells samples 0 and 1 look back at (not written by this frame; never used as such)
+        const int li = RW_LI(l);
+        const int l0 = (SX_DD_MASK + decisionDelay) & SX_DD_MASK;
+        qA[li] = RW_CELL(l0, l);
+        qB[li] = RW_CELL((l0 - 1) & SX_DD_MASK, l);
+    }
+    int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
+    int subfr = 0;
+    int rewhite_k = 0;                                          // the subframe whose start last re-whitened the prediction history
+
+    // MD gain split (md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1401-1417)
+    const i32 inv_gain_p1_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
+    const i32 inv_gain_p2_Q16 = 65536 - inv_gain_p1_Q16;
+    const i32 DeltaGains_p1_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p1_Q16, 1), 32);
+    const i32 DeltaGains_p2_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p2_Q16, 1), 32);
+    const i32 inv_of_delta_p1_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p1_Q16, 1), 32);   // recomputed inside RDCx1
+    const i32 inv_of_delta_p2_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p2_Q16, 1), 32);
+    const i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);       // _OFFSET_MD_ (SKP_Silk_define.h:41)
+    const i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
+    const i32 offset_sum_Q10 = offset_p1_Q10 + offset_p2_Q10;
+
+#define RW_LIN_SLOT(lo_, hi_, pos_) ((int)((((pos_) < 16 ? (u32)(lo_) : (u32)(hi_)) >> (2 * ((pos_) & 15))) & 3u))
+    // outputs of one emitted sample of the lane's track (Agora_Silk_GetWinner{,_Side} / the flush loops); cell_ = the winner's ring cell.
+    // The two histories that the reference shifts down by a frame when the frame ends (the quantised signal and the shaping history)
+    // get every emitted sample twice: at its place in the current-frame half and at the same place of the previous-frame half, which
+    // is what the shift would copy there (the entries are written once and never modified: the gain factors are applied when they are
+    // staged).  No reader of this frame reaches the overwritten entries any more: a window / re-whitening run of subframe k starts at
+    // FRAME + k SUBFR - lag - 12 at the earliest, > k SUBFR, and the entries below k SUBFR - decisionDelay are the ones rewritten.
+#define RW_EMIT_OUT(l_, li_, cell_, pos_)                                                                                    \
+    {                                                                                                                        \
+        const i32 X_ = rw_cell_x(cell_), xq_ = rw_cell_xq(cell_);                                                            \
+        if (RW_T(l_) == 0) SX_AT(i32, Ou, oX[li_] + (u32)(pos_) * 4u) = X_;                                                  \
+        else SX_AT(i8, Ou, oX[li_] + (u32)(pos_)) = (i8)X_;                                                                  \
+        SX_AT(i16, Pu, pXq[li_] + (u32)(SX_FRAME + (pos_)) * 2u) = (i16)xq_;                                                 \
+        SX_AT(i32, Pu, pShp[li_] + (u32)(SX_FRAME + (pos_)) * 4u) = (cell_).w2;                                              \
+        SX_AT(i16, Pu, pXq[li_] + (u32)(pos_) * 2u) = (i16)xq_;                                                              \
+        SX_AT(i32, Pu, pShp[li_] + (u32)(pos_) * 4u) = (cell_).w2;                                                           \
+    }
+    // flush of the winner's lineage (wlo_, whi_), oldest sample at output position pos0_: every lane its own track, the four lanes
+    // of a track every fourth sample
+#define RW_FLUSH(wlo_, whi_, pos0_)                                                                                          \
+    RW_FORK(l) {                                                                                                             \
+        const int li = RW_LI(l);                                                                                             \
+        if (RW_LIVE(l)) {                                                                                                    \
+            for (int base = RW_K(l); base < decisionDelay; base += 16) {                                                     \
+                SxRowCell cl[4];                                                                                             \
+                _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                              \
+                    const int i = base + 4 * u;                                                                              \
+                    const int rp = (smpl_buf_idx + decisionDelay - 1 - i) & SX_DD_MASK;                                      \
+                    if (i < decisionDelay) cl[u] = RW_CELL(rp, (l & ~3) | RW_LIN_SLOT(wlo_, whi_, rp));                      \
+                }                                                                                                            \
+                _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                              \
+                    const int i = base + 4 * u;                                                                              \
+                    if (i < decisionDelay) RW_EMIT_OUT(l, li, cl[u], (pos0_) + i)                                            \
+                }                                                                                                            \
+            }                                                                                                                \
+        }                                                                                                                    \
+    }
+
+    for (int k = 0; k < SX_NB_SUBFR; k++) {
+        const i16* A_Q12 = c->PredCoef_Q12[(k >> 1) | (1 - LSF_interpolation_flag)];
+        const i16* B_Q14 = &c->LTPCoef_Q14[k * SX_LTP_ORDER];
+        const i16* AR_shp_Q13 = &c->AR2_Q13[k * SX_SHAPE_ORDER];
+        i32 HarmShapeFIRPacked_Q14 = c->HarmShapeGain_Q14[k] >> 2;
+        HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[k] >> 1, 16);
+        const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k], Gain_Q16 = c->Gains_Q16[k];
+        // filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form; the same for the
+        // three tracks and the four states of the stream
+        i32 Apre[SX_LPC], ARpre[SX_SHAPE_ORDER], Bpre[SX_LTP_ORDER];
+#pragma unroll
+        for (int j = 0; j < SX_LPC; j++) Apre[j] = sx_pre16(A_Q12[j]);
+#pragma unroll
+        for (int j = 0; j < SX_SHAPE_ORDER; j++) ARpre[j] = sx_pre16(AR_shp_Q13[j]);
+#pragma unroll
+        for (int j = 0; j < SX_LTP_ORDER; j++) Bpre[j] = sx_pre16(B_Q14[j]);
+        i32 warp_pre = sx_pre16(SX_WARPING_Q16);
+        i32 Tilt_pre = sx_pre16(Tilt_Q14);
+        i32 LFb_pre = sx_pre16(LF_shp_Q14), LFt_pre = (i32)((u32)LF_shp_Q14 & 0xFFFF0000u);
+        i32 Hb_pre = sx_pre16(HarmShapeFIRPacked_Q14), Ht_pre = (i32)((u32)HarmShapeFIRPacked_Q14 & 0xFFFF0000u);
+        int rewhite = 0;
+        i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
+        inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
+        i32 inv_gain_Q32 = sx_shl(inv_gain_Q16, 16);                    // scale_states, NSQ_del_dec.c:1611-1616
+        if (k == 0) inv_gain_Q32 = sx_shl(sx_smulwb(inv_gain_Q32, c->LTP_scale_Q14), 2);
+        if (voiced) {
+            lagC = c->pitchL[k];
+            RW_FORK(l) { lagT[RW_LI(l)] = lagC; }
+            if ((k & (3 - sx_shl(LSF_interpolation_flag, 1))) == 0) {
+                if (k == 2) {
+                    subfr = 0;
+                    // Agora_Silk_DelDec_Rewhitening{,_Side} (NSQ_del_dec.c:315, 400): flush the centre winner's lineage
+                    RWT_FROM(jv, RD, 0)
+                    RWK_ARGMIN(jv, mv, mi)
+                    RW_FORK(l) {
+                        if (RW_K(l) != mi[RW_LI(l)]) RD[RW_LI(l)] += SX_I32_MAX >> 4;
+                    }
+                    RWK_GATHER(tq, linLo, mi)
+                    RWK_GATHER(tq2, linHi, mi)
+                    wv_sync();                      // the ring cells of the last samples must have landed
+                    RW_FLUSH(tq[li], tq2[li], k * SX_SUBFR - decisionDelay)
+                    wv_sync();
+                }
+                // re-whiten the quantised signal with the new LPC (SKP_Silk_MA_Prediction from a zero state)
+                const int lag = lagC;
+                const int start_idx = SX_FRAME - lag - SX_LPC - SX_LTP_ORDER / 2;
+                const int len = SX_FRAME - start_idx;
+                // every lane filters a contiguous run of outputs and keeps the last SX_LPC inputs in registers: one load per output
+                const int per = (len + SX_NLANES - 1) / SX_NLANES;
+                const int n0 = SX_LANE * per, n1 = sx_min(len, n0 + per);
+                i32 Ac[SX_LPC];
+#pragma unroll
+                for (int j = 0; j < SX_LPC; j++) Ac[j] = A_Q12[j];
+                for (int t = 0; t < SX_N_TRACKS; t++) {
+                    const i16* in = &P->xq[t][start_idx + k * SX_SUBFR];
+                    i32 h[SX_LPC];                                     // h[j] = in[n - 1 - j], zero before the start (zero initial state)
+#pragma unroll
+                    for (int j = 0; j < SX_LPC; j++) h[j] = (n0 - 1 - j >= 0 && n0 < n1) ? (i32)in[n0 - 1 - j] : 0;
+#pragma unroll 2
+                    for (int n = n0; n < n1; n++) {
+                        i32 acc = 0;
+#pragma unroll
+                        for (int j = 0; j < SX_LPC; j++) acc = sx_smlabb(acc, h[j], Ac[j]);
+                        const i32 xin = in[n];
+                        i32 o = sx_rshift_round(sx_sub(sx_shl(xin, 12), acc), 12);
+                        // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[]) -- and into
+                        // this subframe's tap window, which covers [FRAME - lag - 2, FRAME) of it
+                        const i32 rw = sx_smulwb(inv_gain_Q32, sx_sat16(o));
+                        g->sLTP_Q16[t][start_idx + n] = rw;
+                        const int wi = n - SX_LPC;                            // = (start_idx + n) - (FRAME - lag - LTP_ORDER / 2)
+                        if ((unsigned)wi < (unsigned)SX_TAPL_N) w->tapL[t][wi] = rw;
+#pragma unroll
+                        for (int j = SX_LPC - 1; j > 0; j--) h[j] = h[j - 1];
+                        h[0] = xin;
+                    }
+                }
+                sLTP_buf_idx = SX_FRAME;
+                rewhite = 1;
+                rewhite_k = k;
+            }
+        }
+        // SKP_Silk_nsq_del_dec_scale_states (NSQ_del_dec.c:1593).  The ring cells are NOT rescaled here: gadj[] is applied to the
+        // cells of the previous subframe when (and if) they are emitted.  The histories in HBM are not rescaled either: the factors
+        // are recorded and applied when history entries are staged, below.
+        RW_FORK(l) {
+            const int li = RW_LI(l);
+            gadj[li] = 65536;
+            if (inv_gain_Q16 != prevInv[li]) {
+                const i32 gain_adj_Q16 = sx_div32_varQ(inv_gain_Q16, prevInv[li], 16);
+                gadj[li] = gain_adj_Q16;
+                LF_AR[li] = sx_smulww(gain_adj_Q16, LF_AR[li]);
+                lastShp[li] = sx_smulww(gain_adj_Q16, lastShp[li]);
+#pragma unroll
+                for (int i = 0; i < SX_LPC; i++) sLPC[li][i] = sx_smulww(gain_adj_Q16, sLPC[li][i]);
+#pragma unroll
+                for (int i = 0; i < SX_SHAPE_ORDER; i++) sAR2[li][i] = sx_smulww(gain_adj_Q16, sAR2[li][i]);
+            }
+            prevInv[li] = inv_gain_Q16;
+            if (RW_K(l) == 0 && RW_LIVE(l)) w->gfac[RW_T(l)][SX_NB_SUBFR + k] = gadj[li];
+        }
+        SX_PAR(i, SX_SUBFR) w->xsc[i] = sx_smulbb(c->xfw[k * SX_SUBFR + i], inv_gain_Q16) >> 6;       // Agora_Silk_DelDecScale (NSQ_del_dec.c:1668)
+        wv_sync();                                    // factors visible; the emission stores of the previous subframe have landed
+
+        // ---- the per-sample trellis (SKP_Silk_md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1341) ----
+        const int odd = subfr & 1;
+        const int shp_base = sLTP_shp_buf_idx, pred_base = sLTP_buf_idx;
+        // The long-term prediction / harmonic-shaping histories live in HBM, but the sample loop never reads HBM for them: the entries
+        // this subframe's taps can reach are staged in LDS now (the emission stores of the previous subframes have landed: wv_sync
+        // above).  Entries that are only emitted during this very subframe are not valid yet: the emission writes them into the
+        // window as well (iteration ip emits window entry ip + D + 5 of the prediction history, ip + D + 4 of the shaping history,
+        // D = lag - decisionDelay - 3; the first tap to read it belongs to iteration ip + 1 + D or later).
+        if (lagC <= 0) { Hb_pre = 0; Ht_pre = 0; }            // no harmonic shaping without a pitch lag (the taps are not staged then)
+        if (!voiced) {                                        // (the analysis hands over zero prediction taps for an unvoiced frame; not relied on)
+#pragma unroll
+            for (int j = 0; j < SX_LTP_ORDER; j++) Bpre[j] = 0;
+        }
+#pragma unroll
+        for (int j = 0; j < SX_LPC; j++) SX_OPAQUE(Apre[j]);
+#pragma unroll
+        for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_OPAQUE(ARpre[j]);
+#pragma unroll
+        for (int j = 0; j < SX_LTP_ORDER; j++) SX_OPAQUE(Bpre[j]);
+        SX_OPAQUE(warp_pre); SX_OPAQUE(Tilt_pre); SX_OPAQUE(LFb_pre); SX_OPAQUE(LFt_pre); SX_OPAQUE(Hb_pre); SX_OPAQUE(Ht_pre);
+        {
+            constexpr int NL = (SX_TAPL_N + SX_NLANES - 1) / SX_NLANES, NS = (SX_TAPS_N + SX_NLANES - 1) / SX_NLANES;
+            // A history entry is stored once, unscaled.  What the reference's rescaling passes would have done to it by now is applied
+            // here, in the reference's order (every smulww rounds): the factor of subframe start j for every j between the entry's own
+            // subframe and this one -- shaping history: the newest SX_FRAME entries are rescaled at every start, so all of them
+            // (an entry that a tap can reach is at most four subframes old); prediction history: only the newest lag_j + 2 entries
+            // are, and only at starts that did not re-whiten it.
+            // (unvoiced frame: the side tracks keep THEIR previous lag -- it differs from the centre's only in the first frames
+            // after a reset, where the reference's set-up gives the centre 100 and the sides 0)
+            int lagU[SX_N_TRACKS];
+#pragma unroll
+            for (int t = 0; t < SX_N_TRACKS; t++) lagU[t] = voiced ? lagC : P->nsq[t].lagPrev;
+#pragma unroll
+            for (int t = 0; t < SX_N_TRACKS; t++) {               // per track: all loads of the lane first, then the LDS writes
+                i32 vl[NL], vs[NS];
+                const int iL0 = pred_base - lagU[t] - SX_LTP_ORDER / 2, iS0 = shp_base - lagU[t] - 1;
+                const i32* srcL = &g->sLTP_Q16[t][iL0];                                        // tap j of iteration i sits at srcL[i - j + 4]
+                const i32* srcS = &g->shp[t][iS0];                                             // tap j of iteration i sits at srcS[i - j + 2]
+                const bool stageL = voiced && !rewhite;          // (a re-whitening start has just written its window itself)
+#pragma unroll
+                for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; vl[u] = (stageL && n < SX_TAPL_N) ? srcL[n] : 0; }
+#pragma unroll
+                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; vs[u] = (lagC > 0 && n < SX_TAPS_N) ? srcS[n] : 0; }
+                if (stageL) {
+#pragma unroll
+                    for (int u = 0; u < NL; u++) {
+                        const int n = SX_LANE + u * SX_NLANES, idx = iL0 + n;
+                        const int ep = idx < SX_FRAME ? rewhite_k : rewhite_k + (idx - SX_FRAME) / SX_SUBFR;      // the entry's own subframe
+#pragma unroll
+                        for (int j = 1; j < SX_NB_SUBFR; j++) {
+                            const bool ap = (j > rewhite_k) & (j <= k) & (j > ep) & (idx >= SX_FRAME + SX_SUBFR * (j - rewhite_k) - (w->lagk[j] + SX_LTP_ORDER / 2));
+                            const i32 sc = sx_smulww(w->gfac[t][SX_NB_SUBFR + j], vl[u]);
+                            vl[u] = ap ? sc : vl[u];
+                        }
+                    }
+                }
+                if (lagC > 0) {
+#pragma unroll
+                    for (int u = 0; u < NS; u++) {
+                        const int n = SX_LANE + u * SX_NLANES, idx = iS0 + n;
+                        const int r = idx / SX_SUBFR - SX_NB_SUBFR;                    // the entry's subframe relative to this frame: -4 .. 3
+#pragma unroll
+                        for (int d = SX_NB_SUBFR - 1; d >= 0; d--) {                   // subframe starts k - 3 .. k, in time order
+                            const int j = k - d;
+                            const i32 sc = sx_smulww(w->gfac[t][SX_NB_SUBFR + j], vs[u]);
+                            vs[u] = (j > r) ? sc : vs[u];
+                        }
+                    }
+                }
+                if (stageL) {
+#pragma unroll
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = vl[u]; }
+                } else if (!voiced) {
+#pragma unroll
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = 0; }
+                }
+#pragma unroll
+                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPS_N) w->tapS[t][n] = vs[u]; }
+            }
+        }
+        wv_sync();
+        // the lane's side of the MD gain split in this subframe: MD1 takes the p1 share on even subframes, MD2 on odd ones
+        // (the centre's lanes compute side candidates nobody reads)
+        i32 my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
+        RW_FORK(l) {
+            const int li = RW_LI(l);
+            const bool first = (RW_T(l) == 1) != (odd != 0);
+            my_inv_gain[li] = first ? inv_gain_p1_Q16 : inv_gain_p2_Q16;
+            my_inv_of_delta[li] = first ? inv_of_delta_p1_Q16 : inv_of_delta_p2_Q16;
+            my_offset[li] = first ? offset_p1_Q10 : offset_p2_Q10;
+            my_DG[li] = first ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16;
+        }
+        // one sample of the trellis; qf: the register set (A or B) that holds the ring cell this sample consumes
+        auto sample_step = [&](const int i, SxRowCell (&qf)[RW_NL]) SX_LAMBDA_INLINE {
+            const bool emitted = subfr > 0 || i >= decisionDelay;
+            const int smpl_new = (smpl_buf_idx - 1) & SX_DD_MASK;                  // ring position this sample writes
+            const int last_smple_idx = (smpl_new + decisionDelay) & SX_DD_MASK;    // ring position this sample emits
+            // The sample takes the cell it will emit / test out of its register set (em) and at once refills the set with the
+            // cell sample i + 2 consumes: a whole sample's work (and the other set's turn) lies between a request and its first
+            // use, and the request stands in front of this sample's stores (vector memory operations complete in order).  The
+            // requested cell was written decisionDelay - 2 >= 11 samples ago.
+            SxRowCell em[RW_NL];
+            RW_FORK(l) {
+                const int li = RW_LI(l);
+                em[li] = qf[li];
+                RW_CELL_LD(qf[li], (last_smple_idx - 2) & SX_DD_MASK, l)
+            }
+            // phase A: predictions, shaping, residual, dither of the lane's track and state
+            RW_FORK(l) {
+                const int li = RW_LI(l), tt = RW_TT(l);
+                // The taps of this sample (long-term prediction: 5, harmonic shaping: 3): one LDS read each at a fixed place of the
+                // staged windows.  Issued first, consumed after the shaping filter.  (Unvoiced frame: the prediction
+                // coefficients are zero; no pitch lag: the shaping gains were zeroed above -- whatever the windows hold.)
+                i32 curL[SX_LTP_ORDER], curS[3];
+#pragma unroll
+                for (int j = 0; j < SX_LTP_ORDER; j++) curL[j] = w->tapL[tt][i + (SX_LTP_ORDER - 1) - j];
+#pragma unroll
+                for (int j = 0; j < 3; j++) curS[j] = w->tapS[tt][i + 2 - j];
+                const i32 x_sc_Q10 = w->xsc[i];
+                Seed2[li] = sx_rand(Seed2[li]);                                                // Agora_Silk_Dither (NSQ_del_dec.c:520)
+                const i32 dither = Seed2[li] >> 31;
+                dith[li] = dither;
+                i32 LPC_pred_Q10 = 0;
+#pragma unroll
+                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlaw_pre(LPC_pred_Q10, sLPC[li][j], Apre[j]);
+                // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place
+                i32 tmp2 = sx_smlaw_pre(sLPC[li][0], sAR2[li][0], warp_pre);
+                i32 tmp1 = sx_smlaw_pre(sAR2[li][0], sAR2[li][1] - tmp2, warp_pre);
+                sAR2[li][0] = tmp2;
+                i32 n_AR_Q10 = sx_smulw_pre(tmp2, ARpre[0]);
+#pragma unroll
+                for (int j = 2; j < SX_SHAPE_ORDER; j += 2) {
+                    tmp2 = sx_smlaw_pre(sAR2[li][j - 1], sAR2[li][j] - tmp1, warp_pre);
+                    sAR2[li][j - 1] = tmp1;
+                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[j - 1]);
+                    tmp1 = sx_smlaw_pre(sAR2[li][j], sAR2[li][j + 1] - tmp2, warp_pre);
+                    sAR2[li][j] = tmp2;
+                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp2, ARpre[j]);
+                }
+                sAR2[li][SX_SHAPE_ORDER - 1] = tmp1;
+                n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[SX_SHAPE_ORDER - 1]);
+                n_AR_Q10 = n_AR_Q10 >> 1;
+                n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, LF_AR[li], Tilt_pre);
+                // newest shaping sample of this state's lineage
+                i32 n_LF_Q10 = sx_shl(sx_smulw_pre(lastShp[li], LFb_pre), 2);
+                n_LF_Q10 = sx_smlaw_pre(n_LF_Q10, LF_AR[li], LFt_pre);
+                n_AR[li] = n_AR_Q10;
+                n_LF[li] = n_LF_Q10;
+                LPC_pred[li] = LPC_pred_Q10;
+                // long-term prediction and harmonic shaping (taps are zero in an unvoiced frame / without a pitch lag: no branch;
+                // the reference tests the CENTRE lag for every track, NSQ_del_dec.c:1436-1446)
+                i32 LTP_pred_Q14 = 0;
+#pragma unroll
+                for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, curL[j], Bpre[j]);
+                i32 n_LTP_Q14 = sx_smulw_pre(sx_add(curS[0], curS[2]), Hb_pre);
+                n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, curS[1], Ht_pre);
+                n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
+                // Agora_Silk_DoPred_And_Shap (Agora_SILK_func.c:143)
+                i32 tmp = sx_sub(LTP_pred_Q14, n_LTP_Q14) >> 4;
+                tmp = sx_add(tmp, LPC_pred_Q10);
+                tmp = sx_sub(tmp, n_AR_Q10);
+                tmp = sx_sub(tmp, n_LF_Q10);
+                i32 r_Q10 = sx_sub(x_sc_Q10, tmp);
+                Seed[li] = sx_rand(Seed[li]);
+                r_Q10 = (r_Q10 ^ dither) - dither;
+                LTP_pred[li] = LTP_pred_Q14;
+                rD[li] = r_Q10;
+            }
+            // phase B: the two candidates of each side state (Agora_Silk_RDCx1) from the side's share of the CENTRE residual
+            RWT_FROM(rC, rD, 0)
+            RW_FORK(l) {
+                const int li = RW_LI(l);
+                const i32 r_md_Q10 = sx_smulww(my_inv_gain[li], rC[li]);
+                sx_nsq_rdcx1(RD[li], r_md_Q10, rD[li], my_inv_of_delta[li], Lambda_Q10, my_offset[li], cRD[li], cQ0[li], cQ10[li], sRdInd[li]);
+            }
+            // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152) in the centre's lanes: the centre takes the best two of the four
+            // combinations of side candidates; the side candidates are then re-ordered so that candidate j of every track belongs
+            // to combination w_j
+#if SX_NLANES == 1
+            { i32 a_[12], b_[12], c_[12], d_[12];
+              for (int q_ = 0; q_ < 12; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = sRdInd[q_][0]; d_[q_] = sRdInd[q_][1]; }
+              RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
+              RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
+#else
+            p1q0[0] = RW_DPP_BANK(p1q0[0], cQ10[0][0], RW_SHL(4), 0); p1q1[0] = RW_DPP_BANK(p1q1[0], cQ10[0][1], RW_SHL(4), 0);
+            p1r0[0] = RW_DPP_BANK(p1r0[0], sRdInd[0][0], RW_SHL(4), 0); p1r1[0] = RW_DPP_BANK(p1r1[0], sRdInd[0][1], RW_SHL(4), 0);
+            p2q0[0] = RW_DPP_BANK(p2q0[0], cQ10[0][0], RW_SHL(8), 0); p2q1[0] = RW_DPP_BANK(p2q1[0], cQ10[0][1], RW_SHL(8), 0);
+            p2r0[0] = RW_DPP_BANK(p2r0[0], sRdInd[0][0], RW_SHL(8), 0); p2r1[0] = RW_DPP_BANK(p2r1[0], sRdInd[0][1], RW_SHL(8), 0);
+#endif
+            i32 wpk[RW_NL], ccRD[RW_NL][2], ccQ10[RW_NL][2];
+            RW_FORK(l) {
+                const int li = RW_LI(l);
+                const i32 off = offset_sum_Q10;
+                const i32 qx0 = p1q0[li] + p2q0[li], qx1 = p1q1[li] + p2q1[li], qx2 = p1q0[li] + p2q1[li], qx3 = p1q1[li] + p2q0[li];
+                const i32 r_temp = sx_sub(rD[li], off);
+                const i32 l1r0 = sx_mul_lambda(p1r0[li]), l1r1 = sx_mul_lambda(p1r1[li]), l2r0 = sx_mul_lambda(p2r0[li]), l2r1 = sx_mul_lambda(p2r1[li]);
+                i32 rdx0 = sx_nsq_center_rd1(qx0, r_temp, off, Lambda_Q10), rdx1 = sx_nsq_center_rd1(qx1, r_temp, off, Lambda_Q10);
+                i32 rdx2 = sx_nsq_center_rd1(qx2, r_temp, off, Lambda_Q10), rdx3 = sx_nsq_center_rd1(qx3, r_temp, off, Lambda_Q10);
+                rdx0 = sx_add(sx_add(rdx0, l1r0), l2r0);
+                rdx1 = sx_add(sx_add(rdx1, l1r1), l2r1);
+                rdx2 = sx_add(sx_add(rdx2, l1r0), l2r1);
+                rdx3 = sx_add(sx_add(rdx3, l1r1), l2r0);
+                // best combination (first minimum) and best of the remaining three (first minimum among them): selects, no branches
+                int w1 = 0;
+                i32 m = rdx0;
+                { const bool b = rdx1 < m; m = b ? rdx1 : m; w1 = b ? 1 : w1; }
+                { const bool b = rdx2 < m; m = b ? rdx2 : m; w1 = b ? 2 : w1; }
+                { const bool b = rdx3 < m; m = b ? rdx3 : m; w1 = b ? 3 : w1; }
+                int w2 = w1 == 0 ? 1 : 0;
+                m = w1 == 0 ? rdx1 : rdx0;
+                { const bool b = (w1 != 0) & (w1 != 1) & (rdx1 < m); m = b ? rdx1 : m; w2 = b ? 1 : w2; }
+                { const bool b = (w1 != 2) & (rdx2 < m); m = b ? rdx2 : m; w2 = b ? 2 : w2; }
+                { const bool b = (w1 != 3) & (rdx3 < m); m = b ? rdx3 : m; w2 = b ? 3 : w2; }
+                const i32 q_w1 = sx_sel4(qx0, qx1, qx2, qx3, w1), q_w2 = sx_sel4(qx0, qx1, qx2, qx3, w2);
+                const i32 rd_w1 = sx_sel4(rdx0, rdx1, rdx2, rdx3, w1), rd_w2 = sx_sel4(rdx0, rdx1, rdx2, rdx3, w2);
+                ccRD[li][0] = sx_add(RD[li], rd_w1);
+                ccRD[li][1] = sx_add(RD[li], rd_w2);
+                ccQ10[li][0] = q_w1;
+                ccQ10[li][1] = q_w2;
+                wpk[li] = w1 | (w2 << 2);
+            }
+            RWT_FROM(tq, wpk, 0)
+            RW_FORK(l) {
+                const int li = RW_LI(l), t = RW_T(l);
+                const int w1 = tq[li] & 3, w2 = tq[li] >> 2;
+                // the reference's 12-way memcpy case table (NSQ_del_dec.c:1266-1336) is this selection;
+                // member of combination w: MD1 {0,1,0,1}, MD2 {0,1,1,0}
+                const bool ca = t == 1 ? (w1 & 1) != 0 : (w1 == 1 || w1 == 2), cb = t == 1 ? (w2 & 1) != 0 : (w2 == 1 || w2 == 2);
+                const i32 a0 = cRD[li][0], a1 = cRD[li][1], b0 = cQ0[li][0], b1 = cQ0[li][1], d0 = cQ10[li][0], d1 = cQ10[li][1];
+                const bool ctr = t == 0 || t == 3;
+                cRD[li][0] = ctr ? ccRD[li][0] : (ca ? a1 : a0);   cRD[li][1] = ctr ? ccRD[li][1] : (cb ? a1 : a0);
+                cQ0[li][0] = ctr ? ccQ10[li][0] >> 10 : (ca ? b1 : b0);  cQ0[li][1] = ctr ? ccQ10[li][1] >> 10 : (cb ? b1 : b0);
+                cQ10[li][0] = ctr ? ccQ10[li][0] : (ca ? d1 : d0); cQ10[li][1] = ctr ? ccQ10[li][1] : (cb ? d1 : d0);
+                // the track's share of the joint cost of candidate [0] (Agora_Silk_JudgeWinner, NSQ_del_dec.c:671)
+                tq2[li] = t == 0 ? cRD[li][0] : sx_mul_lambda(cRD[li][0]);
+            }
+            RWT_SUM(jv, tq2)
+            smpl_buf_idx = smpl_new;
+            // phase E: Agora_Silk_JudgeWinner.  States whose decisionDelay-old ancestor differs from the joint winner's, in any
+            // track, are expired (their centre costs are pushed up); then up to (number of expired states) rounds of "the best
+            // second candidate replaces the worst first candidate" -- played on three index registers:
+            //   par   whose filter state the lane continues from,  csrc / csel   whose candidate (and which one) it takes
+            // (the centre's lanes play it; the plan then crosses to the side tracks' lanes as one packed word)
+            {
+                const i32 PEN = SX_I32_MAX >> 4;
+                RWK_ARGMIN(jv, mv, mi)                                   // mi = the joint winner
+                // the delayed random state of this state's lineage: held by the lane that owns the lineage's slot of that ring position;
+                // before the frame has written that position (first decisionDelay samples) the reference reads its zero-initialised ring
+                const bool written = k * SX_SUBFR + i >= decisionDelay;
+                RW_FORK(l) { gq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); tq[RW_LI(l)] = em[RW_LI(l)].w3; }
+                RWK_GATHER(c0, tq, gq)
+                RW_FORK(l) { myRand[RW_LI(l)] = written ? c0[RW_LI(l)] : 0; }
+                RWK_GATHER(c1, myRand, mi)                               // the winner's
+                RW_FORK(l) { tq[RW_LI(l)] = (myRand[RW_LI(l)] ^ c1[RW_LI(l)]) != 0 ? 1 : 0; }
+                RWT_OR(tq2, tq)                                          // expired: differs in any track
+                RW_FORK(l) {
+                    const int li = RW_LI(l);
+                    const bool ctr = RW_T(l) == 0 || RW_T(l) == 3;
+                    const i32 pen_ = (tq2[li] && ctr) ? PEN : 0;
+                    cRD[li][0] = sx_add(cRD[li][0], pen_); cRD[li][1] = sx_add(cRD[li][1], pen_);
+                    par[li] = RW_K(l); csrc[li] = RW_K(l); csel[li] = 0;
+                    c0[li] = cRD[li][0]; c1[li] = cRD[li][1];
+                }
+                RWK_SUM(tq2, nrep)                                       // number of expired states
+                RWK_ARGMIN(c1, mv2, mi2)                                 // best candidate [1] (first minimum): the [1] entries never change
+#if SX_NLANES == 1
+                int RandSyncCtl = RW_UNI(nrep);
+                do {
+                    RWK_ARGMAX(c0, mv, mi)                               // worst candidate [0] (first maximum)
+                    RWK_GATHER(gq, par, mi2)                             // the state lane mi2 holds NOW (it may itself have been replaced)
+                    RW_FORK(l) {
+                        const int li = RW_LI(l);
+                        const bool rep_ = (mv2[li] < mv[li]) & (RW_K(l) == mi[li]);
+                        par[li] = rep_ ? gq[li] : par[li]; csrc[li] = rep_ ? mi2[li] : csrc[li]; csel[li] = rep_ ? 1 : csel[li]; c0[li] = rep_ ? mv2[li] : c0[li];
+                    }
+                } while (--RandSyncCtl > 0);
+#else
+                i32 RandSyncCtl = nrep[0];
+                do {
+                    RWK_ARGMAX(c0, mv, mi)
+                    RWK_GATHER(gq, par, mi2)
+                    const bool rep_ = (mv2[0] < mv[0]) & ((i32)(threadIdx.x & 3u) == mi[0]);
+                    par[0] = rep_ ? gq[0] : par[0]; csrc[0] = rep_ ? mi2[0] : csrc[0]; csel[0] = rep_ ? 1 : csel[0]; c0[0] = rep_ ? mv2[0] : c0[0];
+                } while (--RandSyncCtl > 0);
+#endif
+                RW_FORK(l) { tq[RW_LI(l)] = par[RW_LI(l)] | (csrc[RW_LI(l)] << 2) | (csel[RW_LI(l)] << 4); }
+                RWT_FROM(tq2, tq, 0)
+                RW_FORK(l) { const int li = RW_LI(l); par[li] = tq2[li] & 3; csrc[li] = (tq2[li] >> 2) & 3; csel[li] = tq2[li] >> 4; }
+            }
+            // the survivors move: SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668), every register once.
+            // The last-sample memories shift by one on the way (sLPC[0] takes the new sample in phase G).
+            {
+#define RW_LV_SEED2(q_) Seed2[q_]
+#define RW_LV_SEEDI(q_) SeedInit2[q_]
+#define RW_LV_LINLO(q_) linLo[q_]
+#define RW_LV_LINHI(q_) linHi[q_]
+#define RW_LV_SEED(q_) Seed[q_]
+                RWK_PERM(RW_LV_SEED2, par) RWK_PERM(RW_LV_SEEDI, par) RWK_PERM(RW_LV_LINLO, par) RWK_PERM(RW_LV_LINHI, par) RWK_PERM(RW_LV_SEED, par)
+#pragma unroll
+                for (int j = 0; j < SX_SHAPE_ORDER; j++) {
+#define RW_LV_SAR2(q_) sAR2[q_][j]
+                    RWK_PERM(RW_LV_SAR2, par)
+                }
+#pragma unroll
+                for (int j = SX_LPC - 1; j > 0; j--) {
+#if SX_NLANES == 1
+                    { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = sLPC[q_][j - 1]; for (int q_ = 0; q_ < 12; q_++) sLPC[q_][j] = o_[(q_ & ~3) | par[q_]]; }
+#else
+                    sLPC[0][j] = rwk_from(sLPC[0][j - 1], par[0]);
+#endif
+                }
+                // the chosen candidate [1] and the predictions it was built on come from the lane that produced it
+                // (the long-term prediction is the same in the four states of a track)
+#define RW_LV_C1RD(q_) cRD[q_][1]
+#define RW_LV_C1Q0(q_) cQ0[q_][1]
+#define RW_LV_C1Q10(q_) cQ10[q_][1]
+#define RW_LV_LPCP(q_) LPC_pred[q_]
+#define RW_LV_NAR(q_) n_AR[q_]
+#define RW_LV_NLF(q_) n_LF[q_]
+#define RW_LV_DITH(q_) dith[q_]
+                RWK_PERM(RW_LV_C1RD, csrc) RWK_PERM(RW_LV_C1Q0, csrc) RWK_PERM(RW_LV_C1Q10, csrc)
+                RWK_PERM(RW_LV_LPCP, csrc) RWK_PERM(RW_LV_NAR, csrc) RWK_PERM(RW_LV_NLF, csrc) RWK_PERM(RW_LV_DITH, csrc)
+            }
+            // phase D: undo dither, re-apply the side gains, simulate the decoder (Agora_Silk_UndoPred_And_Shap, NSQ_del_dec.c:482)
+            // for the candidate the lane keeps; joint cost of the survivors
+            i32 fRD[RW_NL], fQ0[RW_NL], cXq14[RW_NL], cLFAR[RW_NL], cShp[RW_NL], cExc10[RW_NL], cX[RW_NL];
+            RW_FORK(l) {
+                const int li = RW_LI(l), t = RW_T(l);
+                const i32 dither = dith[li];
+                const int sel = csel[li];
+                const i32 Q10 = sel ? cQ10[li][1] : cQ10[li][0];
+                fRD[li] = sel ? cRD[li][1] : cRD[li][0];
+                fQ0[li] = sel ? cQ0[li][1] : cQ0[li][0];
+                i32 Q = (Q10 ^ dither) - dither;
+                const bool ctr = t == 0 || t == 3;
+                cX[li] = ctr ? Q : fQ0[li];                          // what the coder gets: centre excitation / side pulse
+                Q = ctr ? Q : sx_smulww(my_DG[li], Q);
+                const i32 LPC_exc_Q10 = Q + sx_rshift_round(LTP_pred[li], 4);
+                const i32 xq_Q10 = sx_add(LPC_exc_Q10, LPC_pred[li]);
+                const i32 sLF_AR_shp_Q10 = sx_sub(xq_Q10, n_AR[li]);
+                cShp[li] = sx_sub(sLF_AR_shp_Q10, n_LF[li]);
+                cLFAR[li] = sx_shl(sLF_AR_shp_Q10, 2);
+                cXq14[li] = sx_shl(xq_Q10, 4);
+                cExc10[li] = LPC_exc_Q10;
+                tq[li] = t == 0 ? fRD[li] : sx_mul_lambda(fRD[li]);
+            }
+            RWT_SUM(jv, tq)
+            // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
+            // that owns the winner's slot of the emitted ring position holds the cell in its prefetch registers.
+            RWK_ARGMIN(jv, mv, mi)
+            if (emitted) {
+                RW_FORK(l) { tq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); }
+                RWK_GATHER(gq, tq, mi)
+                const bool crossed = subfr > 0 && i < decisionDelay;      // the cell was written before this subframe's gain change
+                RW_FORK(l) {
+                    const int li = RW_LI(l);
+                    if (RW_K(l) == gq[li] && RW_LIVE(l)) {
+                        const int pos = k * SX_SUBFR + i - decisionDelay;
+                        const i32 p16 = rw_cell_pred_Q16(em[li]);
+                        const i32 pv = crossed ? sx_smulww(gadj[li], p16) : p16;
+                        const i32 sv = crossed ? sx_smulww(gadj[li], em[li].w2) : em[li].w2;
+                        // (HBM gets the cell as it is -- it belongs to the previous subframe, this start's factor reaches it when
+                        // it is staged --, this subframe's windows get it with the factor applied)
+                        RW_EMIT_OUT(l, li, em[li], pos)
+                        SX_AT(i32, Pu, pLtp[li] + (u32)(pred_base + i - decisionDelay) * 4u) = p16;
+                        const int D = lagT[li] - decisionDelay - (SX_LTP_ORDER / 2 + 1);
+                        if ((unsigned)(i + D + 5) < (unsigned)SX_TAPL_N) w->tapL[RW_T(l)][i + D + 5] = pv;
+                        if ((unsigned)(i + D + 4) < (unsigned)SX_TAPS_N) w->tapS[RW_T(l)][i + D + 4] = sv;
+                    }
+                }
+            }
+            // phase G: Agora_Silk_Update_DelDecState (NSQ_del_dec.c:862): every state pushes its candidate into its own cell
+            RW_FORK(l) {
+                const int li = RW_LI(l), kk = RW_K(l);
+                LF_AR[li] = cLFAR[li];
+                sLPC[li][0] = cXq14[li];
+                lastShp[li] = cShp[li];
+                Seed[li] = sx_add(Seed[li], fQ0[li]);
+                RD[li] = fRD[li];
+                SxRowCell cell;
+                const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[li] >> 4, Gain_Q16), 10));
+                cell.w0 = (i32)(((u32)xq16 & 0xFFFFu) | ((u32)cX[li] << 16));
+                cell.w1 = (i32)(((u32)cExc10[li] & 0x03FFFFFFu) | (((u32)cX[li] << 10) & 0xFC000000u));
+                cell.w2 = cShp[li];
+                cell.w3 = Seed[li];
+                if (RW_LIVE(l)) RW_CELL_ST(smpl_buf_idx, l, cell)
+                // the state's own slot now holds its newest ring entry
+                const u32 m = 3u << (2 * (smpl_buf_idx & 15));
+                if (smpl_buf_idx < 16) linLo[li] = (i32)(((u32)linLo[li] & ~m) | (((u32)kk * 0x55555555u) & m));
+                else linHi[li] = (i32)(((u32)linHi[li] & ~m) | (((u32)kk * 0x55555555u) & m));
+            }
+            wv_sync_lds();
+        };
+        static_assert(SX_SUBFR % 2 == 0, "two samples per iteration");
+        for (int i = 0; i < SX_SUBFR; i += 2) {
+            sample_step(i, qA);
+            sample_step(i + 1, qB);
+        }
+        sLTP_shp_buf_idx += SX_SUBFR;
+        sLTP_buf_idx += SX_SUBFR;
+        subfr++;
+    }
+
+    // Agora_Silk_DelDec_UpdateState_And_Output{,_Side} (NSQ_del_dec.c:175, 245)
+    RWT_FROM(jv, RD, 0)
+    RWK_ARGMIN(jv, mv, mi)
+    RWK_GATHER(tq, SeedInit2, mi)
+    RW_FORK(l) { if (l == 0) out->Seed = tq[RW_LI(l)]; }
+    RWK_GATHER(tq, linLo, mi)
+    RWK_GATHER(tq2, linHi, mi)
+    wv_sync();                                  // the ring cells of the last samples must have landed
+    RW_FLUSH(tq[li], tq2[li], SX_FRAME - decisionDelay)
+    wv_sync();
+    RW_FORK(l) {
+        const int li = RW_LI(l);
+        if (RW_K(l) == mi[li] && RW_LIVE(l)) {
+            SxNSQ* n = &SX_AT(SxNSQ, Pu, pNsq[li]);
+#pragma unroll
+            for (int i = 0; i < SX_MAX_LPC; i++) n->sLPC_Q14[i] = (SX_MAX_LPC - 1 - i) < SX_LPC ? sLPC[li][SX_MAX_LPC - 1 - i] : 0;
+#pragma unroll
+            for (int i = 0; i < SX_SHAPE_ORDER; i++) n->sAR2_Q14[i] = sAR2[li][i];
+            n->sLF_AR_shp_Q12 = LF_AR[li];
+            n->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
+            n->prev_inv_gain_Q16 = prevInv[li];
+#pragma unroll
+            for (int kq = 0; kq < SX_NB_SUBFR; kq++) n->gadjPrev[kq] = w->gfac[RW_T(l)][SX_NB_SUBFR + kq];
+        }
+    }
+    wv_sync();
+#undef RW_EMIT_OUT
+#undef RW_FLUSH
+#undef RW_CELL
+#undef RW_CELL_LD
+#undef RW_CELL_ST
+#undef SX_AT
+}
