@@ -7,15 +7,10 @@
 #pragma once
 #include <stddef.h>
 #include "solo_enc_analysis.h"
-// the quantiser: one lane per (track, state), a 16-lane row per stream (solo_enc_nsq_row.h); -DSX_NSQ_QUAD: round 3's form, one
-// lane per state carrying the three tracks (solo_enc_nsq.h; kept for A/B timing)
-#ifdef SX_NSQ_QUAD
-#include "solo_enc_nsq.h"
-#define SX_NSQ_EMU_STRIDE 4
-#else
+// the quantiser (solo_enc_nsq_row.h: one lane per (track, state), a 16-lane row per stream) has its own kernel file
+// (solo_nsq_row.hip); only the host emulation (tests/emu) runs it from here, in the fused single-stream form at the end of this file
+#if defined(SOLO_HOST_EMU)
 #include "solo_enc_nsq_row.h"
-typedef SxRowWork SxNsqWork;
-#define SX_NSQ_EMU_STRIDE 12
 #endif
 #include "solo_cdf.h"
 
@@ -82,8 +77,8 @@ struct SxEncWork {
     union {
         i16 qmf_tl[63 + SX_PACKET];
         SxFrontWork front;
-#if SX_NLANES == 1
-        SxNsqWork nsq;               // host emulation runs the three stages back to back in one work area
+#if defined(SOLO_HOST_EMU)
+        SxRowWork nsq;               // host emulation runs the three stages back to back in one work area
 #endif
         SxCodeWork code;
         SxHbWork hb;
@@ -596,13 +591,13 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
 }
 #endif
 
-#if SX_NLANES == 1
+#if defined(SOLO_HOST_EMU)
 // Fused single-stream form (host emulation / debugging): A, quantiser for both frames, C
 SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, SxCodeIn* cin, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
     sx_enc_stage_a(rec, w, pcm, rec->nsq_in, cin);
     wv_sync();
     for (int frame = 0; frame < 2; frame++) {
-        sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, SX_NSQ_EMU_STRIDE);
+        sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, 12);
         wv_sync();
     }
     return sx_enc_stage_c(rec, w, cin, rec->nsq_out, bits, buf_size, nBytesOut);

@@ -54,12 +54,13 @@
 // Exchanges.  They stand OUTSIDE the RW_FORK loops (host: they walk the lanes themselves).
 //  inside a quad (the four states of one track):
 //   RWK_GATHER(dst, src, idx)    dst[l] = src[quad(l) + idx[l]]
+//   RWK_PICK(dst, src, idx)      the same for an index that is the same in the four lanes of a quad (cheaper on the GPU)
 //   RWK_ARGMIN / RWK_ARGMAX(val, mv, mi)   extreme of val over the quad and the LOWEST state index holding it, in every lane
 //   RWK_SUM(val, out)
 //   RWK_PERM(LV, idx)            LV(l) = LV(quad(l) + idx[l]) for an lvalue macro LV(lane)
 //  across the quads of a row (the tracks of one state):
-//   RWT_FROM(dst, src, T)        dst[l] = src[4 T + state(l)]                    (every lane receives track T's value)
-//   RWT_TO0(dst, src, T)         the same, but only the centre's lanes receive (the other lanes keep dst)
+//   RWT_FROM(dst, src, T)        dst[l] = src[4 T + state(l)]                    (every live lane receives track T's value)
+//   RWT_TO0(dst, src, T)         the same, but only the centre's lanes receive (the other lanes: undefined)
 //   RWT_SUM(dst, src) / RWT_OR   dst[l] = sum / or over the three tracks of src[4 t + state(l)]
 #if SX_NLANES == 1
 #define RWK_GATHER(dst, src, idx) { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = (src)[q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[(q_ & ~3) | (idx)[q_]]; }
@@ -71,6 +72,7 @@
 #define RWK_SUM(val, out) { for (int b_ = 0; b_ < 12; b_ += 4) { const i32 s_ = sx_add(sx_add((val)[b_], (val)[b_ + 1]), sx_add((val)[b_ + 2], (val)[b_ + 3])); \
         for (int q_ = 0; q_ < 4; q_++) (out)[b_ + q_] = s_; } }
 #define RWK_PERM(LV, idx) { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = LV(q_); for (int q_ = 0; q_ < 12; q_++) LV(q_) = o_[(q_ & ~3) | (idx)[q_]]; }
+#define RWK_PICK(dst, src, idx) RWK_GATHER(dst, src, idx)
 #define RWT_FROM(dst, src, T) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = (src)[4 * (T) + q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
 #define RWT_TO0(dst, src, T) { for (int q_ = 0; q_ < 4; q_++) (dst)[q_] = (src)[4 * (T) + q_]; }
 #define RWT_SUM(dst, src) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = sx_add(sx_add((src)[q_], (src)[4 + q_]), (src)[8 + q_]); for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
@@ -94,18 +96,26 @@ SX_HD i32 rwk_sel(i32 v, i32 idx) {
 }
 SX_HD i32 rwk_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & ~3u) | (u32)src)) << 2), v); }
 #define RWK_GATHER(dst, src, idx) { (dst)[0] = rwk_sel((src)[0], (idx)[0]); }
-#define RWK_ARG_STEP_(CTRL, CMP) { const i32 tv_ = RW_DPP(bv_, CTRL), ti_ = RW_DPP(bi_, CTRL); \
-                                   const bool take_ = (tv_ CMP bv_) | ((tv_ == bv_) & (ti_ < bi_)); bv_ = take_ ? tv_ : bv_; bi_ = take_ ? ti_ : bi_; }
-#define RWK_ARG_(val, mv, mi, CMP) { i32 bv_ = (val)[0], bi_ = (i32)(threadIdx.x & 3u); RWK_ARG_STEP_(0xB1, CMP) RWK_ARG_STEP_(0x4E, CMP) (mv)[0] = bv_; (mi)[0] = bi_; }
-#define RWK_ARGMIN(val, mv, mi) RWK_ARG_(val, mv, mi, <)
-#define RWK_ARGMAX(val, mv, mi) RWK_ARG_(val, mv, mi, >)
+// arg-min / arg-max over the quad: the extreme by two DPP steps, then the FIRST state holding it from the wave's ballot of
+// "my value is the extreme" (the quad's four bits, lowest set bit) -- the reference's serial scans keep the first extreme
+SX_HD i32 rwk_first_(bool eq) {
+    const unsigned long long b_ = __builtin_amdgcn_ballot_w64(eq);
+    return (i32)__builtin_ctz((u32)(b_ >> (threadIdx.x & 60u)) & 15u);
+}
+#define RWK_ARGMIN(val, mv, mi) { i32 m_ = (val)[0]; m_ = sx_min(m_, RW_DPP(m_, 0xB1)); m_ = sx_min(m_, RW_DPP(m_, 0x4E)); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
+#define RWK_ARGMAX(val, mv, mi) { i32 m_ = (val)[0]; m_ = sx_max(m_, RW_DPP(m_, 0xB1)); m_ = sx_max(m_, RW_DPP(m_, 0x4E)); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
+// value of the state a quad-uniform index names: that lane's value or-ed through the quad
+#define RWK_PICK(dst, src, idx) { i32 v_ = (i32)(threadIdx.x & 3u) == (idx)[0] ? (src)[0] : 0; v_ |= RW_DPP(v_, 0xB1); v_ |= RW_DPP(v_, 0x4E); (dst)[0] = v_; }
 #define RWK_SUM(val, out) { i32 s_ = (val)[0]; s_ = sx_add(s_, RW_DPP(s_, 0xB1)); s_ = sx_add(s_, RW_DPP(s_, 0x4E)); (out)[0] = s_; }
 #define RWK_PERM(LV, idx) { LV(0) = rwk_from(LV(0), (idx)[0]); }
-SX_HD i32 rwt_from0(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHR(4), 1); d = RW_DPP_BANK(d, v, RW_SHR(8), 2); return RW_DPP_BANK(d, v, RW_SHR(12), 3); }
-SX_HD i32 rwt_from1(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHL(4), 0); d = RW_DPP_BANK(d, v, RW_SHR(4), 2); return RW_DPP_BANK(d, v, RW_SHR(8), 3); }
-SX_HD i32 rwt_from2(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHL(8), 0); d = RW_DPP_BANK(d, v, RW_SHL(4), 1); return RW_DPP_BANK(d, v, RW_SHR(4), 3); }
+// (two independent row shifts + two selects on lane constants; three bank-masked moves into one register would each wait for the
+// one before: a DPP source written by the previous instruction costs two idle issue slots.  The spare quad keeps its own value.)
+SX_HD i32 rwt_from0(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW_DPP(v, RW_SHR(4)), b_ = RW_DPP(v, RW_SHR(8)); return t_ == 4u ? a_ : (t_ == 8u ? b_ : v); }
+SX_HD i32 rwt_from1(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW_DPP(v, RW_SHL(4)), b_ = RW_DPP(v, RW_SHR(4)); return t_ == 0u ? a_ : (t_ == 8u ? b_ : v); }
+SX_HD i32 rwt_from2(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW_DPP(v, RW_SHL(8)), b_ = RW_DPP(v, RW_SHL(4)); return t_ == 0u ? a_ : (t_ == 4u ? b_ : v); }
 #define RWT_FROM(dst, src, T) { (dst)[0] = (T) == 0 ? rwt_from0((src)[0]) : ((T) == 1 ? rwt_from1((src)[0]) : rwt_from2((src)[0])); }
-#define RWT_TO0(dst, src, T) { (dst)[0] = RW_DPP_BANK((dst)[0], (src)[0], RW_SHL(4 * (T)), 0); }
+// (only the centre's lanes are written; what the other lanes hold afterwards is undefined)
+#define RWT_TO0(dst, src, T) { (dst)[0] = __builtin_amdgcn_mov_dpp((src)[0], RW_SHL(4 * (T)), 0xf, 0x1, false); }
 // (the spare quad contributes nothing; every quad of the row, the spare one included, receives the result)
 #define RWT_SUM(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
         (dst)[0] = sx_add(sx_add(v_, RW_DPP(v_, RW_ROR(4))), sx_add(RW_DPP(v_, RW_ROR(8)), RW_DPP(v_, RW_ROR(12)))); }
@@ -124,19 +134,34 @@ SX_HD i32 rwt_from2(i32 v) { i32 d = RW_DPP_BANK(v, v, RW_SHL(8), 0); d = RW_DPP
 // X = what the track hands to the coder for the sample: the pulse (side tracks) / the excitation Q10 (centre: the high band's gain
 // reference; |excitation| < 2^18), as a 22-bit signed number.
 struct alignas(16) SxRowCell { i32 w0, w1, w2, w3; };
+struct alignas(16) SxRowV4 { i32 x, y, z, w; };              // one 16-byte move
 SX_HD i32 rw_cell_x(const SxRowCell& c) { return (i32)((u32)sx_shl(c.w1 >> 26, 16) | ((u32)c.w0 >> 16)); }
 SX_HD i32 rw_cell_xq(const SxRowCell& c) { return (i32)(i16)c.w0; }
 SX_HD i32 rw_cell_pred_Q16(const SxRowCell& c) { return sx_shl(c.w1, 6); }
 
 #define SX_TAPL_N (SX_SUBFR + SX_LTP_ORDER - 1)              // history entries the five prediction taps of one subframe can reach
 #define SX_TAPS_N (SX_SUBFR + 2)                             // ... the three shaping taps
+// layout of the coefficient block: A[SX_LPC] | AR[16] | B[5], warp, Tilt, LF (bottom, top), Harm (bottom, top), Lambda, offset sum, gain
+#define RW_CA 0
+#define RW_CAR (SX_LPC)
+#define RW_CB (RW_CAR + SX_SHAPE_ORDER)
+#define RW_CM (RW_CB + SX_LTP_ORDER)
+#define RW_NCOEF ((RW_CM + 9 + 3) & ~3)
 struct alignas(16) SxRowWorkBody {   // LDS, per stream
     // Tap windows of the current subframe, per track: the history entries the subframe's taps can reach, staged from HBM when the
     // subframe starts; a sample emitted during the subframe is also written to its place in the window.  Tap j of iteration i is
     // then ONE LDS read at a fixed place: tapL[i - j + 4] / tapS[i - j + 2].
-    i32 tapL[SX_N_TRACKS][SX_TAPL_N];                     // long-term prediction history (sLTP_Q16)
-    i32 tapS[SX_N_TRACKS][SX_TAPS_N];                     // shaping history (sLTP_shp_Q10)
+    // (one more word per row: where an emission that no tap of this subframe can reach is dumped, so that the store needs no branch)
+    // (the two windows of a track side by side: a lane addresses both from one base)
+    struct { i32 tapL[SX_TAPL_N + 1];                     // long-term prediction history (sLTP_Q16)
+             i32 tapS[SX_TAPS_N + 1]; } win[SX_N_TRACKS]; // shaping history (sLTP_shp_Q10)
     i32 xsc[SX_SUBFR];                                    // the subframe's input, scaled by its inverse gain (Q10)
+    // Filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form, and the stream's scalars
+    // of the sample step; the same for the three tracks and the four states of the stream.  They are READ FROM HERE by every sample
+    // (16-byte LDS reads): as registers they would be 40 of every lane's budget, which has to stay at 128 for the analysis kernel's
+    // sixteen waves to fit beside the quantiser's four.
+    alignas(16) i32 coef[RW_NCOEF];
+    alignas(16) i32 mdc[8];                               // the MD gain split of the frame: {inv_gain, inv_of_delta, offset, DeltaGains} x {p1, p2}
     // Gain-adjustment factors of the last eight subframe starts, per track: [0, 4) the previous frame's, [4, 8) this frame's
     // (65536 where the gain did not change), and this frame's pitch lags.  The reference rescales its history arrays at every
     // subframe start (SKP_Silk_nsq_del_dec_scale_states); here the histories in HBM are written ONCE, unscaled, and a history entry
@@ -150,46 +175,38 @@ struct alignas(16) SxRowWorkBody {   // LDS, per stream
 };
 // The four streams of a wavefront read the same member of their own record in one LDS instruction (a quad the same word, the three
 // tracks of a stream three rows of a window): conflict-free when the twelve words fall into twelve different banks.
-constexpr bool rw_stride_ok(int stride, int rowL, int rowS) {
-    for (int pass = 0; pass < 2; pass++) {
-        const int row = pass ? rowS : rowL;
-        bool used[64] = {};
-        for (int s = 0; s < 4; s++)
-            for (int t = 0; t < 3; t++) {
-                const int b = (s * stride + t * row) % 64;
-                if (used[b]) return false;
-                used[b] = true;
-            }
-    }
+constexpr bool rw_stride_ok(int stride, int row) {
+    bool used[64] = {};
+    for (int s = 0; s < 4; s++)
+        for (int t = 0; t < 3; t++) {
+            const int b = (s * stride + t * row) % 64;
+            if (used[b]) return false;
+            used[b] = true;
+        }
     return true;
 }
 constexpr int rw_work_pad_words(int body_words) {
     int pad = 0;
-    while ((body_words + pad) % 4 != 0 || !rw_stride_ok(body_words + pad, SX_TAPL_N, SX_TAPS_N)) pad++;
+    while ((body_words + pad) % 4 != 0 || !rw_stride_ok(body_words + pad, SX_TAPL_N + SX_TAPS_N + 2)) pad++;
     return pad;
 }
 #if SX_NLANES == 1
 struct alignas(16) SxRowWork : SxRowWorkBody {};
 #else
 struct alignas(16) SxRowWork : SxRowWorkBody { i32 pad_[rw_work_pad_words((int)(sizeof(SxRowWorkBody) / 4))]; };
-static_assert(rw_stride_ok((int)(sizeof(SxRowWork) / 4), SX_TAPL_N, SX_TAPS_N) && sizeof(SxRowWork) % 16 == 0, "LDS stride of the per-stream records");
+static_assert(rw_stride_ok((int)(sizeof(SxRowWork) / 4), SX_TAPL_N + SX_TAPS_N + 2) && sizeof(SxRowWork) % 16 == 0, "LDS stride of the per-stream records");
 #endif
 
 // SMULWW(x, INTERNAL_JOINT_LAMBDA) = (x * 90000) >> 16 with 90000 = 65536 + 24464: x + SMULWB(x, 24464), exactly (the first
 // part of the product is a multiple of 65536) -- one high-word multiply instead of a 64-bit product
 SX_HD i32 sx_mul_lambda(i32 x) { return sx_add(x, sx_smulw_pre(x, (i32)((u32)(SX_JOINT_LAMBDA - 65536) << 16))); }
 static_assert(SX_JOINT_LAMBDA - 65536 > 0 && SX_JOINT_LAMBDA - 65536 < 32768, "lambda split");
-SX_HD i32 sx_sel4(i32 a0, i32 a1, i32 a2, i32 a3, int i) {          // i in 0..3; selects on the index bits (no branches)
-    const bool o_ = (i & 1) != 0, h_ = (i & 2) != 0;
-    const i32 lo_ = o_ ? a1 : a0, hi_ = o_ ? a3 : a2;
-    return h_ ? hi_ : lo_;
-}
 
 // Agora_Silk_RDCx1, NSQ_del_dec.c:559: the two quantisation candidates of one side state.  The reference's three cases
 // (r < -1.5, r > 0.5, in between) differ in the two levels and in the sign of the rate term; written with selects so that the
-// lanes of a wavefront never diverge here.
-SX_HD void sx_nsq_rdcx1(i32 RD_prev, i32 r_Q10, i32 r_p_Q10, i32 inv_of_delta_Q16, i32 Lambda_Q10, i32 offset_Q10,
-                        i32* cRD, i32* cQ0, i32* cQ10, i32* cRdInd) {
+// lanes of a wavefront never diverge here.  Outputs: the two candidates' cost increments and quantised values (offset included),
+// the cheaper one first.
+SX_HD void sx_nsq_rdcx1(i32 r_Q10, i32 r_p_Q10, i32 inv_of_delta_Q16, i32 Lambda_Q10, i32 offset_Q10, i32* cRdInd, i32* cQ10) {
     r_p_Q10 = sx_smulww(inv_of_delta_Q16, r_p_Q10);
     r_Q10 = sx_sub(r_Q10, offset_Q10);
     r_p_Q10 = sx_sub(r_p_Q10, offset_Q10);
@@ -203,12 +220,8 @@ SX_HD void sx_nsq_rdcx1(i32 RD_prev, i32 r_Q10, i32 r_p_Q10, i32 inv_of_delta_Q1
     const i32 rd1 = sx_smlabb(sx_mul(hi ? a1 : sx_neg(a1), Lambda_Q10), e1, e1) >> 10;      // rate term negated unless r > 0.5
     const i32 rd2 = sx_smlabb(sx_mul(lo ? sx_neg(a2) : a2, Lambda_Q10), e2, e2) >> 10;      // rate term negated only if r < -1.5
     const bool first = rd1 < rd2;              // candidate 1 takes slot 0
-    cRD[0] = sx_add(RD_prev, first ? rd1 : rd2);
-    cRD[1] = sx_add(RD_prev, first ? rd2 : rd1);
-    cQ0[0] = (i8)((first ? q1 : q2) >> 10);
-    cQ0[1] = (i8)((first ? q2 : q1) >> 10);
-    cQ10[0] = sx_add(offset_Q10, first ? q1 : q2);
-    cQ10[1] = sx_add(offset_Q10, first ? q2 : q1);
+    cQ10[0] = first ? a1 : a2;
+    cQ10[1] = first ? a2 : a1;
     cRdInd[0] = first ? rd1 : rd2;
     cRdInd[1] = first ? rd2 : rd1;
 }
@@ -219,9 +232,14 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
     return sx_smlabb(sx_mul(q_Q10 < 0 ? sx_neg(a) : a, Lambda_Q10), e, e) >> 10;
 }
 
-// SX_OPAQUE(x): hides how a value was computed from the optimiser (an empty asm that "modifies" the register).  Used on the
-// pre-shifted filter coefficients: knowing that the low 16 bits are zero, LLVM rewrites (a * (b << 16)) >> 32 as a 64-bit a * b >> 16,
-// five instructions instead of one v_mul_hi_i32.  SX_SCHED_FENCE: the instruction scheduler does not move code across it.
+// SX_OPAQUE(x): hides how a value was computed from the optimiser (an empty asm that "modifies" the register).
+// RW_MARK(name): with -DRW_MARKS, a scheduling fence + a comment in the assembly (tools/debug/nsq_row_mix.py counts the
+// instructions between the marks: the static instruction mix of the sample step, phase by phase)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(RW_MARKS)
+#define RW_MARK(name) { __builtin_amdgcn_sched_barrier(0); asm volatile("; RW_MARK " name); __builtin_amdgcn_sched_barrier(0); }
+#else
+#define RW_MARK(name)
+#endif
 #if defined(__HIP_DEVICE_COMPILE__)
 #define SX_OPAQUE(x) asm volatile("" : "+v"(x))
 #define SX_SCHED_FENCE() __builtin_amdgcn_sched_barrier(0)
@@ -238,6 +256,10 @@ SX_HD i32 sx_nsq_center_rd1(i32 q_Q10, i32 r_temp_Q10, i32 offset_Q10, i32 Lambd
 #else
 #define SX_NSQ_FN SX_FN
 #endif
+typedef i32 __attribute__((aligned(1))) rw_i32u;             // a 4-byte store to any byte address
+// logical -> physical entry of the two circular histories (solo_enc_state.h, SxNsqTrack); L in [0, 2 SX_FRAME + SX_SUBFR)
+SX_HD int rw_phys(int L, int base) { const int p_ = L + base; return p_ >= 4 * SX_FRAME ? p_ - 4 * SX_FRAME : (p_ >= 2 * SX_FRAME ? p_ - 2 * SX_FRAME : p_); }
+
 // SKP_Silk_NSQ_del_dec, NSQ_del_dec.c:931.  c->xfw: prefiltered input; out->q: pulses of MD1 / MD2, out->r: centre excitation Q10.
 // Addressing: the stores of the sample loop (ring cells, emitted samples) are written as  wave-uniform base + 32-bit lane offset,
 // so that the base stays in scalar registers and no 64-bit per-lane pointers have to be kept alive across the loop:
@@ -248,10 +270,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     SX_IN_LDS(w);
     SxNsqPersist* P = (SxNsqPersist*)(Pu + pOff);
     SxNsqOut* out = (SxNsqOut*)(Ou + oOff);
-    SxNsqGlobal* g = &P->g;
     const int voiced = c->sigtype == 0;
     const i32 offset_Q10 = T_quant_offsets_Q10[c->sigtype * 2 + c->QuantOffsetType];
-    int lagC = P->nsq[0].lagPrev;                              // the centre's lag: governs the decision delay and the shaping taps of all tracks
+    int lagC = P->trk[0].s.lagPrev;                            // the centre's lag: governs the decision delay and the shaping taps of all tracks
+    const int hbase = P->trk[0].s.histBase;                    // circular histories: logical entry 0 sits at physical hbase
+    const int cur0 = SX_FRAME - hbase;                         // ... so this frame's sample `pos` at physical cur0 + pos
     int smpl_buf_idx = 0;
     int decisionDelay = sx_min(SX_DD_DELAY, SX_SUBFR);
     if (voiced) {
@@ -260,7 +283,6 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         decisionDelay = sx_min(decisionDelay, lagC - SX_LTP_ORDER / 2 - 1);
     }
     const int LSF_interpolation_flag = c->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
-    const i32 Lambda_Q10 = c->Lambda_Q10;
 #define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)((pos_) * rstride) + rlane + (u32)(lane_)) * (u32)sizeof(SxRowCell))
     // the sample loop's own ring traffic (every cell is written once and read once, a decision delay later) with the non-temporal
     // cache policy: 32 MB of ring per 4096 streams otherwise sweep everything else -- the stream histories the subframe prologues
@@ -281,17 +303,17 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     i32 LF_AR[RW_NL], Seed[RW_NL], RD[RW_NL], lastShp[RW_NL];
     i32 Seed2[RW_NL], SeedInit2[RW_NL], linLo[RW_NL], linHi[RW_NL];          // per state: identical in the three tracks' lanes
     i32 lagT[RW_NL], prevInv[RW_NL], gadj[RW_NL];                            // per track
-    // byte offsets of the lane's track inside the stream's records
-    u32 pNsq[RW_NL], pXq[RW_NL], pShp[RW_NL], pLtp[RW_NL], oX[RW_NL];
+    // byte offsets of the lane's track inside the stream's records: its SxNsqTrack; where its output row starts (centre: 4-byte
+    // excitations, sides: 1-byte pulses)
+    u32 pTrk[RW_NL], oX[RW_NL];
     // per sample
     i32 LTP_pred[RW_NL], LPC_pred[RW_NL], n_AR[RW_NL], n_LF[RW_NL], rD[RW_NL], rC[RW_NL], dith[RW_NL];
-    i32 cRD[RW_NL][2], cQ0[RW_NL][2], cQ10[RW_NL][2], sRdInd[RW_NL][2];
+    i32 cInc[RW_NL][2], cQ10[RW_NL][2];                          // the two candidates: cost increment, quantised value
     i32 p1q0[RW_NL], p1q1[RW_NL], p1r0[RW_NL], p1r1[RW_NL], p2q0[RW_NL], p2q1[RW_NL], p2r0[RW_NL], p2r1[RW_NL];
-    // The ring is a delay line in HBM; its reads are issued TWO samples before they are used.  Two register sets take turns: even
-    // samples consume set A (the own-slot cell of the ring position the sample emits) and refill it with the cell sample i + 2
-    // will need, odd samples do the same with set B.  The sample loop is written two samples per iteration so that no set is
-    // ever copied into another at the loop's back edge: such a copy would wait for loads issued a few hundred instructions
-    // earlier in the same sample.
+    // The ring is a delay line in HBM; the cell a sample consumes is requested ONE sample before.  Two register sets take turns: an
+    // even sample consumes set A (the own-slot cell of the ring position the sample emits) while set B is in flight for the odd
+    // sample after it, and vice versa.  The sample loop is written two samples per iteration so that no set is ever copied into
+    // another at the loop's back edge (such a copy would wait for the load just issued).
     SxRowCell qA[RW_NL], qB[RW_NL];
     // scratch of the joint decision
     i32 jv[RW_NL], mv[RW_NL], mi[RW_NL], mv2[RW_NL], mi2[RW_NL], tq[RW_NL], tq2[RW_NL], par[RW_NL], csrc[RW_NL], csel[RW_NL], c0[RW_NL], c1[RW_NL], nrep[RW_NL];
@@ -300,7 +322,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     for (int a = 0; a < RW_NL; a++) {
         Seed2[a] = SeedInit2[a] = linLo[a] = linHi[a] = dith[a] = lagT[a] = prevInv[a] = 0;
         gadj[a] = 65536;
-        pNsq[a] = pXq[a] = pShp[a] = pLtp[a] = oX[a] = 0u;
+        pTrk[a] = oX[a] = 0u;
         jv[a] = mv[a] = mi[a] = mv2[a] = mi2[a] = tq[a] = tq2[a] = par[a] = csrc[a] = csel[a] = c0[a] = c1[a] = nrep[a] = gq[a] = myRand[a] = 0;
         p1q0[a] = p1q1[a] = p1r0[a] = p1r1[a] = p2q0[a] = p2q1[a] = p2r0[a] = p2r1[a] = 0;
 #pragma unroll
@@ -309,7 +331,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         for (int j = 0; j < SX_LPC; j++) sLPC[a][j] = 0;
         LF_AR[a] = Seed[a] = RD[a] = lastShp[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = rC[a] = 0;
 #pragma unroll
-        for (int j = 0; j < 2; j++) cRD[a][j] = cQ0[a][j] = cQ10[a][j] = sRdInd[a][j] = 0;
+        for (int j = 0; j < 2; j++) cInc[a][j] = cQ10[a][j] = 0;
         qA[a].w0 = qA[a].w1 = qA[a].w2 = qA[a].w3 = 0;
         qB[a] = qA[a];
     }
@@ -319,18 +341,34 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     {
         SX_PAR(i, SX_N_TRACKS * SX_NB_SUBFR) {
             const int t = i / SX_NB_SUBFR, kq = i - t * SX_NB_SUBFR;
-            w->gfac[t][kq] = P->nsq[t].gadjPrev[kq];
+            w->gfac[t][kq] = P->trk[t].s.gadjPrev[kq];
             w->gfac[t][SX_NB_SUBFR + kq] = 65536;
         }
         SX_PAR(i, SX_NB_SUBFR) w->lagk[i] = c->pitchL[i];
+        // MD gain split (md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1401-1417): frame constants, parked in LDS
+        const i32 inv_gain_p1_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
+        const i32 inv_gain_p2_Q16 = 65536 - inv_gain_p1_Q16;
+        const i32 DeltaGains_p1_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p1_Q16, 1), 32);
+        const i32 DeltaGains_p2_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p2_Q16, 1), 32);
+        const i32 inv_of_delta_p1_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p1_Q16, 1), 32);   // recomputed inside RDCx1
+        const i32 inv_of_delta_p2_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p2_Q16, 1), 32);
+        const i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);       // _OFFSET_MD_ (SKP_Silk_define.h:41)
+        const i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
+        RW_FORK(l) {
+            if (l == 0) {
+                w->mdc[0] = inv_gain_p1_Q16; w->mdc[1] = inv_of_delta_p1_Q16; w->mdc[2] = offset_p1_Q10; w->mdc[3] = DeltaGains_p1_Q16;
+                w->mdc[4] = inv_gain_p2_Q16; w->mdc[5] = inv_of_delta_p2_Q16; w->mdc[6] = offset_p2_Q10; w->mdc[7] = DeltaGains_p2_Q16;
+                w->coef[RW_CM + 6] = c->Lambda_Q10;
+                w->coef[RW_CM + 7] = offset_p1_Q10 + offset_p2_Q10;
+            }
+        }
         RW_FORK(l) {
             const int li = RW_LI(l), tt = RW_TT(l), k = RW_K(l), t = RW_T(l);
-            pNsq[li] = pOff + (u32)(offsetof(SxNsqPersist, nsq) + (size_t)tt * sizeof(SxNSQ));
-            pXq[li] = pOff + (u32)(offsetof(SxNsqPersist, xq) + (size_t)tt * 2 * SX_FRAME * sizeof(i16));
-            pShp[li] = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, shp) + (size_t)tt * (2 * SX_FRAME + 8) * sizeof(i32));
-            pLtp[li] = pOff + (u32)(offsetof(SxNsqPersist, g) + offsetof(SxNsqGlobal, sLTP_Q16) + (size_t)tt * 2 * SX_FRAME * sizeof(i32));
-            oX[li] = t == 0 ? oOff + (u32)offsetof(SxNsqOut, r) : oOff + (u32)(offsetof(SxNsqOut, q) + (size_t)(tt - 1) * SX_FRAME);
-            const SxNSQ* n = &SX_AT(SxNSQ, Pu, pNsq[li]);
+            pTrk[li] = pOff + (u32)(offsetof(SxNsqPersist, trk) + (size_t)tt * sizeof(SxNsqTrack));
+            // (the row's start moved back by this frame's place in the circular histories: the sample step addresses everything with
+            // e4 = 4 x (cur0 + sample position))
+            oX[li] = t == 0 ? oOff + (u32)offsetof(SxNsqOut, r) - (u32)(4 * cur0) : oOff + (u32)(offsetof(SxNsqOut, q) + (size_t)(tt - 1) * (SX_FRAME + 4)) - (u32)cur0;
+            const SxNSQ* n = &SX_AT(SxNSQ, Pu, pTrk[li] + (u32)offsetof(SxNsqTrack, s));
             lagT[li] = n->lagPrev;
             prevInv[li] = n->prev_inv_gain_Q16;
             Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
@@ -338,7 +376,8 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             Seed[li] = (k + c->Seed) & 3;
             RD[li] = 0;
             LF_AR[li] = n->sLF_AR_shp_Q12;
-            lastShp[li] = SX_AT(i32, Pu, pShp[li] + (u32)(SX_FRAME - 1) * 4u);       // the reference seeds ring position 0 of every state with it
+            // the reference seeds ring position 0 of every state with the newest shaping sample of the previous frame
+            lastShp[li] = SX_AT(i32, Pu, pTrk[li] + (u32)(offsetof(SxNsqTrack, shp) + (size_t)rw_phys(SX_FRAME - 1, hbase) * 4));
 #pragma unroll
             for (int i = 0; i < SX_LPC; i++) sLPC[li][i] = n->sLPC_Q14[SX_MAX_LPC - 1 - i];
 #pragma unroll
@@ -346,43 +385,26 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         }
         wv_sync();
     }
-    RW_FORK(l) {       // prime the ring's read queue: the cells samples 0 and 1 look back at (not written by this frame; never used as such)
-        const int li = RW_LI(l);
+    RW_FORK(l) {       // prime the ring's read queue: the cell sample 0 looks back at (not written by this frame; never used as such)
         const int l0 = (SX_DD_MASK + decisionDelay) & SX_DD_MASK;
-        qA[li] = RW_CELL(l0, l);
-        qB[li] = RW_CELL((l0 - 1) & SX_DD_MASK, l);
+        qA[RW_LI(l)] = RW_CELL(l0, l);
     }
     int sLTP_shp_buf_idx = SX_FRAME, sLTP_buf_idx = SX_FRAME;   // identical for all three tracks
     int subfr = 0;
     int rewhite_k = 0;                                          // the subframe whose start last re-whitened the prediction history
 
-    // MD gain split (md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1401-1417)
-    const i32 inv_gain_p1_Q16 = sx_inverse32_varQ(sx_max(c->DeltaGains_Q16, 1), 32);
-    const i32 inv_gain_p2_Q16 = 65536 - inv_gain_p1_Q16;
-    const i32 DeltaGains_p1_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p1_Q16, 1), 32);
-    const i32 DeltaGains_p2_Q16 = sx_inverse32_varQ(sx_max(inv_gain_p2_Q16, 1), 32);
-    const i32 inv_of_delta_p1_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p1_Q16, 1), 32);   // recomputed inside RDCx1
-    const i32 inv_of_delta_p2_Q16 = sx_inverse32_varQ(sx_max(DeltaGains_p2_Q16, 1), 32);
-    const i32 offset_p1_Q10 = sx_smulww(inv_gain_p1_Q16, offset_Q10);       // _OFFSET_MD_ (SKP_Silk_define.h:41)
-    const i32 offset_p2_Q10 = sx_smulww(inv_gain_p2_Q16, offset_Q10);
-    const i32 offset_sum_Q10 = offset_p1_Q10 + offset_p2_Q10;
-
 #define RW_LIN_SLOT(lo_, hi_, pos_) ((int)((((pos_) < 16 ? (u32)(lo_) : (u32)(hi_)) >> (2 * ((pos_) & 15))) & 3u))
-    // outputs of one emitted sample of the lane's track (Agora_Silk_GetWinner{,_Side} / the flush loops); cell_ = the winner's ring cell.
-    // The two histories that the reference shifts down by a frame when the frame ends (the quantised signal and the shaping history)
-    // get every emitted sample twice: at its place in the current-frame half and at the same place of the previous-frame half, which
-    // is what the shift would copy there (the entries are written once and never modified: the gain factors are applied when they are
-    // staged).  No reader of this frame reaches the overwritten entries any more: a window / re-whitening run of subframe k starts at
-    // FRAME + k SUBFR - lag - 12 at the earliest, > k SUBFR, and the entries below k SUBFR - decisionDelay are the ones rewritten.
-#define RW_EMIT_OUT(l_, li_, cell_, pos_)                                                                                    \
+    // outputs of one emitted sample of the lane's track (Agora_Silk_GetWinner{,_Side} / the flush loops); cell_ = the winner's ring
+    // cell, e4_ = 4 x (cur0 + sample position): the coder's value (WIDE: with a 4-byte store whatever the track, see SxNsqOut -- only
+    // where samples are emitted in time order, i.e. in the sample loop, not in the flushes), the quantised signal and the shaping
+    // history at their place in the circular histories
+#define RW_EMIT_OUT(l_, li_, cell_, e4_, WIDE)                                                                               \
     {                                                                                                                        \
-        const i32 X_ = rw_cell_x(cell_), xq_ = rw_cell_xq(cell_);                                                            \
-        if (RW_T(l_) == 0) SX_AT(i32, Ou, oX[li_] + (u32)(pos_) * 4u) = X_;                                                  \
-        else SX_AT(i8, Ou, oX[li_] + (u32)(pos_)) = (i8)X_;                                                                  \
-        SX_AT(i16, Pu, pXq[li_] + (u32)(SX_FRAME + (pos_)) * 2u) = (i16)xq_;                                                 \
-        SX_AT(i32, Pu, pShp[li_] + (u32)(SX_FRAME + (pos_)) * 4u) = (cell_).w2;                                              \
-        SX_AT(i16, Pu, pXq[li_] + (u32)(pos_) * 2u) = (i16)xq_;                                                              \
-        SX_AT(i32, Pu, pShp[li_] + (u32)(pos_) * 4u) = (cell_).w2;                                                           \
+        if (WIDE) SX_AT(rw_i32u, Ou, oX[li_] + (RW_T(l_) == 0 ? (u32)(e4_) : (u32)(e4_) >> 2)) = rw_cell_x(cell_);           \
+        else if (RW_T(l_) == 0) SX_AT(i32, Ou, oX[li_] + (u32)(e4_)) = rw_cell_x(cell_);                                     \
+        else SX_AT(i8, Ou, oX[li_] + ((u32)(e4_) >> 2)) = (i8)rw_cell_x(cell_);                                              \
+        SX_AT(i16, Pu + offsetof(SxNsqTrack, xq), pTrk[li_] + ((u32)(e4_) >> 1)) = (i16)rw_cell_xq(cell_);                    \
+        SX_AT(i32, Pu + offsetof(SxNsqTrack, shp), pTrk[li_] + (u32)(e4_)) = (cell_).w2;                                      \
     }
     // flush of the winner's lineage (wlo_, whi_), oldest sample at output position pos0_: every lane its own track, the four lanes
     // of a track every fourth sample
@@ -399,7 +421,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 }                                                                                                            \
                 _Pragma("unroll") for (int u = 0; u < 4; u++) {                                                              \
                     const int i = base + 4 * u;                                                                              \
-                    if (i < decisionDelay) RW_EMIT_OUT(l, li, cl[u], (pos0_) + i)                                            \
+                    if (i < decisionDelay) RW_EMIT_OUT(l, li, cl[u], 4 * (cur0 + (pos0_) + i), false)                                  \
                 }                                                                                                            \
             }                                                                                                                \
         }                                                                                                                    \
@@ -412,19 +434,6 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         i32 HarmShapeFIRPacked_Q14 = c->HarmShapeGain_Q14[k] >> 2;
         HarmShapeFIRPacked_Q14 |= sx_shl(c->HarmShapeGain_Q14[k] >> 1, 16);
         const i32 Tilt_Q14 = c->Tilt_Q14[k], LF_shp_Q14 = c->LF_shp_Q14[k], Gain_Q16 = c->Gains_Q16[k];
-        // filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form; the same for the
-        // three tracks and the four states of the stream
-        i32 Apre[SX_LPC], ARpre[SX_SHAPE_ORDER], Bpre[SX_LTP_ORDER];
-#pragma unroll
-        for (int j = 0; j < SX_LPC; j++) Apre[j] = sx_pre16(A_Q12[j]);
-#pragma unroll
-        for (int j = 0; j < SX_SHAPE_ORDER; j++) ARpre[j] = sx_pre16(AR_shp_Q13[j]);
-#pragma unroll
-        for (int j = 0; j < SX_LTP_ORDER; j++) Bpre[j] = sx_pre16(B_Q14[j]);
-        i32 warp_pre = sx_pre16(SX_WARPING_Q16);
-        i32 Tilt_pre = sx_pre16(Tilt_Q14);
-        i32 LFb_pre = sx_pre16(LF_shp_Q14), LFt_pre = (i32)((u32)LF_shp_Q14 & 0xFFFF0000u);
-        i32 Hb_pre = sx_pre16(HarmShapeFIRPacked_Q14), Ht_pre = (i32)((u32)HarmShapeFIRPacked_Q14 & 0xFFFF0000u);
         int rewhite = 0;
         i32 inv_gain_Q16 = sx_inverse32_varQ(sx_max(Gain_Q16, 1), 32);
         inv_gain_Q16 = sx_min(inv_gain_Q16, 32767);
@@ -442,8 +451,8 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     RW_FORK(l) {
                         if (RW_K(l) != mi[RW_LI(l)]) RD[RW_LI(l)] += SX_I32_MAX >> 4;
                     }
-                    RWK_GATHER(tq, linLo, mi)
-                    RWK_GATHER(tq2, linHi, mi)
+                    RWK_PICK(tq, linLo, mi)
+                    RWK_PICK(tq2, linHi, mi)
                     wv_sync();                      // the ring cells of the last samples must have landed
                     RW_FLUSH(tq[li], tq2[li], k * SX_SUBFR - decisionDelay)
                     wv_sync();
@@ -459,23 +468,26 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
 #pragma unroll
                 for (int j = 0; j < SX_LPC; j++) Ac[j] = A_Q12[j];
                 for (int t = 0; t < SX_N_TRACKS; t++) {
-                    const i16* in = &P->xq[t][start_idx + k * SX_SUBFR];
+                    const i16* xq = P->trk[t].xq;                      // circular: logical entry L at rw_phys(L, hbase)
+                    const int L0 = start_idx + k * SX_SUBFR;           // logical entry of input 0
                     i32 h[SX_LPC];                                     // h[j] = in[n - 1 - j], zero before the start (zero initial state)
 #pragma unroll
-                    for (int j = 0; j < SX_LPC; j++) h[j] = (n0 - 1 - j >= 0 && n0 < n1) ? (i32)in[n0 - 1 - j] : 0;
+                    for (int j = 0; j < SX_LPC; j++) h[j] = (n0 - 1 - j >= 0 && n0 < n1) ? (i32)xq[rw_phys(L0 + n0 - 1 - j, hbase)] : 0;
+                    int pp = rw_phys(L0 + n0, hbase);
 #pragma unroll 2
                     for (int n = n0; n < n1; n++) {
                         i32 acc = 0;
 #pragma unroll
                         for (int j = 0; j < SX_LPC; j++) acc = sx_smlabb(acc, h[j], Ac[j]);
-                        const i32 xin = in[n];
+                        const i32 xin = xq[pp];
+                        pp = pp + 1 == 2 * SX_FRAME ? 0 : pp + 1;
                         i32 o = sx_rshift_round(sx_sub(sx_shl(xin, 12), acc), 12);
                         // the re-whitened sample goes straight into the scaled LTP state (the reference stages it in sLTP[]) -- and into
                         // this subframe's tap window, which covers [FRAME - lag - 2, FRAME) of it
                         const i32 rw = sx_smulwb(inv_gain_Q32, sx_sat16(o));
-                        g->sLTP_Q16[t][start_idx + n] = rw;
+                        P->trk[t].sLTP_Q16[start_idx + n] = rw;
                         const int wi = n - SX_LPC;                            // = (start_idx + n) - (FRAME - lag - LTP_ORDER / 2)
-                        if ((unsigned)wi < (unsigned)SX_TAPL_N) w->tapL[t][wi] = rw;
+                        if ((unsigned)wi < (unsigned)SX_TAPL_N) w->win[t].tapL[wi] = rw;
 #pragma unroll
                         for (int j = SX_LPC - 1; j > 0; j--) h[j] = h[j - 1];
                         h[0] = xin;
@@ -506,6 +518,23 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             if (RW_K(l) == 0 && RW_LIVE(l)) w->gfac[RW_T(l)][SX_NB_SUBFR + k] = gadj[li];
         }
         SX_PAR(i, SX_SUBFR) w->xsc[i] = sx_smulbb(c->xfw[k * SX_SUBFR + i], inv_gain_Q16) >> 6;       // Agora_Silk_DelDecScale (NSQ_del_dec.c:1668)
+        // filter coefficients of the subframe, pre-shifted for the one-instruction (a * (b << 16)) >> 32 form, into LDS
+        // (no harmonic shaping without a pitch lag: the taps are not staged then; the analysis hands over zero prediction taps for
+        // an unvoiced frame, which is not relied on)
+        SX_PAR(j, SX_LPC) w->coef[RW_CA + j] = sx_pre16(A_Q12[j]);
+        SX_PAR(j, SX_SHAPE_ORDER) w->coef[RW_CAR + j] = sx_pre16(AR_shp_Q13[j]);
+        SX_PAR(j, SX_LTP_ORDER) w->coef[RW_CB + j] = voiced ? sx_pre16(B_Q14[j]) : 0;
+        RW_FORK(l) {
+            if (l == 0) {
+                w->coef[RW_CM + 0] = sx_pre16(SX_WARPING_Q16);
+                w->coef[RW_CM + 1] = sx_pre16(Tilt_Q14);
+                w->coef[RW_CM + 2] = sx_pre16(LF_shp_Q14);
+                w->coef[RW_CM + 3] = (i32)((u32)LF_shp_Q14 & 0xFFFF0000u);
+                w->coef[RW_CM + 4] = lagC > 0 ? sx_pre16(HarmShapeFIRPacked_Q14) : 0;
+                w->coef[RW_CM + 5] = lagC > 0 ? (i32)((u32)HarmShapeFIRPacked_Q14 & 0xFFFF0000u) : 0;
+                w->coef[RW_CM + 8] = Gain_Q16;
+            }
+        }
         wv_sync();                                    // factors visible; the emission stores of the previous subframe have landed
 
         // ---- the per-sample trellis (SKP_Silk_md_noise_shape_quantizer_del_dec, NSQ_del_dec.c:1341) ----
@@ -516,18 +545,6 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         // above).  Entries that are only emitted during this very subframe are not valid yet: the emission writes them into the
         // window as well (iteration ip emits window entry ip + D + 5 of the prediction history, ip + D + 4 of the shaping history,
         // D = lag - decisionDelay - 3; the first tap to read it belongs to iteration ip + 1 + D or later).
-        if (lagC <= 0) { Hb_pre = 0; Ht_pre = 0; }            // no harmonic shaping without a pitch lag (the taps are not staged then)
-        if (!voiced) {                                        // (the analysis hands over zero prediction taps for an unvoiced frame; not relied on)
-#pragma unroll
-            for (int j = 0; j < SX_LTP_ORDER; j++) Bpre[j] = 0;
-        }
-#pragma unroll
-        for (int j = 0; j < SX_LPC; j++) SX_OPAQUE(Apre[j]);
-#pragma unroll
-        for (int j = 0; j < SX_SHAPE_ORDER; j++) SX_OPAQUE(ARpre[j]);
-#pragma unroll
-        for (int j = 0; j < SX_LTP_ORDER; j++) SX_OPAQUE(Bpre[j]);
-        SX_OPAQUE(warp_pre); SX_OPAQUE(Tilt_pre); SX_OPAQUE(LFb_pre); SX_OPAQUE(LFt_pre); SX_OPAQUE(Hb_pre); SX_OPAQUE(Ht_pre);
         {
             constexpr int NL = (SX_TAPL_N + SX_NLANES - 1) / SX_NLANES, NS = (SX_TAPS_N + SX_NLANES - 1) / SX_NLANES;
             // A history entry is stored once, unscaled.  What the reference's rescaling passes would have done to it by now is applied
@@ -539,18 +556,18 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // after a reset, where the reference's set-up gives the centre 100 and the sides 0)
             int lagU[SX_N_TRACKS];
 #pragma unroll
-            for (int t = 0; t < SX_N_TRACKS; t++) lagU[t] = voiced ? lagC : P->nsq[t].lagPrev;
+            for (int t = 0; t < SX_N_TRACKS; t++) lagU[t] = voiced ? lagC : P->trk[t].s.lagPrev;
 #pragma unroll
             for (int t = 0; t < SX_N_TRACKS; t++) {               // per track: all loads of the lane first, then the LDS writes
                 i32 vl[NL], vs[NS];
                 const int iL0 = pred_base - lagU[t] - SX_LTP_ORDER / 2, iS0 = shp_base - lagU[t] - 1;
-                const i32* srcL = &g->sLTP_Q16[t][iL0];                                        // tap j of iteration i sits at srcL[i - j + 4]
-                const i32* srcS = &g->shp[t][iS0];                                             // tap j of iteration i sits at srcS[i - j + 2]
+                const i32* srcL = &P->trk[t].sLTP_Q16[iL0];                                    // tap j of iteration i sits at srcL[i - j + 4]
+                const i32* shpT = P->trk[t].shp;                                               // tap j of iteration i: logical entry iS0 + i - j + 2
                 const bool stageL = voiced && !rewhite;          // (a re-whitening start has just written its window itself)
 #pragma unroll
                 for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; vl[u] = (stageL && n < SX_TAPL_N) ? srcL[n] : 0; }
 #pragma unroll
-                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; vs[u] = (lagC > 0 && n < SX_TAPS_N) ? srcS[n] : 0; }
+                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; vs[u] = (lagC > 0 && n < SX_TAPS_N) ? shpT[rw_phys(iS0 + n, hbase)] : 0; }
                 if (stageL) {
 #pragma unroll
                     for (int u = 0; u < NL; u++) {
@@ -579,60 +596,82 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 }
                 if (stageL) {
 #pragma unroll
-                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = vl[u]; }
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->win[t].tapL[n] = vl[u]; }
                 } else if (!voiced) {
 #pragma unroll
-                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->tapL[t][n] = 0; }
+                    for (int u = 0; u < NL; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPL_N) w->win[t].tapL[n] = 0; }
                 }
 #pragma unroll
-                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPS_N) w->tapS[t][n] = vs[u]; }
+                for (int u = 0; u < NS; u++) { const int n = SX_LANE + u * SX_NLANES; if (n < SX_TAPS_N) w->win[t].tapS[n] = vs[u]; }
             }
         }
         wv_sync();
-        // the lane's side of the MD gain split in this subframe: MD1 takes the p1 share on even subframes, MD2 on odd ones
-        // (the centre's lanes compute side candidates nobody reads)
-        i32 my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
+        // per-lane constants of the subframe:
+        //   sd      the lane's side of the MD gain split (MD1 takes the p1 share on even subframes, MD2 on odd ones; the centre's lanes
+        //           compute side candidates nobody reads), as an offset into w->mdc
+        //   dL4     4 x (entry of the prediction history - entry of the circular histories) of an emitted sample
+        //   wb      window entry of the prediction history that the sample emitted at iteration 0 goes to
+        int sd[RW_NL], dL4[RW_NL], wb[RW_NL];
         RW_FORK(l) {
             const int li = RW_LI(l);
-            const bool first = (RW_T(l) == 1) != (odd != 0);
-            my_inv_gain[li] = first ? inv_gain_p1_Q16 : inv_gain_p2_Q16;
-            my_inv_of_delta[li] = first ? inv_of_delta_p1_Q16 : inv_of_delta_p2_Q16;
-            my_offset[li] = first ? offset_p1_Q10 : offset_p2_Q10;
-            my_DG[li] = first ? DeltaGains_p1_Q16 : DeltaGains_p2_Q16;
+            sd[li] = ((RW_T(l) == 1) != (odd != 0)) ? 0 : 4;
+            dL4[li] = 4 * (pred_base - k * SX_SUBFR - cur0);
+            wb[li] = lagT[li] - decisionDelay + (SX_LTP_ORDER - SX_LTP_ORDER / 2 - 1);
         }
-        // one sample of the trellis; qf: the register set (A or B) that holds the ring cell this sample consumes
-        auto sample_step = [&](const int i, SxRowCell (&qf)[RW_NL]) SX_LAMBDA_INLINE {
+        // one sample of the trellis; qc: the register set that holds the ring cell this sample consumes, qn: the set that takes the next sample's
+        auto sample_step = [&](const int i, SxRowCell (&qc)[RW_NL], SxRowCell (&qn)[RW_NL]) SX_LAMBDA_INLINE {
             const bool emitted = subfr > 0 || i >= decisionDelay;
             const int smpl_new = (smpl_buf_idx - 1) & SX_DD_MASK;                  // ring position this sample writes
             const int last_smple_idx = (smpl_new + decisionDelay) & SX_DD_MASK;    // ring position this sample emits
-            // The sample takes the cell it will emit / test out of its register set (em) and at once refills the set with the
-            // cell sample i + 2 consumes: a whole sample's work (and the other set's turn) lies between a request and its first
+            // The request for the cell the NEXT sample emits / tests: a whole sample's work lies between the request and its first
             // use, and the request stands in front of this sample's stores (vector memory operations complete in order).  The
-            // requested cell was written decisionDelay - 2 >= 11 samples ago.
-            SxRowCell em[RW_NL];
-            RW_FORK(l) {
-                const int li = RW_LI(l);
-                em[li] = qf[li];
-                RW_CELL_LD(qf[li], (last_smple_idx - 2) & SX_DD_MASK, l)
-            }
+            // requested cell was written decisionDelay - 1 >= 12 samples ago.
+            RW_MARK("R")
+            RW_FORK(l) { RW_CELL_LD(qn[RW_LI(l)], (last_smple_idx - 1) & SX_DD_MASK, l) }
+            RW_MARK("A")
             // phase A: predictions, shaping, residual, dither of the lane's track and state
+            i32 Lambda_Q10[RW_NL], offsum[RW_NL], Gain_s[RW_NL], my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
             RW_FORK(l) {
                 const int li = RW_LI(l), tt = RW_TT(l);
                 // The taps of this sample (long-term prediction: 5, harmonic shaping: 3): one LDS read each at a fixed place of the
-                // staged windows.  Issued first, consumed after the shaping filter.  (Unvoiced frame: the prediction
-                // coefficients are zero; no pitch lag: the shaping gains were zeroed above -- whatever the windows hold.)
+                // staged windows.  (Unvoiced frame: the prediction coefficients are zero; no pitch lag: the shaping gains were
+                // zeroed -- whatever the windows hold.)
                 i32 curL[SX_LTP_ORDER], curS[3];
 #pragma unroll
-                for (int j = 0; j < SX_LTP_ORDER; j++) curL[j] = w->tapL[tt][i + (SX_LTP_ORDER - 1) - j];
+                for (int j = 0; j < SX_LTP_ORDER; j++) curL[j] = w->win[tt].tapL[i + (SX_LTP_ORDER - 1) - j];
 #pragma unroll
-                for (int j = 0; j < 3; j++) curS[j] = w->tapS[tt][i + 2 - j];
+                for (int j = 0; j < 3; j++) curS[j] = w->win[tt].tapS[i + 2 - j];
                 const i32 x_sc_Q10 = w->xsc[i];
+                // the subframe's coefficients and the stream's scalars: 16-byte reads through an offset the compiler cannot see
+                // through (it would otherwise hoist the loads out of the sample loop and keep the values in registers)
+                u32 co_ = 0;
+                SX_OPAQUE(co_);
+                const SxRowV4* cv = (const SxRowV4*)__builtin_assume_aligned((const char*)w->coef + co_, 16);
+                // (in three groups, each requested one stage before its use: all at once they would be 40 live registers at the
+                // point of the sample step where the filter states are live as well)
+                i32 cf[RW_NCOEF];
+#define RW_CF_LOAD(j0_, j1_) _Pragma("unroll") for (int j = (j0_); j < (j1_); j++) { const SxRowV4 v_ = cv[j]; cf[4 * j] = v_.x; cf[4 * j + 1] = v_.y; cf[4 * j + 2] = v_.z; cf[4 * j + 3] = v_.w; }
+                constexpr int G1 = (RW_CAR + 3) / 4, G2 = (RW_CB + 3) / 4;      // 16-byte groups that hold A | the rest of AR | the rest
+                RW_CF_LOAD(0, G1)
+                const i32 *Apre = cf + RW_CA, *ARpre = cf + RW_CAR, *Bpre = cf + RW_CB;
                 Seed2[li] = sx_rand(Seed2[li]);                                                // Agora_Silk_Dither (NSQ_del_dec.c:520)
                 const i32 dither = Seed2[li] >> 31;
                 dith[li] = dither;
+                SX_SCHED_FENCE();
+                RW_CF_LOAD(G1, G2)
+                SX_SCHED_FENCE();
                 i32 LPC_pred_Q10 = 0;
 #pragma unroll
                 for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlaw_pre(LPC_pred_Q10, sLPC[li][j], Apre[j]);
+                SX_SCHED_FENCE();
+                RW_CF_LOAD(G2, RW_NCOEF / 4)
+                const i32 warp_pre = cf[RW_CM + 0], Tilt_pre = cf[RW_CM + 1], LFb_pre = cf[RW_CM + 2], LFt_pre = cf[RW_CM + 3], Hb_pre = cf[RW_CM + 4], Ht_pre = cf[RW_CM + 5];
+                Lambda_Q10[li] = cf[RW_CM + 6]; offsum[li] = cf[RW_CM + 7]; Gain_s[li] = cf[RW_CM + 8];
+                {
+                    const SxRowV4 v_ = *(const SxRowV4*)__builtin_assume_aligned((const char*)w->mdc + co_ + 4 * sd[li], 16);
+                    my_inv_gain[li] = v_.x; my_inv_of_delta[li] = v_.y; my_offset[li] = v_.z; my_DG[li] = v_.w;
+                }
+                SX_SCHED_FENCE();
                 // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place
                 i32 tmp2 = sx_smlaw_pre(sLPC[li][0], sAR2[li][0], warp_pre);
                 i32 tmp1 = sx_smlaw_pre(sAR2[li][0], sAR2[li][1] - tmp2, warp_pre);
@@ -676,55 +715,54 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 LTP_pred[li] = LTP_pred_Q14;
                 rD[li] = r_Q10;
             }
+            RW_MARK("B")
             // phase B: the two candidates of each side state (Agora_Silk_RDCx1) from the side's share of the CENTRE residual
             RWT_FROM(rC, rD, 0)
             RW_FORK(l) {
                 const int li = RW_LI(l);
                 const i32 r_md_Q10 = sx_smulww(my_inv_gain[li], rC[li]);
-                sx_nsq_rdcx1(RD[li], r_md_Q10, rD[li], my_inv_of_delta[li], Lambda_Q10, my_offset[li], cRD[li], cQ0[li], cQ10[li], sRdInd[li]);
+                sx_nsq_rdcx1(r_md_Q10, rD[li], my_inv_of_delta[li], Lambda_Q10[li], my_offset[li], cInc[li], cQ10[li]);
             }
+            RW_MARK("C")
             // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152) in the centre's lanes: the centre takes the best two of the four
             // combinations of side candidates; the side candidates are then re-ordered so that candidate j of every track belongs
             // to combination w_j
 #if SX_NLANES == 1
             { i32 a_[12], b_[12], c_[12], d_[12];
-              for (int q_ = 0; q_ < 12; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = sRdInd[q_][0]; d_[q_] = sRdInd[q_][1]; }
+              for (int q_ = 0; q_ < 12; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = cInc[q_][0]; d_[q_] = cInc[q_][1]; }
               RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
               RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
 #else
-            p1q0[0] = RW_DPP_BANK(p1q0[0], cQ10[0][0], RW_SHL(4), 0); p1q1[0] = RW_DPP_BANK(p1q1[0], cQ10[0][1], RW_SHL(4), 0);
-            p1r0[0] = RW_DPP_BANK(p1r0[0], sRdInd[0][0], RW_SHL(4), 0); p1r1[0] = RW_DPP_BANK(p1r1[0], sRdInd[0][1], RW_SHL(4), 0);
-            p2q0[0] = RW_DPP_BANK(p2q0[0], cQ10[0][0], RW_SHL(8), 0); p2q1[0] = RW_DPP_BANK(p2q1[0], cQ10[0][1], RW_SHL(8), 0);
-            p2r0[0] = RW_DPP_BANK(p2r0[0], sRdInd[0][0], RW_SHL(8), 0); p2r1[0] = RW_DPP_BANK(p2r1[0], sRdInd[0][1], RW_SHL(8), 0);
+            { i32 a_[1] = {cQ10[0][0]}, b_[1] = {cQ10[0][1]}, c_[1] = {cInc[0][0]}, d_[1] = {cInc[0][1]};
+              RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
+              RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
 #endif
-            i32 wpk[RW_NL], ccRD[RW_NL][2], ccQ10[RW_NL][2];
+            i32 wpk[RW_NL], ccInc[RW_NL][2], ccQ10[RW_NL][2];
             RW_FORK(l) {
                 const int li = RW_LI(l);
-                const i32 off = offset_sum_Q10;
+                const i32 off = offsum[li];
                 const i32 qx0 = p1q0[li] + p2q0[li], qx1 = p1q1[li] + p2q1[li], qx2 = p1q0[li] + p2q1[li], qx3 = p1q1[li] + p2q0[li];
                 const i32 r_temp = sx_sub(rD[li], off);
                 const i32 l1r0 = sx_mul_lambda(p1r0[li]), l1r1 = sx_mul_lambda(p1r1[li]), l2r0 = sx_mul_lambda(p2r0[li]), l2r1 = sx_mul_lambda(p2r1[li]);
-                i32 rdx0 = sx_nsq_center_rd1(qx0, r_temp, off, Lambda_Q10), rdx1 = sx_nsq_center_rd1(qx1, r_temp, off, Lambda_Q10);
-                i32 rdx2 = sx_nsq_center_rd1(qx2, r_temp, off, Lambda_Q10), rdx3 = sx_nsq_center_rd1(qx3, r_temp, off, Lambda_Q10);
+                i32 rdx0 = sx_nsq_center_rd1(qx0, r_temp, off, Lambda_Q10[li]), rdx1 = sx_nsq_center_rd1(qx1, r_temp, off, Lambda_Q10[li]);
+                i32 rdx2 = sx_nsq_center_rd1(qx2, r_temp, off, Lambda_Q10[li]), rdx3 = sx_nsq_center_rd1(qx3, r_temp, off, Lambda_Q10[li]);
                 rdx0 = sx_add(sx_add(rdx0, l1r0), l2r0);
                 rdx1 = sx_add(sx_add(rdx1, l1r1), l2r1);
                 rdx2 = sx_add(sx_add(rdx2, l1r0), l2r1);
                 rdx3 = sx_add(sx_add(rdx3, l1r1), l2r0);
-                // best combination (first minimum) and best of the remaining three (first minimum among them): selects, no branches
-                int w1 = 0;
-                i32 m = rdx0;
-                { const bool b = rdx1 < m; m = b ? rdx1 : m; w1 = b ? 1 : w1; }
-                { const bool b = rdx2 < m; m = b ? rdx2 : m; w1 = b ? 2 : w1; }
-                { const bool b = rdx3 < m; m = b ? rdx3 : m; w1 = b ? 3 : w1; }
-                int w2 = w1 == 0 ? 1 : 0;
-                m = w1 == 0 ? rdx1 : rdx0;
-                { const bool b = (w1 != 0) & (w1 != 1) & (rdx1 < m); m = b ? rdx1 : m; w2 = b ? 1 : w2; }
-                { const bool b = (w1 != 2) & (rdx2 < m); m = b ? rdx2 : m; w2 = b ? 2 : w2; }
-                { const bool b = (w1 != 3) & (rdx3 < m); m = b ? rdx3 : m; w2 = b ? 3 : w2; }
-                const i32 q_w1 = sx_sel4(qx0, qx1, qx2, qx3, w1), q_w2 = sx_sel4(qx0, qx1, qx2, qx3, w2);
-                const i32 rd_w1 = sx_sel4(rdx0, rdx1, rdx2, rdx3, w1), rd_w2 = sx_sel4(rdx0, rdx1, rdx2, rdx3, w2);
-                ccRD[li][0] = sx_add(RD[li], rd_w1);
-                ccRD[li][1] = sx_add(RD[li], rd_w2);
+                // best combination (first minimum) and best of the remaining three (first minimum among them): selects, no branches.
+                // (the costs are sums of three terms that each went through >> 10: far from INT32_MAX, which can stand for "taken")
+                const i32 m1 = sx_min(sx_min(rdx0, rdx1), sx_min(rdx2, rdx3));
+                const bool e0 = rdx0 == m1, e1 = rdx1 == m1, e2 = rdx2 == m1;
+                const int w1 = e0 ? 0 : (e1 ? 1 : (e2 ? 2 : 3));
+                const i32 q_w1 = e0 ? qx0 : (e1 ? qx1 : (e2 ? qx2 : qx3));
+                const i32 x0 = w1 == 0 ? SX_I32_MAX : rdx0, x1 = w1 == 1 ? SX_I32_MAX : rdx1, x2 = w1 == 2 ? SX_I32_MAX : rdx2, x3 = w1 == 3 ? SX_I32_MAX : rdx3;
+                const i32 m2 = sx_min(sx_min(x0, x1), sx_min(x2, x3));
+                const bool f0 = x0 == m2, f1 = x1 == m2, f2 = x2 == m2;
+                const int w2 = f0 ? 0 : (f1 ? 1 : (f2 ? 2 : 3));
+                const i32 q_w2 = f0 ? qx0 : (f1 ? qx1 : (f2 ? qx2 : qx3));
+                ccInc[li][0] = m1;
+                ccInc[li][1] = m2;
                 ccQ10[li][0] = q_w1;
                 ccQ10[li][1] = q_w2;
                 wpk[li] = w1 | (w2 << 2);
@@ -732,44 +770,46 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             RWT_FROM(tq, wpk, 0)
             RW_FORK(l) {
                 const int li = RW_LI(l), t = RW_T(l);
-                const int w1 = tq[li] & 3, w2 = tq[li] >> 2;
                 // the reference's 12-way memcpy case table (NSQ_del_dec.c:1266-1336) is this selection;
-                // member of combination w: MD1 {0,1,0,1}, MD2 {0,1,1,0}
-                const bool ca = t == 1 ? (w1 & 1) != 0 : (w1 == 1 || w1 == 2), cb = t == 1 ? (w2 & 1) != 0 : (w2 == 1 || w2 == 2);
-                const i32 a0 = cRD[li][0], a1 = cRD[li][1], b0 = cQ0[li][0], b1 = cQ0[li][1], d0 = cQ10[li][0], d1 = cQ10[li][1];
+                // member of combination w: MD1 {0,1,0,1}, MD2 {0,1,1,0} -- bit w of a lane constant
+                const u32 mtab = t == 1 ? 0xAu : 0x6u;
+                const bool ca = ((mtab >> (tq[li] & 3)) & 1u) != 0, cb = ((mtab >> ((tq[li] >> 2) & 3)) & 1u) != 0;
+                const i32 a0 = cInc[li][0], a1 = cInc[li][1], d0 = cQ10[li][0], d1 = cQ10[li][1];
                 const bool ctr = t == 0 || t == 3;
-                cRD[li][0] = ctr ? ccRD[li][0] : (ca ? a1 : a0);   cRD[li][1] = ctr ? ccRD[li][1] : (cb ? a1 : a0);
-                cQ0[li][0] = ctr ? ccQ10[li][0] >> 10 : (ca ? b1 : b0);  cQ0[li][1] = ctr ? ccQ10[li][1] >> 10 : (cb ? b1 : b0);
+                cInc[li][0] = ctr ? ccInc[li][0] : (ca ? a1 : a0);  cInc[li][1] = ctr ? ccInc[li][1] : (cb ? a1 : a0);
                 cQ10[li][0] = ctr ? ccQ10[li][0] : (ca ? d1 : d0); cQ10[li][1] = ctr ? ccQ10[li][1] : (cb ? d1 : d0);
                 // the track's share of the joint cost of candidate [0] (Agora_Silk_JudgeWinner, NSQ_del_dec.c:671)
-                tq2[li] = t == 0 ? cRD[li][0] : sx_mul_lambda(cRD[li][0]);
+                const i32 cand0 = sx_add(RD[li], cInc[li][0]);
+                tq2[li] = t == 0 ? cand0 : sx_mul_lambda(cand0);
             }
             RWT_SUM(jv, tq2)
             smpl_buf_idx = smpl_new;
+            RW_MARK("E")
             // phase E: Agora_Silk_JudgeWinner.  States whose decisionDelay-old ancestor differs from the joint winner's, in any
             // track, are expired (their centre costs are pushed up); then up to (number of expired states) rounds of "the best
             // second candidate replaces the worst first candidate" -- played on three index registers:
             //   par   whose filter state the lane continues from,  csrc / csel   whose candidate (and which one) it takes
             // (the centre's lanes play it; the plan then crosses to the side tracks' lanes as one packed word)
+            i32 pen[RW_NL];
             {
                 const i32 PEN = SX_I32_MAX >> 4;
                 RWK_ARGMIN(jv, mv, mi)                                   // mi = the joint winner
                 // the delayed random state of this state's lineage: held by the lane that owns the lineage's slot of that ring position;
                 // before the frame has written that position (first decisionDelay samples) the reference reads its zero-initialised ring
                 const bool written = k * SX_SUBFR + i >= decisionDelay;
-                RW_FORK(l) { gq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); tq[RW_LI(l)] = em[RW_LI(l)].w3; }
+                RW_FORK(l) { gq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); tq[RW_LI(l)] = qc[RW_LI(l)].w3; }
                 RWK_GATHER(c0, tq, gq)
                 RW_FORK(l) { myRand[RW_LI(l)] = written ? c0[RW_LI(l)] : 0; }
-                RWK_GATHER(c1, myRand, mi)                               // the winner's
+                RWK_PICK(c1, myRand, mi)                                 // the winner's
                 RW_FORK(l) { tq[RW_LI(l)] = (myRand[RW_LI(l)] ^ c1[RW_LI(l)]) != 0 ? 1 : 0; }
                 RWT_OR(tq2, tq)                                          // expired: differs in any track
                 RW_FORK(l) {
                     const int li = RW_LI(l);
                     const bool ctr = RW_T(l) == 0 || RW_T(l) == 3;
-                    const i32 pen_ = (tq2[li] && ctr) ? PEN : 0;
-                    cRD[li][0] = sx_add(cRD[li][0], pen_); cRD[li][1] = sx_add(cRD[li][1], pen_);
+                    pen[li] = (tq2[li] && ctr) ? PEN : 0;                // (only the centre's costs carry the penalty)
                     par[li] = RW_K(l); csrc[li] = RW_K(l); csel[li] = 0;
-                    c0[li] = cRD[li][0]; c1[li] = cRD[li][1];
+                    const i32 rp_ = sx_add(RD[li], pen[li]);
+                    c0[li] = sx_add(rp_, cInc[li][0]); c1[li] = sx_add(rp_, cInc[li][1]);
                 }
                 RWK_SUM(tq2, nrep)                                       // number of expired states
                 RWK_ARGMIN(c1, mv2, mi2)                                 // best candidate [1] (first minimum): the [1] entries never change
@@ -777,7 +817,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 int RandSyncCtl = RW_UNI(nrep);
                 do {
                     RWK_ARGMAX(c0, mv, mi)                               // worst candidate [0] (first maximum)
-                    RWK_GATHER(gq, par, mi2)                             // the state lane mi2 holds NOW (it may itself have been replaced)
+                    RWK_PICK(gq, par, mi2)                               // the state lane mi2 holds NOW (it may itself have been replaced)
                     RW_FORK(l) {
                         const int li = RW_LI(l);
                         const bool rep_ = (mv2[li] < mv[li]) & (RW_K(l) == mi[li]);
@@ -788,18 +828,31 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 i32 RandSyncCtl = nrep[0];
                 do {
                     RWK_ARGMAX(c0, mv, mi)
-                    RWK_GATHER(gq, par, mi2)
+                    RWK_PICK(gq, par, mi2)
                     const bool rep_ = (mv2[0] < mv[0]) & ((i32)(threadIdx.x & 3u) == mi[0]);
                     par[0] = rep_ ? gq[0] : par[0]; csrc[0] = rep_ ? mi2[0] : csrc[0]; csel[0] = rep_ ? 1 : csel[0]; c0[0] = rep_ ? mv2[0] : c0[0];
                 } while (--RandSyncCtl > 0);
 #endif
                 RW_FORK(l) { tq[RW_LI(l)] = par[RW_LI(l)] | (csrc[RW_LI(l)] << 2) | (csel[RW_LI(l)] << 4); }
                 RWT_FROM(tq2, tq, 0)
-                RW_FORK(l) { const int li = RW_LI(l); par[li] = tq2[li] & 3; csrc[li] = (tq2[li] >> 2) & 3; csel[li] = tq2[li] >> 4; }
+                RW_FORK(l) { const int li = RW_LI(l); par[li] = tq2[li] & 3; csrc[li] = (tq2[li] >> 2) & 3; csel[li] = (tq2[li] >> 4) & 1; }
             }
+            RW_MARK("M")
             // the survivors move: SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668), every register once.
             // The last-sample memories shift by one on the way (sLPC[0] takes the new sample in phase G).
+            i32 cand1RD[RW_NL], cand1Q10[RW_NL];
             {
+                // the chosen candidate [1] and the predictions it was built on come from the lane that produced it
+                // (the long-term prediction is the same in the four states of a track)
+                RW_FORK(l) { const int li = RW_LI(l); cand1RD[li] = sx_add(sx_add(RD[li], pen[li]), cInc[li][1]); cand1Q10[li] = cQ10[li][1]; }
+#define RW_LV_C1RD(q_) cand1RD[q_]
+#define RW_LV_C1Q10(q_) cand1Q10[q_]
+#define RW_LV_LPCP(q_) LPC_pred[q_]
+#define RW_LV_NAR(q_) n_AR[q_]
+#define RW_LV_NLF(q_) n_LF[q_]
+#define RW_LV_DITH(q_) dith[q_]
+                RWK_PERM(RW_LV_C1RD, csrc) RWK_PERM(RW_LV_C1Q10, csrc)
+                RWK_PERM(RW_LV_LPCP, csrc) RWK_PERM(RW_LV_NAR, csrc) RWK_PERM(RW_LV_NLF, csrc) RWK_PERM(RW_LV_DITH, csrc)
 #define RW_LV_SEED2(q_) Seed2[q_]
 #define RW_LV_SEEDI(q_) SeedInit2[q_]
 #define RW_LV_LINLO(q_) linLo[q_]
@@ -819,92 +872,85 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     sLPC[0][j] = rwk_from(sLPC[0][j - 1], par[0]);
 #endif
                 }
-                // the chosen candidate [1] and the predictions it was built on come from the lane that produced it
-                // (the long-term prediction is the same in the four states of a track)
-#define RW_LV_C1RD(q_) cRD[q_][1]
-#define RW_LV_C1Q0(q_) cQ0[q_][1]
-#define RW_LV_C1Q10(q_) cQ10[q_][1]
-#define RW_LV_LPCP(q_) LPC_pred[q_]
-#define RW_LV_NAR(q_) n_AR[q_]
-#define RW_LV_NLF(q_) n_LF[q_]
-#define RW_LV_DITH(q_) dith[q_]
-                RWK_PERM(RW_LV_C1RD, csrc) RWK_PERM(RW_LV_C1Q0, csrc) RWK_PERM(RW_LV_C1Q10, csrc)
-                RWK_PERM(RW_LV_LPCP, csrc) RWK_PERM(RW_LV_NAR, csrc) RWK_PERM(RW_LV_NLF, csrc) RWK_PERM(RW_LV_DITH, csrc)
             }
+            RW_MARK("D")
             // phase D: undo dither, re-apply the side gains, simulate the decoder (Agora_Silk_UndoPred_And_Shap, NSQ_del_dec.c:482)
             // for the candidate the lane keeps; joint cost of the survivors
-            i32 fRD[RW_NL], fQ0[RW_NL], cXq14[RW_NL], cLFAR[RW_NL], cShp[RW_NL], cExc10[RW_NL], cX[RW_NL];
+            i32 fRD[RW_NL], fQ0[RW_NL], cXq14[RW_NL], cShp[RW_NL], cExc10[RW_NL], cX[RW_NL];
             RW_FORK(l) {
                 const int li = RW_LI(l), t = RW_T(l);
                 const i32 dither = dith[li];
-                const int sel = csel[li];
-                const i32 Q10 = sel ? cQ10[li][1] : cQ10[li][0];
-                fRD[li] = sel ? cRD[li][1] : cRD[li][0];
-                fQ0[li] = sel ? cQ0[li][1] : cQ0[li][0];
+                const bool sel = csel[li] != 0;
+                const i32 Q10 = sel ? cand1Q10[li] : cQ10[li][0];
+                fRD[li] = sel ? cand1RD[li] : sx_add(sx_add(RD[li], pen[li]), cInc[li][0]);
                 i32 Q = (Q10 ^ dither) - dither;
                 const bool ctr = t == 0 || t == 3;
-                cX[li] = ctr ? Q : fQ0[li];                          // what the coder gets: centre excitation / side pulse
+                // the pulse: the quantised value (a side's without its offset) >> 10; what the coder gets: the centre's excitation / the side's pulse
+                fQ0[li] = ctr ? Q10 >> 10 : (i32)(i8)(sx_sub(Q10, my_offset[li]) >> 10);
+                cX[li] = ctr ? Q : fQ0[li];
                 Q = ctr ? Q : sx_smulww(my_DG[li], Q);
                 const i32 LPC_exc_Q10 = Q + sx_rshift_round(LTP_pred[li], 4);
                 const i32 xq_Q10 = sx_add(LPC_exc_Q10, LPC_pred[li]);
                 const i32 sLF_AR_shp_Q10 = sx_sub(xq_Q10, n_AR[li]);
                 cShp[li] = sx_sub(sLF_AR_shp_Q10, n_LF[li]);
-                cLFAR[li] = sx_shl(sLF_AR_shp_Q10, 2);
+                LF_AR[li] = sx_shl(sLF_AR_shp_Q10, 2);
                 cXq14[li] = sx_shl(xq_Q10, 4);
                 cExc10[li] = LPC_exc_Q10;
                 tq[li] = t == 0 ? fRD[li] : sx_mul_lambda(fRD[li]);
             }
             RWT_SUM(jv, tq)
+            RW_MARK("F")
             // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
             // that owns the winner's slot of the emitted ring position holds the cell in its prefetch registers.
             RWK_ARGMIN(jv, mv, mi)
-            if (emitted) {
+            {
                 RW_FORK(l) { tq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); }
-                RWK_GATHER(gq, tq, mi)
+                RWK_PICK(gq, tq, mi)
                 const bool crossed = subfr > 0 && i < decisionDelay;      // the cell was written before this subframe's gain change
                 RW_FORK(l) {
                     const int li = RW_LI(l);
-                    if (RW_K(l) == gq[li] && RW_LIVE(l)) {
-                        const int pos = k * SX_SUBFR + i - decisionDelay;
-                        const i32 p16 = rw_cell_pred_Q16(em[li]);
-                        const i32 pv = crossed ? sx_smulww(gadj[li], p16) : p16;
-                        const i32 sv = crossed ? sx_smulww(gadj[li], em[li].w2) : em[li].w2;
+                    if (emitted && RW_K(l) == gq[li] && RW_LIVE(l)) {
+                        const u32 e4 = (u32)(4 * (cur0 + k * SX_SUBFR + i - decisionDelay));
+                        const i32 p16 = rw_cell_pred_Q16(qc[li]);
+                        const i32 gx = crossed ? gadj[li] : 65536;               // (x 65536 >> 16: exact)
                         // (HBM gets the cell as it is -- it belongs to the previous subframe, this start's factor reaches it when
-                        // it is staged --, this subframe's windows get it with the factor applied)
-                        RW_EMIT_OUT(l, li, em[li], pos)
-                        SX_AT(i32, Pu, pLtp[li] + (u32)(pred_base + i - decisionDelay) * 4u) = p16;
-                        const int D = lagT[li] - decisionDelay - (SX_LTP_ORDER / 2 + 1);
-                        if ((unsigned)(i + D + 5) < (unsigned)SX_TAPL_N) w->tapL[RW_T(l)][i + D + 5] = pv;
-                        if ((unsigned)(i + D + 4) < (unsigned)SX_TAPS_N) w->tapS[RW_T(l)][i + D + 4] = sv;
+                        // it is staged --, this subframe's windows get it with the factor applied; an entry no tap of this
+                        // subframe can reach goes to the row's dump word)
+                        RW_EMIT_OUT(l, li, qc[li], e4, true)
+                        SX_AT(i32, Pu + offsetof(SxNsqTrack, sLTP_Q16), pTrk[li] + e4 + (u32)dL4[li]) = p16;
+                        const u32 iL = (u32)(i + wb[li]), iS = iL - 1u;
+                        w->win[RW_T(l)].tapL[iL < (u32)SX_TAPL_N ? iL : (u32)SX_TAPL_N] = sx_smulww(gx, p16);
+                        w->win[RW_T(l)].tapS[iS < (u32)SX_TAPS_N ? iS : (u32)SX_TAPS_N] = sx_smulww(gx, qc[li].w2);
                     }
                 }
             }
+            RW_MARK("G")
             // phase G: Agora_Silk_Update_DelDecState (NSQ_del_dec.c:862): every state pushes its candidate into its own cell
             RW_FORK(l) {
                 const int li = RW_LI(l), kk = RW_K(l);
-                LF_AR[li] = cLFAR[li];
                 sLPC[li][0] = cXq14[li];
                 lastShp[li] = cShp[li];
                 Seed[li] = sx_add(Seed[li], fQ0[li]);
                 RD[li] = fRD[li];
                 SxRowCell cell;
-                const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[li] >> 4, Gain_Q16), 10));
+                const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[li] >> 4, Gain_s[li]), 10));
                 cell.w0 = (i32)(((u32)xq16 & 0xFFFFu) | ((u32)cX[li] << 16));
                 cell.w1 = (i32)(((u32)cExc10[li] & 0x03FFFFFFu) | (((u32)cX[li] << 10) & 0xFC000000u));
                 cell.w2 = cShp[li];
                 cell.w3 = Seed[li];
-                if (RW_LIVE(l)) RW_CELL_ST(smpl_buf_idx, l, cell)
+                RW_CELL_ST(smpl_buf_idx, l, cell)                 // (the spare quad writes its own, unread, cells)
                 // the state's own slot now holds its newest ring entry
                 const u32 m = 3u << (2 * (smpl_buf_idx & 15));
                 if (smpl_buf_idx < 16) linLo[li] = (i32)(((u32)linLo[li] & ~m) | (((u32)kk * 0x55555555u) & m));
                 else linHi[li] = (i32)(((u32)linHi[li] & ~m) | (((u32)kk * 0x55555555u) & m));
             }
+            RW_MARK("Z")
             wv_sync_lds();
         };
         static_assert(SX_SUBFR % 2 == 0, "two samples per iteration");
         for (int i = 0; i < SX_SUBFR; i += 2) {
-            sample_step(i, qA);
-            sample_step(i + 1, qB);
+            sample_step(i, qA, qB);
+            sample_step(i + 1, qB, qA);
         }
         sLTP_shp_buf_idx += SX_SUBFR;
         sLTP_buf_idx += SX_SUBFR;
@@ -914,17 +960,17 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     // Agora_Silk_DelDec_UpdateState_And_Output{,_Side} (NSQ_del_dec.c:175, 245)
     RWT_FROM(jv, RD, 0)
     RWK_ARGMIN(jv, mv, mi)
-    RWK_GATHER(tq, SeedInit2, mi)
+    RWK_PICK(tq, SeedInit2, mi)
     RW_FORK(l) { if (l == 0) out->Seed = tq[RW_LI(l)]; }
-    RWK_GATHER(tq, linLo, mi)
-    RWK_GATHER(tq2, linHi, mi)
+    RWK_PICK(tq, linLo, mi)
+    RWK_PICK(tq2, linHi, mi)
     wv_sync();                                  // the ring cells of the last samples must have landed
     RW_FLUSH(tq[li], tq2[li], SX_FRAME - decisionDelay)
     wv_sync();
     RW_FORK(l) {
         const int li = RW_LI(l);
         if (RW_K(l) == mi[li] && RW_LIVE(l)) {
-            SxNSQ* n = &SX_AT(SxNSQ, Pu, pNsq[li]);
+            SxNSQ* n = &SX_AT(SxNSQ, Pu, pTrk[li] + (u32)offsetof(SxNsqTrack, s));
 #pragma unroll
             for (int i = 0; i < SX_MAX_LPC; i++) n->sLPC_Q14[i] = (SX_MAX_LPC - 1 - i) < SX_LPC ? sLPC[li][SX_MAX_LPC - 1 - i] : 0;
 #pragma unroll
@@ -932,6 +978,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             n->sLF_AR_shp_Q12 = LF_AR[li];
             n->lagPrev = c->pitchL[SX_NB_SUBFR - 1];
             n->prev_inv_gain_Q16 = prevInv[li];
+            n->histBase = cur0;                      // the frame just written becomes "the previous frame"
 #pragma unroll
             for (int kq = 0; kq < SX_NB_SUBFR; kq++) n->gadjPrev[kq] = w->gfac[RW_T(l)][SX_NB_SUBFR + kq];
         }

@@ -33,14 +33,15 @@ struct SxVAD {                       // SKP_Silk_VAD_state, SKP_Silk_structs.h:6
     i32 counter;
 };
 
-struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:44: small per-track part (histories: SxEncHist)
+struct SxNSQ {                       // SKP_Silk_nsq_state, SKP_Silk_structs.h:44: small per-track part (histories: SxNsqTrack)
     i32 sLPC_Q14[SX_MAX_LPC];        // newest 16 of the reference's 32-entry tail (only the last 10 are ever read)
     i32 sAR2_Q14[SX_SHAPE_ORDER];
     i32 sLF_AR_shp_Q12;
     i32 lagPrev;
     i32 prev_inv_gain_Q16;
     i32 gadjPrev[SX_NB_SUBFR];       // gain-adjustment factors of the previous frame's four subframe starts (65536 = none): the history
-                                     // arrays are stored unscaled, the factors are applied when history is staged (solo_enc_nsq.h)
+                                     // arrays are stored unscaled, the factors are applied when history is staged (solo_enc_nsq_row.h)
+    i32 histBase;                    // 0 / SX_FRAME: where logical entry 0 of the two circular histories sits (toggles every frame)
 };
 
 // Compact per-stream encoder state: loaded into LDS when a launch starts, written back when it ends.
@@ -68,10 +69,16 @@ struct SxEncState {
     i32 prev_NLSFq_Q15[SX_LPC];
 };
 
-struct alignas(16) SxNsqGlobal {     // per-stream NSQ arrays that live in HBM / L2 (rows 16-byte aligned: the frame shift moves 16 bytes at a time)
-    i32 sLTP_Q16[SX_N_TRACKS][2 * SX_FRAME];
-    i32 shp[SX_N_TRACKS][2 * SX_FRAME + 8];      // sLTP_shp_Q10 of the three tracks: previous frame | current frame (+8: a side track
-                                                 // with lag 0 reads one entry past the frame, always 0 in the reference)
+// Quantiser state + histories of ONE track (centre, MD1, MD2), contiguous: a lane of the quantiser kernel addresses everything of
+// its track from one base.  The quantised signal and the shaping history are kept for two frames (the reference: previous frame |
+// current frame, shifted down by memcpy when a frame ends); here they are CIRCULAR over 2 SX_FRAME entries, logical entry L (0 =
+// first sample of the previous frame) at physical (L + histBase) mod 2 SX_FRAME, and a frame end only toggles histBase: every
+// entry is written exactly once.  sLTP_Q16 (the scaled prediction history) is frame-local: re-whitening regenerates it.
+struct alignas(16) SxNsqTrack {
+    i32 sLTP_Q16[2 * SX_FRAME];
+    i32 shp[2 * SX_FRAME];           // sLTP_shp_Q10, circular
+    i16 xq[2 * SX_FRAME];            // quantised signal, circular
+    SxNSQ s;
 };
 
 // Per-stream history arrays: stay in HBM, staged through LDS by the phase that uses them.
@@ -95,15 +102,16 @@ struct SxNsqIn {                     // what the quantiser needs of one analysed
 };
 struct SxNsqOut {                    // what the quantiser produces for one frame
     i32 Seed;                        // dither seed of the winning path (coded)
-    i8 q[2][SX_FRAME];               // pulses of MD1 / MD2 (the centre stream is never coded)
     i32 r[SX_FRAME];                 // centre excitation Q10 (high-band gain reference)
+    // pulses of MD1 / MD2 (the centre stream is never coded).  The quantiser emits every sample of every track with ONE 4-byte store:
+    // a side track's lands at the pulse's byte, its upper three bytes (sign bytes) fall on the next three pulses of the row, which
+    // are emitted -- and so overwritten -- after it; the last three of a row fall into its four bytes of padding.
+    i8 q[2][SX_FRAME + 4];
 };
 struct alignas(16) SxNsqPersist {    // quantiser state of one stream
-    SxNSQ nsq[SX_N_TRACKS];
-    SxNsqGlobal g;
-    alignas(16) i16 xq[SX_N_TRACKS][2 * SX_FRAME];   // quantised signal: previous frame | current frame
+    SxNsqTrack trk[SX_N_TRACKS];
 };
-static_assert((sizeof(i32) * (2 * SX_FRAME + 8)) % 16 == 0 && (sizeof(i32) * SX_FRAME) % 16 == 0 && (sizeof(i16) * SX_FRAME) % 16 == 0, "history rows must stay 16-byte aligned");
+static_assert(sizeof(SxNsqTrack) % 16 == 0 && sizeof(SxNSQ) % 16 == 0, "track records stay 16-byte aligned");
 
 struct alignas(16) SxEncStream {     // one record per stream in HBM
     SxEncState core;
@@ -167,15 +175,15 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
     }
     st->vad.counter = 15;
     for (int t = 0; t < SX_N_TRACKS; t++) {
-        rec->nsq.nsq[t].prev_inv_gain_Q16 = 65536;
-        for (int k = 0; k < SX_NB_SUBFR; k++) rec->nsq.nsq[t].gadjPrev[k] = 65536;
+        rec->nsq.trk[t].s.prev_inv_gain_Q16 = 65536;
+        for (int k = 0; k < SX_NB_SUBFR; k++) rec->nsq.trk[t].s.gadjPrev[k] = 65536;
     }
     // setup_fs_FIX (control_codec_FIX.c:232): only the CENTRE nsq state gets lagPrev = 100
     st->prevLag = 100;
     st->prev_sigtype = 1;
     st->pf_lagPrev = 100;
     st->LastGainIndex = 1;
-    rec->nsq.nsq[0].lagPrev = 100;
+    rec->nsq.trk[0].s.lagPrev = 100;
     // setup_rate_FIX (control_codec_FIX.c:319): bitrate -> SNR tables, per description and total
     silk_rate_bps = sx_limit(silk_rate_bps, 5000, 100000);           // enc_API.c:187
     i32 md_rate = silk_rate_bps / 2;

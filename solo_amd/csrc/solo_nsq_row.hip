@@ -1,0 +1,104 @@
+// solo_nsq_row.hip -- stage B of the encoder: the multiple-description delayed-decision quantiser (solo_enc_nsq_row.h), compiled
+// with FOUR streams per wavefront: one lane = one delayed-decision state of one track, a stream = one 16-lane DPP row (twelve live
+// lanes: 3 tracks x 4 states).  Everything that is "wave-uniform" in the one-stream-per-wave model is uniform within a row here, and
+// the cross-lane exchanges stay inside the row.  The recursion is serial in time, so one row works through its stream's frames in
+// order: packet by packet, two frames each.  4096 streams = 1024 wavefronts = one per SIMD: the quantiser's wave is a dependent
+// chain that issues every ~5 cycles; the analysis / coding kernels of the neighbouring chunks of the pipeline fill the rest of
+// every SIMD's issue slots.
+#define SX_GROUP 16
+#define SX_PER_WAVE (64 / SX_GROUP)
+#include <hip/hip_runtime.h>
+#include "solo_enc_nsq_row.h"
+
+#ifndef SX_NSQ_PRIO
+#define SX_NSQ_PRIO 3
+#endif
+// SX_NSQ_VGPR_CAP = n: the kernel may use 2 n of the SIMD's 512 registers.  64 -> 128 registers: a SIMD that holds a quantiser
+// wave still takes four analysis waves of 96 (128 + 4 x 96 = 512), so all sixteen analysis workgroups of a compute unit stay
+// resident beside its four quantiser waves.
+#ifndef SX_NSQ_VGPR_CAP
+#define SX_NSQ_VGPR_CAP 64
+#endif
+#if SX_NSQ_VGPR_CAP > 0
+#define SX_NSQ_CAP_ATTR __attribute__((amdgpu_num_vgpr(SX_NSQ_VGPR_CAP)))
+#else
+#define SX_NSQ_CAP_ATTR
+#endif
+// ring: SX_DD_DELAY rows of 64 cells per workgroup (the emission ring of its four streams, rows of 64 lanes = 1 KB)
+#define SX_NSQ_RING_CELLS (SX_DD_DELAY * 64)
+extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
+                                                                 SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
+                                                                 unsigned int* started, SxRowCell* __restrict__ ring) {
+    __shared__ SxRowWork w[SX_PER_WAVE];
+    const int g = threadIdx.x / SX_GROUP;
+    const int s = blockIdx.x * SX_PER_WAVE + g;
+    if (started && threadIdx.x == 0) atomicAdd(started, 1u);     // lets the host-side pipeline start the next analysis chunk once this kernel is resident
+    if (s >= n_streams) return;
+    // a latency-bound wave that shares its SIMD with the analysis / coding kernels of neighbouring chunks: issue first
+    __builtin_amdgcn_s_setprio(SX_NSQ_PRIO);
+    // wave-uniform bases + 32-bit lane offsets (solo_enc_nsq_row.h): the states / records of the wavefront's four streams
+    char* Pu = (char*)&states[(size_t)blockIdx.x * SX_PER_WAVE];
+    const u32 pOff = (u32)g * (u32)sizeof(SxEncStream) + (u32)offsetof(SxEncStream, nsq);
+    const u32 rec_stride = (u32)n_packets * 2u;                     // hand-over records between consecutive streams
+    SxRowCell* rgu = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS;
+    for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
+        for (int f = 0; f < 2; f++) {
+            const size_t r0 = ((size_t)blockIdx.x * SX_PER_WAVE * n_packets + p) * 2 + f;       // record of the wavefront's first stream
+            sx_nsq_del_dec(Pu, pOff, &in[r0 + (size_t)g * rec_stride], (char*)&out[r0], (u32)g * rec_stride * (u32)sizeof(SxNsqOut), &w[g], rgu,
+                           (u32)(g * SX_GROUP), 64);
+            wv_sync();
+        }
+    }
+}
+
+#if SX_FS_KHZ == 8
+// gate: holds a stream until `*flag` has reached `target` (modulo 2^32), i.e. until all workgroups of the quantiser launch that
+// counts into it are resident; gives up after ~20 ms so that a runtime that serialises the streams cannot hang
+extern "C" __global__ void __launch_bounds__(64) solo_gate_kernel(const unsigned int* flag, unsigned int target) {
+    if (threadIdx.x == 0) {
+        for (int it = 0; it < 20000; it++) {
+            if (__atomic_load_n(flag, __ATOMIC_RELAXED) - target < 0x80000000u) break;
+            __builtin_amdgcn_s_sleep(32);
+        }
+    }
+}
+extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream) {
+    hipLaunchKernelGGL(solo_gate_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, flag, target);
+    return (int)hipGetLastError();
+}
+
+// Unit check of the row exchanges (tests/test_gpu_nsq_row.py): out[0..7][lane] = the primitives applied to in[lane]
+extern "C" __global__ void __launch_bounds__(64) solo_debug_rowops_kernel(const i32* in, const i32* idx, i32* out) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int lane = threadIdx.x;
+    i32 v[1] = {in[lane]}, ix[1] = {idx[lane] & 3}, d[1] = {-1}, mv[1], mi[1];
+    RWT_FROM(d, v, 0) out[0 * 64 + lane] = d[0];
+    RWT_FROM(d, v, 1) out[1 * 64 + lane] = d[0];
+    RWT_FROM(d, v, 2) out[2 * 64 + lane] = d[0];
+    d[0] = -1; RWT_TO0(d, v, 1) out[3 * 64 + lane] = d[0];
+    d[0] = -1; RWT_TO0(d, v, 2) out[4 * 64 + lane] = d[0];
+    RWT_SUM(d, v) out[5 * 64 + lane] = d[0];
+    RWT_OR(d, v) out[6 * 64 + lane] = d[0];
+    RWK_GATHER(d, v, ix) out[7 * 64 + lane] = d[0];
+    RWK_ARGMIN(v, mv, mi) out[8 * 64 + lane] = mv[0]; out[9 * 64 + lane] = mi[0];
+    RWK_ARGMAX(v, mv, mi) out[10 * 64 + lane] = mv[0]; out[11 * 64 + lane] = mi[0];
+    RWK_SUM(v, d) out[12 * 64 + lane] = d[0];
+    out[13 * 64 + lane] = rwk_from(v[0], ix[0]);
+#endif
+}
+extern "C" int solo_debug_rowops(const int32_t* d_in, const int32_t* d_idx, int32_t* d_out, void* hip_stream) {
+    hipLaunchKernelGGL(solo_debug_rowops_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, d_in, d_idx, d_out);
+    return (int)hipGetLastError();
+}
+#endif
+extern "C" int SX_K(solo_nsq_workgroups)(int n_streams) { return (n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE; }
+// host-side launcher (called from solo_api.hip); ring: SX_K(solo_nsq_ring_bytes)(n_streams) bytes of device memory (scratch of a launch)
+extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams) {
+    return (size_t)((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE) * SX_NSQ_RING_CELLS * sizeof(SxRowCell);
+}
+extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
+                               void* ring, void* hip_stream) {
+    hipLaunchKernelGGL(SX_K(solo_nsq_kernel), dim3((n_streams + SX_PER_WAVE - 1) / SX_PER_WAVE), dim3(64), 0, (hipStream_t)hip_stream, (SxEncStream*)states,
+                       (const SxNsqIn*)in, (SxNsqOut*)out, n_streams, n_packets, p0, pc, started, (SxRowCell*)ring);
+    return (int)hipGetLastError();
+}
