@@ -611,9 +611,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         //           compute side candidates nobody reads), as an offset into w->mdc
         //   dL4     4 x (entry of the prediction history - entry of the circular histories) of an emitted sample
         //   wb      window entry of the prediction history that the sample emitted at iteration 0 goes to
-        int sd[RW_NL], dL4[RW_NL], wb[RW_NL];
+        //   lamT    the track's weight in the joint cost beyond 1 (centre: 0, sides: INTERNAL_JOINT_LAMBDA - 1), pre-shifted
+        int sd[RW_NL], dL4[RW_NL], wb[RW_NL], lamT[RW_NL];
         RW_FORK(l) {
             const int li = RW_LI(l);
+            lamT[li] = RW_T(l) == 0 ? 0 : (i32)((u32)(SX_JOINT_LAMBDA - 65536) << 16);
             sd[li] = ((RW_T(l) == 1) != (odd != 0)) ? 0 : 4;
             dL4[li] = 4 * (pred_base - k * SX_SUBFR - cur0);
             wb[li] = lagT[li] - decisionDelay + (SX_LTP_ORDER - SX_LTP_ORDER / 2 - 1);
@@ -775,12 +777,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 const u32 mtab = t == 1 ? 0xAu : 0x6u;
                 const bool ca = ((mtab >> (tq[li] & 3)) & 1u) != 0, cb = ((mtab >> ((tq[li] >> 2) & 3)) & 1u) != 0;
                 const i32 a0 = cInc[li][0], a1 = cInc[li][1], d0 = cQ10[li][0], d1 = cQ10[li][1];
-                const bool ctr = t == 0 || t == 3;
+                const bool ctr = t == 0;
                 cInc[li][0] = ctr ? ccInc[li][0] : (ca ? a1 : a0);  cInc[li][1] = ctr ? ccInc[li][1] : (cb ? a1 : a0);
                 cQ10[li][0] = ctr ? ccQ10[li][0] : (ca ? d1 : d0); cQ10[li][1] = ctr ? ccQ10[li][1] : (cb ? d1 : d0);
                 // the track's share of the joint cost of candidate [0] (Agora_Silk_JudgeWinner, NSQ_del_dec.c:671)
                 const i32 cand0 = sx_add(RD[li], cInc[li][0]);
-                tq2[li] = t == 0 ? cand0 : sx_mul_lambda(cand0);
+                tq2[li] = sx_add(cand0, sx_smulw_pre(cand0, lamT[li]));
             }
             RWT_SUM(jv, tq2)
             smpl_buf_idx = smpl_new;
@@ -805,7 +807,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 RWT_OR(tq2, tq)                                          // expired: differs in any track
                 RW_FORK(l) {
                     const int li = RW_LI(l);
-                    const bool ctr = RW_T(l) == 0 || RW_T(l) == 3;
+                    const bool ctr = RW_T(l) == 0;
                     pen[li] = (tq2[li] && ctr) ? PEN : 0;                // (only the centre's costs carry the penalty)
                     par[li] = RW_K(l); csrc[li] = RW_K(l); csel[li] = 0;
                     const i32 rp_ = sx_add(RD[li], pen[li]);
@@ -884,7 +886,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 const i32 Q10 = sel ? cand1Q10[li] : cQ10[li][0];
                 fRD[li] = sel ? cand1RD[li] : sx_add(sx_add(RD[li], pen[li]), cInc[li][0]);
                 i32 Q = (Q10 ^ dither) - dither;
-                const bool ctr = t == 0 || t == 3;
+                const bool ctr = t == 0;
                 // the pulse: the quantised value (a side's without its offset) >> 10; what the coder gets: the centre's excitation / the side's pulse
                 fQ0[li] = ctr ? Q10 >> 10 : (i32)(i8)(sx_sub(Q10, my_offset[li]) >> 10);
                 cX[li] = ctr ? Q : fQ0[li];
@@ -896,7 +898,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 LF_AR[li] = sx_shl(sLF_AR_shp_Q10, 2);
                 cXq14[li] = sx_shl(xq_Q10, 4);
                 cExc10[li] = LPC_exc_Q10;
-                tq[li] = t == 0 ? fRD[li] : sx_mul_lambda(fRD[li]);
+                tq[li] = sx_add(fRD[li], sx_smulw_pre(fRD[li], lamT[li]));
             }
             RWT_SUM(jv, tq)
             RW_MARK("F")

@@ -57,6 +57,10 @@ __global__ void __launch_bounds__(64) k(int* out, unsigned long long* cyc, int s
                 if (OP == 32) asm volatile("v_add_u32_e64 %0, %0, %1" : "+v"(a[j]) : "v"(b));
                 if (OP == 33) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a[j]) : "s"(seed));
                 if (OP == 34) asm volatile("v_ffbl_b32 %0, %0" : "+v"(a[j]));
+                if (OP == 35) { asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "v"(b), "v"(c) : "vcc"); }
+                if (OP == 36) { asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "v"(b), "v"(c) : "vcc"); }
+                if (OP == 37) { asm volatile("v_cmp_lt_i32_e64 %4, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, %4" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "v"(b), "v"(c), "s"(m2[0])); }
+                if (OP == 38) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b) : );
             }
         }
     }
@@ -158,6 +162,9 @@ int main() {
     run<15>("v_bfe_i32", d_out, d_cyc, ncu);
     run<11>("s_nop 0", d_out, d_cyc, ncu);
     run<16>("cndmask_e64 sgpr", d_out, d_cyc, ncu);
+    run<35>("cmp+cnd vcc /2", d_out, d_cyc, ncu);
+    run<36>("cmp+nop+cnd vcc", d_out, d_cyc, ncu);
+    run<37>("cmp+cnd e64 /2", d_out, d_cyc, ncu);
     run<19>("cndmask indep", d_out, d_cyc, ncu);
     run<17>("v_cmp_e64", d_out, d_cyc, ncu);
     run<18>("v_cmp+cndmask /2", d_out, d_cyc, ncu);
