@@ -13,9 +13,6 @@
 
 #include "../../include/solo_mi355x.h"
 #include "solo_dec.h"
-#ifdef SOLO_WITH_ENCODER
-#include "solo_enc.h"
-#endif
 
 #define SOLO_CHECK(expr)                                        \
     do {                                                        \
@@ -65,9 +62,10 @@ hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* 
 }
 
 #ifdef SOLO_WITH_ENCODER
-#include "solo_enc_kernels.h"
-extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq16.hip
-extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_api_wb.hip
+#include "solo_enc_ops.h"
+extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq_row.hip
+extern "C" const solo_enc_ops* solo_nb_enc_ops();                                                      // solo_enc_k.hip
+extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_enc_k_wb.hip
 #endif
 
 // ---------------------------------------------------------------------------------------------------
@@ -279,7 +277,7 @@ solo_batch_t* solo_batch_create(int32_t n_streams, const USER_Ctrl_enc* enc, con
         b->have_enc = 1;
         b->enc_ctrl = *enc;
         if (b->enc_ctrl.targetRate_bps <= 0) b->enc_ctrl.targetRate_bps = 15600;  // AGR_BWE_SDK_API.c:35
-        b->eops = enc->samplerate == 32000 ? solo_wb_enc_ops() : &solo_enc_ops_table;
+        b->eops = enc->samplerate == 32000 ? solo_wb_enc_ops() : solo_nb_enc_ops();
         if (solo_enc_alloc(b) != 0) { solo_batch_destroy(b); return NULL; }
 #else
         delete b;

@@ -4,10 +4,6 @@
 // compile-time constants; solo_api.hip dispatches here when a handle's decoder control asks for it.
 #define SX_FS_KHZ 16
 #include "solo_dec_kernels.h"
-#ifdef SOLO_WITH_ENCODER
-#include "solo_enc_kernels.h"
-extern "C" const solo_enc_ops* solo_wb_enc_ops() { return &solo_enc_ops_table_wb; }
-#endif
 
 extern "C" {
 size_t solo_wb_dec_state_bytes() { return solo_dec_state_bytes_wb(); }

@@ -2140,7 +2140,8 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
 
 // SKP_Silk_residual_energy_FIX, SKP_Silk_residual_energy_FIX.c:32.  LPC_res: 100-sample scratch
 SX_FN1 void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2][SX_MAX_LPC], const i32* gains, i16* LPC_res) {
-    SX_IN_LDS(nrgs); SX_IN_LDS(nrgsQ); SX_IN_LDS(x); SX_IN_LDS(a_Q12); SX_IN_LDS(LPC_res);
+    // (no SX_IN_LDS marks here: with them clang 22 (ROCm 7.2) crashes in correlated-propagation on this function, depending on what else the
+    // translation unit holds)
     const int offset = SX_LPC + SX_SUBFR;
     const i16* x_ptr = x;
     for (int i = 0; i < 2; i++) {

@@ -4,9 +4,15 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include "solo_enc.h"
+// streams per wavefront of the analysis / coding kernels (solo_enc_k.hip: SX_ENC_GROUP lanes per stream; a constant of both
+// compilation passes -- SX_NLANES is 1 in the host pass)
+#ifndef SX_ENC_GROUP
+#define SX_ENC_GROUP 64
+#endif
+#define SX_ENC_PER_WAVE (64 / SX_ENC_GROUP)
 
 __global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX) {
-    const int s = blockIdx.x;
+    const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
     if (s >= n_streams) return;
     sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX);
 }
@@ -39,7 +45,11 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 // section 4): 5 waves on each of the three SIMDs the quantiser leaves + one beside the quantiser's wave (its register cap,
 // solo_nsq16.hip), and 16 x 8.6 KB of LDS + the quantiser's 23 KB <= 160 KB.
 #ifndef SX_ANALYSIS_WAVES
+#if SX_ENC_GROUP == 64
 #define SX_ANALYSIS_WAVES 5
+#else
+#define SX_ANALYSIS_WAVES 2          // two streams per wavefront: half as many waves per SIMD, twice the registers each
+#endif
 #endif
 #ifndef SX_ANALYSIS_PRIO
 #define SX_ANALYSIS_PRIO 3
@@ -47,12 +57,9 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
-    __shared__ SxEncWork w;
-#ifdef SX_EXP_PAD
-    __shared__ volatile char exp_pad_[SX_EXP_PAD];
-    exp_pad_[threadIdx.x] = 0;
-#endif
-    const int s = blockIdx.x;
+    __shared__ SxEncWork wg_[SX_ENC_PER_WAVE];
+    SxEncWork& w = wg_[threadIdx.x / SX_ENC_GROUP];
+    const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
     if (s >= n_streams) return;
     // the same issue priority as the quantiser's wave (solo_nsq16.hip): with the quantiser above the analysis waves the encoder is
     // 0.5 % slower, below them 18 % (the quantiser starves); the range coder / coding kernels of older chunks stay at 0
@@ -131,12 +138,13 @@ __global__ void __launch_bounds__(64) SX_K(solo_enc_rc_kernel)(const SxEncStream
 }
 
 // High-band encoder and payload assembly, one wavefront per stream; the descriptions' bytes come from solo_enc_rc_kernel
-__global__ void __launch_bounds__(64, 5) SX_K(solo_enc_coding_kernel)(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
+__global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_coding_kernel)(SxEncStream* states, const SxCodeIn* __restrict__ code_in,
                                                                 const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
                                                                 int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status,
                                                                 const u8* __restrict__ rcbuf, const SxRcInfo* __restrict__ rcinfo) {
-    __shared__ SxEncWork w;
-    const int s = blockIdx.x;
+    __shared__ SxEncWork wg_[SX_ENC_PER_WAVE];
+    SxEncWork& w = wg_[threadIdx.x / SX_ENC_GROUP];
+    const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
     SX_K(solo_enc_enter)(&w, rec);
@@ -163,30 +171,14 @@ extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, in
 extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
 extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams);
 
-// what the host-side pipeline (solo_api.hip) needs of one build: record sizes and launchers
-#ifndef SOLO_ENC_OPS_DEFINED
-#define SOLO_ENC_OPS_DEFINED
-struct solo_enc_ops {
-    size_t state_bytes, nsq_in_bytes, nsq_out_bytes, code_in_bytes;      // sizeof SxEncStream / SxNsqIn / SxNsqOut / SxCodeIn
-    int packet_samples;
-    hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s);
-    hipError_t (*analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in, void* code_in, hipStream_t s);
-    int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* ring, void* hip_stream);
-    // entropy coding of the descriptions (lane per description) into rc_scratch, then high band + payload assembly
-    hipError_t (*coding)(void* states, const void* code_in, const void* nsq_out, int n_streams, int n_packets, int p0, int pc, int slot,
-                         uint8_t* bits, int16_t* nbytes, int32_t* status, void* rc_scratch, hipStream_t s);
-    size_t (*rc_scratch_bytes)(int n_streams, int pc);                   // scratch of one coding launch (pc packets per stream)
-    int (*nsq_workgroups)(int n_streams);                                // workgroups of one quantiser launch (they count into the residency gate)
-    size_t (*nsq_ring_bytes)(int n_streams);                             // emission-ring scratch of one quantiser launch
-};
-#endif
+#include "solo_enc_ops.h"
 static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX);
+    hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3((n_streams + SX_ENC_PER_WAVE - 1) / SX_ENC_PER_WAVE), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX);
     return hipGetLastError();
 }
 static hipError_t SX_K(solo_enc_launch_analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in,
                                                  void* code_in, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_enc_analysis_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, pcm, n_streams, n_packets, p0, pc,
+    hipLaunchKernelGGL(SX_K(solo_enc_analysis_kernel), dim3((n_streams + SX_ENC_PER_WAVE - 1) / SX_ENC_PER_WAVE), dim3(64), 0, s, (SxEncStream*)states, pcm, n_streams, n_packets, p0, pc,
                        (SxNsqIn*)nsq_in, (SxCodeIn*)code_in);
     return hipGetLastError();
 }
@@ -202,7 +194,7 @@ static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in
                        (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, rcbuf, rcinfo);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(SX_K(solo_enc_coding_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, (const SxCodeIn*)code_in,
+    hipLaunchKernelGGL(SX_K(solo_enc_coding_kernel), dim3((n_streams + SX_ENC_PER_WAVE - 1) / SX_ENC_PER_WAVE), dim3(64), 0, s, (SxEncStream*)states, (const SxCodeIn*)code_in,
                        (const SxNsqOut*)nsq_out, n_streams, n_packets, p0, pc, slot, bits, nbytes, status, (const u8*)rcbuf, (const SxRcInfo*)rcinfo);
     return hipGetLastError();
 }
