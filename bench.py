@@ -264,6 +264,14 @@ def main():
 
     world, rank, local_rank = sdist.env_world()
     sdist.check_world(args.gpus, world)
+    # the rank's input batch, generated by forked worker processes BEFORE the HIP runtime / RCCL come up in this process
+    N = args.streams if args.streams > 0 else (4096 if world == 1 else 8192)
+    P, RATE, SLOT = args.packets, 13600, 512
+    from solo_amd.synth import synth_batch
+    first = args.first_stream if args.first_stream >= 0 else sdist.stream_range(rank, N)[0]
+    ncpu, _ = effective_cores()
+    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
+    pcm_host = synth_batch(first, N, P, workers=workers)
     import torch
     import solo_amd
 
@@ -279,13 +287,6 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", torch.cuda.current_device())
 
-    N = args.streams if args.streams > 0 else (4096 if world == 1 else 8192)
-    P, RATE, SLOT = args.packets, 13600, 512
-    from solo_amd.synth import synth_batch
-    first = args.first_stream if args.first_stream >= 0 else sdist.stream_range(rank, N)[0]
-    ncpu, _ = effective_cores()
-    workers = max(1, min(16, ncpu // max(1, min(world, 8))))
-    pcm_host = synth_batch(first, N, P, workers=workers)
     pcm = torch.from_numpy(pcm_host).to(dev)
     batch = solo_amd.SoloBatch(N, rate=RATE, encoder=True, decoder=True, slot_bytes=SLOT)
     bits = torch.zeros((N, P, SLOT), dtype=torch.uint8, device=dev)
@@ -354,6 +355,9 @@ def main():
     barrier()
     dt_local = time.perf_counter() - t0
     payload_bytes_timed = int(payload_acc.item())
+    # effective shader clock under vector load, right after the timed steps (the boxes of a pool differ by ~10 %: lines are comparable
+    # only with it); a ~1 ms probe kernel of the library, outside the timed region
+    sclk_mhz = solo_amd.shader_clock_mhz()
     # per-kernel durations: a few extra steps outside the timed region (reading the events synchronises the stream)
     if overlap:
         batch.set_async_join(False)
@@ -421,6 +425,28 @@ def main():
                                "packets_lost": int((m == 0).sum()), "parity_checked": chk8, "parity_blocks": det8,
                                "parity_note": "encoder payloads of the 8192 streams and the PCM of the first decode under this loss pattern, per block of "
                                               "4096 streams, against the compiled reference (bench_blocks.json: payload_md5 / pcm_loss30_md5)"}
+        # configs[4], one GPU's share: the SAME per-GPU load as a rank of the 8-GPU job (8192 streams, blocks 0-1 of the 16), encode + decode,
+        # freshly reset streams, first step hashed -- so that an N = 1 line and an N > 1 line can be compared per GPU
+        b8.reset()
+        torch.cuda.synchronize()
+
+        def rt8():
+            b8.encode(pcm8, bits8, nb8, st8)
+            b8.decode(bits8, nb8, None, out8, st8d)
+        rt8()
+        torch.cuda.synchronize()
+        chk4, det4 = (None, [])
+        if not args.no_hash:
+            h4 = sdist.block_hashes(nb8.cpu().numpy(), bits8.cpu().numpy(), out8.cpu().numpy())
+            chk4, det4 = check_blocks(first, h4, gold, gmap, P, RATE, SLOT)
+        n4 = max(2, min(5, args.steps))
+        dt_4 = timed_loop(rt8, n4, 1, barrier)
+        assert int(st8.abs().max()) == 0 and int(st8d.abs().max()) == 0
+        extra["configs[4]_share"] = {"workload": "BASELINE configs[4], ONE GPU's share: %d streams (the load of one rank of the 65536-stream / 8-GPU job), encode then decode "
+                                                 "on one stream, %d packets/stream/step" % (N8, P), "value": round(N8 * P * n4 / dt_4, 1), "unit": "40ms packets/s (encode+decode)",
+                                     "steps": n4, "warmup": 1, "ms_per_step": round(dt_4 / n4 * 1e3, 3), "parity_checked": chk4, "parity_blocks": det4,
+                                     "parity_note": "first step after a reset: payloads and decoded PCM of blocks 0-1 of the 16 reference-hashed blocks (bench_blocks.json); blocks 2-15 "
+                                                    "on one GPU: tests/test_gpu_fullsize.py::test_config4_all_blocks_on_one_gpu"}
         del b8, bits8, nb8, out8, pcm8, recv
 
     if world == 1 and not args.no_extra and P % 2 == 0:
@@ -451,6 +477,7 @@ def main():
     record["parity_checked"] = checked
     record["blocks"] = detail
     record["device"] = torch.cuda.get_device_name(dev)
+    record["shader_clock_mhz_under_vector_load"] = None if sclk_mhz is None else round(sclk_mhz, 1)
     records = sdist.gather_records(record, dist) if world > 1 else [record]
 
     if rank == 0:
@@ -517,6 +544,9 @@ def main():
             "parity": {"what": "first step (freshly reset streams) hashed per block of 4096 streams: md5(nBytes || payload slots) and md5(decoded PCM), "
                                "compared with the compiled reference's hashes of the same streams (tests/golden/bench_blocks.json)",
                        "ranks": [{"rank": r["rank"], "first_stream": r["first_stream"], "checked": r["parity_checked"], "blocks": r["blocks"]} for r in records]},
+            "shader_clock_mhz_under_vector_load": None if sclk_mhz is None else round(sclk_mhz, 1),
+            "clock_note": "effective shader clock of rank 0 right after the timed steps while every SIMD runs vector instructions (solo_debug_clock: shader-clock "
+                          "counter ticks per 100 MHz tick); boxes of a pool differ, compare lines at equal clock",
             "realtime_streams": round(value / 25.0, 1),
             "per_gpu_packets_per_s": [r["packets_per_s"] for r in records],
             "whole_node_packets_per_s": round(value, 1),
@@ -552,7 +582,10 @@ def main():
                                  "all_wave_instructions_per_packet": insts.get("all_per_packet"),
                                  "source": insts.get("source"), "from_this_build": prof_ok,
                                  "note": "SQ_INSTS_VALU per packet of each kernel (rocprofv3 --pmc pass) x packets/s of this run, per GPU; "
-                                         "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction"}
+                                         "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal).  Measured on gfx950 "
+                                         "(tools/debug/mb_valu.hip, profiles/r04_valu_microbench.txt): a SIMD retires one integer multiply / select / DPP / 3-operand "
+                                         "instruction per 2.36 cycles and one add / logic instruction per 1.33 at 8 waves; a single wave issues an independent instruction "
+                                         "every 4.8 cycles and a dependent one every 8.3"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_seconds, args.cpu_packets_per_stream)
             if cb and cb.get("per_core_packets_per_s"):

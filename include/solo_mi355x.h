@@ -165,6 +165,16 @@ int32_t solo_batch_last_encode_chunks(const solo_batch_t *b);
 int32_t solo_debug_l0(int32_t op, int32_t n, const int32_t *d_a, const int32_t *d_b, const int32_t *d_c, int32_t *d_out);
 int32_t solo_debug_sum_sqr_shift(const int16_t *d_x, int32_t rows, int32_t len, int32_t stride, int32_t odd_start,
                                  int32_t *d_energy, int32_t *d_shift);
+/* solo_debug_rowops: the lane exchanges of the quantiser kernel (solo_amd/csrc/solo_enc_nsq_row.h: bank-masked DPP row shifts, row
+ * rotations, quad permutes) applied to 64 input words, 14 rows of 64 results (tests/test_gpu_nsq_row.py).
+ * solo_debug_clock: the effective shader clock in MHz while every SIMD runs vector instructions (~1 ms): lets benchmark lines from
+ * different boxes of a pool be compared (bench.py records it). */
+int32_t solo_debug_rowops(const int32_t *d_in, const int32_t *d_idx, int32_t *d_out, void *hip_stream);
+/* solo_debug_nsq: the quantiser kernel ALONE on freshly initialised streams -- h_in: the arguments of the reference's
+ * SKP_Silk_NSQ_del_dec calls (SKP_Silk_NSQ_del_dec.c:925) as hand-over records [n_streams][n_packets][2] of 660 bytes (16 kHz API rate),
+ * h_out: the kernel's output records {int32 Seed; int32 r[160]; int8 q[2][164]}; HOST pointers; returns the output record size. */
+int32_t solo_debug_nsq(int32_t n_streams, int32_t n_packets, const void *h_in, void *h_out);
+int32_t solo_debug_clock(double *mhz_out);
 /* Library version string. */
 const char *solo_version(void);
 

@@ -99,6 +99,51 @@ void __wrap_SKP_Silk_process_gains_FIX(SKP_Silk_encoder_state_FIX *psEnc, SKP_Si
     __real_SKP_Silk_process_gains_FIX(psEnc, c);
     tap(5, psEnc, c, cur_xfw, 0, 0, 0);
 }
+/* ---- isolated quantiser check (tests/test_gpu_nsq_taps.py): the ARGUMENTS of every SKP_Silk_NSQ_del_dec call (SKP_Silk_NSQ_del_dec.c:925) in the
+ * layout of the build's hand-over record SxNsqIn (solo_amd/csrc/solo_enc_state.h: 660 bytes at the 8 kHz internal rate), and its outputs. */
+#define NSQ_TAP_MAX 512
+struct nsq_tap_in {
+    int sigtype, QuantOffsetType, NLSFInterpCoef_Q2, Seed, Lambda_Q10, LTP_scale_Q14, DeltaGains_Q16;
+    int pitchL[4], Gains_Q16[4], LF_shp_Q14[4], Tilt_Q14[4], HarmShapeGain_Q14[4];
+    short PredCoef_Q12[2][16];
+    short LTPCoef_Q14[20];
+    short AR2_Q13[64];
+    short xfw[160];
+};
+struct nsq_tap_out { int Seed; signed char q[2][160]; int r[160]; };
+int solo_nsq_tap_n = 0;
+struct nsq_tap_in solo_nsq_tap_in[NSQ_TAP_MAX];
+struct nsq_tap_out solo_nsq_tap_out[NSQ_TAP_MAX];
+int solo_nsq_tap_sizeof_in(void) { return (int)sizeof(struct nsq_tap_in); }
+int solo_nsq_tap_sizeof_out(void) { return (int)sizeof(struct nsq_tap_out); }
+static void nsq_tap_before(SKP_Silk_encoder_state *psEncC, SKP_Silk_encoder_control *c, const SKP_int16 *x, int LSFInterpFactor_Q2,
+                           const SKP_int16 *PredCoef_Q12, const SKP_int16 *LTPCoef_Q14, const SKP_int16 *AR2_Q13, const SKP_int *HarmShapeGain_Q14,
+                           const SKP_int *Tilt_Q14, const SKP_int32 *LF_shp_Q14, const SKP_int32 *Gains_Q16, SKP_int32 DeltaGains_Q16, int Lambda_Q10,
+                           int LTP_scale_Q14) {
+    struct nsq_tap_in *t;
+    if (solo_nsq_tap_n >= NSQ_TAP_MAX || psEncC->frame_length != 160) return;
+    t = &solo_nsq_tap_in[solo_nsq_tap_n];
+    memset(t, 0, sizeof(*t));
+    t->sigtype = c->sigtype; t->QuantOffsetType = c->QuantOffsetType; t->NLSFInterpCoef_Q2 = LSFInterpFactor_Q2; t->Seed = c->Seed;
+    t->Lambda_Q10 = Lambda_Q10; t->LTP_scale_Q14 = LTP_scale_Q14; t->DeltaGains_Q16 = DeltaGains_Q16;
+    memcpy(t->pitchL, c->pitchL, sizeof(t->pitchL));
+    memcpy(t->Gains_Q16, Gains_Q16, sizeof(t->Gains_Q16));
+    memcpy(t->LF_shp_Q14, LF_shp_Q14, sizeof(t->LF_shp_Q14));
+    memcpy(t->Tilt_Q14, Tilt_Q14, sizeof(t->Tilt_Q14));
+    memcpy(t->HarmShapeGain_Q14, HarmShapeGain_Q14, sizeof(t->HarmShapeGain_Q14));
+    memcpy(t->PredCoef_Q12, PredCoef_Q12, sizeof(t->PredCoef_Q12));          /* SKP_int16 PredCoef_Q12[2][MAX_LPC_ORDER] */
+    memcpy(t->LTPCoef_Q14, LTPCoef_Q14, sizeof(t->LTPCoef_Q14));
+    memcpy(t->AR2_Q13, AR2_Q13, sizeof(t->AR2_Q13));
+    memcpy(t->xfw, x, sizeof(t->xfw));
+}
+static void nsq_tap_after(SKP_Silk_encoder_control *c, SKP_int8 **q_md, const SKP_int32 *r) {
+    struct nsq_tap_out *t;
+    if (solo_nsq_tap_n >= NSQ_TAP_MAX) return;
+    t = &solo_nsq_tap_out[solo_nsq_tap_n++];
+    t->Seed = c->Seed;
+    memcpy(t->q[0], q_md[0], 160); memcpy(t->q[1], q_md[1], 160);
+    memcpy(t->r, r, sizeof(t->r));
+}
 void __real_SKP_Silk_NSQ_del_dec(SKP_Silk_encoder_state *, SKP_Silk_encoder_control *, SKP_Silk_nsq_state *, SKP_Silk_nsq_state *,
     const SKP_int16 *, SKP_int8 *, SKP_int8 **, SKP_int32 *, const SKP_int, const SKP_int16 *, const SKP_int16 *, const SKP_int16 *,
     const SKP_int *, const SKP_int *, const SKP_int32 *, const SKP_int32 *, const SKP_int32 *, const SKP_int32, const SKP_int, const SKP_int);
@@ -107,8 +152,11 @@ void __wrap_SKP_Silk_NSQ_del_dec(SKP_Silk_encoder_state *psEncC, SKP_Silk_encode
     const SKP_int16 *PredCoef_Q12, const SKP_int16 *LTPCoef_Q14, const SKP_int16 *AR2_Q13, const SKP_int *HarmShapeGain_Q14,
     const SKP_int *Tilt_Q14, const SKP_int32 *LF_shp_Q14, const SKP_int32 *Gains_Q16, const SKP_int32 *MDGains_Q16,
     const SKP_int32 DeltaGains_Q16, const SKP_int Lambda_Q10, const SKP_int LTP_scale_Q14) {
+    nsq_tap_before(psEncC, psEncCtrlC, x, LSFInterpFactor_Q2, PredCoef_Q12, LTPCoef_Q14, AR2_Q13, HarmShapeGain_Q14, Tilt_Q14, LF_shp_Q14, Gains_Q16,
+                   DeltaGains_Q16, Lambda_Q10, LTP_scale_Q14);
     __real_SKP_Silk_NSQ_del_dec(psEncC, psEncCtrlC, NSQ, NSQ_md, x, q, q_md, r, LSFInterpFactor_Q2, PredCoef_Q12, LTPCoef_Q14, AR2_Q13,
         HarmShapeGain_Q14, Tilt_Q14, LF_shp_Q14, Gains_Q16, MDGains_Q16, DeltaGains_Q16, Lambda_Q10, LTP_scale_Q14);
+    nsq_tap_after(psEncCtrlC, q_md, r);
     /* sCmn is the first member of the FIX control / state structs */
     tap(6, cur_enc, (SKP_Silk_encoder_control_FIX *)psEncCtrlC, x, q, q_md, r);
 }

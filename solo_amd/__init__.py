@@ -23,7 +23,7 @@ ABI_SYMBOLS = [
     "solo_batch_create", "solo_batch_destroy", "solo_batch_reset", "solo_batch_encode", "solo_batch_decode",
     "solo_batch_n_streams", "solo_batch_slot_bytes", "solo_kernel_name", "solo_version", "solo_batch_set_timing",
     "solo_batch_last_kernel_ms", "solo_batch_last_encode_chunks", "solo_batch_decode_split", "solo_batch_set_async_join",
-    "solo_batch_wait_encode", "solo_debug_l0", "solo_debug_sum_sqr_shift",
+    "solo_batch_wait_encode", "solo_debug_l0", "solo_debug_sum_sqr_shift", "solo_debug_rowops", "solo_debug_clock", "solo_debug_nsq",
     "solo_recv_create", "solo_recv_insert", "solo_recv_decode", "solo_recv_stats",
 ]
 
@@ -110,6 +110,12 @@ def load_library():
     lib.solo_batch_wait_encode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32]
     lib.solo_batch_last_encode_chunks.restype = C.c_int32
     lib.solo_batch_last_encode_chunks.argtypes = [C.c_void_p]
+    lib.solo_debug_rowops.restype = C.c_int32
+    lib.solo_debug_rowops.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.solo_debug_nsq.restype = C.c_int32
+    lib.solo_debug_nsq.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+    lib.solo_debug_clock.restype = C.c_int32
+    lib.solo_debug_clock.argtypes = [C.c_void_p]
     lib.solo_kernel_name.restype = C.c_char_p
     lib.solo_kernel_name.argtypes = [C.c_int32]
     lib.solo_version.restype = C.c_char_p
@@ -125,6 +131,14 @@ def load_library():
     lib.AGR_Sate_Decoder_Uninit.argtypes = [C.c_void_p]
     _lib = lib
     return lib
+
+
+def shader_clock_mhz():
+    """Effective shader clock (MHz) while every SIMD of the current device runs vector instructions for ~1 ms (solo_debug_clock)."""
+    v = C.c_double(0.0)
+    if load_library().solo_debug_clock(C.byref(v)) != 0:
+        return None
+    return float(v.value)
 
 
 def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000):

@@ -833,6 +833,26 @@ int32_t solo_debug_sum_sqr_shift(const int16_t* d_x, int32_t rows, int32_t len, 
     return 0;
 }
 
+#ifdef SOLO_WITH_ENCODER
+// The quantiser kernel ALONE (tests/test_gpu_nsq_taps.py): h_in = SxNsqIn[n_streams][n_packets][2] as recorded from the reference's
+// SKP_Silk_NSQ_del_dec calls, h_out = SxNsqOut[n_streams][n_packets][2]; host pointers; freshly initialised streams; synchronous.
+int32_t solo_debug_nsq(int32_t n_streams, int32_t n_packets, const void* h_in, void* h_out) {
+    if (n_streams <= 0 || n_packets <= 0 || !h_in || !h_out) return -1;
+    const solo_enc_ops* ops = solo_nb_enc_ops();
+    const size_t sz_in = (size_t)n_streams * n_packets * 2 * ops->nsq_in_bytes, sz_out = (size_t)n_streams * n_packets * 2 * ops->nsq_out_bytes;
+    void *st = NULL, *d_in = NULL, *d_out = NULL, *ring = NULL;
+    int32_t rc = -1;
+    if (hipMalloc(&st, ops->state_bytes * (size_t)n_streams) == hipSuccess && hipMalloc(&d_in, sz_in) == hipSuccess && hipMalloc(&d_out, sz_out) == hipSuccess &&
+        hipMalloc(&ring, ops->nsq_ring_bytes(n_streams)) == hipSuccess && hipMemset(d_out, 0, sz_out) == hipSuccess &&
+        ops->init(st, n_streams, 12000, 0, 0, 0, (hipStream_t)0) == hipSuccess && hipMemcpy(d_in, h_in, sz_in, hipMemcpyHostToDevice) == hipSuccess &&
+        ops->nsq(st, d_in, d_out, n_streams, n_packets, 0, n_packets, NULL, ring, NULL) == 0 && hipDeviceSynchronize() == hipSuccess &&
+        hipMemcpy(h_out, d_out, sz_out, hipMemcpyDeviceToHost) == hipSuccess)
+        rc = (int32_t)ops->nsq_out_bytes;                       // (the caller checks its idea of the record size)
+    (void)hipFree(st); (void)hipFree(d_in); (void)hipFree(d_out); (void)hipFree(ring);
+    return rc;
+}
+#endif
+
 #if defined(SX_PROF) && defined(SOLO_WITH_ENCODER)
 // debug builds only: read (and clear) the per-section cycle counters of the encoder
 int32_t solo_debug_prof(unsigned long long* out32, int32_t reset) {

@@ -86,6 +86,32 @@ extern "C" __global__ void __launch_bounds__(64) solo_debug_rowops_kernel(const 
     out[13 * 64 + lane] = rwk_from(v[0], ix[0]);
 #endif
 }
+// Effective shader clock under vector load: every SIMD of the chip gets two waves that spin ~`iters` x 64 dependent vector
+// instructions; wave 0 reports how far the shader-clock counter (s_memtime) and the constant 100 MHz counter advanced meanwhile.
+extern "C" __global__ void __launch_bounds__(64) solo_debug_clock_kernel(unsigned long long* out2, int iters, int* sink) {
+    int a = threadIdx.x, b = blockIdx.x | 1;
+    const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+    for (int r = 0; r < iters; r++) {
+#pragma unroll
+        for (int u = 0; u < 64; u++) a = a * b + u;
+    }
+    const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
+    if (a == 0x7F123457) *sink = a;
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out2[0] = c1 - c0; out2[1] = w1 - w0; }
+}
+extern "C" int32_t solo_debug_clock(double* mhz_out) {
+    int dev = 0, ncu = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) return -1;
+    unsigned long long* d = NULL;
+    if (hipMalloc((void**)&d, 32) != hipSuccess) return -1;
+    unsigned long long h[2] = {0, 0};
+    hipLaunchKernelGGL(solo_debug_clock_kernel, dim3(ncu * 8), dim3(64), 0, 0, d, 4000, (int*)(d + 2));
+    const hipError_t e = hipMemcpy(h, d, sizeof(h), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess || h[1] == 0) return -1;
+    *mhz_out = 100.0 * (double)h[0] / (double)h[1];
+    return 0;
+}
 extern "C" int solo_debug_rowops(const int32_t* d_in, const int32_t* d_idx, int32_t* d_out, void* hip_stream) {
     hipLaunchKernelGGL(solo_debug_rowops_kernel, dim3(1), dim3(64), 0, (hipStream_t)hip_stream, d_in, d_idx, d_out);
     return (int)hipGetLastError();

@@ -101,6 +101,15 @@ int emu_enc_packet(void* h, const int16_t* pcm, uint8_t* bits, int buf_size, int
     e->rec.core = e->w.st;
     return r;
 }
+// the quantiser alone (tests/test_nsq_taps.py): n frames of ONE freshly initialised stream, in = SxNsqIn[n], out = SxNsqOut[n]
+int emu_nsq_frames(const void* in, int n, void* out) {
+    EmuEnc* e = (EmuEnc*)emu_enc_create(13600, 0);
+    for (int f = 0; f < n; f++)
+        sx_nsq_del_dec((char*)&e->rec.nsq, 0u, (const SxNsqIn*)in + f, (char*)((SxNsqOut*)out + f), 0u, &e->w.u.nsq, e->w.u.nsq.ring_emu, 0u, 12);
+    emu_enc_destroy(e);
+    return (int)sizeof(SxNsqOut);
+}
+int emu_sizeof_nsq_in() { return (int)sizeof(SxNsqIn); }
 int emu_sizeof_enc_state() { return (int)sizeof(SxEncStream); }
 int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
 // debug taps (tests only): last frame's control block, pulses and residual
