@@ -57,9 +57,14 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
+#if SX_ENC_GROUP == 64
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+#else
     __shared__ SxEncWork wg_[SX_ENC_PER_WAVE];
     SxEncWork& w = wg_[threadIdx.x / SX_ENC_GROUP];
     const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
+#endif
     if (s >= n_streams) return;
     // the same issue priority as the quantiser's wave (solo_nsq16.hip): with the quantiser above the analysis waves the encoder is
     // 0.5 % slower, below them 18 % (the quantiser starves); the range coder / coding kernels of older chunks stay at 0
@@ -142,9 +147,14 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_coding_ke
                                                                 const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0,
                                                                 int pc, int slot, u8* __restrict__ bits, i16* __restrict__ nbytes, i32* status,
                                                                 const u8* __restrict__ rcbuf, const SxRcInfo* __restrict__ rcinfo) {
+#if SX_ENC_GROUP == 64
+    __shared__ SxEncWork w;
+    const int s = blockIdx.x;
+#else
     __shared__ SxEncWork wg_[SX_ENC_PER_WAVE];
     SxEncWork& w = wg_[threadIdx.x / SX_ENC_GROUP];
     const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
+#endif
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
     SX_K(solo_enc_enter)(&w, rec);

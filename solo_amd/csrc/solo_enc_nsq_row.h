@@ -629,7 +629,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // use, and the request stands in front of this sample's stores (vector memory operations complete in order).  The
             // requested cell was written decisionDelay - 1 >= 12 samples ago.
             RW_MARK("R")
-            RW_FORK(l) { RW_CELL_LD(qn[RW_LI(l)], (last_smple_idx - 1) & SX_DD_MASK, l) }
+            RW_FORK(l) { if (RW_LIVE(l)) RW_CELL_LD(qn[RW_LI(l)], (last_smple_idx - 1) & SX_DD_MASK, l) }       // (the spare quad: no ring traffic)
             RW_MARK("A")
             // phase A: predictions, shaping, residual, dither of the lane's track and state
             i32 Lambda_Q10[RW_NL], offsum[RW_NL], Gain_s[RW_NL], my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
@@ -940,7 +940,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 cell.w1 = (i32)(((u32)cExc10[li] & 0x03FFFFFFu) | (((u32)cX[li] << 10) & 0xFC000000u));
                 cell.w2 = cShp[li];
                 cell.w3 = Seed[li];
-                RW_CELL_ST(smpl_buf_idx, l, cell)                 // (the spare quad writes its own, unread, cells)
+                if (RW_LIVE(l)) RW_CELL_ST(smpl_buf_idx, l, cell)
                 // the state's own slot now holds its newest ring entry
                 const u32 m = 3u << (2 * (smpl_buf_idx & 15));
                 if (smpl_buf_idx < 16) linLo[li] = (i32)(((u32)linLo[li] & ~m) | (((u32)kk * 0x55555555u) & m));

@@ -96,7 +96,7 @@ wi = {"source": os.path.basename(dst) + "_summary.json (rocprofv3 --pmc SQ_INSTS
       "valu_per_packet": {}, "all_per_packet": {}}
 for k, e in out["kernels"].items():
     w = e.get("wave_instructions_per_packet")
-    if w and "gate" not in k:
+    if w and "gate" not in k and "debug" not in k:
         wi["valu_per_packet"][k] = round(w.get("VALU", 0.0), 1)
         wi["all_per_packet"][k] = round(sum(w.get(c, 0.0) for c in ("VALU", "SALU", "LDS", "SMEM", "VMEM_RD", "VMEM_WR")), 1)
 if wi["valu_per_packet"]:
