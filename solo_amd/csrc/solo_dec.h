@@ -507,13 +507,21 @@ SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int f
     lane_out[3] = y->error;
 }
 
+// (the de-quantisation as a real call of its own: inlined into sx_decode_parameters the pair needs 129 vector registers -- one more
+// than the four-waves-per-SIMD budget of the kernels that call it, i.e. 136 allocated and three waves per SIMD: the decoder's sixteen
+// workgroups per compute unit then take two rounds)
+SX_FN void sx_dequant_parameters_call(const SxFrameSyms* y, int nFramesDecoded, int first_frame_after_reset, int useMDIndex, SxDecDesc* md, SxDecCtrl* c,
+                                      i32* lane_out, i32* nlsf_out) {
+    SX_IN_LDS(y); SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out);
+    sx_dequant_parameters(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
+}
 // the two steps in a row for one description slot of the wave-per-stream decoder (a real call: two call sites per kernel)
 SX_FN void sx_decode_parameters(int nFramesDecoded, int first_frame_after_reset, SxDecDesc* md, i32* dbg, SxDecCtrl* c, SxRangeDec* rc_io,
                                 i16* q, int kDesp, int useMDIndex, const SxCdf* cdf, i32* lane_out, i32* nlsf_out, i32* tmp, SxFrameSyms* y) {
     SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(q); SX_IN_LDS(cdf); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); SX_IN_LDS(tmp); SX_IN_LDS(y);
     i32 top = md->typeOffsetPrev, narrow = 0;
     sx_extract_parameters(nFramesDecoded, &top, dbg, rc_io, q, kDesp, useMDIndex, cdf, y, tmp, &narrow);
-    sx_dequant_parameters(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
+    sx_dequant_parameters_call(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
