@@ -343,7 +343,15 @@ def main():
     torch.cuda.synchronize()
     mean_payload = float(nb[:, :, 0].float().mean().item())
     first_step = (None, None, None) if args.no_hash else (nb.cpu().numpy(), bits.cpu().numpy(), out.cpu().numpy())
-    for _ in range(max(0, args.warmup - 1)):
+    # Steps 2 and 3 run under the TIMED schedule (pipelined: the encode of step 3 is issued before the decode of step 2) and continue the
+    # streams' state; the third step's payloads and PCM are hashed as well (the reference encoded the same 50 packets three times in a row)
+    step()
+    step()
+    jl = (step_no[0] - 1) & 1 if overlap else 0
+    drain()
+    torch.cuda.synchronize()
+    third_step = (None, None, None) if args.no_hash else (nb2[jl].cpu().numpy(), bits2[jl].cpu().numpy(), out.cpu().numpy())
+    for _ in range(max(0, args.warmup - 3)):
         step()
     drain()
     barrier()
@@ -378,6 +386,15 @@ def main():
     gold, gmap = golden_blocks()
     hashes = None if args.no_hash else sdist.block_hashes(*first_step)
     checked, detail = check_blocks(first, hashes, gold, gmap, P, RATE, SLOT)
+    # the state-continued third step under the pipelined schedule (reference hashes exist for block 0)
+    checked3 = None
+    if not args.no_hash and gold is not None and first == 0 and gmap.get(0, {}).get("step3_payload_md5"):
+        b3 = third_step[1][:4096]
+        b3 = np.where(np.arange(b3.shape[2])[None, None, :] < third_step[0][:4096, :, 0:1].astype(np.int64), b3, 0).astype(np.uint8)   # (the slots still hold the tails of step 1's payloads)
+        h3 = sdist.block_hashes(third_step[0][:4096], b3, third_step[2][:4096])[0]
+        checked3 = bool(h3["payload_md5"] == gmap[0]["step3_payload_md5"] and h3["pcm_md5"] == gmap[0]["step3_pcm_md5"])
+        if checked3 is False:
+            checked = False
 
     # ---- extra legs (N = 1): BASELINE configs[1] and configs[3], each its own timed loop ------------------------------------
     extra = {}
@@ -462,13 +479,20 @@ def main():
         def wb_step():
             bw.encode(xw, bits_w, nb_w, st_we)
             bw.decode(bits_w, nb_w, None, out_w, st_wd)
+        wb_step()
+        torch.cuda.synchronize()
+        chk_w = None
+        if not args.no_hash and gold is not None and first == 0 and N >= 4096 and gmap.get(0, {}).get("wb_payload_md5"):
+            hw = sdist.block_hashes(nb_w[:4096].cpu().numpy(), bits_w[:4096].cpu().numpy(), out_w[:4096].cpu().numpy())[0]
+            chk_w = bool(hw["payload_md5"] == gmap[0]["wb_payload_md5"] and hw["pcm_md5"] == gmap[0]["wb_pcm_md5"])
         nw = max(2, min(5, args.steps))
         dt_w = timed_loop(wb_step, nw, 1, barrier)
         assert int(st_we.abs().max()) == 0 and int(st_wd.abs().max()) == 0
         extra["samplerate_32000"] = {"workload": "%d streams in the 32 kHz mode (1280-sample 40 ms packets, SILK wide band + 8-16 kHz high band, 24 kbps), encode then decode, "
                                                  "%d packets/stream/step" % (N, Pw), "value": round(N * Pw * nw / dt_w, 1), "unit": "40ms packets/s (encode+decode, 32 kHz)",
                                      "steps": nw, "warmup": 1, "ms_per_step": round(dt_w / nw * 1e3, 3), "mean_payload_bytes": round(float(nb_w[:, :, 0].float().mean().item()), 2),
-                                     "parity_checked": None, "parity_note": "bit-exactness of the 32 kHz mode is covered by tests/test_wb.py (goldens + compiled reference), not by a hash of this batch"}
+                                     "parity_checked": chk_w, "parity_note": "first call after creation: payloads and decoded PCM of block 0 against the compiled reference run with samplerate = 32000 "
+                                                                           "(bench_blocks.json: wb_payload_md5 / wb_pcm_md5)"}
         del bw, bits_w, nb_w, out_w
 
     # ONE all_gather of the per-rank record (RCCL); no other collective besides the barriers and the max time
@@ -542,7 +566,9 @@ def main():
                                     else "encode then decode on one stream")},
             "parity_checked": parity,
             "parity": {"what": "first step (freshly reset streams) hashed per block of 4096 streams: md5(nBytes || payload slots) and md5(decoded PCM), "
-                               "compared with the compiled reference's hashes of the same streams (tests/golden/bench_blocks.json)",
+                               "compared with the compiled reference's hashes of the same streams (tests/golden/bench_blocks.json); block 0 also after "
+                               "steps 2 and 3 run under the timed (pipelined) schedule: the third, state-continued step against the reference's third pass",
+                       "third_step_pipelined_checked": checked3,
                        "ranks": [{"rank": r["rank"], "first_stream": r["first_stream"], "checked": r["parity_checked"], "blocks": r["blocks"]} for r in records]},
             "shader_clock_mhz_under_vector_load": None if sclk_mhz is None else round(sclk_mhz, 1),
             "clock_note": "effective shader clock of rank 0 right after the timed steps while every SIMD runs vector instructions (solo_debug_clock: shader-clock "

@@ -37,7 +37,9 @@
 // (under hipcc these are __host__ __device__ so that the host pass of a .hip file still parses
 // kernels that call them; the host bodies are the 1-lane identities used by the emulation build)
 SX_HD void wv_sync() {
-#if defined(__HIP_DEVICE_COMPILE__)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_SYNC_LDS_ONLY)
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (timing experiment: no wait for outstanding global memory operations)
+#elif defined(__HIP_DEVICE_COMPILE__)
     __syncthreads();
 #endif
 }

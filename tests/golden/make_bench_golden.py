@@ -20,6 +20,10 @@ Blocks 0 and 1 (the 8192 streams of BASELINE configs[3]) also carry
 
     python tests/golden/make_bench_golden.py [n_blocks=16] [workers=8]      (this container only: needs oracle/_ref; ~10 min)
     python tests/golden/make_bench_golden.py loss [workers=8]               (adds pcm_loss30_md5 to blocks 0-1 of an existing file)
+    python tests/golden/make_bench_golden.py extra [workers=8]              (adds to block 0: the hashes of the THIRD step -- the streams' state
+                                                continued over two earlier steps of the same 50 input packets, what bench.py hashes after running
+                                                steps 2 and 3 under its pipelined schedule -- and of the 32 kHz leg: the same samples taken as
+                                                4096 x 25 packets of 1280 samples at 24 kbps, `samplerate = 32000`)
 """
 import hashlib
 import json
@@ -76,8 +80,53 @@ def _stream(i):
     return nb, bits, pcm, pcm_l
 
 
+def _stream_step3(i):
+    import refcodec as R
+    from solo_amd.synth import synth_stream
+    x = synth_stream(i, PACKETS)
+    e, d = R.RefEncoder("fix", rate=RATE), R.RefDecoder("fix")
+    nb = np.zeros((PACKETS, 2), np.int16); bits = np.zeros((PACKETS, SLOT), np.uint8); pcm = np.zeros((PACKETS, 640), np.int16)
+    for step in range(3):
+        for p in range(PACKETS):
+            pl, n0, n1 = e.encode(x[p])
+            y, ret = d.decode(*R.map_loss(pl, n0, n1, False, False))
+            assert ret == 0
+            if step == 2:
+                nb[p] = (n0, n1); bits[p, :n0] = np.frombuffer(pl, np.uint8); pcm[p] = y
+    e.close(); d.close()
+    return nb, bits, pcm
+
+
+def _stream_wb(i):
+    import refcodec as R
+    from solo_amd.synth import synth_stream
+    x = synth_stream(i, PACKETS).reshape(PACKETS // 2, 1280)
+    e, d = R.RefEncoder("fix", rate=24000, samplerate=32000), R.RefDecoder("fix", samplerate=32000)
+    nb = np.zeros((PACKETS // 2, 2), np.int16); bits = np.zeros((PACKETS // 2, SLOT), np.uint8); pcm = np.zeros((PACKETS // 2, 1280), np.int16)
+    for p in range(PACKETS // 2):
+        pl, n0, n1 = e.encode(x[p])
+        y, ret = d.decode(*R.map_loss(pl, n0, n1, False, False))
+        assert ret == 0
+        nb[p] = (n0, n1); bits[p, :n0] = np.frombuffer(pl, np.uint8); pcm[p] = y
+    e.close(); d.close()
+    return nb, bits, pcm
+
+
 def main():
     path = os.path.join(HERE, "bench_blocks.json")
+    if len(sys.argv) > 1 and sys.argv[1] == "extra":
+        workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+        out = json.load(open(path))
+        with mp.get_context("fork").Pool(workers) as pool:
+            for fn, key in ((_stream_step3, "step3"), (_stream_wb, "wb")):
+                rows = pool.map(fn, range(0, BLOCK), chunksize=16)
+                nb = np.stack([r[0] for r in rows]); bits = np.stack([r[1] for r in rows]); pcm = np.stack([r[2] for r in rows])
+                h = hashlib.md5(); h.update(nb.tobytes()); h.update(bits.tobytes())
+                out["blocks"][0][key + "_payload_md5"] = h.hexdigest()
+                out["blocks"][0][key + "_pcm_md5"] = hashlib.md5(pcm.tobytes()).hexdigest()
+                print(key, "done", flush=True)
+        json.dump(out, open(path, "w"), indent=1)
+        return
     if len(sys.argv) > 1 and sys.argv[1] == "loss":
         workers = int(sys.argv[2]) if len(sys.argv) > 2 else 8
         out = json.load(open(path))
