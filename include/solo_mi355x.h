@@ -88,8 +88,12 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  * Streams keep their codec state in HBM inside the handle between calls (a call with n_packets = P
  * is identical to P calls with n_packets = 1).  Work is enqueued on `hip_stream` (a hipStream_t, may
  * be NULL for the default stream) and is asynchronous; no host synchronisation is performed.
- * Return value: 0 or a negative hipError_t.  solo_batch_encode returns -1 for n_packets >= 148 000 (16 kHz) / 74 000 (32 kHz) per
+ * Return value: 0 or a negative hipError_t.  solo_batch_encode returns -1 for n_packets >= ~700 000 (16 kHz) / ~350 000 (32 kHz) per
  * call -- split longer (offline) inputs over several calls; state carries over.
+ * Device memory a handle holds besides the stream states: encode -- the hand-over records of one call, 4.3 KB per packet of the call
+ * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 1952 B per
+ * packet of a CHUNK (16 kHz API rate): a call is cut into chunks of min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 1952)) packets, so one
+ * buffer never exceeds SOLO_DEC_SCRATCH_CAP bytes (environment, default 1 GiB).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct solo_batch solo_batch_t;
 
@@ -100,7 +104,8 @@ typedef struct solo_batch solo_batch_t;
 solo_batch_t *solo_batch_create(int32_t n_streams, const USER_Ctrl_enc *enc, const USER_Ctrl_dec *dec,
                                 int32_t slot_bytes);
 void solo_batch_destroy(solo_batch_t *b);
-/* Re-initialises all stream states (same as destroy + create). */
+/* Re-initialises all stream states (same as destroy + create) -- EXCEPT the receiver staging ring: descriptions filed with
+ * solo_recv_insert, play-out positions and statistics survive a reset; call solo_recv_create again to start the ring afresh. */
 int32_t solo_batch_reset(solo_batch_t *b, void *hip_stream);
 int32_t solo_batch_encode(solo_batch_t *b, const int16_t *d_pcm, int32_t n_packets, uint8_t *d_bits,
                           int16_t *d_nbytes, int32_t *d_status, void *hip_stream);

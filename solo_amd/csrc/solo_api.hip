@@ -375,10 +375,19 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // decoder proper (one wavefront per stream, packets in order) follows a chunk behind on a second stream; the records go through
     // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
     // (a short first chunk -- its extraction has nothing to hide behind -- then long ones: every decoder launch reloads the stream states)
-    const int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
+    // packets per chunk: the knob, capped so that ONE buffer of extraction records stays below SOLO_DEC_SCRATCH_CAP bytes (default 1 GiB;
+    // the records are 1952 B per packet at the 16 kHz API rate: 4096 streams x 64 packets = 512 MB, 65536 streams -> 8 packets per chunk).
+    // A handle holds at most two such buffers (calls longer than one chunk); include/solo_mi355x.h states the footprint.
+    const size_t rec_bytes = b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes();
+    static const size_t scratch_cap = getenv("SOLO_DEC_SCRATCH_CAP") ? (size_t)strtoull(getenv("SOLO_DEC_SCRATCH_CAP"), NULL, 10) : ((size_t)1 << 30);
+    int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
+    {
+        const size_t fit = scratch_cap / ((size_t)b->n_streams * rec_bytes);
+        if ((size_t)cp > fit) cp = fit < 1 ? 1 : (int)fit;
+    }
     const int c0 = (n_packets > 2 * b->dec_first && cp > b->dec_first) ? b->dec_first : cp;      // (never larger than the buffers: c0 <= cp)
     const int nchunks = 1 + (n_packets - c0 + cp - 1) / cp;
-    const size_t need = (size_t)b->n_streams * (size_t)cp * (b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes());
+    const size_t need = (size_t)b->n_streams * (size_t)cp * rec_bytes;
     if (need > b->parsed_bytes || (nchunks > 1 && !b->parsed_two)) {
         SOLO_CHECK(hipStreamSynchronize(st));
         (void)hipStreamSynchronize(b->sP);
@@ -491,9 +500,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     hipStream_t st = (hipStream_t)hip_stream;
     const size_t np = (size_t)b->n_streams * (size_t)n_packets;
     const solo_enc_ops* ops = b->eops;
-    // the quantiser addresses the hand-over records of its wavefront's sixteen streams with 32-bit offsets from a wave-uniform base
-    // (solo_nsq16.hip): 15 streams x 2 n_packets records must stay below 4 GiB (148 k narrow-band / 74 k wide-band packets per call)
-    if ((unsigned long long)15 * 2ull * (unsigned long long)n_packets * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
+    // the quantiser addresses the hand-over records of its wavefront's four streams with 32-bit offsets from a wave-uniform base
+    // (solo_nsq_row.hip): the records of 3 streams x 2 n_packets, plus one more record for the offsets inside the last one, must stay
+    // below 4 GiB (~700 k packets per call at the 16 kHz API rate)
+    if (((unsigned long long)3 * 2ull * (unsigned long long)n_packets + 1ull) * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));

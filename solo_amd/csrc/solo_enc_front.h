@@ -50,6 +50,9 @@ struct alignas(16) SxV4i { i32 v[4]; };        // 16-byte LDS moves
 // (DPP) and lane 0 stores the low band sat16(rshift_round(o1 + o0, 11)), lane 1 the high band sat16(rshift_round(o1 - o0, 11))
 // (a caller that has no use for it passes a dump area).  S: the two chain states (null = zero state, not written back).  `in` may alias outL (in-place decimation):
 // every block of four pairs is read before any of its outputs is stored, and outputs trail the inputs.
+// npairs must be a multiple of 4 and >= 4 (blocks of four pairs with the next block's inputs prefetched): the callers pass
+// SX_FRAME / 2, / 4, / 8 pairs (VAD filter banks) and 320 / 160 pairs (pitch analysis decimators at the 16 kHz internal rate)
+static_assert((SX_FRAME / 8) % 4 == 0 && SX_FRAME / 8 >= 4, "all-pass pairs are processed in blocks of four");
 SX_HD void sx_allpass2_lanes(const i16* in, int npairs, i32* S, i32 cA, i32 cB, i16* outL, i16* outH) {
     if (SX_LANE < 2) {
         const int l = SX_LANE;
