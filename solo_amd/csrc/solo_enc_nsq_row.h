@@ -35,26 +35,54 @@
 #define SX_DD_MASK (SX_DD_DELAY - 1)
 
 // ---- the lanes of a stream ---------------------------------------------------------------------------------------------------
+// RW_TPL: tracks per lane on the GPU.  1: the row layout above.  3: ONE LANE = ONE STATE carrying its THREE tracks, a stream is a
+// DPP quad, sixteen streams per wavefront (256 wavefronts per 4096 streams): a third of the row layout's instructions per stream --
+// the decision phases are executed once per sixteen streams instead of once per four -- but a three times longer chain per sample.
+// Same source: the loop over "the lanes of a stream" (RW_FORK) then walks the three tracks of the lane's state, per-track values
+// live in arrays of three, per-state values in arrays of one, and the cross-track exchanges are register moves.
+#ifndef RW_TPL
+#define RW_TPL 1
+#endif
 #if SX_NLANES == 1
-#define RW_NL 12
+#define RW_NL 12                                 // per (track, state) values
+#define RW_NS 12                                 // per state values (the emulation keeps a copy per virtual lane)
 #define RW_FORK(l) for (int l = 0; l < 12; l++)
 #define RW_LI(l) (l)
+#define RW_SI(l) (l)
+#define RW_ONCE(l) 1                             // per-state work: every virtual lane maintains its copy
+#define RW_IS_C(l) 1                             // centre-only / side-only work: done by every lane, used where it applies
+#define RW_IS_S(l) 1
+#elif RW_TPL == 3
+#define RW_NL 3
+#define RW_NS 1
+#define RW_FORK(l) _Pragma("unroll") for (int t_ = 0; t_ < 3; t_++) for (int l = 4 * t_ + (int)(threadIdx.x & 3u), once_ = 1; once_; once_ = 0)
+#define RW_LI(l) ((l) >> 2)
+#define RW_SI(l) 0
+#define RW_ONCE(l) (((l) >> 2) == 0)
+#define RW_IS_C(l) (((l) >> 2) == 0)
+#define RW_IS_S(l) (((l) >> 2) != 0)
 #else
 #define RW_NL 1
+#define RW_NS 1
 #define RW_FORK(l) for (int l = SX_LANE, once_ = 1; once_; once_ = 0)
 #define RW_LI(l) 0
+#define RW_SI(l) 0
+#define RW_ONCE(l) 1
+#define RW_IS_C(l) 1
+#define RW_IS_S(l) 1
 #endif
 #define RW_T(l) ((l) >> 2)                       // track of lane l (3: the spare quad of the GPU's row)
 #define RW_K(l) ((l) & 3)                        // delayed-decision state
-#define RW_TT(l) (RW_T(l) > 2 ? 0 : RW_T(l))     // track whose data the lane reads (the spare quad shadows the centre)
+#define RW_TT(l) (RW_T(l) > 2 ? 0 : RW_T(l))     // track whose data the lane reads (the spare quad of a row shadows the centre)
 #define RW_LIVE(l) (RW_T(l) < 3)
 // a value every lane of the stream holds identically, as a scalar for the stream's control flow
 #define RW_UNI(arr) ((arr)[0])
 
 // Exchanges.  They stand OUTSIDE the RW_FORK loops (host: they walk the lanes themselves).
 //  inside a quad (the four states of one track):
-//   RWK_GATHER(dst, src, idx)    dst[l] = src[quad(l) + idx[l]]
+//   RWK_GATHER(dst, src, idx)    dst[l] = src[quad(l) + idx[l]]           per-track values, per-state index
 //   RWK_PICK(dst, src, idx)      the same for an index that is the same in the four lanes of a quad (cheaper on the GPU)
+//   RWS_PICK / RWS_ARGMIN / RWS_ARGMAX / RWS_SUM / RWS_PERM   the same exchanges for per-STATE values (identical in a state's three tracks)
 //   RWK_ARGMIN / RWK_ARGMAX(val, mv, mi)   extreme of val over the quad and the LOWEST state index holding it, in every lane
 //   RWK_SUM(val, out)
 //   RWK_PERM(LV, idx)            LV(l) = LV(quad(l) + idx[l]) for an lvalue macro LV(lane)
@@ -73,14 +101,17 @@
         for (int q_ = 0; q_ < 4; q_++) (out)[b_ + q_] = s_; } }
 #define RWK_PERM(LV, idx) { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = LV(q_); for (int q_ = 0; q_ < 12; q_++) LV(q_) = o_[(q_ & ~3) | (idx)[q_]]; }
 #define RWK_PICK(dst, src, idx) RWK_GATHER(dst, src, idx)
+#define RWS_PICK(dst, src, idx) RWK_GATHER(dst, src, idx)
+#define RWS_ARGMIN(val, mv, mi) RWK_ARGMIN(val, mv, mi)
+#define RWS_ARGMAX(val, mv, mi) RWK_ARGMAX(val, mv, mi)
+#define RWS_SUM(val, out) RWK_SUM(val, out)
+#define RWS_PERM(LV, idx) RWK_PERM(LV, idx)
 #define RWT_FROM(dst, src, T) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = (src)[4 * (T) + q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
 #define RWT_TO0(dst, src, T) { for (int q_ = 0; q_ < 4; q_++) (dst)[q_] = (src)[4 * (T) + q_]; }
 #define RWT_SUM(dst, src) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = sx_add(sx_add((src)[q_], (src)[4 + q_]), (src)[8 + q_]); for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
 #define RWT_OR(dst, src) { i32 o_[4]; for (int q_ = 0; q_ < 4; q_++) o_[q_] = (src)[q_] | (src)[4 + q_] | (src)[8 + q_]; for (int q_ = 0; q_ < 12; q_++) (dst)[q_] = o_[q_ & 3]; }
 #else
 #define RW_DPP(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xf, 0xf, true)
-// the lanes of bank (= quad of every row) `bank` take the value of the lane `ctrl` names, all other lanes keep `old`
-#define RW_DPP_BANK(old, v, ctrl, bank) __builtin_amdgcn_update_dpp((old), (v), (ctrl), 0xf, 1 << (bank), false)
 #define RW_SHR(n) (0x110 + (n))      // row_shr:n  lane i <- lane i - n
 #define RW_SHL(n) (0x100 + (n))      // row_shl:n  lane i <- lane i + n
 #define RW_ROR(n) (0x120 + (n))      // row_ror:n  lane i <- lane (i - n) mod 16
@@ -95,19 +126,42 @@ SX_HD i32 rwk_sel(i32 v, i32 idx) {
     return h_ ? hi_ : lo_;
 }
 SX_HD i32 rwk_from(i32 v, i32 src) { return __builtin_amdgcn_ds_bpermute((int)((((threadIdx.x & ~3u) | (u32)src)) << 2), v); }
-#define RWK_GATHER(dst, src, idx) { (dst)[0] = rwk_sel((src)[0], (idx)[0]); }
 // arg-min / arg-max over the quad: the extreme by two DPP steps, then the FIRST state holding it from the wave's ballot of
 // "my value is the extreme" (the quad's four bits, lowest set bit) -- the reference's serial scans keep the first extreme
 SX_HD i32 rwk_first_(bool eq) {
     const unsigned long long b_ = __builtin_amdgcn_ballot_w64(eq);
     return (i32)__builtin_ctz((u32)(b_ >> (threadIdx.x & 60u)) & 15u);
 }
-#define RWK_ARGMIN(val, mv, mi) { i32 m_ = (val)[0]; m_ = sx_min(m_, RW_DPP(m_, 0xB1)); m_ = sx_min(m_, RW_DPP(m_, 0x4E)); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
-#define RWK_ARGMAX(val, mv, mi) { i32 m_ = (val)[0]; m_ = sx_max(m_, RW_DPP(m_, 0xB1)); m_ = sx_max(m_, RW_DPP(m_, 0x4E)); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
+SX_HD i32 rwk_min_(i32 v) { v = sx_min(v, RW_DPP(v, 0xB1)); return sx_min(v, RW_DPP(v, 0x4E)); }
+SX_HD i32 rwk_max_(i32 v) { v = sx_max(v, RW_DPP(v, 0xB1)); return sx_max(v, RW_DPP(v, 0x4E)); }
+SX_HD i32 rwk_or_(i32 v) { v |= RW_DPP(v, 0xB1); return v | RW_DPP(v, 0x4E); }
+SX_HD i32 rwk_sum_(i32 v) { v = sx_add(v, RW_DPP(v, 0xB1)); return sx_add(v, RW_DPP(v, 0x4E)); }
 // value of the state a quad-uniform index names: that lane's value or-ed through the quad
-#define RWK_PICK(dst, src, idx) { i32 v_ = (i32)(threadIdx.x & 3u) == (idx)[0] ? (src)[0] : 0; v_ |= RW_DPP(v_, 0xB1); v_ |= RW_DPP(v_, 0x4E); (dst)[0] = v_; }
-#define RWK_SUM(val, out) { i32 s_ = (val)[0]; s_ = sx_add(s_, RW_DPP(s_, 0xB1)); s_ = sx_add(s_, RW_DPP(s_, 0x4E)); (out)[0] = s_; }
-#define RWK_PERM(LV, idx) { LV(0) = rwk_from(LV(0), (idx)[0]); }
+SX_HD i32 rwk_pick_(i32 v, i32 idx) { return rwk_or_((i32)(threadIdx.x & 3u) == idx ? v : 0); }
+// per-STATE values (one copy per lane in both GPU layouts)
+#define RWS_ARGMIN(val, mv, mi) { const i32 m_ = rwk_min_((val)[0]); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
+#define RWS_ARGMAX(val, mv, mi) { const i32 m_ = rwk_max_((val)[0]); (mv)[0] = m_; (mi)[0] = rwk_first_((val)[0] == m_); }
+#define RWS_PICK(dst, src, idx) { (dst)[0] = rwk_pick_((src)[0], (idx)[0]); }
+#define RWS_SUM(val, out) { (out)[0] = rwk_sum_((val)[0]); }
+#define RWS_PERM(LV, idx) { LV(0) = rwk_from(LV(0), (idx)[0]); }
+#if RW_TPL == 3
+// ---- a quad per stream: per-track values are three registers of the lane ----
+#define RWK_GATHER(dst, src, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (dst)[q_] = rwk_sel((src)[q_], (idx)[0]); }
+#define RWK_PICK(dst, src, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (dst)[q_] = rwk_pick_((src)[q_], (idx)[0]); }
+#define RWK_PERM(LV, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) LV(q_) = rwk_from(LV(q_), (idx)[0]); }
+#define RWK_ARGMIN(val, mv, mi) RWS_ARGMIN(val, mv, mi)
+#define RWK_ARGMAX(val, mv, mi) RWS_ARGMAX(val, mv, mi)
+#define RWT_FROM(dst, src, T) { (dst)[0] = (src)[T]; }
+#define RWT_TO0(dst, src, T) { (dst)[0] = (src)[T]; }
+#define RWT_SUM(dst, src) { (dst)[0] = sx_add(sx_add((src)[0], (src)[1]), (src)[2]); }
+#define RWT_OR(dst, src) { (dst)[0] = (src)[0] | (src)[1] | (src)[2]; }
+#else
+// ---- a 16-lane row per stream: one (track, state) per lane ----
+#define RWK_GATHER(dst, src, idx) { (dst)[0] = rwk_sel((src)[0], (idx)[0]); }
+#define RWK_PICK(dst, src, idx) RWS_PICK(dst, src, idx)
+#define RWK_PERM(LV, idx) RWS_PERM(LV, idx)
+#define RWK_ARGMIN(val, mv, mi) RWS_ARGMIN(val, mv, mi)
+#define RWK_ARGMAX(val, mv, mi) RWS_ARGMAX(val, mv, mi)
 // (two independent row shifts + two selects on lane constants; three bank-masked moves into one register would each wait for the
 // one before: a DPP source written by the previous instruction costs two idle issue slots.  The spare quad keeps its own value.)
 SX_HD i32 rwt_from0(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW_DPP(v, RW_SHR(4)), b_ = RW_DPP(v, RW_SHR(8)); return t_ == 4u ? a_ : (t_ == 8u ? b_ : v); }
@@ -121,6 +175,7 @@ SX_HD i32 rwt_from2(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW
         (dst)[0] = sx_add(sx_add(v_, RW_DPP(v_, RW_ROR(4))), sx_add(RW_DPP(v_, RW_ROR(8)), RW_DPP(v_, RW_ROR(12)))); }
 #define RWT_OR(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
         (dst)[0] = (v_ | RW_DPP(v_, RW_ROR(4))) | (RW_DPP(v_, RW_ROR(8)) | RW_DPP(v_, RW_ROR(12))); }
+#endif
 #endif
 
 // One cell of the emission ring: what ONE state slot of ONE track wrote at ONE ring position.  16 bytes, written / prefetched as
@@ -283,7 +338,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         decisionDelay = sx_min(decisionDelay, lagC - SX_LTP_ORDER / 2 - 1);
     }
     const int LSF_interpolation_flag = c->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
+#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
+#define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)(((pos_) * 3 + RW_T(lane_)) * rstride) + rlane + (u32)RW_K(lane_)) * (u32)sizeof(SxRowCell))
+#else
 #define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)((pos_) * rstride) + rlane + (u32)(lane_)) * (u32)sizeof(SxRowCell))
+#endif
     // the sample loop's own ring traffic (every cell is written once and read once, a decision delay later) with the non-temporal
     // cache policy: 32 MB of ring per 4096 streams otherwise sweep everything else -- the stream histories the subframe prologues
     // wait for -- out of the 32 MB of L2
@@ -301,35 +360,39 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
     // ---- lane-private state: one delayed-decision state of one track (registers on the GPU) ----
     i32 sAR2[RW_NL][SX_SHAPE_ORDER], sLPC[RW_NL][SX_LPC];        // sLPC[0] = newest quantised sample (Q14)
     i32 LF_AR[RW_NL], Seed[RW_NL], RD[RW_NL], lastShp[RW_NL];
-    i32 Seed2[RW_NL], SeedInit2[RW_NL], linLo[RW_NL], linHi[RW_NL];          // per state: identical in the three tracks' lanes
+    i32 Seed2[RW_NS], SeedInit2[RW_NS], linLo[RW_NS], linHi[RW_NS];          // per state: identical in the three tracks' lanes
     i32 lagT[RW_NL], prevInv[RW_NL], gadj[RW_NL];                            // per track
     // byte offsets of the lane's track inside the stream's records: its SxNsqTrack; where its output row starts (centre: 4-byte
     // excitations, sides: 1-byte pulses)
     u32 pTrk[RW_NL], oX[RW_NL];
     // per sample
-    i32 LTP_pred[RW_NL], LPC_pred[RW_NL], n_AR[RW_NL], n_LF[RW_NL], rD[RW_NL], rC[RW_NL], dith[RW_NL];
+    i32 LTP_pred[RW_NL], LPC_pred[RW_NL], n_AR[RW_NL], n_LF[RW_NL], rD[RW_NL], rC[RW_NS], dith[RW_NS];
     i32 cInc[RW_NL][2], cQ10[RW_NL][2];                          // the two candidates: cost increment, quantised value
-    i32 p1q0[RW_NL], p1q1[RW_NL], p1r0[RW_NL], p1r1[RW_NL], p2q0[RW_NL], p2q1[RW_NL], p2r0[RW_NL], p2r1[RW_NL];
+    i32 p1q0[RW_NS], p1q1[RW_NS], p1r0[RW_NS], p1r1[RW_NS], p2q0[RW_NS], p2q1[RW_NS], p2r0[RW_NS], p2r1[RW_NS];
     // The ring is a delay line in HBM; the cell a sample consumes is requested ONE sample before.  Two register sets take turns: an
     // even sample consumes set A (the own-slot cell of the ring position the sample emits) while set B is in flight for the odd
     // sample after it, and vice versa.  The sample loop is written two samples per iteration so that no set is ever copied into
     // another at the loop's back edge (such a copy would wait for the load just issued).
     SxRowCell qA[RW_NL], qB[RW_NL];
     // scratch of the joint decision
-    i32 jv[RW_NL], mv[RW_NL], mi[RW_NL], mv2[RW_NL], mi2[RW_NL], tq[RW_NL], tq2[RW_NL], par[RW_NL], csrc[RW_NL], csel[RW_NL], c0[RW_NL], c1[RW_NL], nrep[RW_NL];
-    i32 gq[RW_NL], myRand[RW_NL];
+    i32 jv[RW_NS], mv[RW_NS], mi[RW_NS], mv2[RW_NS], mi2[RW_NS], tS[RW_NS], tS2[RW_NS], par[RW_NS], csrc[RW_NS], csel[RW_NS], c0[RW_NS], c1[RW_NS], nrep[RW_NS], gq[RW_NS];
+    i32 tT[RW_NL], tT2[RW_NL], myRand[RW_NL];                    // per-track scratch
+#pragma unroll
+    for (int a = 0; a < RW_NS; a++) {
+        Seed2[a] = SeedInit2[a] = linLo[a] = linHi[a] = dith[a] = rC[a] = 0;
+        jv[a] = mv[a] = mi[a] = mv2[a] = mi2[a] = tS[a] = tS2[a] = par[a] = csrc[a] = csel[a] = c0[a] = c1[a] = nrep[a] = gq[a] = 0;
+        p1q0[a] = p1q1[a] = p1r0[a] = p1r1[a] = p2q0[a] = p2q1[a] = p2r0[a] = p2r1[a] = 0;
+    }
 #pragma unroll
     for (int a = 0; a < RW_NL; a++) {
-        Seed2[a] = SeedInit2[a] = linLo[a] = linHi[a] = dith[a] = lagT[a] = prevInv[a] = 0;
+        lagT[a] = prevInv[a] = tT[a] = tT2[a] = myRand[a] = 0;
         gadj[a] = 65536;
         pTrk[a] = oX[a] = 0u;
-        jv[a] = mv[a] = mi[a] = mv2[a] = mi2[a] = tq[a] = tq2[a] = par[a] = csrc[a] = csel[a] = c0[a] = c1[a] = nrep[a] = gq[a] = myRand[a] = 0;
-        p1q0[a] = p1q1[a] = p1r0[a] = p1r1[a] = p2q0[a] = p2q1[a] = p2r0[a] = p2r1[a] = 0;
 #pragma unroll
         for (int j = 0; j < SX_SHAPE_ORDER; j++) sAR2[a][j] = 0;
 #pragma unroll
         for (int j = 0; j < SX_LPC; j++) sLPC[a][j] = 0;
-        LF_AR[a] = Seed[a] = RD[a] = lastShp[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = rC[a] = 0;
+        LF_AR[a] = Seed[a] = RD[a] = lastShp[a] = LTP_pred[a] = LPC_pred[a] = n_AR[a] = n_LF[a] = rD[a] = 0;
 #pragma unroll
         for (int j = 0; j < 2; j++) cInc[a][j] = cQ10[a][j] = 0;
         qA[a].w0 = qA[a].w1 = qA[a].w2 = qA[a].w3 = 0;
@@ -363,7 +426,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             }
         }
         RW_FORK(l) {
-            const int li = RW_LI(l), tt = RW_TT(l), k = RW_K(l), t = RW_T(l);
+            const int li = RW_LI(l), si = RW_SI(l), tt = RW_TT(l), k = RW_K(l), t = RW_T(l);
             pTrk[li] = pOff + (u32)(offsetof(SxNsqPersist, trk) + (size_t)tt * sizeof(SxNsqTrack));
             // (the row's start moved back by this frame's place in the circular histories: the sample step addresses everything with
             // e4 = 4 x (cur0 + sample position))
@@ -371,8 +434,8 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             const SxNSQ* n = &SX_AT(SxNSQ, Pu, pTrk[li] + (u32)offsetof(SxNsqTrack, s));
             lagT[li] = n->lagPrev;
             prevInv[li] = n->prev_inv_gain_Q16;
-            Seed2[li] = SeedInit2[li] = (k + c->Seed) & 3;
-            linLo[li] = linHi[li] = k * 0x55555555;                  // slot k at every ring position
+            Seed2[si] = SeedInit2[si] = (k + c->Seed) & 3;
+            linLo[si] = linHi[si] = k * 0x55555555;                  // slot k at every ring position
             Seed[li] = (k + c->Seed) & 3;
             RD[li] = 0;
             LF_AR[li] = n->sLF_AR_shp_Q12;
@@ -447,14 +510,14 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                     subfr = 0;
                     // Agora_Silk_DelDec_Rewhitening{,_Side} (NSQ_del_dec.c:315, 400): flush the centre winner's lineage
                     RWT_FROM(jv, RD, 0)
-                    RWK_ARGMIN(jv, mv, mi)
+                    RWS_ARGMIN(jv, mv, mi)
                     RW_FORK(l) {
-                        if (RW_K(l) != mi[RW_LI(l)]) RD[RW_LI(l)] += SX_I32_MAX >> 4;
+                        if (RW_K(l) != mi[RW_SI(l)]) RD[RW_LI(l)] += SX_I32_MAX >> 4;
                     }
-                    RWK_PICK(tq, linLo, mi)
-                    RWK_PICK(tq2, linHi, mi)
+                    RWS_PICK(tS, linLo, mi)
+                    RWS_PICK(tS2, linHi, mi)
                     wv_sync();                      // the ring cells of the last samples must have landed
-                    RW_FLUSH(tq[li], tq2[li], k * SX_SUBFR - decisionDelay)
+                    RW_FLUSH(tS[RW_SI(l)], tS2[RW_SI(l)], k * SX_SUBFR - decisionDelay)
                     wv_sync();
                 }
                 // re-whiten the quantised signal with the new LPC (SKP_Silk_MA_Prediction from a zero state)
@@ -612,12 +675,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         //   dL4     4 x (entry of the prediction history - entry of the circular histories) of an emitted sample
         //   wb      window entry of the prediction history that the sample emitted at iteration 0 goes to
         //   lamT    the track's weight in the joint cost beyond 1 (centre: 0, sides: INTERNAL_JOINT_LAMBDA - 1), pre-shifted
-        int sd[RW_NL], dL4[RW_NL], wb[RW_NL], lamT[RW_NL];
+        int sd[RW_NL], wb[RW_NL], lamT[RW_NL];
+        const int dL4 = 4 * (pred_base - k * SX_SUBFR - cur0);
         RW_FORK(l) {
             const int li = RW_LI(l);
             lamT[li] = RW_T(l) == 0 ? 0 : (i32)((u32)(SX_JOINT_LAMBDA - 65536) << 16);
             sd[li] = ((RW_T(l) == 1) != (odd != 0)) ? 0 : 4;
-            dL4[li] = 4 * (pred_base - k * SX_SUBFR - cur0);
             wb[li] = lagT[li] - decisionDelay + (SX_LTP_ORDER - SX_LTP_ORDER / 2 - 1);
         }
         // one sample of the trellis; qc: the register set that holds the ring cell this sample consumes, qn: the set that takes the next sample's
@@ -632,64 +695,83 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             RW_FORK(l) { if (RW_LIVE(l)) RW_CELL_LD(qn[RW_LI(l)], (last_smple_idx - 1) & SX_DD_MASK, l) }       // (the spare quad: no ring traffic)
             RW_MARK("A")
             // phase A: predictions, shaping, residual, dither of the lane's track and state
-            i32 Lambda_Q10[RW_NL], offsum[RW_NL], Gain_s[RW_NL], my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
+            i32 my_inv_gain[RW_NL], my_inv_of_delta[RW_NL], my_offset[RW_NL], my_DG[RW_NL];
+            // the subframe's coefficients and the stream's scalars: 16-byte reads through an offset the compiler cannot see
+            // through (it would otherwise hoist the loads out of the sample loop and keep the values in registers)
+            u32 co_ = 0;
+            SX_OPAQUE(co_);
+            const SxRowV4* cv = (const SxRowV4*)__builtin_assume_aligned((const char*)w->coef + co_, 16);
+            i32 cf[RW_NCOEF];
+#define RW_CF_LOAD(j0_, j1_) _Pragma("unroll") for (int j = (j0_); j < (j1_); j++) { const SxRowV4 v_ = cv[j]; cf[4 * j] = v_.x; cf[4 * j + 1] = v_.y; cf[4 * j + 2] = v_.z; cf[4 * j + 3] = v_.w; }
+#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
+            RW_CF_LOAD(0, RW_NCOEF / 4)                // (a quad per stream: once for the lane's three tracks; the register budget is 256)
+#define RW_CF_STAGE(j0_, j1_)
+#else
+            // (a row per stream: in three groups, each requested one stage before its use: all at once they would be 40 live registers
+            // at the point of the sample step where the filter states are live as well)
+#define RW_CF_STAGE(j0_, j1_) SX_SCHED_FENCE(); RW_CF_LOAD(j0_, j1_) SX_SCHED_FENCE();
+#endif
+            const i32 *Apre = cf + RW_CA, *ARpre = cf + RW_CAR, *Bpre = cf + RW_CB;
+            constexpr int G1 = (RW_CAR + 3) / 4, G2 = (RW_CB + 3) / 4;      // 16-byte groups that hold A | the rest of AR | the rest
+            // (written as a sequence of short steps over "the lanes of the stream": with three tracks per lane the steps of the three
+            // tracks then alternate in program order, so that the tracks' dependent chains -- the warped all-pass sections above all --
+            // fill each other's issue gaps: a dependent vector instruction issues every ~8 cycles, an independent one every ~5)
+            i32 curL[RW_NL][SX_LTP_ORDER], curS[RW_NL][3], tmp1[RW_NL], tmp2[RW_NL], nAR_[RW_NL];
+            const i32 x_sc_Q10 = w->xsc[i];
             RW_FORK(l) {
-                const int li = RW_LI(l), tt = RW_TT(l);
+                const int li = RW_LI(l), si = RW_SI(l), tt = RW_TT(l);
                 // The taps of this sample (long-term prediction: 5, harmonic shaping: 3): one LDS read each at a fixed place of the
                 // staged windows.  (Unvoiced frame: the prediction coefficients are zero; no pitch lag: the shaping gains were
                 // zeroed -- whatever the windows hold.)
-                i32 curL[SX_LTP_ORDER], curS[3];
 #pragma unroll
-                for (int j = 0; j < SX_LTP_ORDER; j++) curL[j] = w->win[tt].tapL[i + (SX_LTP_ORDER - 1) - j];
+                for (int j = 0; j < SX_LTP_ORDER; j++) curL[li][j] = w->win[tt].tapL[i + (SX_LTP_ORDER - 1) - j];
 #pragma unroll
-                for (int j = 0; j < 3; j++) curS[j] = w->win[tt].tapS[i + 2 - j];
-                const i32 x_sc_Q10 = w->xsc[i];
-                // the subframe's coefficients and the stream's scalars: 16-byte reads through an offset the compiler cannot see
-                // through (it would otherwise hoist the loads out of the sample loop and keep the values in registers)
-                u32 co_ = 0;
-                SX_OPAQUE(co_);
-                const SxRowV4* cv = (const SxRowV4*)__builtin_assume_aligned((const char*)w->coef + co_, 16);
-                // (in three groups, each requested one stage before its use: all at once they would be 40 live registers at the
-                // point of the sample step where the filter states are live as well)
-                i32 cf[RW_NCOEF];
-#define RW_CF_LOAD(j0_, j1_) _Pragma("unroll") for (int j = (j0_); j < (j1_); j++) { const SxRowV4 v_ = cv[j]; cf[4 * j] = v_.x; cf[4 * j + 1] = v_.y; cf[4 * j + 2] = v_.z; cf[4 * j + 3] = v_.w; }
-                constexpr int G1 = (RW_CAR + 3) / 4, G2 = (RW_CB + 3) / 4;      // 16-byte groups that hold A | the rest of AR | the rest
-                RW_CF_LOAD(0, G1)
-                const i32 *Apre = cf + RW_CA, *ARpre = cf + RW_CAR, *Bpre = cf + RW_CB;
-                Seed2[li] = sx_rand(Seed2[li]);                                                // Agora_Silk_Dither (NSQ_del_dec.c:520)
-                const i32 dither = Seed2[li] >> 31;
-                dith[li] = dither;
-                SX_SCHED_FENCE();
-                RW_CF_LOAD(G1, G2)
-                SX_SCHED_FENCE();
-                i32 LPC_pred_Q10 = 0;
-#pragma unroll
-                for (int j = 0; j < SX_LPC; j++) LPC_pred_Q10 = sx_smlaw_pre(LPC_pred_Q10, sLPC[li][j], Apre[j]);
-                SX_SCHED_FENCE();
-                RW_CF_LOAD(G2, RW_NCOEF / 4)
-                const i32 warp_pre = cf[RW_CM + 0], Tilt_pre = cf[RW_CM + 1], LFb_pre = cf[RW_CM + 2], LFt_pre = cf[RW_CM + 3], Hb_pre = cf[RW_CM + 4], Ht_pre = cf[RW_CM + 5];
-                Lambda_Q10[li] = cf[RW_CM + 6]; offsum[li] = cf[RW_CM + 7]; Gain_s[li] = cf[RW_CM + 8];
-                {
-                    const SxRowV4 v_ = *(const SxRowV4*)__builtin_assume_aligned((const char*)w->mdc + co_ + 4 * sd[li], 16);
-                    my_inv_gain[li] = v_.x; my_inv_of_delta[li] = v_.y; my_offset[li] = v_.z; my_DG[li] = v_.w;
+                for (int j = 0; j < 3; j++) curS[li][j] = w->win[tt].tapS[i + 2 - j];
+                if (RW_ONCE(l)) {
+                    Seed2[si] = sx_rand(Seed2[si]);                                            // Agora_Silk_Dither (NSQ_del_dec.c:520)
+                    dith[si] = Seed2[si] >> 31;
                 }
-                SX_SCHED_FENCE();
-                // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place
-                i32 tmp2 = sx_smlaw_pre(sLPC[li][0], sAR2[li][0], warp_pre);
-                i32 tmp1 = sx_smlaw_pre(sAR2[li][0], sAR2[li][1] - tmp2, warp_pre);
-                sAR2[li][0] = tmp2;
-                i32 n_AR_Q10 = sx_smulw_pre(tmp2, ARpre[0]);
+                const SxRowV4 v_ = *(const SxRowV4*)__builtin_assume_aligned((const char*)w->mdc + co_ + 4 * sd[li], 16);
+                my_inv_gain[li] = v_.x; my_inv_of_delta[li] = v_.y; my_offset[li] = v_.z; my_DG[li] = v_.w;
+                LPC_pred[li] = 0;
+            }
+            RW_CF_STAGE(0, G1)
+            RW_CF_STAGE(G1, G2)
 #pragma unroll
-                for (int j = 2; j < SX_SHAPE_ORDER; j += 2) {
-                    tmp2 = sx_smlaw_pre(sAR2[li][j - 1], sAR2[li][j] - tmp1, warp_pre);
-                    sAR2[li][j - 1] = tmp1;
-                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[j - 1]);
-                    tmp1 = sx_smlaw_pre(sAR2[li][j], sAR2[li][j + 1] - tmp2, warp_pre);
-                    sAR2[li][j] = tmp2;
-                    n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp2, ARpre[j]);
-                }
-                sAR2[li][SX_SHAPE_ORDER - 1] = tmp1;
-                n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, tmp1, ARpre[SX_SHAPE_ORDER - 1]);
+            for (int j = 0; j < SX_LPC; j++) {
+                RW_FORK(l) { const int li = RW_LI(l); LPC_pred[li] = sx_smlaw_pre(LPC_pred[li], sLPC[li][j], Apre[j]); }
+            }
+            RW_CF_STAGE(G2, RW_NCOEF / 4)
+            const i32 warp_pre = cf[RW_CM + 0], Tilt_pre = cf[RW_CM + 1], LFb_pre = cf[RW_CM + 2], LFt_pre = cf[RW_CM + 3], Hb_pre = cf[RW_CM + 4], Ht_pre = cf[RW_CM + 5];
+            // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place.  One all-pass section is
+            // difference -> multiply -> add, each waiting for the one before; RW_STEP issues one such operation for every track of
+            // the lane before the next (three tracks per lane: the order is pinned, the tracks hide each other's result latency)
+#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
+#define RW_TIE(a_) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]));
+#else
+#define RW_TIE(a_)
+#endif
+#define RW_STEP(body_) { RW_FORK(l) { const int li = RW_LI(l); body_ } }
+            i32 dd_[RW_NL], mm_[RW_NL];
+            RW_STEP(dd_[li] = sx_smulw_pre(sAR2[li][0], warp_pre);) RW_TIE(dd_)
+            RW_STEP(tmp2[li] = sx_add(sLPC[li][0], dd_[li]);) RW_TIE(tmp2)
+            RW_STEP(dd_[li] = sx_sub(sAR2[li][1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[0]);) RW_TIE(dd_) RW_TIE(mm_)
+            RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = mm_[li];) RW_TIE(dd_)
+            RW_STEP(tmp1[li] = sx_add(sAR2[li][0], dd_[li]); sAR2[li][0] = tmp2[li];) RW_TIE(tmp1)
+#pragma unroll
+            for (int j = 2; j < SX_SHAPE_ORDER; j += 2) {
+                RW_STEP(dd_[li] = sx_sub(sAR2[li][j], tmp1[li]); mm_[li] = sx_smulw_pre(tmp1[li], ARpre[j - 1]);) RW_TIE(dd_) RW_TIE(mm_)
+                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);) RW_TIE(dd_) RW_TIE(nAR_)
+                RW_STEP(tmp2[li] = sx_add(sAR2[li][j - 1], dd_[li]); sAR2[li][j - 1] = tmp1[li];) RW_TIE(tmp2)
+                RW_STEP(dd_[li] = sx_sub(sAR2[li][j + 1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[j]);) RW_TIE(dd_) RW_TIE(mm_)
+                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);) RW_TIE(dd_) RW_TIE(nAR_)
+                RW_STEP(tmp1[li] = sx_add(sAR2[li][j], dd_[li]); sAR2[li][j] = tmp2[li];) RW_TIE(tmp1)
+            }
+            RW_FORK(l) {
+                const int li = RW_LI(l), si = RW_SI(l);
+                const i32 dither = dith[si];
+                sAR2[li][SX_SHAPE_ORDER - 1] = tmp1[li];
+                i32 n_AR_Q10 = sx_smlaw_pre(nAR_[li], tmp1[li], ARpre[SX_SHAPE_ORDER - 1]);
                 n_AR_Q10 = n_AR_Q10 >> 1;
                 n_AR_Q10 = sx_smlaw_pre(n_AR_Q10, LF_AR[li], Tilt_pre);
                 // newest shaping sample of this state's lineage
@@ -697,18 +779,17 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 n_LF_Q10 = sx_smlaw_pre(n_LF_Q10, LF_AR[li], LFt_pre);
                 n_AR[li] = n_AR_Q10;
                 n_LF[li] = n_LF_Q10;
-                LPC_pred[li] = LPC_pred_Q10;
                 // long-term prediction and harmonic shaping (taps are zero in an unvoiced frame / without a pitch lag: no branch;
                 // the reference tests the CENTRE lag for every track, NSQ_del_dec.c:1436-1446)
                 i32 LTP_pred_Q14 = 0;
 #pragma unroll
-                for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, curL[j], Bpre[j]);
-                i32 n_LTP_Q14 = sx_smulw_pre(sx_add(curS[0], curS[2]), Hb_pre);
-                n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, curS[1], Ht_pre);
+                for (int j = 0; j < SX_LTP_ORDER; j++) LTP_pred_Q14 = sx_smlaw_pre(LTP_pred_Q14, curL[li][j], Bpre[j]);
+                i32 n_LTP_Q14 = sx_smulw_pre(sx_add(curS[li][0], curS[li][2]), Hb_pre);
+                n_LTP_Q14 = sx_smlaw_pre(n_LTP_Q14, curS[li][1], Ht_pre);
                 n_LTP_Q14 = sx_shl(n_LTP_Q14, 6);
                 // Agora_Silk_DoPred_And_Shap (Agora_SILK_func.c:143)
                 i32 tmp = sx_sub(LTP_pred_Q14, n_LTP_Q14) >> 4;
-                tmp = sx_add(tmp, LPC_pred_Q10);
+                tmp = sx_add(tmp, LPC_pred[li]);
                 tmp = sx_sub(tmp, n_AR_Q10);
                 tmp = sx_sub(tmp, n_LF_Q10);
                 i32 r_Q10 = sx_sub(x_sc_Q10, tmp);
@@ -719,35 +800,34 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             }
             RW_MARK("B")
             // phase B: the two candidates of each side state (Agora_Silk_RDCx1) from the side's share of the CENTRE residual
+            const i32 Lambda_Q10 = cf[RW_CM + 6], offsum = cf[RW_CM + 7], Gain_s = cf[RW_CM + 8];      // (the stream's scalars of the sample step)
             RWT_FROM(rC, rD, 0)
             RW_FORK(l) {
-                const int li = RW_LI(l);
-                const i32 r_md_Q10 = sx_smulww(my_inv_gain[li], rC[li]);
-                sx_nsq_rdcx1(r_md_Q10, rD[li], my_inv_of_delta[li], Lambda_Q10[li], my_offset[li], cInc[li], cQ10[li]);
+                const int li = RW_LI(l), si = RW_SI(l);
+                if (RW_IS_S(l)) {
+                    const i32 r_md_Q10 = sx_smulww(my_inv_gain[li], rC[si]);
+                    sx_nsq_rdcx1(r_md_Q10, rD[li], my_inv_of_delta[li], Lambda_Q10, my_offset[li], cInc[li], cQ10[li]);
+                }
             }
             RW_MARK("C")
             // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152) in the centre's lanes: the centre takes the best two of the four
             // combinations of side candidates; the side candidates are then re-ordered so that candidate j of every track belongs
             // to combination w_j
-#if SX_NLANES == 1
-            { i32 a_[12], b_[12], c_[12], d_[12];
-              for (int q_ = 0; q_ < 12; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = cInc[q_][0]; d_[q_] = cInc[q_][1]; }
+            { i32 a_[RW_NL], b_[RW_NL], c_[RW_NL], d_[RW_NL];
+#pragma unroll
+              for (int q_ = 0; q_ < RW_NL; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = cInc[q_][0]; d_[q_] = cInc[q_][1]; }
               RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
               RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
-#else
-            { i32 a_[1] = {cQ10[0][0]}, b_[1] = {cQ10[0][1]}, c_[1] = {cInc[0][0]}, d_[1] = {cInc[0][1]};
-              RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
-              RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
-#endif
-            i32 wpk[RW_NL], ccInc[RW_NL][2], ccQ10[RW_NL][2];
+            i32 wpk[RW_NS], ccInc[RW_NS][2], ccQ10[RW_NS][2];
             RW_FORK(l) {
-                const int li = RW_LI(l);
-                const i32 off = offsum[li];
-                const i32 qx0 = p1q0[li] + p2q0[li], qx1 = p1q1[li] + p2q1[li], qx2 = p1q0[li] + p2q1[li], qx3 = p1q1[li] + p2q0[li];
+              if (RW_IS_C(l)) {
+                const int li = RW_LI(l), si = RW_SI(l);
+                const i32 off = offsum;
+                const i32 qx0 = p1q0[si] + p2q0[si], qx1 = p1q1[si] + p2q1[si], qx2 = p1q0[si] + p2q1[si], qx3 = p1q1[si] + p2q0[si];
                 const i32 r_temp = sx_sub(rD[li], off);
-                const i32 l1r0 = sx_mul_lambda(p1r0[li]), l1r1 = sx_mul_lambda(p1r1[li]), l2r0 = sx_mul_lambda(p2r0[li]), l2r1 = sx_mul_lambda(p2r1[li]);
-                i32 rdx0 = sx_nsq_center_rd1(qx0, r_temp, off, Lambda_Q10[li]), rdx1 = sx_nsq_center_rd1(qx1, r_temp, off, Lambda_Q10[li]);
-                i32 rdx2 = sx_nsq_center_rd1(qx2, r_temp, off, Lambda_Q10[li]), rdx3 = sx_nsq_center_rd1(qx3, r_temp, off, Lambda_Q10[li]);
+                const i32 l1r0 = sx_mul_lambda(p1r0[si]), l1r1 = sx_mul_lambda(p1r1[si]), l2r0 = sx_mul_lambda(p2r0[si]), l2r1 = sx_mul_lambda(p2r1[si]);
+                i32 rdx0 = sx_nsq_center_rd1(qx0, r_temp, off, Lambda_Q10), rdx1 = sx_nsq_center_rd1(qx1, r_temp, off, Lambda_Q10);
+                i32 rdx2 = sx_nsq_center_rd1(qx2, r_temp, off, Lambda_Q10), rdx3 = sx_nsq_center_rd1(qx3, r_temp, off, Lambda_Q10);
                 rdx0 = sx_add(sx_add(rdx0, l1r0), l2r0);
                 rdx1 = sx_add(sx_add(rdx1, l1r1), l2r1);
                 rdx2 = sx_add(sx_add(rdx2, l1r0), l2r1);
@@ -763,28 +843,29 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 const bool f0 = x0 == m2, f1 = x1 == m2, f2 = x2 == m2;
                 const int w2 = f0 ? 0 : (f1 ? 1 : (f2 ? 2 : 3));
                 const i32 q_w2 = f0 ? qx0 : (f1 ? qx1 : (f2 ? qx2 : qx3));
-                ccInc[li][0] = m1;
-                ccInc[li][1] = m2;
-                ccQ10[li][0] = q_w1;
-                ccQ10[li][1] = q_w2;
-                wpk[li] = w1 | (w2 << 2);
+                ccInc[si][0] = m1;
+                ccInc[si][1] = m2;
+                ccQ10[si][0] = q_w1;
+                ccQ10[si][1] = q_w2;
+                wpk[si] = w1 | (w2 << 2);
+              }
             }
-            RWT_FROM(tq, wpk, 0)
+            RWT_FROM(tS, wpk, 0)
             RW_FORK(l) {
-                const int li = RW_LI(l), t = RW_T(l);
+                const int li = RW_LI(l), si = RW_SI(l), t = RW_T(l);
                 // the reference's 12-way memcpy case table (NSQ_del_dec.c:1266-1336) is this selection;
                 // member of combination w: MD1 {0,1,0,1}, MD2 {0,1,1,0} -- bit w of a lane constant
                 const u32 mtab = t == 1 ? 0xAu : 0x6u;
-                const bool ca = ((mtab >> (tq[li] & 3)) & 1u) != 0, cb = ((mtab >> ((tq[li] >> 2) & 3)) & 1u) != 0;
+                const bool ca = ((mtab >> (tS[si] & 3)) & 1u) != 0, cb = ((mtab >> ((tS[si] >> 2) & 3)) & 1u) != 0;
                 const i32 a0 = cInc[li][0], a1 = cInc[li][1], d0 = cQ10[li][0], d1 = cQ10[li][1];
                 const bool ctr = t == 0;
-                cInc[li][0] = ctr ? ccInc[li][0] : (ca ? a1 : a0);  cInc[li][1] = ctr ? ccInc[li][1] : (cb ? a1 : a0);
-                cQ10[li][0] = ctr ? ccQ10[li][0] : (ca ? d1 : d0); cQ10[li][1] = ctr ? ccQ10[li][1] : (cb ? d1 : d0);
+                cInc[li][0] = ctr ? ccInc[si][0] : (ca ? a1 : a0);  cInc[li][1] = ctr ? ccInc[si][1] : (cb ? a1 : a0);
+                cQ10[li][0] = ctr ? ccQ10[si][0] : (ca ? d1 : d0); cQ10[li][1] = ctr ? ccQ10[si][1] : (cb ? d1 : d0);
                 // the track's share of the joint cost of candidate [0] (Agora_Silk_JudgeWinner, NSQ_del_dec.c:671)
                 const i32 cand0 = sx_add(RD[li], cInc[li][0]);
-                tq2[li] = sx_add(cand0, sx_smulw_pre(cand0, lamT[li]));
+                tT[li] = sx_add(cand0, sx_smulw_pre(cand0, lamT[li]));
             }
-            RWT_SUM(jv, tq2)
+            RWT_SUM(jv, tT)
             smpl_buf_idx = smpl_new;
             RW_MARK("E")
             // phase E: Agora_Silk_JudgeWinner.  States whose decisionDelay-old ancestor differs from the joint winner's, in any
@@ -792,61 +873,71 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // second candidate replaces the worst first candidate" -- played on three index registers:
             //   par   whose filter state the lane continues from,  csrc / csel   whose candidate (and which one) it takes
             // (the centre's lanes play it; the plan then crosses to the side tracks' lanes as one packed word)
-            i32 pen[RW_NL];
+            i32 pen[RW_NS];
             {
                 const i32 PEN = SX_I32_MAX >> 4;
-                RWK_ARGMIN(jv, mv, mi)                                   // mi = the joint winner
+                RWS_ARGMIN(jv, mv, mi)                                   // mi = the joint winner
                 // the delayed random state of this state's lineage: held by the lane that owns the lineage's slot of that ring position;
                 // before the frame has written that position (first decisionDelay samples) the reference reads its zero-initialised ring
                 const bool written = k * SX_SUBFR + i >= decisionDelay;
-                RW_FORK(l) { gq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); tq[RW_LI(l)] = qc[RW_LI(l)].w3; }
-                RWK_GATHER(c0, tq, gq)
-                RW_FORK(l) { myRand[RW_LI(l)] = written ? c0[RW_LI(l)] : 0; }
-                RWK_PICK(c1, myRand, mi)                                 // the winner's
-                RW_FORK(l) { tq[RW_LI(l)] = (myRand[RW_LI(l)] ^ c1[RW_LI(l)]) != 0 ? 1 : 0; }
-                RWT_OR(tq2, tq)                                          // expired: differs in any track
                 RW_FORK(l) {
-                    const int li = RW_LI(l);
-                    const bool ctr = RW_T(l) == 0;
-                    pen[li] = (tq2[li] && ctr) ? PEN : 0;                // (only the centre's costs carry the penalty)
-                    par[li] = RW_K(l); csrc[li] = RW_K(l); csel[li] = 0;
-                    const i32 rp_ = sx_add(RD[li], pen[li]);
-                    c0[li] = sx_add(rp_, cInc[li][0]); c1[li] = sx_add(rp_, cInc[li][1]);
+                    if (RW_ONCE(l)) gq[RW_SI(l)] = RW_LIN_SLOT(linLo[RW_SI(l)], linHi[RW_SI(l)], last_smple_idx);
+                    tT[RW_LI(l)] = qc[RW_LI(l)].w3;
                 }
-                RWK_SUM(tq2, nrep)                                       // number of expired states
-                RWK_ARGMIN(c1, mv2, mi2)                                 // best candidate [1] (first minimum): the [1] entries never change
+                RWK_GATHER(tT2, tT, gq)
+                RW_FORK(l) { myRand[RW_LI(l)] = written ? tT2[RW_LI(l)] : 0; }
+                RWK_PICK(tT2, myRand, mi)                                // the winner's
+                RW_FORK(l) { tT[RW_LI(l)] = (myRand[RW_LI(l)] ^ tT2[RW_LI(l)]) != 0 ? 1 : 0; }
+                RWT_OR(tS2, tT)                                          // expired: differs in any track
+                RW_FORK(l) {
+                    if (RW_IS_C(l)) {                                    // (only the centre's costs carry the penalty and take part in the rounds)
+                        const int li = RW_LI(l), si = RW_SI(l);
+                        pen[si] = tS2[si] ? PEN : 0;
+                        par[si] = RW_K(l); csrc[si] = RW_K(l); csel[si] = 0;
+                        const i32 rp_ = sx_add(RD[li], pen[si]);
+                        c0[si] = sx_add(rp_, cInc[li][0]); c1[si] = sx_add(rp_, cInc[li][1]);
+                    }
+                }
+                RWS_SUM(tS2, nrep)                                       // number of expired states
+                RWS_ARGMIN(c1, mv2, mi2)                                 // best candidate [1] (first minimum): the [1] entries never change
 #if SX_NLANES == 1
                 int RandSyncCtl = RW_UNI(nrep);
                 do {
-                    RWK_ARGMAX(c0, mv, mi)                               // worst candidate [0] (first maximum)
-                    RWK_PICK(gq, par, mi2)                               // the state lane mi2 holds NOW (it may itself have been replaced)
+                    RWS_ARGMAX(c0, mv, mi)                               // worst candidate [0] (first maximum)
+                    RWS_PICK(gq, par, mi2)                               // the state lane mi2 holds NOW (it may itself have been replaced)
                     RW_FORK(l) {
-                        const int li = RW_LI(l);
-                        const bool rep_ = (mv2[li] < mv[li]) & (RW_K(l) == mi[li]);
-                        par[li] = rep_ ? gq[li] : par[li]; csrc[li] = rep_ ? mi2[li] : csrc[li]; csel[li] = rep_ ? 1 : csel[li]; c0[li] = rep_ ? mv2[li] : c0[li];
+                        const int si = RW_SI(l);
+                        const bool rep_ = (mv2[si] < mv[si]) & (RW_K(l) == mi[si]);
+                        par[si] = rep_ ? gq[si] : par[si]; csrc[si] = rep_ ? mi2[si] : csrc[si]; csel[si] = rep_ ? 1 : csel[si]; c0[si] = rep_ ? mv2[si] : c0[si];
                     }
                 } while (--RandSyncCtl > 0);
 #else
                 i32 RandSyncCtl = nrep[0];
                 do {
-                    RWK_ARGMAX(c0, mv, mi)
-                    RWK_PICK(gq, par, mi2)
+                    RWS_ARGMAX(c0, mv, mi)
+                    RWS_PICK(gq, par, mi2)
                     const bool rep_ = (mv2[0] < mv[0]) & ((i32)(threadIdx.x & 3u) == mi[0]);
                     par[0] = rep_ ? gq[0] : par[0]; csrc[0] = rep_ ? mi2[0] : csrc[0]; csel[0] = rep_ ? 1 : csel[0]; c0[0] = rep_ ? mv2[0] : c0[0];
                 } while (--RandSyncCtl > 0);
 #endif
-                RW_FORK(l) { tq[RW_LI(l)] = par[RW_LI(l)] | (csrc[RW_LI(l)] << 2) | (csel[RW_LI(l)] << 4); }
-                RWT_FROM(tq2, tq, 0)
-                RW_FORK(l) { const int li = RW_LI(l); par[li] = tq2[li] & 3; csrc[li] = (tq2[li] >> 2) & 3; csel[li] = (tq2[li] >> 4) & 1; }
+                // (a row per stream: the plan crosses from the centre's lanes to the side tracks' as one packed word; in the emulation
+                // every virtual lane's copy of the centre's costs was garbage except the centre's)
+                RW_FORK(l) { if (RW_ONCE(l)) tS[RW_SI(l)] = par[RW_SI(l)] | (csrc[RW_SI(l)] << 2) | (csel[RW_SI(l)] << 4); }
+                RWT_FROM(tS2, tS, 0)
+                RW_FORK(l) { if (RW_ONCE(l)) { const int si = RW_SI(l); par[si] = tS2[si] & 3; csrc[si] = (tS2[si] >> 2) & 3; csel[si] = (tS2[si] >> 4) & 1; } }
             }
             RW_MARK("M")
             // the survivors move: SKP_Silk_copy_del_dec_state (NSQ_del_dec.c:1668), every register once.
             // The last-sample memories shift by one on the way (sLPC[0] takes the new sample in phase G).
-            i32 cand1RD[RW_NL], cand1Q10[RW_NL];
+            i32 cand1RD[RW_NL], cand1Q10[RW_NL], penT[RW_NL];
             {
                 // the chosen candidate [1] and the predictions it was built on come from the lane that produced it
                 // (the long-term prediction is the same in the four states of a track)
-                RW_FORK(l) { const int li = RW_LI(l); cand1RD[li] = sx_add(sx_add(RD[li], pen[li]), cInc[li][1]); cand1Q10[li] = cQ10[li][1]; }
+                RW_FORK(l) {
+                    const int li = RW_LI(l);
+                    penT[li] = RW_T(l) == 0 ? pen[RW_SI(l)] : 0;
+                    cand1RD[li] = sx_add(sx_add(RD[li], penT[li]), cInc[li][1]); cand1Q10[li] = cQ10[li][1];
+                }
 #define RW_LV_C1RD(q_) cand1RD[q_]
 #define RW_LV_C1Q10(q_) cand1Q10[q_]
 #define RW_LV_LPCP(q_) LPC_pred[q_]
@@ -854,13 +945,13 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
 #define RW_LV_NLF(q_) n_LF[q_]
 #define RW_LV_DITH(q_) dith[q_]
                 RWK_PERM(RW_LV_C1RD, csrc) RWK_PERM(RW_LV_C1Q10, csrc)
-                RWK_PERM(RW_LV_LPCP, csrc) RWK_PERM(RW_LV_NAR, csrc) RWK_PERM(RW_LV_NLF, csrc) RWK_PERM(RW_LV_DITH, csrc)
+                RWK_PERM(RW_LV_LPCP, csrc) RWK_PERM(RW_LV_NAR, csrc) RWK_PERM(RW_LV_NLF, csrc) RWS_PERM(RW_LV_DITH, csrc)
 #define RW_LV_SEED2(q_) Seed2[q_]
 #define RW_LV_SEEDI(q_) SeedInit2[q_]
 #define RW_LV_LINLO(q_) linLo[q_]
 #define RW_LV_LINHI(q_) linHi[q_]
 #define RW_LV_SEED(q_) Seed[q_]
-                RWK_PERM(RW_LV_SEED2, par) RWK_PERM(RW_LV_SEEDI, par) RWK_PERM(RW_LV_LINLO, par) RWK_PERM(RW_LV_LINHI, par) RWK_PERM(RW_LV_SEED, par)
+                RWS_PERM(RW_LV_SEED2, par) RWS_PERM(RW_LV_SEEDI, par) RWS_PERM(RW_LV_LINLO, par) RWS_PERM(RW_LV_LINHI, par) RWK_PERM(RW_LV_SEED, par)
 #pragma unroll
                 for (int j = 0; j < SX_SHAPE_ORDER; j++) {
 #define RW_LV_SAR2(q_) sAR2[q_][j]
@@ -871,7 +962,8 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
 #if SX_NLANES == 1
                     { i32 o_[12]; for (int q_ = 0; q_ < 12; q_++) o_[q_] = sLPC[q_][j - 1]; for (int q_ = 0; q_ < 12; q_++) sLPC[q_][j] = o_[(q_ & ~3) | par[q_]]; }
 #else
-                    sLPC[0][j] = rwk_from(sLPC[0][j - 1], par[0]);
+#pragma unroll
+                    for (int q_ = 0; q_ < RW_NL; q_++) sLPC[q_][j] = rwk_from(sLPC[q_][j - 1], par[0]);
 #endif
                 }
             }
@@ -880,11 +972,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // for the candidate the lane keeps; joint cost of the survivors
             i32 fRD[RW_NL], fQ0[RW_NL], cXq14[RW_NL], cShp[RW_NL], cExc10[RW_NL], cX[RW_NL];
             RW_FORK(l) {
-                const int li = RW_LI(l), t = RW_T(l);
-                const i32 dither = dith[li];
-                const bool sel = csel[li] != 0;
+                const int li = RW_LI(l), si = RW_SI(l), t = RW_T(l);
+                const i32 dither = dith[si];
+                const bool sel = csel[si] != 0;
                 const i32 Q10 = sel ? cand1Q10[li] : cQ10[li][0];
-                fRD[li] = sel ? cand1RD[li] : sx_add(sx_add(RD[li], pen[li]), cInc[li][0]);
+                fRD[li] = sel ? cand1RD[li] : sx_add(sx_add(RD[li], penT[li]), cInc[li][0]);
                 i32 Q = (Q10 ^ dither) - dither;
                 const bool ctr = t == 0;
                 // the pulse: the quantised value (a side's without its offset) >> 10; what the coder gets: the centre's excitation / the side's pulse
@@ -898,20 +990,20 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 LF_AR[li] = sx_shl(sLF_AR_shp_Q10, 2);
                 cXq14[li] = sx_shl(xq_Q10, 4);
                 cExc10[li] = LPC_exc_Q10;
-                tq[li] = sx_add(fRD[li], sx_smulw_pre(fRD[li], lamT[li]));
+                tT[li] = sx_add(fRD[li], sx_smulw_pre(fRD[li], lamT[li]));
             }
-            RWT_SUM(jv, tq)
+            RWT_SUM(jv, tT)
             RW_MARK("F")
             // phase F: Agora_Silk_GetWinner{,_Side} (NSQ_del_dec.c:757, 820): emit the delayed sample of the joint winner.  The lane
             // that owns the winner's slot of the emitted ring position holds the cell in its prefetch registers.
-            RWK_ARGMIN(jv, mv, mi)
+            RWS_ARGMIN(jv, mv, mi)
             {
-                RW_FORK(l) { tq[RW_LI(l)] = RW_LIN_SLOT(linLo[RW_LI(l)], linHi[RW_LI(l)], last_smple_idx); }
-                RWK_PICK(gq, tq, mi)
+                RW_FORK(l) { if (RW_ONCE(l)) tS[RW_SI(l)] = RW_LIN_SLOT(linLo[RW_SI(l)], linHi[RW_SI(l)], last_smple_idx); }
+                RWS_PICK(gq, tS, mi)
                 const bool crossed = subfr > 0 && i < decisionDelay;      // the cell was written before this subframe's gain change
                 RW_FORK(l) {
                     const int li = RW_LI(l);
-                    if (emitted && RW_K(l) == gq[li] && RW_LIVE(l)) {
+                    if (emitted && RW_K(l) == gq[RW_SI(l)] && RW_LIVE(l)) {
                         const u32 e4 = (u32)(4 * (cur0 + k * SX_SUBFR + i - decisionDelay));
                         const i32 p16 = rw_cell_pred_Q16(qc[li]);
                         const i32 gx = crossed ? gadj[li] : 65536;               // (x 65536 >> 16: exact)
@@ -919,7 +1011,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                         // it is staged --, this subframe's windows get it with the factor applied; an entry no tap of this
                         // subframe can reach goes to the row's dump word)
                         RW_EMIT_OUT(l, li, qc[li], e4, true)
-                        SX_AT(i32, Pu + offsetof(SxNsqTrack, sLTP_Q16), pTrk[li] + e4 + (u32)dL4[li]) = p16;
+                        SX_AT(i32, Pu + offsetof(SxNsqTrack, sLTP_Q16), pTrk[li] + e4 + (u32)dL4) = p16;
                         const u32 iL = (u32)(i + wb[li]), iS = iL - 1u;
                         w->win[RW_T(l)].tapL[iL < (u32)SX_TAPL_N ? iL : (u32)SX_TAPL_N] = sx_smulww(gx, p16);
                         w->win[RW_T(l)].tapS[iS < (u32)SX_TAPS_N ? iS : (u32)SX_TAPS_N] = sx_smulww(gx, qc[li].w2);
@@ -929,22 +1021,24 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             RW_MARK("G")
             // phase G: Agora_Silk_Update_DelDecState (NSQ_del_dec.c:862): every state pushes its candidate into its own cell
             RW_FORK(l) {
-                const int li = RW_LI(l), kk = RW_K(l);
+                const int li = RW_LI(l), si = RW_SI(l), kk = RW_K(l);
                 sLPC[li][0] = cXq14[li];
                 lastShp[li] = cShp[li];
                 Seed[li] = sx_add(Seed[li], fQ0[li]);
                 RD[li] = fRD[li];
                 SxRowCell cell;
-                const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[li] >> 4, Gain_s[li]), 10));
+                const i32 xq16 = sx_sat16(sx_rshift_round(sx_smulww(cXq14[li] >> 4, Gain_s), 10));
                 cell.w0 = (i32)(((u32)xq16 & 0xFFFFu) | ((u32)cX[li] << 16));
                 cell.w1 = (i32)(((u32)cExc10[li] & 0x03FFFFFFu) | (((u32)cX[li] << 10) & 0xFC000000u));
                 cell.w2 = cShp[li];
                 cell.w3 = Seed[li];
                 if (RW_LIVE(l)) RW_CELL_ST(smpl_buf_idx, l, cell)
                 // the state's own slot now holds its newest ring entry
-                const u32 m = 3u << (2 * (smpl_buf_idx & 15));
-                if (smpl_buf_idx < 16) linLo[li] = (i32)(((u32)linLo[li] & ~m) | (((u32)kk * 0x55555555u) & m));
-                else linHi[li] = (i32)(((u32)linHi[li] & ~m) | (((u32)kk * 0x55555555u) & m));
+                if (RW_ONCE(l)) {
+                    const u32 m = 3u << (2 * (smpl_buf_idx & 15));
+                    if (smpl_buf_idx < 16) linLo[si] = (i32)(((u32)linLo[si] & ~m) | (((u32)kk * 0x55555555u) & m));
+                    else linHi[si] = (i32)(((u32)linHi[si] & ~m) | (((u32)kk * 0x55555555u) & m));
+                }
             }
             RW_MARK("Z")
             wv_sync_lds();
@@ -961,17 +1055,17 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
 
     // Agora_Silk_DelDec_UpdateState_And_Output{,_Side} (NSQ_del_dec.c:175, 245)
     RWT_FROM(jv, RD, 0)
-    RWK_ARGMIN(jv, mv, mi)
-    RWK_PICK(tq, SeedInit2, mi)
-    RW_FORK(l) { if (l == 0) out->Seed = tq[RW_LI(l)]; }
-    RWK_PICK(tq, linLo, mi)
-    RWK_PICK(tq2, linHi, mi)
+    RWS_ARGMIN(jv, mv, mi)
+    RWS_PICK(tS, SeedInit2, mi)
+    RW_FORK(l) { if (l == 0) out->Seed = tS[RW_SI(l)]; }
+    RWS_PICK(tS, linLo, mi)
+    RWS_PICK(tS2, linHi, mi)
     wv_sync();                                  // the ring cells of the last samples must have landed
-    RW_FLUSH(tq[li], tq2[li], SX_FRAME - decisionDelay)
+    RW_FLUSH(tS[RW_SI(l)], tS2[RW_SI(l)], SX_FRAME - decisionDelay)
     wv_sync();
     RW_FORK(l) {
         const int li = RW_LI(l);
-        if (RW_K(l) == mi[li] && RW_LIVE(l)) {
+        if (RW_K(l) == mi[RW_SI(l)] && RW_LIVE(l)) {
             SxNSQ* n = &SX_AT(SxNSQ, Pu, pTrk[li] + (u32)offsetof(SxNsqTrack, s));
 #pragma unroll
             for (int i = 0; i < SX_MAX_LPC; i++) n->sLPC_Q14[i] = (SX_MAX_LPC - 1 - i) < SX_LPC ? sLPC[li][SX_MAX_LPC - 1 - i] : 0;
