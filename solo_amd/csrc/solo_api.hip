@@ -863,22 +863,14 @@ int32_t solo_debug_nsq(int32_t n_streams, int32_t n_packets, const void* h_in, v
 }
 #endif
 
-#if defined(SX_PROF) && defined(SOLO_WITH_ENCODER)
-// debug builds only: read (and clear) the per-section cycle counters of the encoder
-int32_t solo_debug_prof(unsigned long long* out32, int32_t reset) {
-    if (hipMemcpyFromSymbol(out32, HIP_SYMBOL(g_sx_prof), 32 * sizeof(unsigned long long)) != hipSuccess) return -1;
+#if defined(SX_PROF)
+// debug builds only: read (and clear) the per-section cycle counters of the decoder kernels (tools/prof_dec.py; the encoder kernels'
+// counters live in their own translation unit: solo_debug_prof_enc, solo_enc_k.hip)
+int32_t solo_debug_prof(unsigned long long* out64, int32_t reset) {
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sx_prof), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[32] = {0};
+        unsigned long long z[64] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_prof), z, sizeof(z)) != hipSuccess) return -1;
-    }
-    return 0;
-}
-// ... and the histogram of the analysis waves' lifetimes (4 SIMDs x 64 bins of 50 us)
-int32_t solo_debug_hist(unsigned long long* out256, int32_t reset) {
-    if (hipMemcpyFromSymbol(out256, HIP_SYMBOL(g_sx_hist), 256 * sizeof(unsigned long long)) != hipSuccess) return -1;
-    if (reset) {
-        unsigned long long z[256] = {0};
-        if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_hist), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
 }

@@ -406,6 +406,7 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     sx_vad(st, c, f->res_pitch, f->Wsig, &SNR_dB_Q7);
     wv_sync();
     static_assert(sizeof(f->u) >= SX_HP_SCRATCH_WORDS * sizeof(i32), "the pitch work area doubles as the high-pass filter's scratch");
+    SX_S(32)
     sx_hp_variable_cutoff(st, c, f->x_buf + SX_FRAME + SX_LA_SHAPE, f->res_pitch, (i32*)&f->u);
     wv_sync();
     SX_T(1)

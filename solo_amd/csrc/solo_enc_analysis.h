@@ -475,6 +475,7 @@ SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pit
         SNR_adj_dB_Q7 = sx_smlawb(SNR_adj_dB_Q7, K_SPARSE_SNR_INCR_dB_Q15, c->sparseness_Q8 - K_0p5_Q8);
         md_SNR_adj_dB_Q7 = sx_smlawb(md_SNR_adj_dB_Q7, K_SPARSE_SNR_INCR_dB_Q15, c->sparseness_Q8 - K_0p5_Q8);
     }
+    SX_S(37)
     // bandwidth expansion
     i32 strength_Q16 = sx_smulwb(c->predGain_Q16, K_FIND_PITCH_WHITE_NOISE_FRACTION_Q16);
     i32 BWExp1_Q16, BWExp2_Q16;
@@ -513,7 +514,9 @@ SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pit
                                            : (i < SX_LA_SHAPE + 5 * SX_FS_KHZ ? v : (i16)sx_smulwb(sw->win[1][i - (SX_LA_SHAPE + 5 * SX_FS_KHZ)], v));
         }
         wv_sync();
+        SX_S(38)
         sx_warped_autocorr4(sw, (i16)warping_Q16);
+        SX_S(39)
     }
     SX_T_BEGIN
 #ifdef SX_LANE_STREAM
@@ -653,28 +656,55 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
                   a2 = sx_pre16(c->AR1_Q13[2 * SX_SHAPE_ORDER + l]), a3 = sx_pre16(c->AR1_Q13[3 * SX_SHAPE_ORDER + l]);
         const i32 lam = sx_pre16(lambda_Q16);
         pw->st_res[0] = (i16)st->pf_sHarmHP;
-        i32 out = 0, acc = 0, vend = 0, vend0 = 0;
+        i32 out = 0, acc = 0;
         i32 xn = (0 - l >= 0) ? (i32)x[0] : 0;                        // x[n] of the coming step (n = t - 1 - l), fetched a step ahead
-        for (int t = 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) {
-            const int n = t - 1 - l;
-            const i32 xcur = xn;
-            {   // prefetch for step t + 1
-                const int nn = n + 1;
-                xn = (nn >= 0 && nn < SX_FRAME) ? (i32)x[nn] : 0;
-            }
-            const i32 in_prev = SX_DPP_(out, 0x111), acc_prev = SX_DPP_(acc, 0x111);     // lane l - 1's results of step t - 1
-            if (n >= 0 && n < SX_FRAME) {
-                const i32 in = l == 0 ? sx_shl(xcur, 14) : in_prev;
-                const i32 o = l == 0 ? sx_smlaw_pre(pin, pv, lam) : sx_smlaw_pre(pin, pv - in, lam);
-                const i32 coef = n < 2 * SX_SUBFR ? (n < SX_SUBFR ? a0 : a1) : (n < 3 * SX_SUBFR ? a2 : a3);
-                acc = sx_smlaw_pre(l == 0 ? 0 : acc_prev, o, coef);
-                pin = in;
-                pv = o;
-                out = o;
-                if (l == SX_SHAPE_ORDER - 1) pw->st_res[1 + n] = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));
-                if (n == SX_FRAME - 1) { vend = o; vend0 = in; }
-            }
+        // the first and last 16 steps, where only the lanes whose sample lies inside the frame work
+#define SX_PF_EDGE_STEP                                                                                                               \
+        {   const int n = t - 1 - l;                                                                                                  \
+            const i32 xcur = xn;                                                                                                      \
+            { const int nn = n + 1; xn = (nn >= 0 && nn < SX_FRAME) ? (i32)x[nn] : 0; }                                               \
+            const i32 in_prev = SX_DPP_(out, 0x111), acc_prev = SX_DPP_(acc, 0x111);     /* lane l - 1's results of step t - 1 */      \
+            if (n >= 0 && n < SX_FRAME) {                                                                                             \
+                const i32 in = l == 0 ? sx_shl(xcur, 14) : in_prev;                                                                   \
+                const i32 o = l == 0 ? sx_smlaw_pre(pin, pv, lam) : sx_smlaw_pre(pin, pv - in, lam);                                  \
+                const i32 coef = n < 2 * SX_SUBFR ? (n < SX_SUBFR ? a0 : a1) : (n < 3 * SX_SUBFR ? a2 : a3);                          \
+                acc = sx_smlaw_pre(l == 0 ? 0 : acc_prev, o, coef);                                                                   \
+                pin = in; pv = o; out = o;                                                                                            \
+                if (l == SX_SHAPE_ORDER - 1) pw->st_res[1 + n] = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));                      \
+            }                                                                                                                         \
         }
+        // steps 17 .. 160: every lane holds a sample of the frame -- no range checks; lane 0's input comes in through the DPP move's
+        // `old` operand, its partial sum through the move's zero fill; the coefficient set changes at sample bnd (lane by lane as the
+        // skew passes it); lane 15 stores through a walking pointer, the other lanes through a pointer that stays on a dump word
+#define SX_PF_STEADY(T0, T1, CA, CB, BND)                                                                                             \
+        for (int t = (T0); t <= (T1); t++) {                                                                                          \
+            const i32 xcur = xn;                                                                                                      \
+            xn = (i32)xp[t];                                                                                                          \
+            const i32 in = __builtin_amdgcn_update_dpp(sx_shl(xcur, 14), out, 0x111, 0xF, 0xF, false);                                 \
+            const i32 acc_prev = SX_DPP_(acc, 0x111);                                                                                 \
+            const i32 o = sx_smlaw_pre(pin, pv - (in & not_first), lam);                                                              \
+            const i32 coef = ((BND) == 0 || t - 1 - l >= (BND)) ? (CA) : (CB);                                                        \
+            acc = sx_smlaw_pre(acc_prev, o, coef);                                                                                    \
+            pin = in; pv = o; out = o;                                                                                                \
+            *op = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));                                                                     \
+            op += ostride;                                                                                                            \
+        }
+        static_assert(SX_SHAPE_ORDER == 16 && SX_SUBFR > SX_SHAPE_ORDER && SX_FRAME == 4 * SX_SUBFR, "the steady-state split of the warped filter");
+        for (int t = 1; t <= SX_SHAPE_ORDER; t++) SX_PF_EDGE_STEP
+        {
+            const i32 not_first = l == 0 ? 0 : -1;
+            const i16* xp = x - l;                                                      // xp[t] = x[n + 1] of step t
+            const int ostride = l == SX_SHAPE_ORDER - 1 ? 1 : 0;
+            i16* op = l == SX_SHAPE_ORDER - 1 ? &pw->st_res[1 + SX_SHAPE_ORDER + 1 - 1 - l] : (i16*)&pw->o[0][l][0];
+            SX_PF_STEADY(SX_SHAPE_ORDER + 1, SX_SUBFR, a0, a0, 0)
+            SX_PF_STEADY(SX_SUBFR + 1, 2 * SX_SUBFR, a1, a0, SX_SUBFR)
+            SX_PF_STEADY(2 * SX_SUBFR + 1, 3 * SX_SUBFR, a2, a1, 2 * SX_SUBFR)
+            SX_PF_STEADY(3 * SX_SUBFR + 1, 4 * SX_SUBFR, a3, a2, 3 * SX_SUBFR)
+        }
+        for (int t = SX_FRAME + 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) SX_PF_EDGE_STEP
+#undef SX_PF_EDGE_STEP
+#undef SX_PF_STEADY
+        const i32 vend = pv, vend0 = pin;                               // (a lane's last update was its sample SX_FRAME - 1)
         if (SX_LANE < SX_SHAPE_ORDER) {
             st->pf_sAR_shp[l + 1] = vend;
             if (l == 0) st->pf_sAR_shp[0] = vend0;
@@ -716,6 +746,7 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
         wv_sync();
     }
 #endif
+    SX_S(40)
     // ---- per-subframe FIR on the residual, then prefilt_FIX (SKP_Silk_prefilter_FIX.c:174): serial shaping recursion ----
     SX_PAR(n, SX_FRAME) {
         const int k = n / SX_SUBFR;
@@ -1818,6 +1849,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
             sx_nlsf2a_stable_ws(lw->u.it.a_Q12[k], lw->u.it.NLSF0[k], order, lw->u.it.ws[k]);
         }
         wv_sync();
+        SX_S(53)
         {
             const int len = 2 * subfr_length;
             SX_PAR(t, 4 * len) {
@@ -1833,6 +1865,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
             }
         }
         wv_sync();
+        SX_S(54)
         SX_PAR(kh, 8) {
             const int k = kh >> 1, h = kh & 1;
             i32 e, sh;
@@ -2002,6 +2035,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         // rate-distortion of every (survivor, codebook vector) pair: a lane owns up to four pairs and keeps them in registers as
         // sorted (value, pair index) keys; the reference's insertion sort (cur_survivors best, value ascending, first index wins
         // ties) is then cur_survivors wave minima over the lanes' heads
+        SX_S(47)
         const i64 KEY_MAX = 0x7FFFFFFFFFFFFFFFLL;
         i64 k0 = KEY_MAX, k1 = KEY_MAX, k2 = KEY_MAX, k3 = KEY_MAX;
 #pragma unroll
@@ -2022,6 +2056,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                 if (j == 0) k0 = key; else if (j == 1) k1 = key; else if (j == 2) k2 = key; else k3 = key;
             }
         }
+        SX_S(52)
         if (total > 64) { SX_KEY_CX(k0, k1) SX_KEY_CX(k2, k3) SX_KEY_CX(k0, k2) SX_KEY_CX(k1, k3) SX_KEY_CX(k1, k2) }
         // heads as (value, index) register pairs; one selection round = wave minimum of the values, then wave minimum of the
         // indices among the lanes that hold that value (two 32-bit DPP ladders instead of one 64-bit compare ladder)
@@ -2039,11 +2074,13 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
             x->TempIndices[SX_LANE] = mine_i;
         }
 #endif
+        SX_S(48)
         wv_sync();
         if (w->RateDist_Q18[0] < SX_I32_MAX / 16) {
             i32 thr = sx_smlawb(w->RateDist_Q18[0], sx_mul(S, w->RateDist_Q18[0]), K_NLSF_MSVQ_SURV_MAX_REL_RD_Q16);
             while (w->RateDist_Q18[cur_survivors - 1] > thr && cur_survivors > min_survivors) cur_survivors--;
         }
+        SX_S(49)
         // new residuals, rates and paths of the survivors: lane (k, i)
         // (a row of SX_MSVQ_ROW lanes per survivor: SX_LPC residual entries, the rate, up to nStages - 1 inherited path entries, the new one)
         SX_PAR(ki, cur_survivors * SX_MSVQ_ROW) {
@@ -2068,6 +2105,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         prev_survivors = cur_survivors;
         cb_base += K;
     }
+    SX_S(51)
     i32 bestRateDist_Q20 = SX_I32_MAX, bestIndex = 0;
     if (deactivate_fluc_red != 1) {
         // every survivor is decoded (and stabilised) by its own lane into its own row of Res_Q15
@@ -2121,8 +2159,10 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
         SX_PAR(i, SX_LPC) pNLSFW_Q6[i] = sx_smlawb(pNLSFW_Q6[i] >> 1, w->W0_Q6[i], i_sqr_Q15);
     }
     wv_sync();
+    SX_S(46)
     sx_nlsf_msvq_encode(c->NLSFIndices, pNLSF_Q15, c->sigtype, st->prev_NLSFq_Q15, pNLSFW_Q6, NLSF_mu_Q15, NLSF_mu_fluc_red_Q16,
                         st->first_frame_after_reset, w, aux);
+    SX_S(50)
     // quantised NLSFs -> LPC for the two frame halves: half v on lane v, both lanes in step
     if (doInterpolate) {
         SX_PAR(i, SX_LPC) w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
@@ -2199,7 +2239,9 @@ SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     SX_STRETCH_DENSE();
     if (c->sigtype == 0) {
         sx_find_LTP(c->LTPCoef_Q14, w->WLTP, &c->LTPredCodGain_Q7, res_pitch, c->pitchL, Wght_Q15, &w->u.ltp);
+        SX_S(42)
         sx_quant_LTP_gains(c->LTPCoef_Q14, c->LTPIndex, &c->PERIndex, w->WLTP, K_MU_LTP_QUANT_Q8, w->u.vq.rd, w->u.vq.best);
+        SX_S(43)
         sx_LTP_scale_ctrl(st, c);
         sx_LTP_analysis_filter(w->LPC_in_pre, x_buf + SX_FRAME - SX_LPC, c->LTPCoef_Q14, c->pitchL, invGains_Q16);
         wv_sync();

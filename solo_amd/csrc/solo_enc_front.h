@@ -567,6 +567,7 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
         SX_PAR(i, 160) w->sig4[i] = (i16)(w->sig4[i] >> shift);
         wv_sync();
     }
+    SX_S(34)
     // ---- first stage (4 kHz): normalised correlation of two 10 ms targets against lags 8..72 ----
     for (int k = 0; k < 2; k++) {
         const i16* target = &w->sig4[80 + k * sf8];
@@ -699,6 +700,7 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
         wv_sync();
     }
 #endif
+    SX_S(35)
     // ---- second stage (8 kHz) ----
     shift = sx_pitch_find_scaling(w->sig8, 320, sf8);
     if (shift > 0) {
@@ -740,6 +742,7 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
 #endif
     i32 prevLag_log2_Q7 = prevLag > 0 ? sx_lin2log(prevLag) : 0;
     i32 corr_thres_Q15 = sx_smulbb(search_thres2_Q15, search_thres2_Q15) >> 13;
+    SX_S(36)
     const int nb_cbks = SX_FS_KHZ == 8 ? 11 : 3;        // PITCH_EST_NB_CBKS_STAGE2_EXT when 8 kHz is the last stage, else _STAGE2
 #if SX_NLANES == 1
     for (int k = 0; k < length_d_srch; k++) {
@@ -929,6 +932,7 @@ SX_FN1 void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     thr = sx_smlabb(thr, K_0p15_Q15, st->prev_sigtype);
     thr = sx_smlawb(thr, K_m0p1_Q16, c->input_tilt_Q15);
     thr = sx_sat16(thr);
+    SX_S(33)
     c->sigtype = sx_pitch_analysis_core(res, c->pitchL, &c->lagIndex, &c->contourIndex, &st->LTPCorr_Q15, st->prevLag,
                                         K_FIND_PITCH_CORRELATION_THRESHOLD_HC_MODE_Q16, (i16)thr, pw);
 }

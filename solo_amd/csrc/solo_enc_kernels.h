@@ -79,6 +79,9 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
     const unsigned long long hist_t0_ = wall_clock64();
 #endif
+#if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
+    sx_site_hits_[threadIdx.x & 63] = 0;
+#endif
     SX_K(solo_enc_enter)(&w, rec);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
         const size_t pk = (size_t)s * n_packets + p;

@@ -264,17 +264,36 @@ SX_HD void wv_move_down(T* dst, const T* src, int n) {
 #define SX_STRETCH_DENSE()
 #endif
 
-// optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array)
+// optional section timer (debug builds with -DSX_PROF: cycles per section accumulated into a device array), or section STOPS (debug
+// builds with -DSX_STOPS, tools/debug/analysis_sections.py: a wave ends -- s_endpgm, nothing saved -- when it reaches site `id` for
+// the hit-th time of its launch, g_sx_stop = id << 8 | hit; the SQ instruction counters of launches stopped at successive sites,
+// subtracted, are the wave-instructions of each section.  g_sx_stop = 0: the launch runs through and counts the sites it passes)
 #if defined(SX_PROF) && defined(__HIPCC__)
-static __device__ unsigned long long g_sx_prof[32];
+static __device__ unsigned long long g_sx_prof[64];
 static __device__ unsigned long long g_sx_hist[4][64];
+#endif
+#if defined(SX_STOPS) && defined(__HIPCC__)
+static __device__ int g_sx_stop;
+static __device__ unsigned long long g_sx_site_hits[64];
 #endif
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();
 #define SX_T_RESET sx_t_last_ = __builtin_readcyclecounter();
 #define SX_T(id) { unsigned long long t_ = __builtin_readcyclecounter(); if (SX_LANE == 0) atomicAdd(&g_sx_prof[id], t_ - sx_t_last_); sx_t_last_ = __builtin_readcyclecounter(); }
+#elif defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
+static __shared__ unsigned char sx_site_hits_[64];       // (one stream per workgroup; cleared by the kernel wrapper)
+#define SX_T_BEGIN
+#define SX_T_RESET
+#define SX_T(id) { const int h_ = sx_site_hits_[id] + 1; const int stop_ = g_sx_stop; sx_site_hits_[id] = (unsigned char)h_;                \
+        if (stop_ == 0) { if (SX_LANE == 0) atomicAdd(&g_sx_site_hits[id], 1ull); } else if (stop_ == (((id) << 8) | h_)) __builtin_amdgcn_endpgm(); }
 #else
 #define SX_T_BEGIN
 #define SX_T_RESET
 #define SX_T(id)
+#endif
+// (sites that only the stop builds know: finer than the timer's sections)
+#if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
+#define SX_S(id) SX_T(id)
+#else
+#define SX_S(id)
 #endif

@@ -1,0 +1,108 @@
+#!/usr/bin/env python3
+"""Wave-instructions of the analysis kernel, section by section (debug build with -DSX_STOPS, solo_wave.h).
+
+A launch whose waves END at site (id, hit) executes exactly the instructions that precede that site; the SQ instruction counters of
+launches stopped at successive sites, subtracted, are the instructions of each section.  Every wave of a measurement launch encodes the
+SAME packet of the SAME stream (so all of them take the same path and the counters are N x one wave's count); the result is averaged
+over SAMPLES different (stream, packet) pairs.
+
+  on the GPU box (tools/gpu_sections.sh):
+    cd /tmp; SOLO_EXP_SKIP=3 SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_stops.so rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS \
+        SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES -d $OUT/sections -o s --output-format csv -- \
+        python $ROOT/tools/debug/analysis_sections.py run $OUT/sections_plan.json
+    python tools/debug/analysis_sections.py report $OUT/sections_plan.json $OUT/sections > profiles/rNN_analysis_sections.txt
+"""
+import csv, ctypes, glob, json, os, sys
+from collections import defaultdict
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+# what ENDS at each site
+NAMES = {0: "qmf split", 32: "vad", 1: "variable high-pass", 33: "pitch: window, autocorrelation, Schur, whitening filter",
+         34: "pitch: decimation 8 -> 4 kHz, scaling", 35: "pitch: stage 1 (4 kHz correlations, candidates)",
+         36: "pitch: stage 2 correlations (8 kHz)", 2: "pitch: stage 2 search, lags", 37: "noise shape: SNR, sparseness",
+         38: "noise shape: window gains + windowing", 39: "noise shape: warped autocorrelation (4 subframes)",
+         26: "noise shape: Schur .. coefficient limiting (rows)", 3: "noise shape: gains, tilt, harmonic shaping",
+         40: "prefilter: warped analysis filter", 4: "prefilter: FIR, low-frequency + harmonic shaping, history",
+         42: "pred: inverse gains + find_LTP", 43: "pred: quant_LTP_gains", 16: "pred: LTP scale + LTP analysis filter / unvoiced scaling",
+         23: "burg: sum_sqr_shift", 24: "burg: first row of correlations", 25: "burg: recursion", 22: "find_LPC: (after second burg) expand",
+         21: "find_LPC: A2NLSF of the second half", 53: "find_LPC interp: 4 x NLSF2A", 54: "find_LPC interp: 4 whitening filters",
+         18: "find_LPC interp: energies, decision", 17: "find_LPC: final A2NLSF / exit", 46: "NLSF: weights (Laroia)",
+         47: "msvq: stage head (first: codebook staging; later: survivor copy)", 52: "msvq: rate-distortion of the pairs",
+         48: "msvq: sort network + selection rounds", 49: "msvq: survivor threshold", 51: "msvq: new residuals / paths of the last stage",
+         50: "msvq: fluctuation reduction, winner, decode", 19: "NLSF2A x 2 (quantised)", 20: "residual energy", 5: "pred: tail",
+         6: "process gains", 7: "history + hand-over record", 8: "frame end"}
+COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
+NEVER = (63 << 8) | 1
+
+
+def run(plan_path):
+    import numpy as np, torch, solo_amd
+    from solo_amd.synth import synth_stream
+    N = int(os.environ.get("SECTIONS_N", "256"))
+    samples = [(j, 3 + (j % 4)) for j in range(int(os.environ.get("SECTIONS_SAMPLES", "8")))]
+    lib = solo_amd.load_library()
+    lib.solo_debug_stop.argtypes = [ctypes.c_int32]
+    lib.solo_debug_site_hits.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
+    hits = (ctypes.c_ulonglong * 64)()
+    plan, disp = [], 0          # disp = index of the next analysis dispatch (one per packet of every encode call)
+    for j, W in samples:
+        one = synth_stream(j, W + 1)
+        x = torch.from_numpy(np.broadcast_to(one[None], (N, W + 1, 640)).copy()).cuda()
+        warm, last = x[:, :W].contiguous(), x[:, W:].contiguous()
+        b.reset(); lib.solo_debug_stop(0); b.encode(warm); torch.cuda.synchronize(); disp += W
+        lib.solo_debug_site_hits(hits, 1)
+        b.encode(last); torch.cuda.synchronize(); disp += 1
+        lib.solo_debug_site_hits(hits, 1)
+        per = {s: int(hits[s]) // N for s in range(64) if hits[s]}
+        stops = [(s, h) for s, n in per.items() for h in range(1, n + 1)] + [(63, 1)]
+        for s, h in stops:
+            b.reset(); lib.solo_debug_stop(NEVER); b.encode(warm); disp += W
+            lib.solo_debug_stop((s << 8) | h); b.encode(last); torch.cuda.synchronize()
+            plan.append({"sample": j, "warm": W, "site": s, "hit": h, "dispatch": disp}); disp += 1
+        lib.solo_debug_stop(0)
+    json.dump({"n_streams": N, "samples": samples, "plan": plan}, open(plan_path, "w"))
+    print("analysis_sections: %d measurement launches, %d analysis dispatches" % (len(plan), disp))
+
+
+def report(plan_path, prof_dir):
+    P = json.load(open(plan_path))
+    N = P["n_streams"]
+    rows = defaultdict(dict)          # dispatch id -> counter -> value (analysis kernel only)
+    for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if "enc_analysis" in r["Kernel_Name"]:
+                rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = rows[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    order = sorted(rows)
+    per_site = defaultdict(lambda: defaultdict(float))
+    totals = []
+    for j, W in P["samples"]:
+        ms = [m for m in P["plan"] if m["sample"] == j]
+        pts = []
+        for m in ms:
+            c = rows[order[m["dispatch"]]]
+            v = {k: c.get(k, 0.0) / N for k in COUNTERS}
+            pts.append((sum(v.values()), m["site"], m["hit"], v))
+        pts.sort(key=lambda t: t[0])
+        prev = {k: 0.0 for k in COUNTERS}
+        for tot, s, h, v in pts:
+            for k in COUNTERS: per_site[s][k] += v[k] - prev[k]
+            per_site[s]["hits"] += 1
+            prev = v
+        totals.append(pts[-1][0])
+    n = len(P["samples"])
+    print("analysis kernel: wave-instructions per packet by section (mean of %d (stream, packet) samples x %d identical waves; the section" % (n, N))
+    print("ENDS at the named site; SX_STOPS build: + ~8 instructions per site passed).  total %.0f (min %.0f, max %.0f)" % (sum(totals) / n, min(totals), max(totals)))
+    print("%-66s %6s %8s %8s %7s %7s %7s" % ("section", "passes", "all", "VALU", "SALU", "LDS", "mem"))
+    tot_all = sum(totals) / n
+    items = sorted(per_site.items(), key=lambda kv: -sum(kv[1][k] for k in COUNTERS))
+    for s, v in items:
+        allv = sum(v[k] for k in COUNTERS) / n
+        print("%-66s %6.1f %8.0f %8.0f %7.0f %7.0f %7.0f  %4.1f %%" % (NAMES.get(s, "end" if s == 63 else str(s)), v["hits"] / n, allv, v["SQ_INSTS_VALU"] / n,
+              v["SQ_INSTS_SALU"] / n, v["SQ_INSTS_LDS"] / n, (v["SQ_INSTS_SMEM"] + v["SQ_INSTS_VMEM_RD"] + v["SQ_INSTS_VMEM_WR"]) / n, 100.0 * allv / tot_all))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run": run(sys.argv[2])
+    else: report(sys.argv[2], sys.argv[3])

@@ -14,14 +14,14 @@ pcm = torch.from_numpy(synth_batch(0, N, P)).cuda()
 bits, nb, st = b.encode(pcm)
 b.decode(bits, nb, None); torch.cuda.synchronize()
 lib = solo_amd.load_library()
-buf = (ctypes.c_ulonglong * 32)()
+buf = (ctypes.c_ulonglong * 64)()
 lib.solo_debug_prof(buf, 1)
 t0 = torch.cuda.Event(enable_timing=True); t1 = torch.cuda.Event(enable_timing=True)
 t0.record(); b.decode(bits, nb, None); t1.record(); torch.cuda.synchronize()
 lib.solo_debug_prof(buf, 1)
 tot = sum(buf[i] for i in range(8))
 print("decode %.2f ms for %d packets -> %.0f packets/s" % (t0.elapsed_time(t1), N * P, N * P / t0.elapsed_time(t1) * 1e3))
-for i in range(32):
+for i in range(64):
     if buf[i]:
         print("%-22s %8.0f cycles/packet  %5.1f %%" % (NAMES.get(i, str(i)), buf[i] / (N * P), 100.0 * buf[i] / tot))
 print("total %.0f cycles/packet" % (tot / (N * P)))
