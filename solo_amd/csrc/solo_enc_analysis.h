@@ -2065,7 +2065,15 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         i32 mine_v = SX_I32_MAX, mine_i = 0;
         for (int r = 0; r < cur_survivors; r++) {
             const i32 vmin = wv_min(v0);
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
+            // (equal rate-distortion values in two lanes are rare: one lane holds the minimum -> its index is read straight out of it)
+            const unsigned long long tie_ = __builtin_amdgcn_ballot_w64(v0 == vmin);
+            i32 imin;
+            if (__builtin_popcountll(tie_) == 1) imin = __builtin_amdgcn_readlane(i0, __builtin_ctzll(tie_));
+            else imin = wv_min(v0 == vmin ? i0 : SX_I32_MAX);
+#else
             const i32 imin = wv_min(v0 == vmin ? i0 : SX_I32_MAX);
+#endif
             if (v0 == vmin && i0 == imin) { v0 = v1; i0 = i1; v1 = v2; i1 = i2; v2 = v3; i2 = i3; v3 = SX_I32_MAX; i3 = SX_I32_MAX; }
             if (SX_LANE == r) { mine_v = vmin; mine_i = imin; }
         }

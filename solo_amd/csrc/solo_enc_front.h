@@ -155,78 +155,95 @@ SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pS
     SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(X);
     SxVAD* v = &st->vad;
     i16* X0 = X, *X1 = X + 80, *X2 = X + 160, *X3 = X + 240;
-    i32 Xnrg[4], NrgToNoiseRatio_Q8[4];
     sx_ana_filt_bank_1(pIn, v->AnaState, X0, X3, SX_FRAME);
     sx_ana_filt_bank_1(X0, v->AnaState1, X0, X2, SX_FRAME >> 1);
     sx_ana_filt_bank_1(X0, v->AnaState2, X0, X1, SX_FRAME >> 2);
-    // HP filter on lowest band (differentiator)
-    int dfl = SX_FRAME >> 3;
-    X0[dfl - 1] = (i16)(X0[dfl - 1] >> 1);
-    i16 HPstateTmp = X0[dfl - 1];
-    for (int i = dfl - 1; i > 0; i--) {
-        X0[i - 1] = (i16)(X0[i - 1] >> 1);
-        X0[i] = (i16)(X0[i] - X0[i - 1]);
-    }
-    X0[0] = (i16)(X0[0] - (i16)v->HPstate);
-    v->HPstate = HPstateTmp;
-    // band energies
-    for (int b = 0; b < 4; b++) {
-        const i16* Xb = X + 80 * b;
-        int dec_len = SX_FRAME >> sx_min(4 - b, 3);
-        int sub_len = dec_len >> 2, off = 0;
-        i32 sumSquared = 0;
-        Xnrg[b] = v->XnrgSubfr[b];
-        for (int s = 0; s < 4; s++) {
-            sumSquared = 0;
-            for (int i = 0; i < sub_len; i++) {
-                i32 x_tmp = Xb[i + off] >> 3;
-                sumSquared = sx_smlabb(sumSquared, x_tmp, x_tmp);
-            }
-            if (s < 3) Xnrg[b] = sx_add_pos_sat32(Xnrg[b], sumSquared);
-            else Xnrg[b] = sx_add_pos_sat32(Xnrg[b], sumSquared >> 1);
-            off += sub_len;
-        }
-        v->XnrgSubfr[b] = sumSquared;
-    }
-    // noise levels (SKP_Silk_VAD_GetNoiseLevels, VAD.c:260)
+    // HP filter on lowest band (differentiator): h[i] = X0[i] >> 1, X0[i] = h[i] - h[i - 1] (h[-1] = the state), state = h[last]
+    const int dfl = SX_FRAME >> 3;
+    static_assert((SX_FRAME >> 3) % 2 == 0 && (SX_FRAME >> 3) + 2 * 16 <= 80, "the tail of X0 (its band is SX_FRAME / 8 long by now) is the scratch of the band statistics");
+    i32* part = (i32*)(X + dfl);
+#if SX_NLANES == 1
     {
-        i32 min_coef = v->counter < 1000 ? 32767 / ((v->counter >> 4) + 1) : 0;
-        for (int k = 0; k < 4; k++) {
-            i32 nl = v->NL[k];
-            i32 nrg = sx_add_pos_sat32(Xnrg[k], v->NoiseLevelBias[k]);
-            i32 inv_nrg = SX_I32_MAX / nrg;
+        X0[dfl - 1] = (i16)(X0[dfl - 1] >> 1);
+        const i16 HPstateTmp = X0[dfl - 1];
+        for (int i = dfl - 1; i > 0; i--) {
+            X0[i - 1] = (i16)(X0[i - 1] >> 1);
+            X0[i] = (i16)(X0[i] - X0[i - 1]);
+        }
+        X0[0] = (i16)(X0[0] - (i16)v->HPstate);
+        v->HPstate = HPstateTmp;
+    }
+#else
+    {
+        static_assert((SX_FRAME >> 3) <= 64, "one sample of the lowest band per lane");
+        const int i = SX_LANE < dfl ? SX_LANE : 0;
+        const i16 h = (i16)(X0[i] >> 1), hm = (i16)(i > 0 ? X0[i - 1] >> 1 : (i16)v->HPstate);
+        wv_sync();
+        if (SX_LANE < dfl) X0[i] = (i16)(h - hm);
+        if (SX_LANE == dfl - 1) v->HPstate = h;
+        wv_sync();
+    }
+#endif
+    // band energies: lane (b, s) sums the squares of quarter s of band b (a wrapping 32-bit sum: the order is free) ...
+    SX_PAR(t, 16) {
+        const int b = t >> 2, q = t & 3;
+        const int sub_len = (SX_FRAME >> sx_min(4 - b, 3)) >> 2;
+        const i16* Xb = X + 80 * b + q * sub_len;
+        i32 sum = 0;
+        for (int i = 0; i < sub_len; i++) {
+            const i32 x_tmp = Xb[i] >> 3;
+            sum = sx_smlabb(sum, x_tmp, x_tmp);
+        }
+        part[t] = sum;
+    }
+    wv_sync();
+    // ... and lane b folds its band's four with the reference's saturating adds, then runs the band's noise-level tracker
+    // (SKP_Silk_VAD_GetNoiseLevels, VAD.c:260) and signal-to-noise terms; the sums over the bands are wrapping adds of per-band terms
+    const i32 min_coef = v->counter < 1000 ? 32767 / ((v->counter >> 4) + 1) : 0;
+    SX_PAR(b, 4) {
+        i32 e = v->XnrgSubfr[b];
+        for (int q = 0; q < 3; q++) e = sx_add_pos_sat32(e, part[4 * b + q]);
+        const i32 last = part[4 * b + 3];
+        e = sx_add_pos_sat32(e, last >> 1);
+        v->XnrgSubfr[b] = last;
+        i32 nl = v->NL[b];
+        {
+            const i32 nrg = sx_add_pos_sat32(e, v->NoiseLevelBias[b]);
+            const i32 inv_nrg = SX_I32_MAX / nrg;
             i32 coef;
             if (nrg > sx_shl(nl, 3)) coef = 1024 >> 3;
             else if (nrg < nl) coef = 1024;
             else coef = sx_smulwb(sx_smulww(inv_nrg, nl), 1024 << 1);
             coef = sx_max(coef, min_coef);
-            v->inv_NL[k] = sx_smlawb(v->inv_NL[k], inv_nrg - v->inv_NL[k], coef);
-            nl = SX_I32_MAX / v->inv_NL[k];
+            v->inv_NL[b] = sx_smlawb(v->inv_NL[b], inv_nrg - v->inv_NL[b], coef);
+            nl = SX_I32_MAX / v->inv_NL[b];
             nl = sx_min(nl, 0x00FFFFFF);
-            v->NL[k] = nl;
+            v->NL[b] = nl;
         }
-        v->counter++;
+        i32 ratio = 256, sq = 0, tilt = 0;
+        const i32 speech_nrg_b = e - nl;
+        if (speech_nrg_b > 0) {
+            if ((e & 0xFF800000) == 0) ratio = sx_shl(e, 8) / (nl + 1);
+            else ratio = e / ((nl >> 8) + 1);
+            i32 SNR_Q7 = sx_lin2log(ratio) - 8 * 128;
+            sq = sx_smulbb(SNR_Q7, SNR_Q7);
+            if (speech_nrg_b < (1 << 20)) SNR_Q7 = sx_smulwb(sx_shl(sx_sqrt_approx(speech_nrg_b), 6), SNR_Q7);
+            tilt = sx_smulwb(T_vad_tilt_weights[b], SNR_Q7);
+        }
+        part[4 * b] = ratio; part[4 * b + 1] = sq; part[4 * b + 2] = tilt; part[4 * b + 3] = (b + 1) * (speech_nrg_b >> 4);
     }
-    i32 sumSquared = 0, input_tilt = 0;
+    v->counter++;
+    wv_sync();
+    i32 sumSquared = 0, input_tilt = 0, speech_nrg = 0;
     for (int b = 0; b < 4; b++) {
-        i32 speech_nrg = Xnrg[b] - v->NL[b];
-        if (speech_nrg > 0) {
-            if ((Xnrg[b] & 0xFF800000) == 0) NrgToNoiseRatio_Q8[b] = sx_shl(Xnrg[b], 8) / (v->NL[b] + 1);
-            else NrgToNoiseRatio_Q8[b] = Xnrg[b] / ((v->NL[b] >> 8) + 1);
-            i32 SNR_Q7 = sx_lin2log(NrgToNoiseRatio_Q8[b]) - 8 * 128;
-            sumSquared = sx_smlabb(sumSquared, SNR_Q7, SNR_Q7);
-            if (speech_nrg < (1 << 20)) SNR_Q7 = sx_smulwb(sx_shl(sx_sqrt_approx(speech_nrg), 6), SNR_Q7);
-            input_tilt = sx_smlawb(input_tilt, T_vad_tilt_weights[b], SNR_Q7);
-        } else {
-            NrgToNoiseRatio_Q8[b] = 256;
-        }
+        sumSquared = sx_add(sumSquared, part[4 * b + 1]);
+        input_tilt = sx_add(input_tilt, part[4 * b + 2]);
+        speech_nrg = sx_add(speech_nrg, part[4 * b + 3]);
     }
     sumSquared = sumSquared / 4;
     *pSNR_dB_Q7 = (i16)(3 * sx_sqrt_approx(sumSquared));
     i32 SA_Q15 = sx_sigm_Q15(sx_smulwb(45000, *pSNR_dB_Q7) - 128);
     c->input_tilt_Q15 = sx_shl(sx_sigm_Q15(input_tilt) - 16384, 1);
-    i32 speech_nrg = 0;
-    for (int b = 0; b < 4; b++) speech_nrg += (b + 1) * ((Xnrg[b] - v->NL[b]) >> 4);
     if (speech_nrg <= 0) {
         SA_Q15 = SA_Q15 >> 1;
     } else if (speech_nrg < 32768) {
@@ -235,11 +252,12 @@ SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pS
     }
     st->speech_activity_Q8 = sx_min(SA_Q15 >> 7, 255);
     i32 smooth_coef_Q16 = (i16)sx_smulwb(4096, sx_smulwb(SA_Q15, SA_Q15));
-    for (int b = 0; b < 4; b++) {
-        v->NrgRatioSmth_Q8[b] = sx_smlawb(v->NrgRatioSmth_Q8[b], NrgToNoiseRatio_Q8[b] - v->NrgRatioSmth_Q8[b], smooth_coef_Q16);
+    SX_PAR(b, 4) {
+        v->NrgRatioSmth_Q8[b] = sx_smlawb(v->NrgRatioSmth_Q8[b], part[4 * b] - v->NrgRatioSmth_Q8[b], smooth_coef_Q16);
         i32 SNR_Q7 = 3 * (sx_lin2log(v->NrgRatioSmth_Q8[b]) - 8 * 128);
         c->input_quality_bands_Q15[b] = sx_sigm_Q15((SNR_Q7 - 16 * 128) >> 4);
     }
+    wv_sync();
 }
 
 // SKP_Silk_HP_variable_cutoff_FIX (HP_variable_cutoff_FIX.c:37) + SKP_Silk_biquad_alt (biquad_alt.c:38)

@@ -173,13 +173,29 @@ SX_HD i32 sx_log2lin(i32 inLog_Q7) {
     if (inLog_Q7 < 2048) return sx_add(out, sx_mul(out, p) >> 7);
     return sx_add(out, sx_mul(out >> 7, p));
 }
+// (INT32_MAX >> 2) / d, C division, for the normalised divisor of DIV32_varQ / INVERSE32_varQ below (Inlines.h:136, :182): 16384 <= |d| <= 32768
+SX_HD i32 sx_div_q29(i32 d) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    // the compiler's generic signed 32-bit division is ~30 instructions.  The quotient is at most 2^15 here, so a single-precision
+    // reciprocal estimate is off by far less than one, and one exact remainder check either way restores the truncated quotient
+    // (tests/test_l0_primitives.py runs every divisor of the domain on the device)
+    const i32 ad = d < 0 ? -d : d;
+    i32 q = (i32)(536870912.0f * __builtin_amdgcn_rcpf((float)ad));
+    const i32 r = (SX_I32_MAX >> 2) - q * ad;
+    q += r >= ad ? 1 : 0;
+    q -= r < 0 ? 1 : 0;
+    return d < 0 ? -q : q;
+#else
+    return (SX_I32_MAX >> 2) / d;
+#endif
+}
 // SKP_DIV32_varQ (Inlines.h:124)
 SX_HD i32 sx_div32_varQ(i32 a32, i32 b32, int Qres) {
     int a_headrm = sx_clz32(sx_abs(a32)) - 1;
     i32 a_nrm = sx_shl(a32, a_headrm);
     int b_headrm = sx_clz32(sx_abs(b32)) - 1;
     i32 b_nrm = sx_shl(b32, b_headrm);
-    i32 b_inv = (SX_I32_MAX >> 2) / (b_nrm >> 16);
+    i32 b_inv = sx_div_q29(b_nrm >> 16);
     i32 result = sx_smulwb(a_nrm, b_inv);
     a_nrm = sx_sub(a_nrm, sx_shl(sx_smmul(b_nrm, result), 3));
     result = sx_smlawb(result, a_nrm, b_inv);
@@ -191,7 +207,7 @@ SX_HD i32 sx_div32_varQ(i32 a32, i32 b32, int Qres) {
 SX_HD i32 sx_inverse32_varQ(i32 b32, int Qres) {
     int b_headrm = sx_clz32(sx_abs(b32)) - 1;
     i32 b_nrm = sx_shl(b32, b_headrm);
-    i32 b_inv = (SX_I32_MAX >> 2) / (b_nrm >> 16);
+    i32 b_inv = sx_div_q29(b_nrm >> 16);
     i32 result = sx_shl(b_inv, 16);
     i32 err_Q32 = sx_shl(sx_neg(sx_smulwb(b_nrm, b_inv)), 3);
     result = sx_smlaww(result, err_Q32, b_inv);

@@ -189,6 +189,25 @@ def test_l0_vocabulary_gfx950_vs_reference_macros():
 
 
 @pytest.mark.gpu
+def test_varq_reciprocal_gfx950_every_divisor():
+    """sx_div_q29 (solo_fix.h): the device form -- reciprocal estimate + exact remainder correction -- of (INT32_MAX >> 2) / d, the C
+    division inside SKP_DIV32_varQ / SKP_INVERSE32_varQ (Inlines.h:136, :182), for EVERY divisor the normalisation can produce"""
+    import torch
+    import solo_amd
+    lib = solo_amd.load_library()
+    lib.solo_debug_l0.restype = C.c_int32
+    lib.solo_debug_l0.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    d = np.concatenate([np.arange(16384, 32769), -np.arange(16384, 32769)]).astype(np.int32)
+    want = (np.sign(d.astype(np.int64)) * (0x1FFFFFFF // np.abs(d.astype(np.int64)))).astype(np.int32)      # C division truncates
+    dd = torch.from_numpy(d).cuda()
+    out = torch.zeros(d.size, dtype=torch.int32, device="cuda")
+    assert lib.solo_debug_l0(33, d.size, dd.data_ptr(), dd.data_ptr(), dd.data_ptr(), out.data_ptr()) == 0
+    got = out.cpu().numpy()
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (int(d[bad[0]]), int(got[bad[0]]), int(want[bad[0]]))
+
+
+@pytest.mark.gpu
 @need_ref
 def test_sum_sqr_shift_wave_form_gfx950_vs_reference():
     """the wave-cooperative saturating-scan form of SKP_Silk_sum_sqr_shift (solo_common.h) against the reference function"""
