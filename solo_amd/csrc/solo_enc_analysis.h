@@ -177,25 +177,38 @@ SX_HD void sx_warped_autocorr4(SxShapeWork* sw, i32 warping_Q16) {
         const i32 lam = sx_pre16(warping_Q16);
         i32 pin = 0, pout = 0, out = 0;
         i32 xn = j == 0 ? (i32)sw->xw[k][0] : 0;
-        for (int t = 0; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) {
-            const int n = t - j;
-            const i32 xcur = xn;
-            {
-                const int nn = n + 1;
-                xn = (nn >= 0 && nn < SX_SHAPE_WIN) ? (i32)sw->xw[k][nn] : 0;
-            }
-            const i32 in_prev = SX_DPP_(out, 0x111);
-            if (n >= 0 && n < SX_SHAPE_WIN) {
+        // the first and last 15 steps: only the sections whose sample lies inside the window work
+#define SX_WA_EDGE_STEP                                                                                         \
+        {   const int n = t - j;                                                                                \
+            const i32 xcur = xn;                                                                                \
+            { const int nn = n + 1; xn = (nn >= 0 && nn < SX_SHAPE_WIN) ? (i32)sw->xw[k][nn] : 0; }             \
+            const i32 in_prev = SX_DPP_(out, 0x111);                                                            \
+            if (n >= 0 && n < SX_SHAPE_WIN) {                                                                   \
+                const i32 x0 = sx_shl(xcur, 14);                                                                \
+                const i32 in = j == 0 ? x0 : in_prev;                                                           \
+                const i32 o = sx_smlaw_pre(pin, pout - in, lam);                                                \
+                acc_l += sx_smull(in, x0) >> 18;                                                                \
+                if (j == SX_SHAPE_ORDER - 1) acc16_l += sx_smull(o, x0) >> 18;                                  \
+                pin = in; pout = o; out = o;                                                                    \
+            }                                                                                                   \
+        }
+        for (int t = 0; t < SX_SHAPE_ORDER - 1; t++) SX_WA_EDGE_STEP
+        {   // steps 15 .. SX_SHAPE_WIN - 1: every section holds a sample of the window -- no range checks, section 0's input comes in
+            // through the DPP move's `old` operand, every lane accumulates the last correlation (only section 15's is kept)
+            const i16* xp = &sw->xw[k][0] - j + 1;                      // xp[t] = x(n + 1) of step t
+            for (int t = SX_SHAPE_ORDER - 1; t < SX_SHAPE_WIN; t++) {
+                const i32 xcur = xn;
+                xn = (i32)xp[t];
                 const i32 x0 = sx_shl(xcur, 14);
-                const i32 in = j == 0 ? x0 : in_prev;
+                const i32 in = __builtin_amdgcn_update_dpp(x0, out, 0x111, 0xF, 0xF, false);
                 const i32 o = sx_smlaw_pre(pin, pout - in, lam);
                 acc_l += sx_smull(in, x0) >> 18;
-                if (j == SX_SHAPE_ORDER - 1) acc16_l += sx_smull(o, x0) >> 18;
-                pin = in;
-                pout = o;
-                out = o;
+                acc16_l += sx_smull(o, x0) >> 18;
+                pin = in; pout = o; out = o;
             }
         }
+        for (int t = SX_SHAPE_WIN; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) SX_WA_EDGE_STEP
+#undef SX_WA_EDGE_STEP
     }
     {
         const int k = SX_LANE >> 4, j = SX_LANE & 15;

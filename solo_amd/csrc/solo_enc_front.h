@@ -79,9 +79,11 @@ SX_HD void sx_allpass2_lanes(const i16* in, int npairs, i32* S, i32 cA, i32 cB, 
                 const i32 X = sx_add(sx_smulw_pre(Y, cpre), Y & mask);
                 const i32 o = sx_add(s, X);
                 s = sx_add(in32, X);
-                const i32 p = SX_DPP_(o, 0xB1);       // the other chain's output (quad_perm [1,0,3,2])
-                const i32 v = l ? sx_sub(o, p) : sx_add(p, o);
-                op[k + u] = (i16)sx_sat16(sx_rshift_round(v, 11));
+                // lane 0 stores o1 + o0, lane 1 o1 - o0: each lane hands the other what that one has to ADD (quad_perm [1,0,3,2]).
+                // |in32| <= 2^25 and the sections are all-pass: |o| < 2^28, so the rounding cannot overflow (sx_rshift_round_small)
+                const i32 p = SX_DPP_(l ? o : sx_neg(o), 0xB1);
+                const i32 v = sx_add(o, p);
+                op[k + u] = (i16)sx_sat16(sx_rshift_round_small(v, 11));
             }
         }
         if (S) S[l] = s;
@@ -296,7 +298,7 @@ SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const 
 #ifdef SX_LANE_STREAM
     // The three products with the input sample feed nothing back: they are formed for the whole frame at once, lane-parallel.
     // What remains of the recursion per sample -- the two products with the new output and their rounding -- runs on the vector
-    // unit of ONE lane (SX_VEC: see sx_allpass2_lanes), reading its input terms 16 bytes at a time and storing the output sample.
+    // unit (SX_VEC: see sx_allpass2_lanes), reading its input terms 16 bytes at a time and storing the output sample.
     {
         SxV4i* bx = (SxV4i*)scratch;
         const i32 b0p = B0, b1p = B1, b2p = B2;
@@ -307,31 +309,37 @@ SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const 
             bx[k] = v;
         }
         wv_sync();
-        if (SX_LANE == 0) {
+        {
+            // the four products with the new output are taken by the four lanes of a quad (every quad of the wave runs the same
+            // recursion; their stores coincide): lane q multiplies by its coefficient (A0_L, A0_U, A1_L, A1_U), the _L lanes round
+            // their product by 14 bits ((m + 2^13) >> 14 = RSHIFT_ROUND(m, 14): |m| < 2^29, the coefficient has 14 bits), lane pairs
+            // add up, and both sums go back to all four lanes (quad_perm broadcasts), which keep the two states replicated
+            const int q = SX_LANE & 3;
             i32 s0 = S0, s1 = S1;
-            i32 a0l = sx_pre16(A0_L), a0u = sx_pre16(A0_U), a1l = sx_pre16(A1_L), a1u = sx_pre16(A1_U);
-            SX_VEC(s0); SX_VEC(s1); SX_VEC(a0l); SX_VEC(a0u); SX_VEC(a1l); SX_VEC(a1u);
+            i32 coef = sx_pre16(q == 0 ? A0_L : (q == 1 ? A0_U : (q == 2 ? A1_L : A1_U)));
+            i32 radd = (q & 1) ? 0 : (1 << 13), rsh = (q & 1) ? 0 : 14;
+            SX_VEC(s0); SX_VEC(s1); SX_VEC(coef); SX_VEC(radd); SX_VEC(rsh);
             SxV4i cur = bx[0];
 #pragma unroll 4
             for (int k = 0; k < SX_FRAME; k++) {
                 const SxV4i t = cur;
                 cur = bx[k + 1];
                 const i32 out32_Q14 = sx_shl(sx_add(s0, t.v[0]), 2);
-                // (SX_VEC on each high word: the compiler would otherwise fuse the rounding shift into a 64-bit product -- low word,
+                // (SX_VEC on the high word: the compiler would otherwise fuse the rounding shift into a 64-bit product -- low word,
                 // unsigned high word and sign corrections -- three times the instructions of v_mul_hi_i32 + shift)
-                i32 m0 = sx_smulw_pre(out32_Q14, a0l), m1 = sx_smulw_pre(out32_Q14, a1l), u0 = sx_smulw_pre(out32_Q14, a0u), u1 = sx_smulw_pre(out32_Q14, a1u);
-                SX_VEC(m0); SX_VEC(m1); SX_VEC(u0); SX_VEC(u1);
-                i32 n0 = sx_add(s1, sx_rshift_round(m0, 14));
-                n0 = sx_add(n0, u0);
-                n0 = sx_add(n0, t.v[1]);
-                i32 n1 = sx_rshift_round(m1, 14);
-                n1 = sx_add(n1, u1);
-                n1 = sx_add(n1, t.v[2]);
+                i32 p = sx_smulw_pre(out32_Q14, coef);
+                SX_VEC(p);
+                const i32 r = sx_add(p, radd) >> rsh;
+                const i32 w = sx_add(r, SX_DPP_(r, 0xB1));                                   // lanes 0, 1: round(m0) + u0; lanes 2, 3: round(m1) + u1
+                const i32 n0 = sx_add(sx_add(s1, t.v[1]), SX_DPP_(w, 0x00));
+                const i32 n1 = sx_add(t.v[2], SX_DPP_(w, 0xAA));
                 s0 = n0; s1 = n1;
                 out[k] = (i16)sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14);
             }
-            st->In_HP_State[0] = s0;
-            st->In_HP_State[1] = s1;
+            if (SX_LANE == 0) {
+                st->In_HP_State[0] = s0;
+                st->In_HP_State[1] = s1;
+            }
         }
         wv_sync();
         return;

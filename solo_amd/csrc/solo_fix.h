@@ -103,6 +103,8 @@ SX_HD i32 sx_smulbt(i32 a, i32 b) { return sx_mul((i32)(i16)a, b >> 16); }
 SX_HD i32 sx_smultt(i32 a, i32 b) { return sx_mul(a >> 16, b >> 16); }
 // SKP_RSHIFT_ROUND (SigProc_FIX.h:592); shift >= 1
 SX_HD i32 sx_rshift_round(i32 a, int s) { return s == 1 ? sx_add(a >> 1, a & 1) : (sx_add(a >> (s - 1), 1) >> 1); }
+// ... in two instructions where a + 2^(s-1) cannot overflow (|a| < 2^30): floor((floor(a / 2^(s-1)) + 1) / 2) = floor((a + 2^(s-1)) / 2^s)
+SX_HD i32 sx_rshift_round_small(i32 a, int s) { return sx_add(a, 1 << (s - 1)) >> s; }
 SX_HD i64 sx_rshift_round64(i64 a, int s) { return s == 1 ? (a >> 1) + (a & 1) : (((a >> (s - 1)) + 1) >> 1); }
 // SKP_SMULWW = MLA(SMULWB(a,b), a, RSHIFT_ROUND(b,16))   (macros.h:61) -- NOT a plain 64-bit product
 // SKP_SMULWW = SMULWB(a,b) + a * RSHIFT_ROUND(b,16) (32-bit wrapping) is exactly the low word of (a * b) >> 16

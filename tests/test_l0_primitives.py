@@ -115,6 +115,10 @@ def test_derived_forms_equal_their_definitions():
         return out
     assert np.array_equal(run(30, a, b, c), run(0, a, b, c))
     assert np.array_equal(run(31, a, b, c), run(3, a, b, c))
+    # the two-instruction rounding shift equals RSHIFT_ROUND wherever a + 2^(s-1) cannot overflow (|a| < 2^30)
+    aa = np.clip(a.astype(np.int64), -(1 << 30) + 1, (1 << 30) - 1).astype(np.int32)
+    ss = (1 + (np.abs(b.astype(np.int64)) % 29)).astype(np.int32)
+    assert np.array_equal(run(34, aa, ss, c), run(9, aa, ss, c))
     seeds = a[:64].copy()
     steps = np.arange(64, dtype=np.int32) * 8
     want = seeds.copy()
