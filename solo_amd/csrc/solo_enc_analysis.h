@@ -883,17 +883,20 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
 // LTP analysis
 // ---------------------------------------------------------------------------------------------------
 // SKP_Silk_corrMatrix_FIX + corrVector_FIX, SKP_Silk_corrMatrix_FIX.c:35-152 (order 5, L = 40)
-SX_FN1 void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* XX, i32* rshifts, int x_odd) {
-    SX_IN_LDS(x); SX_IN_LDS(XX);
+// The inner products over the L samples -- the first column of the matrix and the whole vector: 9 per subframe, 4 x 9 of the
+// frame -- are taken side by side (one lane each) between the energy part and the recurrences along the diagonals, which stay with
+// the subframe's lane.
+// part 1: energy of x, the right shift of all correlations of the subframe, the main diagonal
+SX_HD int sx_corr_matrix_diag(const i16* x, int L, int order, int head_room, i32* XX, int rshifts_in, int x_odd) {
     i32 energy, rshifts_local;
     sx_sum_sqr_shift(&energy, &rshifts_local, x, L + order - 1, x_odd);
     int head_room_rshifts = sx_max(head_room - sx_clz32(energy), 0);
     energy = energy >> head_room_rshifts;
     rshifts_local += head_room_rshifts;
     for (int i = 0; i < order - 1; i++) energy -= sx_smulbb(x[i], x[i]) >> rshifts_local;
-    if (rshifts_local < *rshifts) {
-        energy = energy >> (*rshifts - rshifts_local);
-        rshifts_local = *rshifts;
+    if (rshifts_local < rshifts_in) {
+        energy = energy >> (rshifts_in - rshifts_local);
+        rshifts_local = rshifts_in;
     }
     XX[0] = energy;
     const i16* ptr1 = &x[order - 1];
@@ -902,14 +905,24 @@ SX_FN1 void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* X
         energy = sx_add(energy, sx_smulbb(ptr1[-j], ptr1[-j]) >> rshifts_local);
         XX[j * order + j] = energy;
     }
+    return rshifts_local;
+}
+// inner product m of a subframe: m < order - 1: x[order-1 ..] . x[order-1-lag ..], lag = m + 1 (matrix, corrMatrix_FIX.c:118);
+// m >= order - 1: x[order-1-lag ..] . t, lag = m - (order - 1) (vector, corrMatrix_FIX.c:35).  Every term is shifted before it
+// is added (no shift: the reference's wrapping multiply-accumulate)
+SX_HD i32 sx_corr_inner(const i16* x, const i16* t, int L, int order, int m, int rshifts) {
+    const i16* pa = m < order - 1 ? &x[order - 1] : &x[order - 1 - (m - (order - 1))];
+    const i16* pb = m < order - 1 ? &x[order - 2 - m] : t;
+    i32 acc = 0;
+    for (int i = 0; i < L; i++) acc = sx_add(acc, sx_smulbb(pa[i], pb[i]) >> rshifts);
+    return acc;
+}
+// part 2: the off-diagonals from their first elements ip[lag - 1]
+SX_HD void sx_corr_matrix_off(const i16* x, int L, int order, i32* XX, int rshifts_local, const i32* ip) {
+    const i16* ptr1 = &x[order - 1];
     const i16* ptr2 = &x[order - 2];
     for (int lag = 1; lag < order; lag++) {
-        energy = 0;
-        if (rshifts_local > 0) {
-            for (int i = 0; i < L; i++) energy += sx_smulbb(ptr1[i], ptr2[i]) >> rshifts_local;
-        } else {
-            for (int i = 0; i < L; i++) energy = sx_smlabb(energy, ptr1[i], ptr2[i]);
-        }
+        i32 energy = ip[lag - 1];
         XX[lag * order] = energy;
         XX[lag] = energy;
         for (int j = 1; j < order - lag; j++) {
@@ -919,20 +932,6 @@ SX_FN1 void sx_corr_matrix(const i16* x, int L, int order, int head_room, i32* X
             XX[j * order + lag + j] = energy;
         }
         ptr2--;
-    }
-    *rshifts = rshifts_local;
-}
-SX_HD void sx_corr_vector(const i16* x, const i16* t, int L, int order, i32* Xt, int rshifts) {
-    const i16* ptr1 = &x[order - 1];
-    for (int lag = 0; lag < order; lag++) {
-        i32 ip = 0;
-        if (rshifts > 0) {
-            for (int i = 0; i < L; i++) ip += sx_smulbb(ptr1[i], t[i]) >> rshifts;
-        } else {
-            for (int i = 0; i < L; i++) ip = sx_smlabb(ip, ptr1[i], t[i]);
-        }
-        Xt[lag] = ip;
-        ptr1--;
     }
 }
 
@@ -1027,6 +1026,7 @@ struct SxLtpWork {                   // LDS scratch of the LTP analysis: subfram
     i32 b_Q16[SX_NB_SUBFR][SX_LTP_ORDER], Rr[SX_NB_SUBFR][SX_LTP_ORDER], delta_b_Q14[SX_NB_SUBFR][SX_LTP_ORDER];
     i32 rr[SX_NB_SUBFR], nrg[SX_NB_SUBFR], w[SX_NB_SUBFR], corr_rshifts[SX_NB_SUBFR], d_Q14[SX_NB_SUBFR];
     i32 ldl[SX_NB_SUBFR][50];
+    i32 ip[SX_NB_SUBFR][2 * SX_LTP_ORDER - 1], rr_shifts[SX_NB_SUBFR];
 };
 
 // SKP_Silk_find_LTP_FIX, SKP_Silk_find_LTP_FIX.c:39.  res_pitch: LPC residual buffer (336 samples)
@@ -1040,10 +1040,7 @@ SX_FN1 void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16*
     i32* rr = lw->rr;
     i32* corr_rshifts = lw->corr_rshifts;
     SX_PAR(k, SX_NB_SUBFR) {
-        i16* b_Q14_ptr = b_Q14 + k * SX_LTP_ORDER;
         i32* WLTP_ptr = WLTP + k * 25;
-        i32* Rr = lw->Rr[k];
-        i32* b_Q16 = lw->b_Q16[k];
         const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;     // r_first / r_last of the reference address one timeline
         const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
         i32 rr_shifts, rrk;
@@ -1053,9 +1050,28 @@ SX_FN1 void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16*
             rrk = sx_rshift_round(rrk, HEAD - LZs);
             rr_shifts += HEAD - LZs;
         }
-        i32 crs = rr_shifts;
-        sx_corr_matrix(lag_ptr, subfr_length, SX_LTP_ORDER, HEAD, WLTP_ptr, &crs, lag[k] & 1);
-        sx_corr_vector(lag_ptr, r_ptr, subfr_length, SX_LTP_ORDER, Rr, crs);
+        corr_rshifts[k] = sx_corr_matrix_diag(lag_ptr, subfr_length, SX_LTP_ORDER, HEAD, WLTP_ptr, rr_shifts, lag[k] & 1);
+        rr[k] = rrk;
+        lw->rr_shifts[k] = rr_shifts;
+    }
+    wv_sync();
+    SX_PAR(t, SX_NB_SUBFR * (2 * SX_LTP_ORDER - 1)) {
+        const int k = t / (2 * SX_LTP_ORDER - 1), m = t - k * (2 * SX_LTP_ORDER - 1);
+        const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;
+        lw->ip[k][m] = sx_corr_inner(r_ptr - (lag[k] + SX_LTP_ORDER / 2), r_ptr, subfr_length, SX_LTP_ORDER, m, corr_rshifts[k]);
+    }
+    wv_sync();
+    SX_PAR(k, SX_NB_SUBFR) {
+        i16* b_Q14_ptr = b_Q14 + k * SX_LTP_ORDER;
+        i32* WLTP_ptr = WLTP + k * 25;
+        i32* Rr = lw->Rr[k];
+        i32* b_Q16 = lw->b_Q16[k];
+        const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;
+        const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
+        const i32 rr_shifts = lw->rr_shifts[k], crs = corr_rshifts[k];
+        i32 rrk = rr[k];
+        sx_corr_matrix_off(lag_ptr, subfr_length, SX_LTP_ORDER, WLTP_ptr, crs, lw->ip[k]);
+        for (int i = 0; i < SX_LTP_ORDER; i++) Rr[i] = lw->ip[k][SX_LTP_ORDER - 1 + i];
         if (crs > rr_shifts) rrk = rrk >> (crs - rr_shifts);
         i32 regu = 1;
         regu = sx_smlawb(regu, rrk, K_LTP_DAMPING_DIV3_Q16);
@@ -1364,6 +1380,8 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         i32 Af_k = 0, Cf_k = bw->Cf[k], Cl_k = Cf_k;
         i32 CAf_k = k == 0 ? CA0 : 0, CAb_k = CAf_k;
         const bool hi = rshifts > -2;
+        // element index of step (c)'s gather, gidx_a + (n & gidx_n): rows 0, 1: n - k - 1; row 2: n - k; row 3: k + 1
+        const int gidx_a = row < 2 ? -k - 1 : (row == 2 ? -k : k + 1), gidx_n = row < 3 ? -1 : 0;
 #define SX_GATHER(v, idx) __shfl((v), rowbase | ((idx) & 15), 64)
         for (int n = 0; n < D; n++) {
             // (a) forward / backward prediction errors at the two edges of subframe `row`
@@ -1413,26 +1431,24 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
                 if (k < n) { Cf_k = sx_add(Cf_k, dcf); Cl_k = sx_add(Cl_k, dcl); }
                 if (k <= n) { CAf_k = sx_add(CAf_k, dcaf); CAb_k = sx_add(CAb_k, dcab); }
             }
-            // (c) reflection coefficient: numerator / denominator terms of column k < n
-            i32 p1 = 0, p2 = 0, q3 = 0, q4 = 0;
+            // (c) reflection coefficient: numerator / denominator terms of column k < n.  The four sums over k (against the reversed
+            // Cl, Cf, CAb and the shifted CAb + CAf) are taken by the four rows, one each: the rows hold identical copies of the vectors
+            i32 s1, s2, num, den;
             {
-                const i32 Cl_r = SX_GATHER(Cl_k, n - k - 1), Cf_r = SX_GATHER(Cf_k, n - k - 1), CAb_r = SX_GATHER(CAb_k, n - k);
-                const i32 CA_next = SX_GATHER(sx_add(CAb_k, CAf_k), k + 1);
+                const i32 src = row < 2 ? (row == 0 ? Cl_k : Cf_k) : (row == 2 ? CAb_k : sx_add(CAb_k, CAf_k));
+                const i32 g = SX_GATHER(src, gidx_a + (n & gidx_n));
+                i32 pq = 0;
                 if (k < n) {
                     int lz = sx_clz32(sx_abs(Af_k)) - 1;
                     lz = sx_min(32 - QA, lz);
-                    const i32 Atmp1 = sx_shl(Af_k, lz);
-                    const int sh = 32 - QA - lz;
-                    p1 = sx_shl(sx_smmul(Cl_r, Atmp1), sh);
-                    p2 = sx_shl(sx_smmul(Cf_r, Atmp1), sh);
-                    q3 = sx_shl(sx_smmul(CAb_r, Atmp1), sh);
-                    q4 = sx_shl(sx_smmul(CA_next, Atmp1), sh);
+                    pq = sx_shl(sx_smmul(g, sx_shl(Af_k, lz)), 32 - QA - lz);
                 }
+                const i32 tot = wv_row_sum(pq);
+                s1 = sx_add(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(Cf_k, n));
+                s2 = sx_add(__builtin_amdgcn_readlane(tot, 16), __builtin_amdgcn_readlane(Cl_k, n));
+                num = __builtin_amdgcn_readlane(tot, 32);
+                den = sx_add(__builtin_amdgcn_readlane(tot, 48), sx_add(__builtin_amdgcn_readlane(CAb_k, 0), __builtin_amdgcn_readlane(CAf_k, 0)));
             }
-            const i32 s1 = sx_add(SX_UNI(wv_row_sum(p1)), __builtin_amdgcn_readlane(Cf_k, n));
-            const i32 s2 = sx_add(SX_UNI(wv_row_sum(p2)), __builtin_amdgcn_readlane(Cl_k, n));
-            i32 num = SX_UNI(wv_row_sum(q3));
-            const i32 den = sx_add(SX_UNI(wv_row_sum(q4)), sx_add(__builtin_amdgcn_readlane(CAb_k, 0), __builtin_amdgcn_readlane(CAf_k, 0)));
             if (k == n + 1) { CAf_k = s1; CAb_k = s2; }
             num = sx_add(num, s2);
             num = sx_shl(sx_neg(num), 1);

@@ -83,9 +83,23 @@ SX_HD i32 wv_col_sum(i32 v) {
     return sx_add((i32)b[0], (i32)b[1]);
 }
 #endif
+#if SX_NLANES == 64
+// the four row results folded with the two row-broadcast DPP steps of gfx9 (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and
+// 3: lane 63 then holds the wave's result) and ONE v_readlane -- 3 instructions less than four v_readlane + scalar / vector folding.
+// (Written as assembly: the compiler does not fuse the masked-row form into the DPP operand of v_min / v_max / v_add.  The s_nop are
+// the two wait states a DPP read needs after the VALU write of its source.)
+#define SX_BCAST_FOLD(v, INSN)                                                                                           \
+    asm volatile("s_nop 1\n\t" INSN " %0, %0, %0 row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"               \
+                 INSN " %0, %0, %0 row_bcast:31 row_mask:0xc bank_mask:0xf\n\ts_nop 0" : "+v"(v));                       \
+    v = __builtin_amdgcn_readlane(v, 63);
+SX_HD i32 wv_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) SX_BCAST_FOLD(v, "v_add_u32_dpp") return v; }
+SX_HD i32 wv_max(i32 v) { SX_ROW_REDUCE(v, (t_ > v ? t_ : v)) SX_BCAST_FOLD(v, "v_max_i32_dpp") return v; }
+SX_HD i32 wv_min(i32 v) { SX_ROW_REDUCE(v, (t_ < v ? t_ : v)) SX_BCAST_FOLD(v, "v_min_i32_dpp") return v; }
+#else
 SX_HD i32 wv_sum(i32 v) { SX_ROW_REDUCE(v, sx_add(v, t_)) SX_ROWS_COMBINE(v, sx_add(v, t_)) return v; }
 SX_HD i32 wv_max(i32 v) { SX_ROW_REDUCE(v, (t_ > v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ > v ? t_ : v)) return v; }
 SX_HD i32 wv_min(i32 v) { SX_ROW_REDUCE(v, (t_ < v ? t_ : v)) SX_ROWS_COMBINE(v, (t_ < v ? t_ : v)) return v; }
+#endif
 SX_HD i64 wv_sum64(i64 v) {
     u32 lo = (u32)v, hi = (u32)((u64)v >> 32);
 #pragma unroll
