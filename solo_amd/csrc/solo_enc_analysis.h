@@ -279,12 +279,13 @@ SX_HD float sx_fdiv(float a, float b) {
 
 // SKP_Silk_LPC_inverse_pred_gain_Q24 (SKP_Silk_LPC_inv_pred_gain.c:134 -> :43): a = coefficient j in Q16; returns invGain_Q30 as
 // the reference leaves it (also when it bails out on an unstable filter)
-SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
+template <int ORDER>
+SX_HD i32 sx_row_inv_pred_gain_Q16_n(i32 a, bool* unstable) {
     const i32 A_LIMIT = 65520;
     const int j = SX_LANE & 15;
     i32 inv = 1 << 30;
     bool done = false;
-    for (int k = SX_SHAPE_ORDER - 1; k > 0; k--) {
+    for (int k = ORDER - 1; k > 0; k--) {
         const i32 ak = SX_ROWB(a, k);
         done = done || ak > A_LIMIT || ak < -A_LIMIT;
         const i32 rc_Q31 = sx_neg(sx_shl(ak, 31 - 16));
@@ -302,13 +303,64 @@ SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
         }
     }
     const i32 a0 = SX_ROWB(a, 0);
-    if (!done && !(a0 > A_LIMIT || a0 < -A_LIMIT)) {
+    done = done || a0 > A_LIMIT || a0 < -A_LIMIT;
+    if (!done) {
         const i32 rc_Q31 = sx_neg(sx_shl(a0, 31 - 16));
         const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
         inv = sx_shl(sx_smmul(inv, m1), 2);
     }
+    *unstable = done;
     return inv;
 }
+SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
+    bool unstable;
+    return sx_row_inv_pred_gain_Q16_n<SX_SHAPE_ORDER>(a, &unstable);
+}
+
+#if SX_LPC <= 12
+#define SX_HAVE_ROW_NLSF2A 1
+// SKP_Silk_NLSF2A_stable (SKP_Silk_NLSF2A_stable.c:31, SKP_Silk_NLSF2A.c:59) for one vector per 16-lane row, the common case only:
+// lane j of the row ends up with coefficient j.  The two polynomials are built side by side -- P in lanes 0 .. dd, Q in lanes 8 ..
+// 8 + dd of the row (dd + 1 <= 8) -- one step of find_poly per k for all n at once (the reference walks n downwards, so every update
+// reads values of the previous step).  Returns false where the reference would start correcting -- a coefficient beyond int16
+// (NLSF2A.c:93) or an unstable filter (NLSF2A_stable.c:44) -- the caller then runs the serial restatement for that call.
+SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) {
+    static_assert(SX_LPC % 2 == 0 && SX_LPC / 2 + 1 <= 8, "two polynomials per 16-lane row");
+    const int j = SX_LANE & 15, dd = SX_LPC / 2;
+    const int h = j >> 3, n = j & 7;                          // polynomial (0: P, 1: Q) and coefficient index of this lane
+    i32 cosv = 0;
+    if (j < SX_LPC) {
+        const i32 v = pNLSF[j];
+        const i32 f_int = v >> 8, f_frac = v - (f_int << 8);
+        const i32 cos_val = T_lsf_cos_Q12[f_int];
+        cosv = sx_add(sx_shl(cos_val, 8), sx_mul(T_lsf_cos_Q12[f_int + 1] - cos_val, f_frac));
+    }
+    const i32 c0 = SX_ROWG(cosv, h);                          // (lane exchanges stay outside conditionals: every lane must take part)
+    i32 out = n == 0 ? (1 << 20) : (n == 1 ? sx_neg(c0) : 0);
+#pragma unroll
+    for (int k = 1; k < dd; k++) {
+        const i32 ftmp = SX_ROWG(cosv, 2 * k + h);
+        const i32 o1 = SX_DPP_(out, 0x111), o2 = SX_DPP_(out, 0x112);          // out[n - 1], out[n - 2] (row_shr:1, :2)
+        const i32 R = (i32)sx_rshift_round64(sx_smull(ftmp, o1), 20);
+        i32 nv = out;
+        if (n >= 2 && n <= k) nv = sx_add(out, sx_sub(o2, R));
+        if (n == k + 1) nv = sx_sub(sx_shl(o2, 1), R);
+        if (n == 1) nv = sx_sub(out, ftmp);
+        out = nv;
+    }
+    // a32[k] = -rshift_round(Ptmp + Qtmp, 9), a32[d - 1 - k] = rshift_round(Qtmp - Ptmp, 9), Ptmp = P[k + 1] + P[k], Qtmp = Q[k + 1] - Q[k]
+    const int kk = j < dd ? j : SX_LPC - 1 - j;
+    const i32 Ptmp = sx_add(SX_ROWG(out, kk + 1), SX_ROWG(out, kk)), Qtmp = sx_sub(SX_ROWG(out, 8 + kk + 1), SX_ROWG(out, 8 + kk));
+    i32 a32 = j < dd ? sx_neg(sx_rshift_round(sx_add(Ptmp, Qtmp), 9)) : sx_rshift_round(sx_sub(Qtmp, Ptmp), 9);
+    if (j >= SX_LPC) a32 = 0;
+    i32 maxabs = sx_abs(a32);
+    SX_ROW_REDUCE(maxabs, (t_ > maxabs ? t_ : maxabs))
+    bool unstable;
+    (void)sx_row_inv_pred_gain_Q16_n<SX_LPC>(sx_shl((i32)(i16)a32, 4), &unstable);
+    if (j < SX_LPC) pAR_Q12[j] = (i16)a32;
+    return maxabs <= 32767 && !unstable;
+}
+#endif
 
 // x[i-1] = smlawb(x[i-1], x[i], lambda) for i = 15 .. 1 (every element sees its already updated upper neighbour), two vectors
 #define SX_ROW_SUFFIX2(xa, xb, lam_)                                                                                    \
@@ -1873,11 +1925,25 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
         SX_T(21)
         // the four interpolation candidates (SKP_Silk_find_LPC_FIX.c:81-140) are evaluated side by side: candidate k on lane k
         // for the NLSF -> LPC conversion, lane-strided for the whitening filter, lane (k, half) for the residual energies
-        SX_PAR(k, 4) {
-            for (int i = 0; i < order; i++) lw->u.it.NLSF0[k][i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
-            sx_nlsf2a_stable_ws(lw->u.it.a_Q12[k], lw->u.it.NLSF0[k], order, lw->u.it.ws[k]);
+#if defined(SX_LANE_STREAM) && defined(SX_HAVE_ROW_NLSF2A)
+        bool all_ok;
+        {   // candidate k on row k (sx_row_nlsf2a_stable); the serial form below only when a row needs the reference's corrections
+            const int k = SX_LANE >> 4, i = SX_LANE & 15;
+            if (i < SX_LPC) lw->u.it.NLSF0[k][i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
+            wv_sync();
+            all_ok = __builtin_amdgcn_ballot_w64(!sx_row_nlsf2a_stable(lw->u.it.a_Q12[k], lw->u.it.NLSF0[k])) == 0;
+            wv_sync();
         }
-        wv_sync();
+        if (!all_ok)
+#endif
+        {
+            SX_S(55)
+            SX_PAR(k, 4) {
+                for (int i = 0; i < order; i++) lw->u.it.NLSF0[k][i] = prev_NLSFq_Q15[i] + (sx_mul(NLSF_Q15[i] - prev_NLSFq_Q15[i], k) >> 2);
+                sx_nlsf2a_stable_ws(lw->u.it.a_Q12[k], lw->u.it.NLSF0[k], order, lw->u.it.ws[k]);
+            }
+            wv_sync();
+        }
         SX_S(53)
         {
             const int len = 2 * subfr_length;
@@ -2205,10 +2271,25 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
         SX_PAR(i, SX_LPC) w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
         wv_sync();
     }
-    SX_PAR(v, 2) {
-        if (v == 1 || doInterpolate) sx_nlsf2a_stable_ws(c->PredCoef_Q12[v], v ? pNLSF_Q15 : w->NLSF0, SX_LPC, w->ws[v]);
+#if defined(SX_LANE_STREAM) && defined(SX_HAVE_ROW_NLSF2A)
+    bool both_ok;
+    {   // half v on row v (rows 2, 3 repeat them and store the same values)
+        const int v = (SX_LANE >> 4) & 1;
+        bool ok = true;
+        if (doInterpolate) ok = sx_row_nlsf2a_stable(c->PredCoef_Q12[v], v ? pNLSF_Q15 : w->NLSF0);
+        else ok = sx_row_nlsf2a_stable(c->PredCoef_Q12[1], pNLSF_Q15);
+        both_ok = __builtin_amdgcn_ballot_w64(!ok) == 0;
+        wv_sync();
     }
-    wv_sync();
+    if (!both_ok)
+#endif
+    {
+        SX_S(56)
+        SX_PAR(v, 2) {
+            if (v == 1 || doInterpolate) sx_nlsf2a_stable_ws(c->PredCoef_Q12[v], v ? pNLSF_Q15 : w->NLSF0, SX_LPC, w->ws[v]);
+        }
+        wv_sync();
+    }
     if (!doInterpolate) {
         SX_PAR(i, SX_LPC) c->PredCoef_Q12[0][i] = c->PredCoef_Q12[1][i];
         wv_sync();

@@ -31,6 +31,7 @@ NAMES = {0: "qmf split", 32: "vad", 1: "variable high-pass", 33: "pitch: window,
          47: "msvq: stage head (first: codebook staging; later: survivor copy)", 52: "msvq: rate-distortion of the pairs",
          48: "msvq: sort network + selection rounds", 49: "msvq: survivor threshold", 51: "msvq: new residuals / paths of the last stage",
          50: "msvq: fluctuation reduction, winner, decode", 19: "NLSF2A x 2 (quantised)", 20: "residual energy", 5: "pred: tail",
+         55: "(serial NLSF2A of the interpolation search is needed: up to here)", 56: "(serial NLSF2A of the quantised vector is needed: up to here)",
          6: "process gains", 7: "history + hand-over record", 8: "frame end"}
 COUNTERS = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_INSTS_VMEM_RD", "SQ_INSTS_VMEM_WR"]
 NEVER = (63 << 8) | 1
