@@ -334,7 +334,14 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     const i32 hb_lsp_idx = (idx2 << 8) + idx1;
     i16* A_Q12 = hw->A_Q12;
-    if (SX_LANE == 0) sx_nlsf2a_stable_ws(SX_VPTR(A_Q12), SX_VPTR(NLSF_Q15), SX_HB_LPC, SX_VPTR(hw->ws));
+#if defined(SX_LANE_STREAM)
+    // (every row converts the same vector -- sx_row_nlsf2a_stable_n, solo_enc_analysis.h; the serial form only for the reference's corrections)
+    if (__builtin_amdgcn_ballot_w64(!sx_row_nlsf2a_stable_n<SX_HB_LPC>(A_Q12, NLSF_Q15)) != 0)
+#endif
+    {
+        wv_sync();
+        if (SX_LANE == 0) sx_nlsf2a_stable_ws(SX_VPTR(A_Q12), SX_VPTR(NLSF_Q15), SX_HB_LPC, SX_VPTR(hw->ws));
+    }
     wv_sync();
     u32 word = (u32)hb_lsp_idx << 20;
     // the four blocks of N / 4 samples are filtered from zero state (the reference calls the filter once per block)

@@ -317,19 +317,18 @@ SX_HD i32 sx_row_inv_pred_gain_Q16(i32 a) {
     return sx_row_inv_pred_gain_Q16_n<SX_SHAPE_ORDER>(a, &unstable);
 }
 
-#if SX_LPC <= 12
-#define SX_HAVE_ROW_NLSF2A 1
 // SKP_Silk_NLSF2A_stable (SKP_Silk_NLSF2A_stable.c:31, SKP_Silk_NLSF2A.c:59) for one vector per 16-lane row, the common case only:
 // lane j of the row ends up with coefficient j.  The two polynomials are built side by side -- P in lanes 0 .. dd, Q in lanes 8 ..
 // 8 + dd of the row (dd + 1 <= 8) -- one step of find_poly per k for all n at once (the reference walks n downwards, so every update
 // reads values of the previous step).  Returns false where the reference would start correcting -- a coefficient beyond int16
 // (NLSF2A.c:93) or an unstable filter (NLSF2A_stable.c:44) -- the caller then runs the serial restatement for that call.
-SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) {
-    static_assert(SX_LPC % 2 == 0 && SX_LPC / 2 + 1 <= 8, "two polynomials per 16-lane row");
-    const int j = SX_LANE & 15, dd = SX_LPC / 2;
+template <int ORDER>
+SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
+    static_assert(ORDER % 2 == 0 && ORDER / 2 + 1 <= 8, "two polynomials per 16-lane row");
+    const int j = SX_LANE & 15, dd = ORDER / 2;
     const int h = j >> 3, n = j & 7;                          // polynomial (0: P, 1: Q) and coefficient index of this lane
     i32 cosv = 0;
-    if (j < SX_LPC) {
+    if (j < ORDER) {
         const i32 v = pNLSF[j];
         const i32 f_int = v >> 8, f_frac = v - (f_int << 8);
         const i32 cos_val = T_lsf_cos_Q12[f_int];
@@ -349,17 +348,20 @@ SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) {
         out = nv;
     }
     // a32[k] = -rshift_round(Ptmp + Qtmp, 9), a32[d - 1 - k] = rshift_round(Qtmp - Ptmp, 9), Ptmp = P[k + 1] + P[k], Qtmp = Q[k + 1] - Q[k]
-    const int kk = j < dd ? j : SX_LPC - 1 - j;
+    const int kk = j < dd ? j : ORDER - 1 - j;
     const i32 Ptmp = sx_add(SX_ROWG(out, kk + 1), SX_ROWG(out, kk)), Qtmp = sx_sub(SX_ROWG(out, 8 + kk + 1), SX_ROWG(out, 8 + kk));
     i32 a32 = j < dd ? sx_neg(sx_rshift_round(sx_add(Ptmp, Qtmp), 9)) : sx_rshift_round(sx_sub(Qtmp, Ptmp), 9);
-    if (j >= SX_LPC) a32 = 0;
+    if (j >= ORDER) a32 = 0;
     i32 maxabs = sx_abs(a32);
     SX_ROW_REDUCE(maxabs, (t_ > maxabs ? t_ : maxabs))
     bool unstable;
-    (void)sx_row_inv_pred_gain_Q16_n<SX_LPC>(sx_shl((i32)(i16)a32, 4), &unstable);
-    if (j < SX_LPC) pAR_Q12[j] = (i16)a32;
+    (void)sx_row_inv_pred_gain_Q16_n<ORDER>(sx_shl((i32)(i16)a32, 4), &unstable);
+    if (j < ORDER) pAR_Q12[j] = (i16)a32;
     return maxabs <= 32767 && !unstable;
 }
+#if SX_LPC <= 14
+#define SX_HAVE_ROW_NLSF2A 1            // (order 16, the 32 kHz build: 2 x 9 polynomial coefficients do not fit a row)
+SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) { return sx_row_nlsf2a_stable_n<SX_LPC>(pAR_Q12, pNLSF); }
 #endif
 
 // x[i-1] = smlawb(x[i-1], x[i], lambda) for i = 15 .. 1 (every element sees its already updated upper neighbour), two vectors
