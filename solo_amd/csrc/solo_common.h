@@ -499,3 +499,95 @@ SX_HD i32 sx_sigm_Q15(i32 in_Q5) {
     int ind = in_Q5 >> 5;
     return T_sigm_pos_Q15[ind] + sx_smulbb(T_sigm_slope_Q10[ind], in_Q5 & 0x1F);
 }
+
+#ifdef SX_LANE_STREAM
+// ---- one vector per 16-lane row (gfx950 build): lane j of a row holds element j in a register; the reference's inner loops over the
+// element index disappear, reversals / broadcasts are lane gathers inside the row, neighbour recursions are DPP row shifts.  (Lane
+// exchanges stay outside conditionals: every lane must take part.)
+#define SX_ROWB(v, jj) __shfl((v), (SX_LANE & 48) | (jj), 64)                 // element jj of the own row, in all of its lanes
+#define SX_ROWG(v, idx) __shfl((v), (SX_LANE & 48) | ((idx) & 15), 64)          // element idx (per lane) of the own row
+#define SX_ROW_NEXT(v) SX_DPP_((v), 0x101)                                      // element j + 1 (row_shl:1; 0 beyond the row)
+
+// SKP_Silk_LPC_inverse_pred_gain_Q24 (SKP_Silk_LPC_inv_pred_gain.c:134 -> :43): a = coefficient j in Q16; returns invGain_Q30 as
+// the reference leaves it (also when it bails out on an unstable filter)
+template <int ORDER>
+SX_HD i32 sx_row_inv_pred_gain_Q16_n(i32 a, bool* unstable) {
+    const i32 A_LIMIT = 65520;
+    const int j = SX_LANE & 15;
+    i32 inv = 1 << 30;
+    bool done = false;
+    for (int k = ORDER - 1; k > 0; k--) {
+        const i32 ak = SX_ROWB(a, k);
+        done = done || ak > A_LIMIT || ak < -A_LIMIT;
+        const i32 rc_Q31 = sx_neg(sx_shl(ak, 31 - 16));
+        const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+        i32 m2 = sx_inverse32_varQ(m1, 46);
+        const i32 inv_n = sx_shl(sx_smmul(inv, m1), 2);
+        const int headrm = sx_clz32(m2) - 1;
+        m2 = sx_shl(m2, headrm);
+        const i32 ar = SX_ROWG(a, k - 1 - j);
+        const i32 tmp = sx_sub(a, sx_shl(sx_smmul(ar, rc_Q31), 1));
+        const i32 an = sx_shl(sx_smmul(tmp, m2), 16 - headrm);
+        if (!done) {
+            inv = inv_n;
+            if (j < k) a = an;
+        }
+    }
+    const i32 a0 = SX_ROWB(a, 0);
+    done = done || a0 > A_LIMIT || a0 < -A_LIMIT;
+    if (!done) {
+        const i32 rc_Q31 = sx_neg(sx_shl(a0, 31 - 16));
+        const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
+        inv = sx_shl(sx_smmul(inv, m1), 2);
+    }
+    *unstable = done;
+    return inv;
+}
+
+// SKP_Silk_NLSF2A_stable (SKP_Silk_NLSF2A_stable.c:31, SKP_Silk_NLSF2A.c:59) for one vector per 16-lane row, the common case only:
+// lane j of the row ends up with coefficient j.  The two polynomials are built side by side -- P in lanes 0 .. dd, Q in lanes 8 ..
+// 8 + dd of the row (dd + 1 <= 8) -- one step of find_poly per k for all n at once (the reference walks n downwards, so every update
+// reads values of the previous step).  Returns false where the reference would start correcting -- a coefficient beyond int16
+// (NLSF2A.c:93) or an unstable filter (NLSF2A_stable.c:44) -- the caller then runs the serial restatement for that call.
+template <int ORDER>
+SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
+    static_assert(ORDER % 2 == 0 && ORDER / 2 + 1 <= 8, "two polynomials per 16-lane row");
+    const int j = SX_LANE & 15, dd = ORDER / 2;
+    const int h = j >> 3, n = j & 7;                          // polynomial (0: P, 1: Q) and coefficient index of this lane
+    i32 cosv = 0;
+    if (j < ORDER) {
+        const i32 v = pNLSF[j];
+        const i32 f_int = v >> 8, f_frac = v - (f_int << 8);
+        const i32 cos_val = T_lsf_cos_Q12[f_int];
+        cosv = sx_add(sx_shl(cos_val, 8), sx_mul(T_lsf_cos_Q12[f_int + 1] - cos_val, f_frac));
+    }
+    const i32 c0 = SX_ROWG(cosv, h);                          // (lane exchanges stay outside conditionals: every lane must take part)
+    i32 out = n == 0 ? (1 << 20) : (n == 1 ? sx_neg(c0) : 0);
+#pragma unroll
+    for (int k = 1; k < dd; k++) {
+        const i32 ftmp = SX_ROWG(cosv, 2 * k + h);
+        const i32 o1 = SX_DPP_(out, 0x111), o2 = SX_DPP_(out, 0x112);          // out[n - 1], out[n - 2] (row_shr:1, :2)
+        const i32 R = (i32)sx_rshift_round64(sx_smull(ftmp, o1), 20);
+        i32 nv = out;
+        if (n >= 2 && n <= k) nv = sx_add(out, sx_sub(o2, R));
+        if (n == k + 1) nv = sx_sub(sx_shl(o2, 1), R);
+        if (n == 1) nv = sx_sub(out, ftmp);
+        out = nv;
+    }
+    // a32[k] = -rshift_round(Ptmp + Qtmp, 9), a32[d - 1 - k] = rshift_round(Qtmp - Ptmp, 9), Ptmp = P[k + 1] + P[k], Qtmp = Q[k + 1] - Q[k]
+    const int kk = j < dd ? j : ORDER - 1 - j;
+    const i32 Ptmp = sx_add(SX_ROWG(out, kk + 1), SX_ROWG(out, kk)), Qtmp = sx_sub(SX_ROWG(out, 8 + kk + 1), SX_ROWG(out, 8 + kk));
+    i32 a32 = j < dd ? sx_neg(sx_rshift_round(sx_add(Ptmp, Qtmp), 9)) : sx_rshift_round(sx_sub(Qtmp, Ptmp), 9);
+    if (j >= ORDER) a32 = 0;
+    i32 maxabs = sx_abs(a32);
+    SX_ROW_REDUCE(maxabs, (t_ > maxabs ? t_ : maxabs))
+    bool unstable;
+    (void)sx_row_inv_pred_gain_Q16_n<ORDER>(sx_shl((i32)(i16)a32, 4), &unstable);
+    if (j < ORDER) pAR_Q12[j] = (i16)a32;
+    return maxabs <= 32767 && !unstable;
+}
+#if SX_LPC <= 14
+#define SX_HAVE_ROW_NLSF2A 1            // (order 16, the 32 kHz build: 2 x 9 polynomial coefficients do not fit a row)
+SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) { return sx_row_nlsf2a_stable_n<SX_LPC>(pAR_Q12, pNLSF); }
+#endif
+#endif

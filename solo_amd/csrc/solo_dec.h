@@ -1191,7 +1191,13 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     // vector (it interpolates with the previous packet's) is converted here, on one lane
                     SX_PAR(i, SX_LPC) w->PredCoef_Q12[1][i] = pa->A_final[f][i];
                     if (interp && f == 1) { SX_PAR(i, SX_LPC) w->PredCoef_Q12[0][i] = pa->A_interp1[i]; }
-                    if (interp && f == 0) { SX_PAR(v, 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1); }
+                    if (interp && f == 0) {
+#if defined(SX_LANE_STREAM) && defined(SX_HAVE_ROW_NLSF2A)
+                        // (every row converts the vector: sx_row_nlsf2a_stable, solo_common.h; the serial form only for the reference's corrections)
+                        if (__builtin_amdgcn_ballot_w64(!sx_row_nlsf2a_stable(w->PredCoef_Q12[0], nl)) != 0)
+#endif
+                        { wv_sync(); SX_PAR(v, 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1); }
+                    }
                 } else {
                 SX_PAR(v, 2) {
                     if (v == 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[1], nl + SX_LPC, SX_LPC, &w->res_Q10[4 * SX_LPC]);
