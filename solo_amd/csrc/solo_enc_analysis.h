@@ -1821,6 +1821,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
     i32* a_Q16 = lw->a_Q16;
     i32* a_tmp_Q16 = lw->a_tmp_Q16;
     i32 res_nrg, res_tmp_nrg, res_nrg_Q, res_tmp_nrg_Q;
+    order = SX_LPC; subfr_length = SX_SUBFR + SX_LPC;       // (what the one caller passes: loop bounds and index arithmetic become constants)
     *interpIndex = 4;
     sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, x, subfr_length, 4, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
     sx_bwexpander_32(a_Q16, order, K_FIND_LPC_CHIRP_Q16);
@@ -1864,7 +1865,8 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
         }
         SX_S(53)
         {
-            const int len = 2 * subfr_length;
+            // (the one caller passes SX_SUBFR + SX_LPC: t / len by a constant instead of a run-time division per lane and round)
+            const int len = 2 * (SX_SUBFR + SX_LPC);
             SX_PAR(t, 4 * len) {
                 const int k = t / len, n = t - k * len;
                 const i16* B = lw->u.it.a_Q12[k];
@@ -2014,6 +2016,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
     int cb_base = 0;
     for (int s = 0; s < nStages; s++) {
         const int K = nvec[s];
+        const int lgK = 31 - sx_clz32(K);          // every stage size is a power of two (static_assert below the function): t / K is a shift
         const i16* cbs = cb + cb_base * SX_LPC;
         const i16* rts = rates + cb_base;
         cur_survivors = sx_min(S, sx_smulbb(prev_survivors, K));
@@ -2021,7 +2024,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
 #if SX_NLANES == 1
         // rate-distortion of every (survivor, codebook vector) pair
         SX_PAR(t, total) {
-            int n = t / K, i = t - n * K;
+            int n = t >> lgK, i = t - (n << lgK);
             const i32* in = &w->Res_Q15[n * SX_LPC];
             const i16* cv = &cbs[i * SX_LPC];
             i32 sum_error = 0;
@@ -2055,7 +2058,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         for (int j = 0; j < 4; j++) {
             const int t = SX_LANE + 64 * j;
             if (j * 64 < total && t < total) {
-                int n = t / K, i = t - n * K;
+                int n = t >> lgK, i = t - (n << lgK);
                 const i32* in = &w->Res_Q15[n * SX_LPC];
                 const i16* cv = &cbs[i * SX_LPC];
                 i32 sum_error = 0;
@@ -2108,8 +2111,8 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
             const int k = ki / SX_MSVQ_ROW, i = ki % SX_MSVQ_ROW;
             int input_index = 0, cb_index = x->TempIndices[k];
             if (s > 0) {
-                input_index = cb_index / K;
-                cb_index = cb_index - input_index * K;
+                input_index = cb_index >> lgK;
+                cb_index = cb_index - (input_index << lgK);
             }
             if (i < SX_LPC) x->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
             if (i == SX_LPC) x->Rate_new_Q5[k] = x->Rate_Q5[input_index] + rts[cb_index];
@@ -2151,6 +2154,10 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
     sx_nlsf_msvq_decode_cb(pNLSF_Q15, NLSFIndices, cb, nvec, w->ndelta);
     wv_sync();
 }
+
+constexpr bool sx_all_pow2(const int* v, int n) { for (int i = 0; i < n; i++) if (v[i] <= 0 || (v[i] & (v[i] - 1))) return false; return true; }
+constexpr int sx_nvec0_[SX_NLSF_STAGES] = T_NLSF_CB0_NVEC, sx_nvec1_[SX_NLSF_STAGES] = T_NLSF_CB1_NVEC;
+static_assert(sx_all_pow2(sx_nvec0_, SX_NLSF_STAGES) && sx_all_pow2(sx_nvec1_, SX_NLSF_STAGES), "the survivor search divides by the stage sizes with shifts");
 
 // SKP_Silk_process_NLSFs_FIX, SKP_Silk_process_NLSFs_FIX.c:31
 SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsvqWork* w, SxMsvqAux* aux) {
