@@ -595,26 +595,29 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
     }
     SX_S(34)
     // ---- first stage (4 kHz): normalised correlation of two 10 ms targets against lags 8..72 ----
-    for (int k = 0; k < 2; k++) {
-        const i16* target = &w->sig4[80 + k * sf8];
+    {
         // energies of the basis window at every lag: E(d) = sum_{n<40} b_d[n]^2, b_d = target - d
         // reference: N(8) = add_sat32(E(8), 40*4000), N(d) = N(d-1) + b_d[0]^2 - b_d[40]^2 (wrapping) = N(8) + E(d) - E(8)
-        i32 E8 = 0;
-        {
-            const i16* b = target - min_lag_4;
+        i32 E8k[2], N8k[2];
+        for (int k = 0; k < 2; k++) {
+            const i16* b = &w->sig4[80 + k * sf8] - min_lag_4;
+            i32 E8 = 0;
             SX_PAR(n, sf8) E8 = sx_smlabb(E8, b[n], b[n]);
             E8 = wv_sum(E8);
+            E8k[k] = E8;
+            N8k[k] = sx_add_sat32(E8, sx_smulbb(sf8, 4000));
         }
-        i32 N8 = sx_add_sat32(E8, sx_smulbb(sf8, 4000));
-        SX_PAR(d, max_lag_4 + 1) {
-            if (d >= min_lag_4) {
-                const i16* b = target - d;
-                i32 cc = 0, E = 0;
-                for (int n = 0; n < sf8; n++) { cc = sx_smlabb(cc, target[n], b[n]); E = sx_smlabb(E, b[n], b[n]); }
-                i32 normalizer = sx_add(N8, sx_sub(E, E8));
-                i32 t = cc / (sx_sqrt_approx(normalizer) + 1);
-                w->C[k][d] = (i16)sx_sat16(t);
-            }
+        // (target, lag) pairs side by side: 2 x 65 of them are three rounds of the wave (a round per target would be four)
+        const int nlag = max_lag_4 - min_lag_4 + 1;
+        SX_PAR(t, 2 * nlag) {
+            const int k = t / nlag, d = min_lag_4 + (t - k * nlag);
+            const i16* target = &w->sig4[80 + k * sf8];
+            const i16* b = target - d;
+            i32 cc = 0, E = 0;
+            for (int n = 0; n < sf8; n++) { cc = sx_smlabb(cc, target[n], b[n]); E = sx_smlabb(E, b[n], b[n]); }
+            i32 normalizer = sx_add(k ? N8k[1] : N8k[0], sx_sub(E, k ? E8k[1] : E8k[0]));
+            i32 tq = cc / (sx_sqrt_approx(normalizer) + 1);
+            w->C[k][d] = (i16)sx_sat16(tq);
         }
         wv_sync();
     }
@@ -629,6 +632,23 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
     // insertion_sort_decreasing_int16 of C[0][8..72], top-8 (value desc, index asc): rank by counting
     int length_d_srch = 4 + 2 * 2;
     const int L = max_lag_4 - min_lag_4 + 1;
+#if SX_NLANES == 64 && defined(__HIP_DEVICE_COMPILE__)
+    {
+        // (L = 65: lane i ranks element i against all of them; the last element, which every other one precedes, is ranked with a ballot)
+        static_assert(72 - 8 + 1 == 65, "one element more than lanes");
+        const int i = SX_LANE;
+        const i32 v = (i16)w->tmp32[min_lag_4 + i], vl = (i16)w->tmp32[min_lag_4 + L - 1];
+        int rank = 0;
+        for (int j = 0; j < L; j++) {
+            i32 u = (i16)w->tmp32[min_lag_4 + j];
+            rank += (u > v || (u == v && j < i)) ? 1 : 0;
+        }
+        const int rank_last = __builtin_popcountll(__builtin_amdgcn_ballot_w64(v >= vl));
+        wv_sync();
+        if (rank < length_d_srch) { w->C[0][min_lag_4 + rank] = (i16)v; w->d_srch[rank] = i; }
+        if (SX_LANE == 0 && rank_last < length_d_srch) { w->C[0][min_lag_4 + rank_last] = (i16)vl; w->d_srch[rank_last] = L - 1; }
+    }
+#else
     SX_PAR(i, L) {
         i32 v = (i16)w->tmp32[min_lag_4 + i];
         int rank = 0;
@@ -638,6 +658,7 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
         }
         if (rank < length_d_srch) { w->C[0][min_lag_4 + rank] = (i16)v; w->d_srch[rank] = i; }
     }
+#endif
     wv_sync();
     const i16* target = &w->sig4[80];
     i32 energy = 0;

@@ -12,7 +12,7 @@ template <int OP>
 __global__ void __launch_bounds__(64) k(int* out, unsigned long long* cyc, int seed, unsigned long long* wall = nullptr) {
     const unsigned long long w0 = wall_clock64();
     int a[CHAINS];
-    int b = seed * 3 + threadIdx.x, c = seed + 7;
+    int b = (OP == 39 || OP == 46) ? (int)((threadIdx.x * 4 + seed * 8) & 252) : seed * 3 + threadIdx.x, c = seed + 7;
     unsigned long long m64 = 0x5555AAAA3333CCCCull * (unsigned)seed, m2[2] = {0, 0}, w64[4] = {1, 2, 3, 4};
 #pragma unroll
     for (int j = 0; j < CHAINS; j++) a[j] = threadIdx.x * (j + 1) + seed;
@@ -61,7 +61,17 @@ __global__ void __launch_bounds__(64) k(int* out, unsigned long long* cyc, int s
                 if (OP == 36) { asm volatile("v_cmp_lt_i32 vcc, %1, %2\n\ts_nop 1\n\tv_cndmask_b32 %0, %0, %3, vcc" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "v"(b), "v"(c) : "vcc"); }
                 if (OP == 37) { asm volatile("v_cmp_lt_i32_e64 %4, %1, %2\n\tv_cndmask_b32_e64 %0, %0, %3, %4" : "+v"(a[j]) : "v"(a[(j + 1) & 7]), "v"(b), "v"(c), "s"(m2[0])); }
                 if (OP == 38) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[j]) : "v"(b) : );
+                if (OP == 39) asm volatile("ds_bpermute_b32 %0, %1, %0" : "+v"(a[j]) : "v"(b));
+                if (OP == 40) asm volatile("v_mad_i64_i32 %0, %1, %2, %3, %0" : "+v"(w64[j & 3]), "=s"(m2[0]) : "v"(b), "v"(c));
+                if (OP == 41) asm volatile("v_ashrrev_i64 %0, 18, %0" : "+v"(w64[j & 3]));
+                if (OP == 42) asm volatile("v_lshl_add_u64 %0, %0, 0, %1" : "+v"(w64[j & 3]) : "v"(w64[(j + 1) & 3]));
+                if (OP == 43) { int sl_; asm volatile("v_readlane_b32 %0, %1, 5" : "=s"(sl_) : "v"(a[j])); m2[j & 1] += sl_; }
+                if (OP == 44) asm volatile("s_add_u32 %0, %0, %1" : "+s"(seed) : "s"(c));
+                if (OP == 45) asm volatile("v_permlane32_swap_b32 %0, %1" : "+v"(a[j]), "+v"(a[(j + 1) & 7]));
+                if (OP == 46) asm volatile("ds_read_b32 %0, %1" : "=v"(a[j]) : "v"(b));
+                if (OP == 47) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a[j]) : "s"(seed));
             }
+            if (OP == 39 || OP == 46) asm volatile("s_waitcnt lgkmcnt(0)");
         }
     }
     unsigned long long t1 = __builtin_readcyclecounter();
@@ -183,6 +193,15 @@ int main() {
     run<32>("v_add_u32_e64", d_out, d_cyc, ncu);
     run<33>("v_add_u32 sgpr", d_out, d_cyc, ncu);
     run<34>("v_ffbl_b32", d_out, d_cyc, ncu);
+    run<39>("ds_bpermute_b32", d_out, d_cyc, ncu);
+    run<46>("ds_read_b32", d_out, d_cyc, ncu);
+    run<40>("v_mad_i64_i32", d_out, d_cyc, ncu);
+    run<41>("v_ashrrev_i64", d_out, d_cyc, ncu);
+    run<42>("v_lshl_add_u64", d_out, d_cyc, ncu);
+    run<43>("v_readlane_b32", d_out, d_cyc, ncu);
+    run<44>("s_add_u32", d_out, d_cyc, ncu);
+    run<45>("v_permlane32_swap", d_out, d_cyc, ncu);
+    run<47>("v_mul_hi_i32 sgpr", d_out, d_cyc, ncu);
     rund<0>("v_add_u32", d_out, d_cyc, ncu);
     rund<1>("v_mul_hi_i32", d_out, d_cyc, ncu);
     rund<2>("v_mul_lo_u32", d_out, d_cyc, ncu);
