@@ -177,38 +177,29 @@ SX_HD void sx_warped_autocorr4(SxShapeWork* sw, i32 warping_Q16) {
         const i32 lam = sx_pre16(warping_Q16);
         i32 pin = 0, pout = 0, out = 0;
         i32 xn = j == 0 ? (i32)sw->xw[k][0] : 0;
-        // the first and last 15 steps: only the sections whose sample lies inside the window work
-#define SX_WA_EDGE_STEP                                                                                         \
-        {   const int n = t - j;                                                                                \
-            const i32 xcur = xn;                                                                                \
-            { const int nn = n + 1; xn = (nn >= 0 && nn < SX_SHAPE_WIN) ? (i32)sw->xw[k][nn] : 0; }             \
-            const i32 in_prev = SX_DPP_(out, 0x111);                                                            \
-            if (n >= 0 && n < SX_SHAPE_WIN) {                                                                   \
-                const i32 x0 = sx_shl(xcur, 14);                                                                \
-                const i32 in = j == 0 ? x0 : in_prev;                                                           \
+        // steps 15 .. SX_SHAPE_WIN - 1: every section holds a sample of the window; section 0's input comes in through the DPP move's
+        // `old` operand, every lane accumulates the last correlation (only section 15's is kept).  The first and last 15 steps are the
+        // same body with the updates under the section's range check (loads outside the window: never used)
+#define SX_WA_BODY(ACTIVE, LAST)                                                                                \
+        {   const i32 xcur = xn;                                                                                \
+            xn = (i32)xp[t];                                                                                    \
+            const i32 x0 = sx_shl(xcur, 14);                                                                    \
+            const i32 in = __builtin_amdgcn_update_dpp(x0, out, 0x111, 0xF, 0xF, false);                         \
+            if (ACTIVE) {                                                                                       \
                 const i32 o = sx_smlaw_pre(pin, pout - in, lam);                                                \
                 acc_l += sx_smull(in, x0) >> 18;                                                                \
-                if (j == SX_SHAPE_ORDER - 1) acc16_l += sx_smull(o, x0) >> 18;                                  \
+                if (LAST) acc16_l += sx_smull(o, x0) >> 18;                                                     \
                 pin = in; pout = o; out = o;                                                                    \
             }                                                                                                   \
         }
-        for (int t = 0; t < SX_SHAPE_ORDER - 1; t++) SX_WA_EDGE_STEP
-        {   // steps 15 .. SX_SHAPE_WIN - 1: every section holds a sample of the window -- no range checks, section 0's input comes in
-            // through the DPP move's `old` operand, every lane accumulates the last correlation (only section 15's is kept)
+        {
             const i16* xp = &sw->xw[k][0] - j + 1;                      // xp[t] = x(n + 1) of step t
-            for (int t = SX_SHAPE_ORDER - 1; t < SX_SHAPE_WIN; t++) {
-                const i32 xcur = xn;
-                xn = (i32)xp[t];
-                const i32 x0 = sx_shl(xcur, 14);
-                const i32 in = __builtin_amdgcn_update_dpp(x0, out, 0x111, 0xF, 0xF, false);
-                const i32 o = sx_smlaw_pre(pin, pout - in, lam);
-                acc_l += sx_smull(in, x0) >> 18;
-                acc16_l += sx_smull(o, x0) >> 18;
-                pin = in; pout = o; out = o;
-            }
+            for (int t = 0; t < SX_SHAPE_ORDER - 1; t++) SX_WA_BODY(j <= t, false)                      // (section 15 joins at step 15)
+#pragma unroll 5
+            for (int t = SX_SHAPE_ORDER - 1; t < SX_SHAPE_WIN; t++) SX_WA_BODY(true, true)
+            for (int t = SX_SHAPE_WIN; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) SX_WA_BODY(j > t - SX_SHAPE_WIN, true)
         }
-        for (int t = SX_SHAPE_WIN; t < SX_SHAPE_WIN + SX_SHAPE_ORDER - 1; t++) SX_WA_EDGE_STEP
-#undef SX_WA_EDGE_STEP
+#undef SX_WA_BODY
     }
     {
         const int k = SX_LANE >> 4, j = SX_LANE & 15;
@@ -641,51 +632,40 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
         pw->st_res[0] = (i16)st->pf_sHarmHP;
         i32 out = 0, acc = 0;
         i32 xn = (0 - l >= 0) ? (i32)x[0] : 0;                        // x[n] of the coming step (n = t - 1 - l), fetched a step ahead
-        // the first and last 16 steps, where only the lanes whose sample lies inside the frame work
-#define SX_PF_EDGE_STEP                                                                                                               \
-        {   const int n = t - 1 - l;                                                                                                  \
-            const i32 xcur = xn;                                                                                                      \
-            { const int nn = n + 1; xn = (nn >= 0 && nn < SX_FRAME) ? (i32)x[nn] : 0; }                                               \
-            const i32 in_prev = SX_DPP_(out, 0x111), acc_prev = SX_DPP_(acc, 0x111);     /* lane l - 1's results of step t - 1 */      \
-            if (n >= 0 && n < SX_FRAME) {                                                                                             \
-                const i32 in = l == 0 ? sx_shl(xcur, 14) : in_prev;                                                                   \
-                const i32 o = l == 0 ? sx_smlaw_pre(pin, pv, lam) : sx_smlaw_pre(pin, pv - in, lam);                                  \
-                const i32 coef = n < 2 * SX_SUBFR ? (n < SX_SUBFR ? a0 : a1) : (n < 3 * SX_SUBFR ? a2 : a3);                          \
-                acc = sx_smlaw_pre(l == 0 ? 0 : acc_prev, o, coef);                                                                   \
-                pin = in; pv = o; out = o;                                                                                            \
-                if (l == SX_SHAPE_ORDER - 1) pw->st_res[1 + n] = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));                      \
-            }                                                                                                                         \
-        }
-        // steps 17 .. 160: every lane holds a sample of the frame -- no range checks; lane 0's input comes in through the DPP move's
-        // `old` operand, its partial sum through the move's zero fill; the coefficient set changes at sample bnd (lane by lane as the
-        // skew passes it); lane 15 stores through a walking pointer, the other lanes through a pointer that stays on a dump word
-#define SX_PF_STEADY(T0, T1, CA, CB, BND)                                                                                             \
-        for (int t = (T0); t <= (T1); t++) {                                                                                          \
-            const i32 xcur = xn;                                                                                                      \
+        // Steps 16 .. 160: every lane holds a sample of the frame.  Lane 0's input comes in through the DPP move's `old` operand, its
+        // partial sum through the move's zero fill; the coefficient set changes at sample bnd (lane by lane as the skew passes it);
+        // lane 15 stores through a walking pointer, the other lanes through a pointer that stays on a dump word.  The first and last
+        // 15 steps are the same body with the state update (and the store) under the lane's range check; their loads may fall outside
+        // the frame (the neighbouring samples of the buffer: never used)
+#define SX_PF_BODY(ACTIVE, COEF, STORE)                                                                                               \
+        {   const i32 xcur = xn;                                                                                                      \
             xn = (i32)xp[t];                                                                                                          \
             const i32 in = __builtin_amdgcn_update_dpp(sx_shl(xcur, 14), out, 0x111, 0xF, 0xF, false);                                 \
             const i32 acc_prev = SX_DPP_(acc, 0x111);                                                                                 \
-            const i32 o = sx_smlaw_pre(pin, pv - (in & not_first), lam);                                                              \
-            const i32 coef = ((BND) == 0 || t - 1 - l >= (BND)) ? (CA) : (CB);                                                        \
-            acc = sx_smlaw_pre(acc_prev, o, coef);                                                                                    \
-            pin = in; pv = o; out = o;                                                                                                \
-            *op = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11));                                                                     \
-            op += ostride;                                                                                                            \
+            if (ACTIVE) {                                                                                                             \
+                const i32 o = sx_smlaw_pre(pin, pv - (in & not_first), lam);                                                          \
+                acc = sx_smlaw_pre(acc_prev, o, (COEF));                                                                              \
+                pin = in; pv = o; out = o;                                                                                            \
+                if (STORE) { *op = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11)); op += ostride; }                                   \
+            }                                                                                                                         \
         }
+#define SX_PF_STEADY(T0, T1, CA, CB, BND)                                                                                             \
+        _Pragma("unroll 4")                                                                                                           \
+        for (int t = (T0); t <= (T1); t++) SX_PF_BODY(true, ((BND) == 0 || t - 1 - l >= (BND)) ? (CA) : (CB), true)
         static_assert(SX_SHAPE_ORDER == 16 && SX_SUBFR > SX_SHAPE_ORDER && SX_FRAME == 4 * SX_SUBFR, "the steady-state split of the warped filter");
-        for (int t = 1; t <= SX_SHAPE_ORDER; t++) SX_PF_EDGE_STEP
         {
             const i32 not_first = l == 0 ? 0 : -1;
             const i16* xp = x - l;                                                      // xp[t] = x[n + 1] of step t
             const int ostride = l == SX_SHAPE_ORDER - 1 ? 1 : 0;
-            i16* op = l == SX_SHAPE_ORDER - 1 ? &pw->st_res[1 + SX_SHAPE_ORDER + 1 - 1 - l] : (i16*)&pw->o[0][l][0];
-            SX_PF_STEADY(SX_SHAPE_ORDER + 1, SX_SUBFR, a0, a0, 0)
+            i16* op = l == SX_SHAPE_ORDER - 1 ? &pw->st_res[1] : (i16*)&pw->o[0][l][0];
+            for (int t = 1; t < SX_SHAPE_ORDER; t++) SX_PF_BODY(l < t, a0, false)                        // lanes join one by one (lane 15 at step 16)
+            SX_PF_STEADY(SX_SHAPE_ORDER, SX_SUBFR, a0, a0, 0)
             SX_PF_STEADY(SX_SUBFR + 1, 2 * SX_SUBFR, a1, a0, SX_SUBFR)
             SX_PF_STEADY(2 * SX_SUBFR + 1, 3 * SX_SUBFR, a2, a1, 2 * SX_SUBFR)
             SX_PF_STEADY(3 * SX_SUBFR + 1, 4 * SX_SUBFR, a3, a2, 3 * SX_SUBFR)
+            for (int t = SX_FRAME + 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) SX_PF_BODY(l >= t - SX_FRAME, a3, true)   // ... and leave one by one
         }
-        for (int t = SX_FRAME + 1; t < SX_FRAME + SX_SHAPE_ORDER; t++) SX_PF_EDGE_STEP
-#undef SX_PF_EDGE_STEP
+#undef SX_PF_BODY
 #undef SX_PF_STEADY
         const i32 vend = pv, vend0 = pin;                               // (a lane's last update was its sample SX_FRAME - 1)
         if (SX_LANE < SX_SHAPE_ORDER) {
