@@ -634,7 +634,7 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
         i32 xn = (0 - l >= 0) ? (i32)x[0] : 0;                        // x[n] of the coming step (n = t - 1 - l), fetched a step ahead
         // Steps 16 .. 160: every lane holds a sample of the frame.  Lane 0's input comes in through the DPP move's `old` operand, its
         // partial sum through the move's zero fill; the coefficient set changes at sample bnd (lane by lane as the skew passes it);
-        // lane 15 stores through a walking pointer, the other lanes through a pointer that stays on a dump word.  The first and last
+        // lane 15 stores its sum through a walking pointer, the other lanes through a pointer that stays on a dump word.  The first and last
         // 15 steps are the same body with the state update (and the store) under the lane's range check; their loads may fall outside
         // the frame (the neighbouring samples of the buffer: never used)
 #define SX_PF_BODY(ACTIVE, COEF, STORE)                                                                                               \
@@ -646,7 +646,7 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
                 const i32 o = sx_smlaw_pre(pin, pv - (in & not_first), lam);                                                          \
                 acc = sx_smlaw_pre(acc_prev, o, (COEF));                                                                              \
                 pin = in; pv = o; out = o;                                                                                            \
-                if (STORE) { *op = (i16)sx_sat16(xcur - sx_rshift_round(acc, 11)); op += ostride; }                                   \
+                if (STORE) { *op = acc; op += ostride; }                                                                               \
             }                                                                                                                         \
         }
 #define SX_PF_STEADY(T0, T1, CA, CB, BND)                                                                                             \
@@ -656,8 +656,10 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
         {
             const i32 not_first = l == 0 ? 0 : -1;
             const i16* xp = x - l;                                                      // xp[t] = x[n + 1] of step t
+            // (section 15's sums go to x_filt_Q12 -- free until the next step fills it -- as they are; the residual is formed from
+            // them afterwards, all samples side by side, instead of five more instructions in every step of the recursion)
             const int ostride = l == SX_SHAPE_ORDER - 1 ? 1 : 0;
-            i16* op = l == SX_SHAPE_ORDER - 1 ? &pw->st_res[1] : (i16*)&pw->o[0][l][0];
+            i32* op = l == SX_SHAPE_ORDER - 1 ? &pw->x_filt_Q12[0] : &pw->o[0][l][0];
             for (int t = 1; t < SX_SHAPE_ORDER; t++) SX_PF_BODY(l < t, a0, false)                        // lanes join one by one (lane 15 at step 16)
             SX_PF_STEADY(SX_SHAPE_ORDER, SX_SUBFR, a0, a0, 0)
             SX_PF_STEADY(SX_SUBFR + 1, 2 * SX_SUBFR, a1, a0, SX_SUBFR)
@@ -672,6 +674,8 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
             st->pf_sAR_shp[l + 1] = vend;
             if (l == 0) st->pf_sAR_shp[0] = vend0;
         }
+        wv_sync();
+        SX_PAR(n, SX_FRAME) pw->st_res[1 + n] = (i16)sx_sat16((i32)x[n] - sx_rshift_round(pw->x_filt_Q12[n], 11));
         wv_sync();
     }
 #else

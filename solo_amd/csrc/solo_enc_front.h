@@ -334,13 +334,15 @@ SX_FN1 void sx_hp_variable_cutoff(SxEncState* st, SxEncCtrl* c, i16* out, const 
                 const i32 n0 = sx_add(sx_add(s1, t.v[1]), SX_DPP_(w, 0x00));
                 const i32 n1 = sx_add(t.v[2], SX_DPP_(w, 0xAA));
                 s0 = n0; s1 = n1;
-                out[k] = (i16)sx_sat16(sx_add(out32_Q14, (1 << 14) - 1) >> 14);
+                bx[k].v[3] = out32_Q14;                  // (the record's spare word; rounded and saturated below, all samples side by side)
             }
             if (SX_LANE == 0) {
                 st->In_HP_State[0] = s0;
                 st->In_HP_State[1] = s1;
             }
         }
+        wv_sync();
+        SX_PAR(k, SX_FRAME) out[k] = (i16)sx_sat16(sx_add(bx[k].v[3], (1 << 14) - 1) >> 14);
         wv_sync();
         return;
     }
