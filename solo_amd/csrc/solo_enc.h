@@ -410,7 +410,12 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     SX_PAR(i, SX_FRAME) f->res_pitch[i] = pIn[i];          // res_pitch doubles as the staging buffer of the raw input
     wv_sync();
     SX_STRETCH_LATENCY();
-    sx_vad(st, c, f->res_pitch, f->Wsig, &SNR_dB_Q7);
+    // (the four bands -- at X + 0, 80, 160, 240, the last one SX_FRAME / 2 samples long -- start in Wsig and run on into the work area
+    // behind it; the filter banks' raw sums follow them)
+    constexpr int vad_bands_ = 240 + SX_FRAME / 2;
+    static_assert(offsetof(SxFrontWork, u) == offsetof(SxFrontWork, Wsig) + sizeof(f->Wsig) && (offsetof(SxFrontWork, Wsig) + vad_bands_ * sizeof(i16)) % 16 == 0 &&
+                  sizeof(f->Wsig) + sizeof(f->u) >= vad_bands_ * sizeof(i16) + SX_FRAME * sizeof(i32), "VAD bands + raw band sums in Wsig and the work area");
+    sx_vad(st, c, f->res_pitch, f->Wsig, &SNR_dB_Q7, (i32*)(void*)(f->Wsig + vad_bands_));
     wv_sync();
     static_assert(sizeof(f->u) >= SX_HP_SCRATCH_WORDS * sizeof(i32), "the pitch work area doubles as the high-pass filter's scratch");
     SX_S(32)

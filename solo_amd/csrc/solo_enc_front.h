@@ -92,10 +92,64 @@ SX_HD void sx_allpass2_lanes(const i16* in, int npairs, i32* S, i32 cA, i32 cB, 
 }
 #endif
 
-// SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
-SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N) {
-    const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
 #ifdef SX_LANE_STREAM
+// The same pair of chains with the band sums left as they are: lane 0 writes o1 + o0, lane 1 o1 - o0, 32 bits each, to rawL / rawH
+// (rawH null: nowhere); the caller rounds and saturates them afterwards, all samples side by side (sx_allpass2_finish) -- three
+// instructions less in every step of the recursion.  `in` must not overlap the raw buffers.
+SX_HD void sx_allpass2_lanes_raw(const i16* in, int npairs, i32* S, i32 cA, i32 cB, i32* rawL, i32* rawH, i32* dump4) {
+    if (SX_LANE < 2) {
+        const int l = SX_LANE;
+        i32 s = S ? S[l] : 0;
+        i32 cpre = sx_pre16(l ? cB : cA);
+        SX_VEC(cpre);
+        const i32 mask = l ? 0 : -1;
+        const i16* ip = in + l;                       // the lane's samples: in[2k + l]
+        SxV4i* op = (SxV4i*)(l ? (rawH ? rawH : dump4) : rawL);
+        const int ostep = (l && !rawH) ? 0 : 1;
+        i32 x[4], xn[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) xn[u] = ip[2 * u];
+        for (int k = 0; k < npairs; k += 4) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) x[u] = xn[u];
+            if (k + 4 < npairs) {
+#pragma unroll
+                for (int u = 0; u < 4; u++) xn[u] = ip[2 * (k + 4 + u)];
+            }
+            SxV4i r;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const i32 in32 = sx_shl(x[u], 10);
+                const i32 Y = sx_sub(in32, s);
+                const i32 X = sx_add(sx_smulw_pre(Y, cpre), Y & mask);
+                const i32 o = sx_add(s, X);
+                s = sx_add(in32, X);
+                const i32 p = SX_DPP_(l ? o : sx_neg(o), 0xB1);
+                r.v[u] = sx_add(o, p);
+            }
+            *op = r;
+            op += ostep;
+        }
+        if (S) S[l] = s;
+    }
+    wv_sync();
+}
+// out[i] = sat16(RSHIFT_ROUND(raw[i], 11)) (|raw| < 2^29: sx_rshift_round_small)
+SX_HD void sx_allpass2_finish(i16* out, const i32* raw, int n) {
+    SX_PAR(i, n) out[i] = (i16)sx_sat16(sx_rshift_round_small(raw[i], 11));
+}
+#endif
+
+// SKP_Silk_ana_filt_bank_1, SKP_Silk_ana_filt_bank_1.c:45 (serial first-order all-pass pair)
+// raw: N words of LDS scratch (gfx950 build: the band sums before rounding)
+SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N, i32* raw) {
+    const i32 A20 = (i16)(5394 << 1), A21 = (i16)(20623 << 1);   // the int16 wrap of A_fb1_21 is intentional
+#if defined(SX_LANE_STREAM) && !defined(SX_NO_RAW_VAD)
+    sx_allpass2_lanes_raw(in, N >> 1, S, A21, A20, raw, raw + (N >> 1), (i32*)0);
+    sx_allpass2_finish(outL, raw, N >> 1);
+    sx_allpass2_finish(outH, raw + (N >> 1), N >> 1);
+    wv_sync();
+#elif defined(SX_LANE_STREAM)
     sx_allpass2_lanes(in, N >> 1, S, A21, A20, outL, outH);
 #elif 0
     // N <= 64 * SX_FCH samples in (a frame), half as many out per band (in may alias outL: everything is read before anything is stored)
@@ -153,13 +207,14 @@ SX_HD void sx_ana_filt_bank_1(const i16* in, i32* S, i16* outL, i16* outH, int N
 }
 
 // SKP_Silk_VAD_GetSA_Q8 (+ GetNoiseLevels), SKP_Silk_VAD.c:75-318.  X is a 4 x 80 int16 scratch (LDS).
-SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSNR_dB_Q7) {
-    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(X);
+// raw: SX_FRAME words of LDS scratch (see sx_ana_filt_bank_1)
+SX_FN1 void sx_vad(SxEncState* st, SxEncCtrl* c, const i16* pIn, i16* X, i32* pSNR_dB_Q7, i32* raw) {
+    SX_IN_LDS(st); SX_IN_LDS(c); SX_IN_LDS(X); SX_IN_LDS(raw);
     SxVAD* v = &st->vad;
     i16* X0 = X, *X1 = X + 80, *X2 = X + 160, *X3 = X + 240;
-    sx_ana_filt_bank_1(pIn, v->AnaState, X0, X3, SX_FRAME);
-    sx_ana_filt_bank_1(X0, v->AnaState1, X0, X2, SX_FRAME >> 1);
-    sx_ana_filt_bank_1(X0, v->AnaState2, X0, X1, SX_FRAME >> 2);
+    sx_ana_filt_bank_1(pIn, v->AnaState, X0, X3, SX_FRAME, raw);
+    sx_ana_filt_bank_1(X0, v->AnaState1, X0, X2, SX_FRAME >> 1, raw);
+    sx_ana_filt_bank_1(X0, v->AnaState2, X0, X1, SX_FRAME >> 2, raw);
     // HP filter on lowest band (differentiator): h[i] = X0[i] >> 1, X0[i] = h[i] - h[i - 1] (h[-1] = the state), state = h[last]
     const int dfl = SX_FRAME >> 3;
     static_assert((SX_FRAME >> 3) % 2 == 0 && (SX_FRAME >> 3) + 2 * 16 <= 80, "the tail of X0 (its band is SX_FRAME / 8 long by now) is the scratch of the band statistics");
@@ -547,12 +602,12 @@ SX_HD i32 sx_pitch_find_scaling(const i16* sig, int len, int sum_sqr_len) {
 }
 
 struct SxPitchWork {                 // LDS scratch of the pitch analysis
+    alignas(16) i32 tmp32[160];      // (first, 16-byte aligned: also the raw band sums of the 8 -> 4 kHz decimator, stored 16 bytes at a time)
+    alignas(16) i32 d_srch[24];
     i16 sig8[320];
     i16 sig4[160];
     i16 C[4][221];
     i16 d_comp[221];
-    i32 d_srch[24];
-    i32 tmp32[160];
 #if SX_FS_KHZ == 16
     i16 sig16[640];                  // third stage: the (scaled) 16 kHz input
     i32 corr3[4][24], nrg3[4][24];   // per subframe: cross-correlation / basis energy over its stage-3 lag range (SCRATCH_SIZE = 22)
@@ -573,7 +628,15 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
     sx_down2_zero_state(w->sig8, signal, 640, (i16*)w->tmp32);      // 16 -> 8 kHz (pitch_analysis_core.c:127-129)
     wv_sync();
 #endif
+#if defined(SX_LANE_STREAM) && !defined(SX_NO_RAW_DECIM)
+    // (the 160 low-band sums land in tmp32 as they are, the unused high band on d_srch, which is free until the first stage; rounded below)
+    static_assert(sizeof(w->tmp32) >= 160 * sizeof(i32) && sizeof(w->d_srch) >= 16, "raw band sums of the 8 -> 4 kHz decimator");
+    sx_allpass2_lanes_raw(w->sig8, 160, (i32*)0, T_down2_c1[0], T_down2_c0[0], w->tmp32, (i32*)0, w->d_srch);
+    sx_allpass2_finish(w->sig4, w->tmp32, 160);
+    wv_sync();
+#else
     sx_down2_zero_state(w->sig4, w->sig8, 320, (i16*)w->tmp32);
+#endif
 #if SX_NLANES == 1
     for (int i = 159; i > 0; i--) w->sig4[i] = (i16)sx_sat16((i32)w->sig4[i] + (i32)w->sig4[i - 1]);
 #else
