@@ -521,7 +521,7 @@ SX_HD i32 sx_row_inv_pred_gain_Q16_n(i32 a, bool* unstable) {
         done = done || ak > A_LIMIT || ak < -A_LIMIT;
         const i32 rc_Q31 = sx_neg(sx_shl(ak, 31 - 16));
         const i32 m1 = (SX_I32_MAX >> 1) - sx_smmul(rc_Q31, rc_Q31);
-        i32 m2 = sx_inverse32_varQ(m1, 46);
+        i32 m2 = sx_inverse32_varQ_pos(m1, 46);                  // (m1 >= 2^19 while the filter is stable: |ak| <= A_LIMIT)
         const i32 inv_n = sx_shl(sx_smmul(inv, m1), 2);
         const int headrm = sx_clz32(m2) - 1;
         m2 = sx_shl(m2, headrm);

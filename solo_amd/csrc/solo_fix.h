@@ -217,6 +217,27 @@ SX_HD i32 sx_inverse32_varQ(i32 b32, int Qres) {
     if (lshift <= 0) return sx_lshift_sat32(result, -lshift);
     return lshift < 32 ? (result >> lshift) : 0;
 }
+// SKP_INVERSE32_varQ for a divisor known to be POSITIVE and a result that is shifted RIGHT (61 - headroom - Qres in 1 .. 31): what is
+// left of it then -- no absolute values, no sign handling in the reciprocal, no saturating-left-shift branch.  (The step-down recursion
+// of LPC_inverse_pred_gain: 1 - rc^2 in Q30 with |rc| <= 0.99975, Qres 46; lanes whose filter was found unstable compute garbage here and
+// are masked by the caller.)
+SX_HD i32 sx_inverse32_varQ_pos(i32 b32, int Qres) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int b_headrm = sx_clz32(b32) - 1;
+    const i32 b_nrm = sx_shl(b32, b_headrm);
+    const i32 d = b_nrm >> 16;                                   // 16384 .. 32767
+    i32 b_inv = (i32)(536870912.0f * __builtin_amdgcn_rcpf((float)d));
+    const i32 r = (SX_I32_MAX >> 2) - b_inv * d;
+    b_inv += r >= d ? 1 : 0;
+    b_inv -= r < 0 ? 1 : 0;
+    i32 result = sx_shl(b_inv, 16);
+    const i32 err_Q32 = sx_shl(sx_neg(sx_smulwb(b_nrm, b_inv)), 3);
+    result = sx_smlaww(result, err_Q32, b_inv);
+    return result >> (61 - b_headrm - Qres);
+#else
+    return sx_inverse32_varQ(b32, Qres);
+#endif
+}
 // SKP_RAND (SigProc_FIX.h:650)
 SX_HD i32 sx_rand(i32 seed) { return (i32)(907633515u + (u32)seed * 196314165u); }
 // n-th iterate of sx_rand (n >= 0) by square-and-multiply on the affine map x -> A x + C (mod 2^32): lets every lane of a

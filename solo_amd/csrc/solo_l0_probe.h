@@ -41,6 +41,7 @@ SX_HD i32 sx_l0_probe(int op, i32 a, i32 b, i32 c) {
         case 31: return sx_smlaw_pre(c, a, sx_pre16(b));
         case 32: return sx_rand_skip(a, (u32)b & 511u);         // b-th iterate of SKP_RAND
         case 34: return sx_rshift_round_small(a, b);            // = RSHIFT_ROUND for |a| < 2^30
+        case 35: return sx_inverse32_varQ_pos(a, b);            // = INVERSE32_varQ for a > 0 and 61 - headroom - b in 1 .. 31
         case 33: return sx_div_q29(a);                          // (INT32_MAX >> 2) / a on the divisor domain of the varQ divisions
         // Speex-derived helpers of the QMF (libBWE/AGR_BWE_fixed_generic.h)
         case 40: return sx_pshr32(a, b);

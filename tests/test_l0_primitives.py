@@ -212,6 +212,27 @@ def test_varq_reciprocal_gfx950_every_divisor():
 
 
 @pytest.mark.gpu
+def test_positive_inverse_gfx950_equals_inverse32_varq():
+    """sx_inverse32_varQ_pos (solo_fix.h), the form of SKP_INVERSE32_varQ the step-down recursions call for a positive divisor and a
+    right-shifted result, against sx_inverse32_varQ (pinned to the reference's inline by the vocabulary test) on that domain:
+    every value the recursion can produce at the top (1 - rc^2 in Q30, Qres 46) is >= 2^19; swept with strides plus random values"""
+    import torch
+    import solo_amd
+    lib = solo_amd.load_library()
+    lib.solo_debug_l0.restype = C.c_int32
+    lib.solo_debug_l0.argtypes = [C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    rng = np.random.default_rng(11)
+    a = np.concatenate([np.arange(1 << 19, 1 << 30, 40961), rng.integers(1 << 19, 1 << 30, 200000), (1 << np.arange(19, 30)), (1 << np.arange(20, 31)) - 1]).astype(np.int32)
+    b = np.full(a.size, 46, np.int32)
+    da, db = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    o1 = torch.zeros(a.size, dtype=torch.int32, device="cuda"); o2 = torch.zeros_like(o1)
+    assert lib.solo_debug_l0(35, a.size, da.data_ptr(), db.data_ptr(), db.data_ptr(), o1.data_ptr()) == 0
+    assert lib.solo_debug_l0(21, a.size, da.data_ptr(), db.data_ptr(), db.data_ptr(), o2.data_ptr()) == 0
+    bad = torch.nonzero(o1 != o2).flatten().cpu().numpy()
+    assert bad.size == 0, (int(a[bad[0]]), int(o1[bad[0]]), int(o2[bad[0]]))
+
+
+@pytest.mark.gpu
 @need_ref
 def test_sum_sqr_shift_wave_form_gfx950_vs_reference():
     """the wave-cooperative saturating-scan form of SKP_Silk_sum_sqr_shift (solo_common.h) against the reference function"""
