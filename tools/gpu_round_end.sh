@@ -38,7 +38,7 @@ if [ -n "$VARIANTS" ]; then
 fi
 
 # ---- 2. what is new this round
-timeout 300 python -m pytest tests/test_recv_ring.py tests/test_wb.py tests/test_pinned_corners.py -m gpu -x -q > "$OUT/gputest_new.log" 2>&1
+timeout 300 python -m pytest tests/test_gpu_nsq_row.py tests/test_nsq_taps.py tests/test_l0_primitives.py tests/test_gpu_encoder.py -m gpu -x -q > "$OUT/gputest_new.log" 2>&1
 log "new GPU tests: rc=$? $(tail -1 "$OUT/gputest_new.log")"
 
 # ---- 3. profile, first half
@@ -57,10 +57,18 @@ log "profile passes 2: $(tr '\n' ' ' < "$OUT/profile2.log" | cut -c1-200)"
 timeout 600 python -m pytest tests -m gpu -x -q > "$OUT/gputest.log" 2>&1
 log "GPU suite: rc=$? $(tail -1 "$OUT/gputest.log")"
 
-# ---- 7. section / phase timers of the profiling build (build/libsolo_prof.so = the same sources with -DSX_PROF), if there is time left
+# ---- 7. section timers of the profiling build (build/libsolo_prof.so = the same sources with -DSX_PROF, tools/build_prof.sh), the analysis
+# kernel's wave-instructions by section (build/libsolo_stops.so, tools/build_stops.sh), the legs the default command does not profile, the
+# issue-rate microbenchmark
 if [ -f build/libsolo_prof.so ]; then
-  { SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_sections.py 4096 10
-    SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_nsq.py 4096 10
+  { SOLO_ENC_CHUNK=0 SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_sections.py 4096 10
     SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_prof.so timeout 120 python tools/prof_dec.py 4096 10; } > "$OUT/prof_sections.log" 2>&1
   log "section timers: $(grep -c cycles "$OUT/prof_sections.log") lines"
 fi
+if [ -f build/libsolo_stops.so ]; then
+  SECTIONS_SAMPLES=8 bash tools/gpu_sections.sh > "$OUT/sections.log" 2>&1
+  log "analysis sections: $(grep -c "%" "$OUT/analysis_sections.txt") lines"
+fi
+bash tools/profile_legs.sh > "$OUT/profile_legs.log" 2>&1
+log "legs: $(grep "^leg" "$OUT/profile_legs.log" | cut -c1-120 | tr '\n' ' ')"
+if [ -x build/mb_valu ]; then timeout 120 build/mb_valu > "$OUT/mb_valu.txt" 2>&1; log "microbenchmark: $(wc -l < "$OUT/mb_valu.txt") lines"; fi
