@@ -1,5 +1,5 @@
 // solo_enc_kernels.h -- the encoder's analysis / coding kernels and the launch table of one build (the quantiser kernel lives in
-// solo_nsq16.hip).  Compiled once per internal rate like solo_dec_kernels.h: solo_api.hip (SX_FS_KHZ = 8, 16 kHz API rate) and
+// solo_nsq_row.hip).  Compiled once per internal rate like solo_dec_kernels.h: solo_api.hip (SX_FS_KHZ = 8, 16 kHz API rate) and
 // solo_api_wb.hip (SX_FS_KHZ = 16, 32 kHz API rate).
 #pragma once
 #include <hip/hip_runtime.h>
@@ -19,7 +19,7 @@ __global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* st
 
 // Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
 //   A  solo_enc_analysis_kernel  one wavefront per stream: QMF split + analysis chain of every frame of the launch
-//   B  solo_nsq_kernel           four streams per wavefront (solo_nsq16.hip): the delayed-decision quantiser
+//   B  solo_nsq_kernel           four streams per wavefront (solo_nsq_row.hip): the delayed-decision quantiser
 //   C  solo_enc_coding_kernel    one wavefront per stream: high-band encoder, range coding, payload assembly
 #ifdef SX_OUTLINE_WRAPPERS
 #define SX_ENTER_FN static __device__ __attribute__((noinline))
@@ -40,10 +40,9 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 }
 
 // waves-per-SIMD target of the analysis kernel = its register budget (5: <= 96 VGPRs, 4: <= 128).  All 16 analysis workgroups
-// of a compute unit (4096 streams / 256 CUs) must be resident BESIDE the quantiser's workgroup, or the last ones run as a second
-// round that costs a whole single-wave latency (round 2: 12 resident, 1.24 ms per launch; 16 resident: 0.9 ms, DESIGN.md
-// section 4): 5 waves on each of the three SIMDs the quantiser leaves + one beside the quantiser's wave (its register cap,
-// solo_nsq16.hip), and 16 x 8.6 KB of LDS + the quantiser's 23 KB <= 160 KB.
+// of a compute unit (4096 streams / 256 CUs) must be resident BESIDE the quantiser's four (one wave per SIMD, 128 registers,
+// solo_nsq_row.hip), or the last ones run as a second round that costs a whole single-wave latency:
+// 4 x 96 + 128 registers = the 512 of a SIMD, and 16 x 8 704 B of LDS + the quantiser's 4 x 6 144 B = 160 KB.
 #ifndef SX_ANALYSIS_WAVES
 #if SX_ENC_GROUP == 64
 #define SX_ANALYSIS_WAVES 5
@@ -66,7 +65,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
     const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
 #endif
     if (s >= n_streams) return;
-    // the same issue priority as the quantiser's wave (solo_nsq16.hip): with the quantiser above the analysis waves the encoder is
+    // the same issue priority as the quantiser's wave (solo_nsq_row.hip): with the quantiser above the analysis waves the encoder is
     // 0.5 % slower, below them 18 % (the quantiser starves); the range coder / coding kernels of older chunks stay at 0
     __builtin_amdgcn_s_setprio(SX_ANALYSIS_PRIO);
 #ifdef SX_EXP_STAGGER     // timing experiment: the waves that share a SIMD start a fraction of a frame apart
@@ -180,7 +179,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_coding_ke
 
 
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
-                                     void* ring, void* hip_stream);   // solo_nsq16.hip / solo_nsq16_wb.hip
+                                     void* ring, void* hip_stream);   // solo_nsq_row.hip / solo_nsq_row_wb.hip
 extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
 extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams);
 

@@ -2,7 +2,7 @@
 """Static look at the gfx950 code of a kernel source file: largest loops with their instruction mix, register / scratch use, and
 the "tiny divergent regions" (an exec-mask region of <= 3 vector instructions and no memory access: usually a select that the
 compiler turned into a branch -- chains of ?: on one index, short-circuit || / && on lane conditions).
-    python tools/debug/asm_report.py solo_amd/csrc/solo_nsq16.hip [-DFLAG ...]
+    python tools/debug/asm_report.py solo_amd/csrc/solo_nsq_row.hip [-DFLAG ...]
 Compiles with hipcc -S --cuda-device-only into /tmp (no GPU needed)."""
 import os, re, subprocess, sys, tempfile
 from collections import Counter
