@@ -436,11 +436,19 @@ SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pit
     } else {
         const int nSamples = 2 * SX_FS_KHZ;      // energy per 2 ms (noise_shape_analysis_FIX.c:253)
         i32 energy_variation_Q7 = 0, log_energy_prev_Q7 = 0;
-        for (int k = 0; k < 10; k++) {
+        // (the ten segment energies side by side, one lane each; the sum of their log differences afterwards)
+        i32* lg = sw->scale;                     // ten words of the shape work area, free until the warped autocorrelation
+        static_assert(sizeof(sw->scale) + sizeof(sw->C) >= 10 * sizeof(i32) && offsetof(SxShapeWork, C) == offsetof(SxShapeWork, scale) + sizeof(sw->scale),
+                      "scratch of the sparseness measure");
+        SX_PAR(k, 10) {
             i32 e, sh;
             sx_sum_sqr_shift(&e, &sh, pitch_res + k * nSamples, nSamples, 0);
             e += nSamples >> sh;
-            i32 log_energy_Q7 = sx_lin2log(e);
+            lg[k] = sx_lin2log(e);
+        }
+        wv_sync();
+        for (int k = 0; k < 10; k++) {
+            const i32 log_energy_Q7 = lg[k];
             if (k > 0) energy_variation_Q7 += sx_abs(log_energy_Q7 - log_energy_prev_Q7);
             log_energy_prev_Q7 = log_energy_Q7;
         }
