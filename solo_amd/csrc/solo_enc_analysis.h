@@ -1617,6 +1617,7 @@ SX_HD void sx_a2nlsf_init(const i32* a_Q16, i32* P, i32* Q, int dd) {
 // those values from LDS -- only the three bisection points per root are evaluated on the spot.
 SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid* g) {
     SX_IN_LDS(NLSF); SX_IN_LDS(a_Q16); SX_IN_LDS(P); SX_IN_LDS(Q); SX_IN_LDS(g);
+    d = SX_UNI(d);                           // (an argument of a real call arrives in a vector register: the root scan below is scalar code)
     const int dd = d >> 1;
     int i = 0;
     for (;;) {                               // one pass per bandwidth-expansion retry (A2NLSF.c:259-281)
@@ -1654,43 +1655,43 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid*
                 leP1 = __builtin_amdgcn_ballot_w64(p1 <= 0); geP1 = __builtin_amdgcn_ballot_w64(p1 >= 0);
                 leQ1 = __builtin_amdgcn_ballot_w64(q1 <= 0); geQ1 = __builtin_amdgcn_ballot_w64(q1 >= 0);
             }
-            int root_ix = 0, poly = 0, k = 1;
-            i32 art = 0;                                 // 0: the interval's real left value; else the reference's artificial +-4096
+            // Root r is a root of P (r even) or Q (r odd); after the first one the reference restarts each search from an artificial
+            // left value of +4096 (r & 2 == 0) or -4096, so the first test of root r looks at "y <= 0" resp. "y >= 0" of its interval.
+            // Which masks a step uses therefore depends on r & 3 only: the scan is written four roots per round with the masks
+            // named in the source (no selects among the twelve), each step ~20 scalar instructions.
+            int k = 1;
             const int first_root = SX_UNI(g->yP[0]) < 0 ? 1 : 0;
-            if (first_root) { root_ix = 1; poly = 1; }
             int my_k = 0;
             i32 my_art = 0;
-            bool fail = false;
-            while (root_ix < d) {
-                int kk = 129;
-                bool hit = false;
-                if (art != 0) {                          // first test after a switch: only the sign of y[k] matters
-                    const u64m mle = poly ? (k > 64 ? leQ1 : leQ0) : (k > 64 ? leP1 : leP0);
-                    const u64m mge = poly ? (k > 64 ? geQ1 : geQ0) : (k > 64 ? geP1 : geP0);
-                    const u64m m = art > 0 ? mle : mge;
-                    hit = (m >> ((k - 1) & 63)) & 1;
-                }
-                if (hit) {
-                    kk = k;
-                } else {
-                    int k0 = art != 0 ? k + 1 : k;       // real crossings from here on
-                    const u64m c0 = poly ? crQ0 : crP0, c1 = poly ? crQ1 : crP1;
-                    if (k0 <= 64) {
-                        const u64m t = c0 >> (k0 - 1);
-                        if (t) kk = k0 + __builtin_ctzll(t); else k0 = 65;
-                    }
-                    if (kk == 129 && k0 <= 128) {
-                        const u64m t = c1 >> (k0 - 65);
-                        if (t) kk = k0 + __builtin_ctzll(t);
-                    }
-                }
-                if (kk > 128) { fail = true; break; }
-                if (SX_LANE == root_ix) { my_k = kk; my_art = hit ? art : 0; }
-                root_ix++;
-                k = kk;
-                poly = root_ix & 1;
-                art = sx_shl(1 - (root_ix & 2), 12);
+            bool fail = false, have_art = false;
+#define SX_ROOT_STEP(R, SGN0, SGN1, CR0, CR1, ART)                                                                      \
+            if (!fail && (R) >= first_root && (R) < d) {                                                                  \
+                int kk = 129;                                                                                           \
+                bool hit = false;                                                                                       \
+                if (have_art) hit = ((k > 64 ? (SGN1) : (SGN0)) >> ((k - 1) & 63)) & 1;   /* only the sign of y[k] matters */ \
+                if (hit) {                                                                                              \
+                    kk = k;                                                                                             \
+                } else {                                                                                                \
+                    int k0 = have_art ? k + 1 : k;       /* real crossings from here on */                              \
+                    if (k0 <= 64) {                                                                                     \
+                        const u64m t = (CR0) >> (k0 - 1);                                                               \
+                        if (t) kk = k0 + __builtin_ctzll(t); else k0 = 65;                                              \
+                    }                                                                                                   \
+                    if (kk == 129 && k0 <= 128) {                                                                       \
+                        const u64m t = (CR1) >> (k0 - 65);                                                              \
+                        if (t) kk = k0 + __builtin_ctzll(t);                                                            \
+                    }                                                                                                   \
+                }                                                                                                       \
+                if (kk > 128) fail = true;                                                                              \
+                else { if (SX_LANE == (R)) { my_k = kk; my_art = hit ? (ART) : 0; } k = kk; have_art = true; }           \
             }
+            for (int r4 = 0; r4 < d; r4 += 4) {
+                SX_ROOT_STEP(r4, leP0, leP1, crP0, crP1, 4096)
+                SX_ROOT_STEP(r4 + 1, leQ0, leQ1, crQ0, crQ1, 4096)
+                SX_ROOT_STEP(r4 + 2, geP0, geP1, crP0, crP1, -4096)
+                SX_ROOT_STEP(r4 + 3, geQ0, geQ1, crQ0, crQ1, -4096)
+            }
+#undef SX_ROOT_STEP
             if (!fail) {
                 if (first_root && SX_LANE == 0) NLSF[0] = 0;
                 if (SX_LANE >= first_root && SX_LANE < d) {
