@@ -549,22 +549,14 @@ SX_HD i32 sx_row_inv_pred_gain_Q16_n(i32 a, bool* unstable) {
 // 8 + dd of the row (dd + 1 <= 8) -- one step of find_poly per k for all n at once (the reference walks n downwards, so every update
 // reads values of the previous step).  Returns false where the reference would start correcting -- a coefficient beyond int16
 // (NLSF2A.c:93) or an unstable filter (NLSF2A_stable.c:44) -- the caller then runs the serial restatement for that call.
-template <int ORDER>
-SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
-    static_assert(ORDER % 2 == 0 && ORDER / 2 + 1 <= 8, "two polynomials per 16-lane row");
-    const int j = SX_LANE & 15, dd = ORDER / 2;
-    const int h = j >> 3, n = j & 7;                          // polynomial (0: P, 1: Q) and coefficient index of this lane
-    i32 cosv = 0;
-    if (j < ORDER) {
-        const i32 v = pNLSF[j];
-        const i32 f_int = v >> 8, f_frac = v - (f_int << 8);
-        const i32 cos_val = T_lsf_cos_Q12[f_int];
-        cosv = sx_add(sx_shl(cos_val, 8), sx_mul(T_lsf_cos_Q12[f_int + 1] - cos_val, f_frac));
-    }
+// one polynomial of NLSF2A_find_poly in the lanes n = 0 .. dd of `lane n`'s row: h = 0: P (even cosines), 1: Q (odd); `n` is the lane's
+// coefficient index, lanes past dd compute zeros
+template <int DD>
+SX_HD i32 sx_row_find_poly(i32 cosv, int n, int h) {
     const i32 c0 = SX_ROWG(cosv, h);                          // (lane exchanges stay outside conditionals: every lane must take part)
     i32 out = n == 0 ? (1 << 20) : (n == 1 ? sx_neg(c0) : 0);
 #pragma unroll
-    for (int k = 1; k < dd; k++) {
+    for (int k = 1; k < DD; k++) {
         const i32 ftmp = SX_ROWG(cosv, 2 * k + h);
         const i32 o1 = SX_DPP_(out, 0x111), o2 = SX_DPP_(out, 0x112);          // out[n - 1], out[n - 2] (row_shr:1, :2)
         const i32 R = (i32)sx_rshift_round64(sx_smull(ftmp, o1), 20);
@@ -574,9 +566,33 @@ SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
         if (n == 1) nv = sx_sub(out, ftmp);
         out = nv;
     }
+    return out;
+}
+template <int ORDER>
+SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
+    static_assert(ORDER % 2 == 0 && ORDER <= 16, "one vector per 16-lane row");
+    constexpr int dd = ORDER / 2;
+    constexpr bool SIDE_BY_SIDE = dd + 1 <= 8;                // both polynomials in one pass: P in lanes 0 .. dd, Q in lanes 8 .. 8 + dd
+    const int j = SX_LANE & 15;
+    i32 cosv = 0;
+    if (j < ORDER) {
+        const i32 v = pNLSF[j];
+        const i32 f_int = v >> 8, f_frac = v - (f_int << 8);
+        const i32 cos_val = T_lsf_cos_Q12[f_int];
+        cosv = sx_add(sx_shl(cos_val, 8), sx_mul(T_lsf_cos_Q12[f_int + 1] - cos_val, f_frac));
+    }
     // a32[k] = -rshift_round(Ptmp + Qtmp, 9), a32[d - 1 - k] = rshift_round(Qtmp - Ptmp, 9), Ptmp = P[k + 1] + P[k], Qtmp = Q[k + 1] - Q[k]
     const int kk = j < dd ? j : ORDER - 1 - j;
-    const i32 Ptmp = sx_add(SX_ROWG(out, kk + 1), SX_ROWG(out, kk)), Qtmp = sx_sub(SX_ROWG(out, 8 + kk + 1), SX_ROWG(out, 8 + kk));
+    i32 Ptmp, Qtmp;
+    if constexpr (SIDE_BY_SIDE) {
+        const i32 out = sx_row_find_poly<dd>(cosv, j & 7, j >> 3);
+        Ptmp = sx_add(SX_ROWG(out, kk + 1), SX_ROWG(out, kk));
+        Qtmp = sx_sub(SX_ROWG(out, 8 + kk + 1), SX_ROWG(out, 8 + kk));
+    } else {                                                  // (order 16: nine coefficients each, one polynomial after the other)
+        const i32 outP = sx_row_find_poly<dd>(cosv, j, 0), outQ = sx_row_find_poly<dd>(cosv, j, 1);
+        Ptmp = sx_add(SX_ROWG(outP, kk + 1), SX_ROWG(outP, kk));
+        Qtmp = sx_sub(SX_ROWG(outQ, kk + 1), SX_ROWG(outQ, kk));
+    }
     i32 a32 = j < dd ? sx_neg(sx_rshift_round(sx_add(Ptmp, Qtmp), 9)) : sx_rshift_round(sx_sub(Qtmp, Ptmp), 9);
     if (j >= ORDER) a32 = 0;
     i32 maxabs = sx_abs(a32);
@@ -586,8 +602,6 @@ SX_HD bool sx_row_nlsf2a_stable_n(i16* pAR_Q12, const i32* pNLSF) {
     if (j < ORDER) pAR_Q12[j] = (i16)a32;
     return maxabs <= 32767 && !unstable;
 }
-#if SX_LPC <= 14
-#define SX_HAVE_ROW_NLSF2A 1            // (order 16, the 32 kHz build: 2 x 9 polynomial coefficients do not fit a row)
+#define SX_HAVE_ROW_NLSF2A 1
 SX_HD bool sx_row_nlsf2a_stable(i16* pAR_Q12, const i32* pNLSF) { return sx_row_nlsf2a_stable_n<SX_LPC>(pAR_Q12, pNLSF); }
-#endif
 #endif

@@ -1192,8 +1192,9 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                     SX_PAR(i, SX_LPC) w->PredCoef_Q12[1][i] = pa->A_final[f][i];
                     if (interp && f == 1) { SX_PAR(i, SX_LPC) w->PredCoef_Q12[0][i] = pa->A_interp1[i]; }
                     if (interp && f == 0) {
-#if defined(SX_LANE_STREAM) && defined(SX_HAVE_ROW_NLSF2A)
-                        // (every row converts the vector: sx_row_nlsf2a_stable, solo_common.h; the serial form only for the reference's corrections)
+#if defined(SX_LANE_STREAM) && defined(SX_HAVE_ROW_NLSF2A) && SX_LPC <= 14
+                        // (every row converts the vector: sx_row_nlsf2a_stable, solo_common.h; the serial form only for the reference's corrections.
+                        // Not in the 32 kHz build: inlined there it takes the synthesis kernel past 256 registers = one wave per SIMD)
                         if (__builtin_amdgcn_ballot_w64(!sx_row_nlsf2a_stable(w->PredCoef_Q12[0], nl)) != 0)
 #endif
                         { wv_sync(); SX_PAR(v, 1) sx_nlsf2a_stable_ws(w->PredCoef_Q12[0], nl, SX_LPC, w->u.ws1); }
