@@ -652,25 +652,32 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 const i32 hh = j < SX_HB_LPC ? hp->S[SX_HB_LPC - 1 - (j < SX_HB_LPC ? j : 0)] : 0;
                 const i32 aj = hbl ? ah : al;
                 i32 hj = hbl ? hh : hl;
-                const i32* in = hbl ? pexc_Q10 : pres_Q10;
-                i16* out = hbl ? hb_out : pxq;
+                // What a sample step does NOT need stays outside the recursion: the high band's excitation is scaled for the whole
+                // subframe beforehand (xs: the tail of sLPC_Q14, which only the other builds use), the filter values v are left
+                // where their inputs were (the low band's residual, xs), and gain / rounding / saturation of both bands' outputs
+                // follow for all samples side by side.  The two roles then differ in a saturating vs a wrapping add and a clamp
+                // before the state's shift: selects, no branch.
+                i32* xs = &w->u.syn.sLPC_Q14[SX_MAX_LPC];
                 const bool hb_zero = hp->lost != 0;
+                if (piggy) { SX_PAR(i, SX_SUBFR) xs[i] = sx_smulww(hbGain_Q16, hb_zero ? 0 : pexc_Q10[i]); }
+                wv_sync();
+                i32* io = hbl ? xs : pres_Q10;
                 for (int i = 0; i < SX_SUBFR; i++) {
                     const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
-                    const i32 x = in[i];
-                    i32 hn, o;
-                    if (hbl) {
-                        const i32 v = sx_add_sat32(p, sx_smulww(hbGain_Q16, hb_zero ? 0 : x));
-                        hn = sx_lshift_sat32(v, 4);
-                        o = v;
-                    } else {
-                        const i32 v = sx_add(x, p);
-                        hn = sx_shl(v, 4);
-                        o = sx_smulww(v, Gain_Q16);
-                    }
+                    const i32 x = io[i];
+                    const i32 v = hbl ? sx_add_sat32(p, x) : sx_add(x, p);
+                    const i32 vc = hbl ? sx_limit(v, SX_I32_MIN >> 4, SX_I32_MAX >> 4) : v;    // lshift_sat32(v, 4) = clamp, then shift
+                    const i32 hn = sx_shl(vc, 4);
                     const i32 sh = __builtin_amdgcn_update_dpp(0, hj, 0x111, 0xF, 0xF, true);      // row_shr:1: lane j takes lane j - 1
                     hj = j == 0 ? hn : sh;
-                    out[i] = (i16)sx_sat16(sx_rshift_round(o, 10));
+                    io[i] = v;
+                }
+                wv_sync();
+                SX_PAR(t, (piggy ? 2 : 1) * SX_SUBFR) {
+                    const bool hb = t >= SX_SUBFR;
+                    const int i = hb ? t - SX_SUBFR : t;
+                    const i32 o = hb ? xs[i] : sx_smulww(pres_Q10[i], Gain_Q16);
+                    (hb ? hb_out : pxq)[i] = (i16)sx_sat16(sx_rshift_round(o, 10));
                 }
                 wv_sync();
                 if (row == 0) w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j] = hj;                // the last SX_MAX_LPC outputs: the next subframe starts from them

@@ -67,13 +67,56 @@ def run(plan_path):
     print("analysis_sections: %d measurement launches, %d analysis dispatches" % (len(plan), disp))
 
 
+DEC_NAMES = {0: "symbols staged, de-quantisation (two lanes)", 1: "merge + inverse NSQ (+ frame-0 NLSF -> LPC)", 2: "decode_core (LTP / LPC synthesis)",
+             3: "PLC update", 4: "outBuf + glue frames", 5: "CNG", 8: "high band: side information", 6: "high band: finish", 7: "QMF synthesis",
+             9: "decode_core: excitation, subframe set-up", 10: "decode_core: LTP synthesis", 11: "decode_core: LPC synthesis", 12: "CNG: smoothing + excitation"}
+
+
+def run_dec(plan_path):
+    """the same for the decoder's synthesis kernel (-DSX_STOPS solo_api.hip): one decode call = one launch"""
+    import numpy as np, torch, solo_amd
+    from solo_amd.synth import synth_stream
+    N = int(os.environ.get("SECTIONS_N", "256"))
+    samples = [(j, 3 + (j % 4)) for j in range(int(os.environ.get("SECTIONS_SAMPLES", "8")))]
+    lib = solo_amd.load_library()
+    lib.solo_debug_stop_dec.argtypes = [ctypes.c_int32]
+    lib.solo_debug_site_hits_dec.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    lib.solo_debug_stop.argtypes = [ctypes.c_int32]
+    lib.solo_debug_stop(0)
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
+    hits = (ctypes.c_ulonglong * 64)()
+    plan, disp = [], 0
+    for j, W in samples:
+        one = synth_stream(j, W + 1)
+        x = torch.from_numpy(np.broadcast_to(one[None], (N, W + 1, 640)).copy()).cuda()
+        b.reset(); lib.solo_debug_stop_dec(0)
+        bits, nb, st = b.encode(x); torch.cuda.synchronize()
+        wb, wn, lb, ln = bits[:, :W].contiguous(), nb[:, :W].contiguous(), bits[:, W:].contiguous(), nb[:, W:].contiguous()
+        b.decode(wb, wn); torch.cuda.synchronize(); disp += 1
+        lib.solo_debug_site_hits_dec(hits, 1)
+        b.decode(lb, ln); torch.cuda.synchronize(); disp += 1
+        lib.solo_debug_site_hits_dec(hits, 1)
+        per = {s: int(hits[s]) // N for s in range(64) if hits[s]}
+        stops = [(s, h) for s, n in per.items() for h in range(1, n + 1)] + [(63, 1)]
+        for s, h in stops:
+            b.reset(); lib.solo_debug_stop_dec(NEVER); b.decode(wb, wn); disp += 1
+            lib.solo_debug_stop_dec((s << 8) | h); b.decode(lb, ln); torch.cuda.synchronize()
+            plan.append({"sample": j, "warm": W, "site": s, "hit": h, "dispatch": disp}); disp += 1
+        lib.solo_debug_stop_dec(0)
+    json.dump({"n_streams": N, "samples": samples, "plan": plan, "kernel": "dec_synth"}, open(plan_path, "w"))
+    print("analysis_sections: %d measurement launches, %d synthesis dispatches" % (len(plan), disp))
+
+
 def report(plan_path, prof_dir):
     P = json.load(open(plan_path))
     N = P["n_streams"]
+    KERNEL = P.get("kernel", "enc_analysis")
+    global NAMES
+    if KERNEL == "dec_synth": NAMES = DEC_NAMES
     rows = defaultdict(dict)          # dispatch id -> counter -> value (analysis kernel only)
     for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
-            if "enc_analysis" in r["Kernel_Name"]:
+            if KERNEL in r["Kernel_Name"]:
                 rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = rows[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
     order = sorted(rows)
     per_site = defaultdict(lambda: defaultdict(float))
@@ -93,7 +136,7 @@ def report(plan_path, prof_dir):
             prev = v
         totals.append(pts[-1][0])
     n = len(P["samples"])
-    print("analysis kernel: wave-instructions per packet by section (mean of %d (stream, packet) samples x %d identical waves; the section" % (n, N))
+    print("%s kernel: wave-instructions per packet by section (mean of %d (stream, packet) samples x %d identical waves; the section" % (KERNEL, n, N))
     print("ENDS at the named site; SX_STOPS build: + ~8 instructions per site passed).  total %.0f (min %.0f, max %.0f)" % (sum(totals) / n, min(totals), max(totals)))
     print("%-66s %6s %8s %8s %7s %7s %7s" % ("section", "passes", "all", "VALU", "SALU", "LDS", "mem"))
     tot_all = sum(totals) / n
@@ -106,4 +149,5 @@ def report(plan_path, prof_dir):
 
 if __name__ == "__main__":
     if sys.argv[1] == "run": run(sys.argv[2])
+    elif sys.argv[1] == "rundec": run_dec(sys.argv[2])
     else: report(sys.argv[2], sys.argv[3])

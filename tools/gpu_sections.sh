@@ -4,10 +4,12 @@
 set -u
 ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"
 export TMPDIR=/tmp
+MODE=${1:-run}            # run: the encoder's analysis kernel; rundec: the decoder's synthesis kernel
 rm -rf "$OUT/sections"
 cd /tmp
-SOLO_EXP_SKIP=3 SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_stops.so timeout -k 5 ${SECTIONS_TIMEOUT:-400} rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES \
-    -d "$OUT/sections" -o s --output-format csv -- python $ROOT/tools/debug/analysis_sections.py run "$OUT/sections_plan.json" > "$OUT/sections_run.log" 2>&1
+[ "$MODE" = run ] && export SOLO_EXP_SKIP=3        # (the analysis kernel alone: the stopped launches leave the later stages nothing to work on)
+SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_stops.so timeout -k 5 ${SECTIONS_TIMEOUT:-400} rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_WAVES \
+    -d "$OUT/sections" -o s --output-format csv -- python $ROOT/tools/debug/analysis_sections.py $MODE "$OUT/sections_plan.json" > "$OUT/sections_run.log" 2>&1
 echo "rc=$?"; tail -3 "$OUT/sections_run.log"
 cd $ROOT
 python tools/debug/analysis_sections.py report "$OUT/sections_plan.json" "$OUT/sections" > "$OUT/analysis_sections.txt" 2>&1
