@@ -662,14 +662,14 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 if (piggy) { SX_PAR(i, SX_SUBFR) xs[i] = sx_smulww(hbGain_Q16, hb_zero ? 0 : pexc_Q10[i]); }
                 wv_sync();
                 i32* io = hbl ? xs : pres_Q10;
+                i32 clo = hbl ? (SX_I32_MIN >> 4) : SX_I32_MIN, chi = hbl ? (SX_I32_MAX >> 4) : SX_I32_MAX;   // lshift_sat32(v, 4) = clamp, then shift
+                SX_VEC(clo); SX_VEC(chi);
                 for (int i = 0; i < SX_SUBFR; i++) {
                     const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
                     const i32 x = io[i];
                     const i32 v = hbl ? sx_add_sat32(p, x) : sx_add(x, p);
-                    const i32 vc = hbl ? sx_limit(v, SX_I32_MIN >> 4, SX_I32_MAX >> 4) : v;    // lshift_sat32(v, 4) = clamp, then shift
-                    const i32 hn = sx_shl(vc, 4);
-                    const i32 sh = __builtin_amdgcn_update_dpp(0, hj, 0x111, 0xF, 0xF, true);      // row_shr:1: lane j takes lane j - 1
-                    hj = j == 0 ? hn : sh;
+                    const i32 hn = sx_shl(sx_max(sx_min(v, chi), clo), 4);
+                    hj = __builtin_amdgcn_update_dpp(hn, hj, 0x111, 0xF, 0xF, false);              // row_shr:1: lane j takes lane j - 1, lane 0 the new sample
                     io[i] = v;
                 }
                 wv_sync();

@@ -43,7 +43,6 @@ struct alignas(16) SxV4i { i32 v[4]; };        // 16-byte LDS moves
 // recursions left to the scalar unit are the dearest instructions of the analysis kernel (tools/debug/mb_issue.hip,
 // DESIGN.md section 4).  SX_VEC(x) pins a value to a vector register and hides its uniformity from the compiler, so the
 // arithmetic that depends on it is emitted for the vector unit.
-#define SX_VEC(x) asm volatile("" : "+v"(x))
 // Two first-order all-pass chains side by side -- the structure of SKP_Silk_ana_filt_bank_1 (ana_filt_bank_1.c:45) and of
 // SKP_Silk_resampler_down2 (resampler_down2.c:41): lane 0 runs the chain of the EVEN input samples, X = Y + (Y * cA >> 16),
 // lane 1 that of the ODD ones, X = Y * cB >> 16; per pair of samples the two chain outputs are exchanged inside the lane pair

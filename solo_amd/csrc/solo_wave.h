@@ -220,8 +220,11 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
 SX_HD int sx_vzero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return z; }
 #define SX_VPTR(p) ((p) + sx_vzero())
+// pins a value to a vector register and hides its uniformity from the compiler (see solo_enc_front.h: recursions on the vector unit)
+#define SX_VEC(x) asm volatile("" : "+v"(x))
 #else
 #define SX_VPTR(p) (p)
+#define SX_VEC(x)
 #endif
 
 // Serial recursions over a block of samples (IIR sections that cannot be re-cut over the lanes) read and write their samples
