@@ -881,9 +881,9 @@ int32_t solo_debug_prof(unsigned long long* out64, int32_t reset) {
 // each site was passed by the launches that ran through
 int32_t solo_debug_stop_dec(int32_t site_hit) { return hipMemcpyToSymbol(HIP_SYMBOL(g_sx_stop), &site_hit, sizeof(site_hit)) == hipSuccess ? 0 : -1; }
 int32_t solo_debug_site_hits_dec(unsigned long long* out64, int32_t reset) {
-    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sx_site_hits), 64 * sizeof(unsigned long long)) != hipSuccess) return -1;
+    if (hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_sx_site_hits), 128 * sizeof(unsigned long long)) != hipSuccess) return -1;
     if (reset) {
-        unsigned long long z[64] = {0};
+        unsigned long long z[128] = {0};
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_site_hits), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;

@@ -143,7 +143,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
     const int s = blockIdx.x;
     if (s >= n_streams) return;
 #if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
-    sx_site_hits_[threadIdx.x & 63] = 0;
+    SX_STOPS_ENTER(0)
 #endif
     SX_K(solo_dec_enter)(&w, &states[s]);
     i32 first_err = 0;

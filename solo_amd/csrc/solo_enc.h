@@ -288,11 +288,14 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     i32* weight = hw->weight;
     i32* a_Q16 = hw->lpc.a_Q16;
     i32* NLSF_Q15 = hw->NLSF_Q15;
+    SX_S(57)
     sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, SX_HB_LPCBLK, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
     sx_bwexpander_32(a_Q16, SX_HB_LPC, K_FIND_LPC_CHIRP_Q16);
     wv_sync();
+    SX_S(58)
     sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q, &hw->lpc.u.grid);
     wv_sync();
+    SX_S(59)
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
     if (SX_LANE == 0) sx_nlsf_weights_laroia(SX_VPTR(weight), SX_VPTR(NLSF_Q15), SX_HB_LPC);      // (one lane, vector unit: SX_VPTR)
     wv_sync();
@@ -332,6 +335,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     for (int j = 0; j < SX_HB_LPC; j++) NLSF_Q15[j] = (i32)T_hb_lsp_cb1[idx1 * SX_HB_LPC + j] + (i32)T_hb_lsp_cb2[idx2 * SX_HB_LPC + j];
     wv_sync();
+    SX_S(60)
     const i32 hb_lsp_idx = (idx2 << 8) + idx1;
     i16* A_Q12 = hw->A_Q12;
 #if defined(SX_LANE_STREAM)
@@ -343,6 +347,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         if (SX_LANE == 0) sx_nlsf2a_stable_ws(SX_VPTR(A_Q12), SX_VPTR(NLSF_Q15), SX_HB_LPC, SX_VPTR(hw->ws));
     }
     wv_sync();
+    SX_S(61)
     u32 word = (u32)hb_lsp_idx << 20;
     // the four blocks of N / 4 samples are filtered from zero state (the reference calls the filter once per block)
     SX_PAR(t, N) {
@@ -357,6 +362,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         exc[t] = (i16)sx_sat16(sx_rshift_round(o, 12));
     }
     wv_sync();
+    SX_S(62)
     for (int sub = 0; sub < 4; sub++) {
         i32 res_nrg0 = 0, res_nrg1 = 0;
         SX_PAR(i, sub_len) {
@@ -381,6 +387,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         wv_argmin(&min_dist, &gidx);
         word |= (u32)gidx << (15 - 5 * sub);
     }
+    SX_S(45)
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
     // slide the buffer: the last 200 samples are the next frame's history
     SX_PAR(i, N + SX_HB_DELAY) hist->x_hb_buf[i] = xb[N + i];

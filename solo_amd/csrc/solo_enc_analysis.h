@@ -1658,38 +1658,37 @@ SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid*
             // Root r is a root of P (r even) or Q (r odd); after the first one the reference restarts each search from an artificial
             // left value of +4096 (r & 2 == 0) or -4096, so the first test of root r looks at "y <= 0" resp. "y >= 0" of its interval.
             // Which masks a step uses therefore depends on r & 3 only: the scan is written four roots per round with the masks
-            // named in the source (no selects among the twelve), each step ~20 scalar instructions.
+            // named in the source.  "The first crossing at or after interval k" is tabulated beforehand, interval k by lane k - 1
+            // (k <= 64) / k - 65, so that a step fetches it with a v_readlane instead of shifting and scanning two 64-bit masks.
+            i32 nxP0, nxP1, nxQ0, nxQ1;
+            {
+                const int l = SX_LANE;
+                const u64m tp0 = crP0 >> l, tp1 = crP1 >> l, tq0 = crQ0 >> l, tq1 = crQ1 >> l;
+                nxP1 = tp1 ? l + 65 + (int)__builtin_ctzll(tp1) : 129;
+                nxQ1 = tq1 ? l + 65 + (int)__builtin_ctzll(tq1) : 129;
+                nxP0 = tp0 ? l + 1 + (int)__builtin_ctzll(tp0) : (crP1 ? 65 + (int)__builtin_ctzll(crP1) : 129);
+                nxQ0 = tq0 ? l + 1 + (int)__builtin_ctzll(tq0) : (crQ1 ? 65 + (int)__builtin_ctzll(crQ1) : 129);
+            }
             int k = 1;
             const int first_root = SX_UNI(g->yP[0]) < 0 ? 1 : 0;
             int my_k = 0;
             i32 my_art = 0;
             bool fail = false, have_art = false;
-#define SX_ROOT_STEP(R, SGN0, SGN1, CR0, CR1, ART)                                                                      \
+#define SX_ROOT_STEP(R, SGN0, SGN1, NX0, NX1, ART)                                                                      \
             if (!fail && (R) >= first_root && (R) < d) {                                                                  \
-                int kk = 129;                                                                                           \
                 bool hit = false;                                                                                       \
                 if (have_art) hit = ((k > 64 ? (SGN1) : (SGN0)) >> ((k - 1) & 63)) & 1;   /* only the sign of y[k] matters */ \
-                if (hit) {                                                                                              \
-                    kk = k;                                                                                             \
-                } else {                                                                                                \
-                    int k0 = have_art ? k + 1 : k;       /* real crossings from here on */                              \
-                    if (k0 <= 64) {                                                                                     \
-                        const u64m t = (CR0) >> (k0 - 1);                                                               \
-                        if (t) kk = k0 + __builtin_ctzll(t); else k0 = 65;                                              \
-                    }                                                                                                   \
-                    if (kk == 129 && k0 <= 128) {                                                                       \
-                        const u64m t = (CR1) >> (k0 - 65);                                                              \
-                        if (t) kk = k0 + __builtin_ctzll(t);                                                            \
-                    }                                                                                                   \
-                }                                                                                                       \
+                const int k0 = have_art ? k + 1 : k;         /* real crossings from here on: 1 .. 129 */                \
+                const int n0_ = __builtin_amdgcn_readlane((NX0), (k0 - 1) & 63), n1_ = __builtin_amdgcn_readlane((NX1), (k0 - 65) & 63); \
+                const int kk = hit ? k : (k0 <= 64 ? n0_ : (k0 <= 128 ? n1_ : 129));                                     \
                 if (kk > 128) fail = true;                                                                              \
                 else { if (SX_LANE == (R)) { my_k = kk; my_art = hit ? (ART) : 0; } k = kk; have_art = true; }           \
             }
             for (int r4 = 0; r4 < d; r4 += 4) {
-                SX_ROOT_STEP(r4, leP0, leP1, crP0, crP1, 4096)
-                SX_ROOT_STEP(r4 + 1, leQ0, leQ1, crQ0, crQ1, 4096)
-                SX_ROOT_STEP(r4 + 2, geP0, geP1, crP0, crP1, -4096)
-                SX_ROOT_STEP(r4 + 3, geQ0, geQ1, crQ0, crQ1, -4096)
+                SX_ROOT_STEP(r4, leP0, leP1, nxP0, nxP1, 4096)
+                SX_ROOT_STEP(r4 + 1, leQ0, leQ1, nxQ0, nxQ1, 4096)
+                SX_ROOT_STEP(r4 + 2, geP0, geP1, nxP0, nxP1, -4096)
+                SX_ROOT_STEP(r4 + 3, geQ0, geQ1, nxQ0, nxQ1, -4096)
             }
 #undef SX_ROOT_STEP
             if (!fail) {

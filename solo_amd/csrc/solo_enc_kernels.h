@@ -79,7 +79,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
     const unsigned long long hist_t0_ = wall_clock64();
 #endif
 #if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
-    sx_site_hits_[threadIdx.x & 63] = 0;
+    SX_STOPS_ENTER(0)
 #endif
     SX_K(solo_enc_enter)(&w, rec);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
@@ -159,6 +159,9 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_coding_ke
 #endif
     if (s >= n_streams) return;
     SxEncStream* rec = &states[s];
+#if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
+    SX_STOPS_ENTER(1)
+#endif
     SX_K(solo_enc_enter)(&w, rec);
     i32 first_err = 0;
     for (int p = p0; p < p0 + pc; p++) {

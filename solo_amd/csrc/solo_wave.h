@@ -290,19 +290,21 @@ static __device__ unsigned long long g_sx_prof[64];
 static __device__ unsigned long long g_sx_hist[4][64];
 #endif
 #if defined(SX_STOPS) && defined(__HIPCC__)
-static __device__ int g_sx_stop;
-static __device__ unsigned long long g_sx_site_hits[64];
+static __device__ int g_sx_stop;                          // kernel tag << 16 | site << 8 | hit (0: run through and count)
+static __device__ unsigned long long g_sx_site_hits[2][64];
 #endif
 #if defined(SX_PROF) && defined(__HIP_DEVICE_COMPILE__)
 #define SX_T_BEGIN unsigned long long sx_t_last_ = __builtin_readcyclecounter();
 #define SX_T_RESET sx_t_last_ = __builtin_readcyclecounter();
 #define SX_T(id) { unsigned long long t_ = __builtin_readcyclecounter(); if (SX_LANE == 0) atomicAdd(&g_sx_prof[id], t_ - sx_t_last_); sx_t_last_ = __builtin_readcyclecounter(); }
 #elif defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
-static __shared__ unsigned char sx_site_hits_[64];       // (one stream per workgroup; cleared by the kernel wrapper)
-#define SX_T_BEGIN
+static __shared__ unsigned char sx_site_hits_[64];       // (one stream per workgroup; cleared by the kernel wrapper; [63] = the kernel's tag:
+#define SX_T_BEGIN                                       //  stages shared by two kernels -- Burg, A2NLSF -- stop in the tagged one only)
 #define SX_T_RESET
-#define SX_T(id) { const int h_ = sx_site_hits_[id] + 1; const int stop_ = g_sx_stop; sx_site_hits_[id] = (unsigned char)h_;                \
-        if (stop_ == 0) { if (SX_LANE == 0) atomicAdd(&g_sx_site_hits[id], 1ull); } else if (stop_ == (((id) << 8) | h_)) __builtin_amdgcn_endpgm(); }
+#define SX_STOPS_ENTER(tag_) { sx_site_hits_[threadIdx.x & 63] = (threadIdx.x & 63) == 63 ? (unsigned char)(tag_) : (unsigned char)0; }
+#define SX_T(id) { const int h_ = sx_site_hits_[id] + 1; const int stop_ = g_sx_stop; const int tag_ = sx_site_hits_[63]; sx_site_hits_[id] = (unsigned char)h_; \
+        if (stop_ == 0) { if (SX_LANE == 0) atomicAdd(&g_sx_site_hits[tag_ & 1][id], 1ull); }                                                 \
+        else if (stop_ == ((tag_ << 16) | ((id) << 8) | h_)) __builtin_amdgcn_endpgm(); }
 #else
 #define SX_T_BEGIN
 #define SX_T_RESET

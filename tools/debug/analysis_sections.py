@@ -46,7 +46,7 @@ def run(plan_path):
     lib.solo_debug_stop.argtypes = [ctypes.c_int32]
     lib.solo_debug_site_hits.argtypes = [ctypes.c_void_p, ctypes.c_int32]
     b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
-    hits = (ctypes.c_ulonglong * 64)()
+    hits = (ctypes.c_ulonglong * 128)()
     plan, disp = [], 0          # disp = index of the next analysis dispatch (one per packet of every encode call)
     for j, W in samples:
         one = synth_stream(j, W + 1)
@@ -72,6 +72,43 @@ DEC_NAMES = {0: "symbols staged, de-quantisation (two lanes)", 1: "merge + inver
              9: "decode_core: excitation, subframe set-up", 10: "decode_core: LTP synthesis", 11: "decode_core: LPC synthesis", 12: "CNG: smoothing + excitation"}
 
 
+COD_NAMES = {57: "high band: buffers staged, LPC blocks", 23: "burg: sum_sqr_shift", 24: "burg: first row of correlations", 25: "burg: recursion", 58: "high band: burg tail, expand",
+             59: "high band: A2NLSF", 60: "high band: LSP weights + two-stage VQ", 61: "high band: NLSF -> LPC", 62: "high band: whitening filter",
+             45: "high band: four gains", 9: "high band: history write-back", 11: "payload assembly"}
+
+
+def run_cod(plan_path):
+    """the same for the coding kernel (kernel tag 1 of the -DSX_STOPS encoder build): the whole encoder runs, only coding waves stop"""
+    import numpy as np, torch, solo_amd
+    from solo_amd.synth import synth_stream
+    N = int(os.environ.get("SECTIONS_N", "256"))
+    samples = [(j, 3 + (j % 4)) for j in range(int(os.environ.get("SECTIONS_SAMPLES", "8")))]
+    lib = solo_amd.load_library()
+    lib.solo_debug_stop.argtypes = [ctypes.c_int32]
+    lib.solo_debug_site_hits.argtypes = [ctypes.c_void_p, ctypes.c_int32]
+    b = solo_amd.SoloBatch(N, encoder=True, decoder=False, slot_bytes=512)
+    hits = (ctypes.c_ulonglong * 128)()
+    plan, disp = [], 0
+    never = (1 << 16) | NEVER
+    for j, W in samples:
+        one = synth_stream(j, W + 1)
+        x = torch.from_numpy(np.broadcast_to(one[None], (N, W + 1, 640)).copy()).cuda()
+        warm, last = x[:, :W].contiguous(), x[:, W:].contiguous()
+        b.reset(); lib.solo_debug_stop(0); b.encode(warm); torch.cuda.synchronize(); disp += W
+        lib.solo_debug_site_hits(hits, 1)
+        b.encode(last); torch.cuda.synchronize(); disp += 1
+        lib.solo_debug_site_hits(hits, 1)
+        per = {s: int(hits[64 + s]) // N for s in range(64) if hits[64 + s]}
+        stops = [(s, h) for s, n in per.items() for h in range(1, n + 1)] + [(62 + 0 * 1, 99)]
+        for s, h in stops:
+            b.reset(); lib.solo_debug_stop(never); b.encode(warm); disp += W
+            lib.solo_debug_stop((1 << 16) | (s << 8) | h); b.encode(last); torch.cuda.synchronize()
+            plan.append({"sample": j, "warm": W, "site": s if h != 99 else 63, "hit": h, "dispatch": disp}); disp += 1
+        lib.solo_debug_stop(0)
+    json.dump({"n_streams": N, "samples": samples, "plan": plan, "kernel": "enc_coding"}, open(plan_path, "w"))
+    print("analysis_sections: %d measurement launches, %d coding dispatches" % (len(plan), disp))
+
+
 def run_dec(plan_path):
     """the same for the decoder's synthesis kernel (-DSX_STOPS solo_api.hip): one decode call = one launch"""
     import numpy as np, torch, solo_amd
@@ -84,7 +121,7 @@ def run_dec(plan_path):
     lib.solo_debug_stop.argtypes = [ctypes.c_int32]
     lib.solo_debug_stop(0)
     b = solo_amd.SoloBatch(N, encoder=True, decoder=True, slot_bytes=512)
-    hits = (ctypes.c_ulonglong * 64)()
+    hits = (ctypes.c_ulonglong * 128)()
     plan, disp = [], 0
     for j, W in samples:
         one = synth_stream(j, W + 1)
@@ -113,6 +150,7 @@ def report(plan_path, prof_dir):
     KERNEL = P.get("kernel", "enc_analysis")
     global NAMES
     if KERNEL == "dec_synth": NAMES = DEC_NAMES
+    if KERNEL == "enc_coding": NAMES = COD_NAMES
     rows = defaultdict(dict)          # dispatch id -> counter -> value (analysis kernel only)
     for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
         for r in csv.DictReader(open(f)):
@@ -150,4 +188,5 @@ def report(plan_path, prof_dir):
 if __name__ == "__main__":
     if sys.argv[1] == "run": run(sys.argv[2])
     elif sys.argv[1] == "rundec": run_dec(sys.argv[2])
+    elif sys.argv[1] == "runcod": run_cod(sys.argv[2])
     else: report(sys.argv[2], sys.argv[3])
