@@ -57,3 +57,19 @@ def test_decoder_suite_with_small_decode_chunks():
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail
     assert " passed" in r.stdout and "failed" not in r.stdout, tail
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("knobs", [{"SOLO_ENC_ACHUNK": "2"}, {"SOLO_ENC_CHUNK": "2"}, {"SOLO_ENC_CHUNK": "0"}, {"SOLO_ENC_GATE": "1"},
+                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+def test_encoder_suite_under_the_pipeline_knobs(knobs):
+    """The encoder's pipeline has run-time knobs that change how a call is cut into launches (chunks of several packets, one analysis
+    launch over several chunks, no pipeline at all, the residency gate, small launch groups) but must never change a bit of the
+    output: the encoder parity tests (goldens, packet-wise vs batched calls, joint mode, DTX, both rates) once more under each."""
+    env = dict(os.environ, **knobs)
+    r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
+                        os.path.join(T.ROOT, "tests", "test_gpu_encoder.py")],
+                       env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
+    tail = (r.stdout + r.stderr)[-1500:]
+    assert r.returncode == 0, tail
+    assert " passed" in r.stdout and "failed" not in r.stdout, tail
