@@ -28,6 +28,9 @@
 #ifndef SX_NSQ_VGPR_CAP
 #if RW_TPL == 3
 #define SX_NSQ_VGPR_CAP 128          // (three tracks per lane: 256 registers; one such wave per compute unit)
+#elif SX_FS_KHZ == 16
+#define SX_NSQ_VGPR_CAP 80           // (32 kHz build: order-16 prediction spills inside the sample loop at 128 registers -- 160: encode 72.0 -> 67.0 ms
+                                     // per 4096 x 25 packets; its analysis workgroups are LDS-bound to nine per compute unit, the registers are free)
 #else
 #define SX_NSQ_VGPR_CAP 64
 #endif
