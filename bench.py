@@ -280,7 +280,11 @@ def main():
     if torch.cuda.device_count() < (local_rank + 1):
         raise SystemExit("rank %d: LOCAL_RANK %d but only %d HIP device(s) visible" % (rank, local_rank, torch.cuda.device_count()))
     dist = None
-    if world > 1:
+    # SOLO_FORCE_DIST=1 (tests/test_gpu_dist_nccl.py): run the N > 1 code path -- process group over RCCL, barriers, all_reduce(MAX),
+    # all_gather_object of the per-rank records -- also when the launcher started ONE rank, so that the collectives of the
+    # multi-GPU path execute on hardware on a one-GPU box; the record must equal the plain single-process run's
+    use_dist = world > 1 or (launched and os.environ.get("SOLO_FORCE_DIST") == "1")
+    if use_dist:
         torch.cuda.set_device(local_rank)
         dist = sdist.init("nccl", torch.device("cuda", local_rank))
     else:
@@ -332,7 +336,7 @@ def main():
             step_no[0] = 0
 
     def barrier():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -377,7 +381,7 @@ def main():
             kms[name].append(v)
     batch.set_timing(False)
     enc_chunks = max(1, batch.last_encode_chunks())
-    dt = sdist.max_over_ranks(dt_local, dist, dev) if world > 1 else dt_local
+    dt = sdist.max_over_ranks(dt_local, dist, dev) if use_dist else dt_local
     assert int(st_e.abs().max()) == 0 and int(st_d.abs().max()) == 0, "codec status != 0"
     kavg = {n: float(np.mean(v)) for n, v in kms.items()}
     packets_step = N * P
@@ -502,7 +506,7 @@ def main():
     record["blocks"] = detail
     record["device"] = torch.cuda.get_device_name(dev)
     record["shader_clock_mhz_under_vector_load"] = None if sclk_mhz is None else round(sclk_mhz, 1)
-    records = sdist.gather_records(record, dist) if world > 1 else [record]
+    records = sdist.gather_records(record, dist) if use_dist else [record]
 
     if rank == 0:
         all_checked = [r["parity_checked"] for r in records]
@@ -576,7 +580,7 @@ def main():
             "realtime_streams": round(value / 25.0, 1),
             "per_gpu_packets_per_s": [r["packets_per_s"] for r in records],
             "whole_node_packets_per_s": round(value, 1),
-            "rccl_ranks": world if world > 1 else 0,
+            "rccl_ranks": world if use_dist else 0,
             "ranks": [{k: v for k, v in r.items() if k != "blocks"} for r in records],
             "roofline": {"kernel": kname[dom], "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": tr_launch(dom),
@@ -618,7 +622,7 @@ def main():
                 cb["gpu_equals_reference_cores"] = round(value / cb["per_core_packets_per_s"], 1)
             res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if checked is False:

@@ -92,8 +92,9 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  * call -- split longer (offline) inputs over several calls; state carries over.
  * Device memory a handle holds besides the stream states: encode -- the hand-over records of one call, 4.3 KB per packet of the call
  * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 1952 B per
- * packet of a CHUNK (16 kHz API rate): a call is cut into chunks of min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 1952)) packets, so one
- * buffer never exceeds SOLO_DEC_SCRATCH_CAP bytes (environment, default 1 GiB).
+ * packet of a CHUNK (16 kHz API rate): a call is cut into chunks of min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 1952)) packets but never
+ * less than ONE, so one buffer holds max(n_streams x 1952 B, at most SOLO_DEC_SCRATCH_CAP bytes) (environment, read when the handle
+ * decodes for the first time; default -- also for 0 or an unparsable value -- 1 GiB).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct solo_batch solo_batch_t;
 

@@ -90,6 +90,7 @@ struct solo_batch {
     size_t parsed_bytes;             // size of each
     int parsed_two;                  // both buffers have that size (a call of one chunk needs only the first)
     int dec_pipe_ready, dec_split, dec_chunk, dec_first;
+    size_t dec_scratch_cap;          // env SOLO_DEC_SCRATCH_CAP, read when the handle's decode pipeline is set up
     unsigned int dec_calls;          // two-kernel decode calls so far (evDJoin / evDJoin2 are recorded once > 0)
     void* d_rc_scratch;              // range-coder byte buffers of one coding launch (the launches of a call run in order on sC)
     size_t rc_scratch_bytes;
@@ -349,6 +350,10 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
         e = getenv("SOLO_DEC_FIRST_CHUNK");
         b->dec_first = e ? atoi(e) : SOLO_DEC_FIRST_CHUNK;
         if (b->dec_first <= 0) b->dec_first = SOLO_DEC_FIRST_CHUNK;
+        // (read per handle like the other SOLO_DEC_* knobs; a value that does not parse to a positive number means the default)
+        e = getenv("SOLO_DEC_SCRATCH_CAP");
+        b->dec_scratch_cap = e ? (size_t)strtoull(e, NULL, 10) : 0;
+        if (b->dec_scratch_cap == 0) b->dec_scratch_cap = (size_t)1 << 30;
         if (b->dec_split) {
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sP, hipStreamNonBlocking));
             SOLO_CHECK(hipStreamCreateWithFlags(&b->sS, hipStreamNonBlocking));
@@ -379,10 +384,9 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // the records are 1952 B per packet at the 16 kHz API rate: 4096 streams x 64 packets = 512 MB, 65536 streams -> 8 packets per chunk).
     // A handle holds at most two such buffers (calls longer than one chunk); include/solo_mi355x.h states the footprint.
     const size_t rec_bytes = b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes();
-    static const size_t scratch_cap = getenv("SOLO_DEC_SCRATCH_CAP") ? (size_t)strtoull(getenv("SOLO_DEC_SCRATCH_CAP"), NULL, 10) : ((size_t)1 << 30);
     int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
-    {
-        const size_t fit = scratch_cap / ((size_t)b->n_streams * rec_bytes);
+    {   // (floor: one packet per chunk -- a handle with more than cap / 1952 streams holds n_streams x 1952 B per buffer, see the header)
+        const size_t fit = b->dec_scratch_cap / ((size_t)b->n_streams * rec_bytes);
         if ((size_t)cp > fit) cp = fit < 1 ? 1 : (int)fit;
     }
     const int c0 = (n_packets > 2 * b->dec_first && cp > b->dec_first) ? b->dec_first : cp;      // (never larger than the buffers: c0 <= cp)
@@ -503,7 +507,9 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     // the quantiser addresses the hand-over records of its wavefront's four streams with 32-bit offsets from a wave-uniform base
     // (solo_nsq_row.hip): the records of 3 streams x 2 n_packets, plus one more record for the offsets inside the last one, must stay
     // below 4 GiB (~700 k packets per call at the 16 kHz API rate)
-    if (((unsigned long long)3 * 2ull * (unsigned long long)n_packets + 1ull) * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
+    // (streams per wavefront of THIS build's quantiser: four in the row layout, sixteen with -DRW_TPL=3)
+    const unsigned long long per_wave = 64ull / (unsigned long long)ops->nsq_workgroups(64);
+    if (((per_wave - 1ull) * 2ull * (unsigned long long)n_packets + 1ull) * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
@@ -844,7 +850,7 @@ int32_t solo_debug_sum_sqr_shift(const int16_t* d_x, int32_t rows, int32_t len, 
 }
 
 #ifdef SOLO_WITH_ENCODER
-// The quantiser kernel ALONE (tests/test_gpu_nsq_taps.py): h_in = SxNsqIn[n_streams][n_packets][2] as recorded from the reference's
+// The quantiser kernel ALONE (tests/test_nsq_taps.py): h_in = SxNsqIn[n_streams][n_packets][2] as recorded from the reference's
 // SKP_Silk_NSQ_del_dec calls, h_out = SxNsqOut[n_streams][n_packets][2]; host pointers; freshly initialised streams; synchronous.
 int32_t solo_debug_nsq(int32_t n_streams, int32_t n_packets, const void* h_in, void* h_out) {
     if (n_streams <= 0 || n_packets <= 0 || !h_in || !h_out) return -1;

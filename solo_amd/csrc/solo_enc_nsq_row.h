@@ -194,6 +194,8 @@ SX_HD i32 rw_cell_x(const SxRowCell& c) { return (i32)((u32)sx_shl(c.w1 >> 26, 1
 SX_HD i32 rw_cell_xq(const SxRowCell& c) { return (i32)(i16)c.w0; }
 SX_HD i32 rw_cell_pred_Q16(const SxRowCell& c) { return sx_shl(c.w1, 6); }
 
+static_assert(sizeof(((SxNsqOut*)0)->q[0]) >= SX_FRAME + 3 && offsetof(SxNsqOut, q) % 4 == 0 && sizeof(((SxNsqOut*)0)->q[0]) % 4 == 0,
+              "a side track's pulses are emitted with 4-byte stores: three bytes of padding behind every row");
 #define SX_TAPL_N (SX_SUBFR + SX_LTP_ORDER - 1)              // history entries the five prediction taps of one subframe can reach
 #define SX_TAPS_N (SX_SUBFR + 2)                             // ... the three shaping taps
 // layout of the coefficient block: A[SX_LPC] | AR[16] | B[5], warp, Tilt, LF (bottom, top), Harm (bottom, top), Lambda, offset sum, gain
@@ -470,7 +472,9 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         SX_AT(i32, Pu + offsetof(SxNsqTrack, shp), pTrk[li_] + (u32)(e4_)) = (cell_).w2;                                      \
     }
     // flush of the winner's lineage (wlo_, whi_), oldest sample at output position pos0_: every lane its own track, the four lanes
-    // of a track every fourth sample
+    // of a track every fourth sample.  WIDE stays false here: the four lanes of a track write interleaved positions, so a 4-byte
+    // store would clobber pulses another lane has already written (the wide form relies on stores in strict time order; the
+    // flushes follow the loop's wide stores behind a wv_sync and rewrite whatever those spilled into)
 #define RW_FLUSH(wlo_, whi_, pos0_)                                                                                          \
     RW_FORK(l) {                                                                                                             \
         const int li = RW_LI(l);                                                                                             \

@@ -3,7 +3,7 @@
 reference makes while it encodes (a) the first 100 packets of its own speech sample Ch_f1_raw.pcm and (b) 100 packets of a synthetic
 stream -- 2 x 200 quantiser calls.  Needs oracle/_ref/libsolo_ref_fix_taps.so (`make -C oracle taps`: the unmodified reference linked
 with oracle/ref_taps.c through -Wl,--wrap), i.e. runs in the build container only; the file it writes is data (inputs and expected
-outputs) and travels.  tests/test_gpu_nsq_taps.py feeds the recorded arguments to the quantiser kernel ALONE and compares."""
+outputs) and travels.  tests/test_nsq_taps.py feeds the recorded arguments to the quantiser kernel ALONE and compares."""
 import ctypes as C
 import os
 import sys

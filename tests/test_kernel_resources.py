@@ -15,7 +15,7 @@ import solo_amd
 
 LLVM = "/opt/rocm/lib/llvm/bin"
 BUDGET = {                        # kernel name fragment -> (max vector registers, max LDS bytes)
-    "solo_enc_analysis_kernel": (96, 8704), "solo_enc_coding_kernel": (96, 8704), "solo_nsq_kernel": (128, 6656),
+    "solo_enc_analysis_kernel": (96, 8704), "solo_enc_coding_kernel": (96, 8704), "solo_nsq_kernel": (128, 6144),
     "solo_dec_synth_kernel": (128, 10240), "solo_decode_kernel": (128, 10240), "solo_decode_split_kernel": (128, 10240),
     "solo_decode_ring_kernel": (128, 10240), "solo_dec_extract_kernel": (96, 14336),
 }
