@@ -82,3 +82,46 @@ def test_dtx_file_against_the_reference_cli(tmp_path):
         want = np.fromfile(out, np.int16)
         got = H.decode_records(H.parse_bit_container(raw), loss_perc=loss)
         assert got.size == want.size and np.array_equal(got, want), loss
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not (os.path.exists(REF_ENC) and os.path.exists(REF_DEC)), reason="oracle/_ref/JC1*_ref not built")
+def test_dec_mode_against_the_reference_cli(tmp_path):
+    """`-dec_mode 1|2` of the decoder CLI (test/dec_main.c:123-145,341-361): the whole file decoded from ONE description.  The
+    reference CLI on the reference's speech sample (and a DTX file, whose empty packets repeat the previous buffer) against the
+    harness on the GPU."""
+    import subprocess
+    import torch
+    assert torch.cuda.is_available()
+    with pytest.raises(ValueError):
+        H.decode_records([(b"\0" * 8, 8, 8)], loss_perc=10, dec_mode=1)
+    raw = open(os.path.join(T.GOLDEN, "ch_f1.bit"), "rb").read()
+    bit = str(tmp_path / "in.bit")
+    open(bit, "wb").write(raw)
+    outs = {}
+    for mode in (1, 2):
+        out = str(tmp_path / ("ref_m%d.pcm" % mode))
+        subprocess.run([REF_DEC, bit, out, "-Fs_API", "16000", "-dec_mode", str(mode)], check=True, stdout=subprocess.DEVNULL, timeout=300)
+        want = np.fromfile(out, np.int16)
+        got = H.decode_records(H.parse_bit_container(raw), dec_mode=mode)
+        assert got.size == want.size and np.array_equal(got, want), mode
+        outs[mode] = want
+    assert not np.array_equal(outs[1], outs[2])              # the two descriptions do decode differently
+    # a DTX file (empty records)
+    P = 40
+    rng = np.random.default_rng(5)
+    pcm = R.synth_stream(1311, P).copy()
+    pcm[8:30] = (rng.standard_normal((22, 640)) * 3).astype(np.int16)
+    src, dbit = str(tmp_path / "dtx.pcm"), str(tmp_path / "dtx.bit")
+    pcm.tofile(src)
+    subprocess.run([REF_ENC, src, dbit, "-Fs_API", "16000", "-rate", "13600", "-DTX", "1"], check=True, stdout=subprocess.DEVNULL, timeout=300)
+    draw = open(dbit, "rb").read()
+    assert sum(1 for r in H.parse_bit_container(draw) if r[1] == 0) >= 8
+    for path, fs in ((dbit, 16000),):            # (the reference CLIs refuse -Fs_API 32000: "only support wideband")
+        data = open(path, "rb").read()
+        for mode in (1, 2):
+            out = str(tmp_path / "o.pcm")
+            subprocess.run([REF_DEC, path, out, "-Fs_API", str(fs), "-dec_mode", str(mode)], check=True, stdout=subprocess.DEVNULL, timeout=300)
+            want = np.fromfile(out, np.int16)
+            got = H.decode_records(H.parse_bit_container(data), dec_mode=mode, samplerate=fs)
+            assert got.size == want.size and np.array_equal(got, want), (path, mode)

@@ -185,8 +185,52 @@ def report(plan_path, prof_dir):
               v["SQ_INSTS_SALU"] / n, v["SQ_INSTS_LDS"] / n, (v["SQ_INSTS_SMEM"] + v["SQ_INSTS_VMEM_RD"] + v["SQ_INSTS_VMEM_WR"]) / n, 100.0 * allv / tot_all))
 
 
+def report_cycles(plan_path, prof_dir):
+    """the same subtraction for a counter pass that carries cycle counters: wave cycles, cycles parked in s_waitcnt, issue stalls per section
+    (256 identical waves, ONE per compute unit: what a lone wave's dependent chain and its LDS / memory round trips cost; quad-cycle units x 4)"""
+    P = json.load(open(plan_path))
+    N = P["n_streams"]
+    KERNEL = P.get("kernel", "enc_analysis")
+    global NAMES
+    if KERNEL == "dec_synth": NAMES = DEC_NAMES
+    if KERNEL == "enc_coding": NAMES = COD_NAMES
+    CYC = ["SQ_WAVE_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_VMEM_RD"]
+    rows = defaultdict(dict)
+    for f in glob.glob(os.path.join(prof_dir, "**", "*counter_collection.csv"), recursive=True):
+        for r in csv.DictReader(open(f)):
+            if KERNEL in r["Kernel_Name"]:
+                rows[int(r["Dispatch_Id"])][r["Counter_Name"]] = rows[int(r["Dispatch_Id"])].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    order = sorted(rows)
+    per_site = defaultdict(lambda: defaultdict(float))
+    n = len(P["samples"])
+    tot = defaultdict(float)
+    for j, W in P["samples"]:
+        pts = []
+        for m in [m for m in P["plan"] if m["sample"] == j]:
+            c = rows[order[m["dispatch"]]]
+            v = {k: c.get(k, 0.0) / N for k in CYC}
+            pts.append((v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"], m["site"], v))
+        pts.sort(key=lambda t: t[0])
+        prev = {k: 0.0 for k in CYC}
+        for _, s, v in pts:
+            for k in CYC: per_site[s][k] += v[k] - prev[k]
+            prev = v
+        for k in CYC: tot[k] += pts[-1][2][k]
+    print("%s kernel, one wave per compute unit: cycles per packet by section (mean of %d samples; SQ cycle counters x 4)" % (KERNEL, n))
+    print("total: %.0f instructions (VALU + SALU + LDS), %.0f wave cycles = %.1f per instruction; parked in s_waitcnt %.0f %%, issue stall %.0f %%" % (
+        (tot["SQ_INSTS_VALU"] + tot["SQ_INSTS_SALU"] + tot["SQ_INSTS_LDS"]) / n, 4 * tot["SQ_WAVE_CYCLES"] / n,
+        4 * tot["SQ_WAVE_CYCLES"] / (tot["SQ_INSTS_VALU"] + tot["SQ_INSTS_SALU"] + tot["SQ_INSTS_LDS"]), 100 * tot["SQ_WAIT_ANY"] / tot["SQ_WAVE_CYCLES"], 100 * tot["SQ_WAIT_INST_ANY"] / tot["SQ_WAVE_CYCLES"]))
+    print("%-66s %8s %9s %7s %8s %8s %6s %6s" % ("section", "instr", "cycles", "cyc/ins", "waitcnt", "stall", "LDS", "share"))
+    for s, v in sorted(per_site.items(), key=lambda kv: -kv[1]["SQ_WAVE_CYCLES"]):
+        ins = (v["SQ_INSTS_VALU"] + v["SQ_INSTS_SALU"] + v["SQ_INSTS_LDS"]) / n
+        cyc = 4 * v["SQ_WAVE_CYCLES"] / n
+        print("%-66s %8.0f %9.0f %7.1f %8.0f %8.0f %6.0f %5.1f %%" % (NAMES.get(s, "end" if s == 63 else str(s)), ins, cyc, cyc / max(ins, 1.0), 4 * v["SQ_WAIT_ANY"] / n,
+              4 * v["SQ_WAIT_INST_ANY"] / n, v["SQ_INSTS_LDS"] / n, 100.0 * v["SQ_WAVE_CYCLES"] / tot["SQ_WAVE_CYCLES"] * n / n))
+
+
 if __name__ == "__main__":
     if sys.argv[1] == "run": run(sys.argv[2])
     elif sys.argv[1] == "rundec": run_dec(sys.argv[2])
     elif sys.argv[1] == "runcod": run_cod(sys.argv[2])
+    elif sys.argv[1] == "reportcyc": report_cycles(sys.argv[2], sys.argv[3])
     else: report(sys.argv[2], sys.argv[3])

@@ -1,0 +1,10 @@
+#!/bin/bash
+# timing experiment: the encoder pipeline with stages left out (SX_EXPERIMENTS build: SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding; wrong output)
+ROOT=$(pwd); OUT=$ROOT/gpurun_out; mkdir -p "$OUT"; export TMPDIR=/tmp
+: > "$OUT/exp_skip.log"
+for rep in 1 2; do
+for sk in 0 2 1 3; do
+  echo "== SOLO_EXP_SKIP=$sk" >> "$OUT/exp_skip.log"
+  SOLO_EXP_SKIP=$sk SOLO_LIB_OVERRIDE=$ROOT/build/libsolo_exp.so timeout 120 python tools/quick_bench.py 4096 20 2>&1 | grep -v amdgpu.ids >> "$OUT/exp_skip.log"
+done; done
+cat "$OUT/exp_skip.log"
