@@ -154,6 +154,13 @@ struct alignas(16) SxExtracted {
     i32 hb_lsp[2][SX_HB_LPC];
     i16 hb_lpc[2][SX_HB_LPC];
     i16 hb_gain[2][4];
+    // The side information of each frame DE-QUANTISED (sx_dequant_parameters with a blank description state: everything in it but
+    // frame 0's interpolated NLSF vector and the first-frame override of the interpolation factor depends on this packet's symbols
+    // only -- frame 0 codes its gains unconditionally, frame 1 relative to frame 0), and the gain index the description's state is
+    // left with after each frame.  The decoder copies the block instead of walking the pitch / LTP / gain tables on two lanes with a
+    // memory round trip per look-up (a third of a lone decoder wave's time, profiles/r05_decoder_sections_cycles.txt).
+    SxDecCtrl ctl[2];
+    i32 lastGain[2];
 };
 #define SX_DEC_PAYLOAD_LDS 252      // packets up to this size are staged in LDS (13.6 kbps packets are ~80 B; larger ones are read from HBM)
 // High band of a packet, decoded up front (side information) and synthesised next to the low band: see sx_hb_decode_side
@@ -458,9 +465,11 @@ SX_HD void sx_extract_parameters(int nFramesDecoded, i32* typeOffsetPrev, i32* d
 // md: the state of the description slot being decoded; c: its control block; lane_out: {vadFlag, FrameTermination, bytes left, coder
 // error}; nlsf_out[2][SX_LPC]: interpolated / final NLSF vector -- their conversion to prediction coefficients only matters for the
 // description that is used and is done by the caller (all LDS)
-SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int first_frame_after_reset, int useMDIndex, SxDecDesc* md, SxDecCtrl* c,
+// (sx_dequant_parameters_any: the same for records anywhere -- the extraction kernel runs it on private / HBM data)
+template <bool IN_LDS>
+SX_HD void sx_dequant_parameters_t(const SxFrameSyms* y, int nFramesDecoded, int first_frame_after_reset, int useMDIndex, SxDecDesc* md, SxDecCtrl* c,
                                  i32* lane_out, i32* nlsf_out) {
-    SX_IN_LDS(y); SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out);
+    if (IN_LDS) { SX_IN_LDS(y); SX_IN_LDS(md); SX_IN_LDS(c); SX_IN_LDS(lane_out); SX_IN_LDS(nlsf_out); }
     if (y->fs_bad) { lane_out[3] = y->error; return; }
     i32 *pNLSF0_Q15 = nlsf_out, *pNLSF_Q15 = nlsf_out + SX_LPC;
     if (nFramesDecoded == 0 && useMDIndex == 1) c->MDIndex = y->MDIndex;
@@ -505,6 +514,10 @@ SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int f
     lane_out[1] = y->FrameTermination;
     lane_out[2] = y->left;
     lane_out[3] = y->error;
+}
+SX_HD void sx_dequant_parameters(const SxFrameSyms* y, int nFramesDecoded, int first_frame_after_reset, int useMDIndex, SxDecDesc* md, SxDecCtrl* c,
+                                 i32* lane_out, i32* nlsf_out) {
+    sx_dequant_parameters_t<true>(y, nFramesDecoded, first_frame_after_reset, useMDIndex, md, c, lane_out, nlsf_out);
 }
 
 // (the de-quantisation as a real call of its own: inlined into sx_decode_parameters the pair needs 129 vector registers -- one more
@@ -1052,6 +1065,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
     int ret = 0;
     SxDecCtrl* c = &w->ctrl;
     SX_T_BEGIN
+    SX_S(14)
     if (st->moreInternalDecoderFrames == 0) st->nFramesDecoded = 0;
     c->LTP_scale_Q14 = 0;
     int used = 0;
@@ -1100,27 +1114,51 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
             for (int d = 0; d < 2; d++) {
                 if (len[d] >= 0 && len[d] <= SX_MAX_ARITHM_BYTES) { SX_PAR(i, len[d]) sh->b[d][i] = payload[off[d] + i]; }
             }
-            wv_sync();
+            if (!pre2) wv_sync();        // (read ahead: nothing of this frame reads the shadow; its copy travels with the record loads below)
         }
+        SX_S(13)
         if (pre2) {
-            // the symbols were read ahead (and do not depend on the bytes behind the description): stage them where the serial
-            // path would have put them
-            for (int d = 0; d < ndesc; d++) {
-                const i32* sy = (const i32*)&pre2[d].y[f];
-                i32* dy = (i32*)sx_dec_syms(w, d);
-                SX_PAR(i, (int)(sizeof(SxFrameSyms) / 4)) dy[i] = sy[i];
-                SX_PAR(i, SX_FRAME) w->u.parse.pulses[d][i] = (i16)pre2[d].pulses[f][i];
+            // The symbols were read ahead and de-quantised by the extraction kernel (SxExtracted::ctl): everything the frame takes from
+            // the records is requested here in ONE batch of loads -- the control block of the description in use, the pulses, and per
+            // description slot the few values its state moves on with (sx_dequant_parameters: the type offset, the delta-gain and
+            // last gain indices, the NLSF vector; frame 0 interpolates with the slot's previous vector, which only the decoder has).
+            const int fa = st->first_frame_after_reset == 1;
+            for (int d = 0; d < ndesc; d++) { SX_PAR(i, SX_FRAME) w->u.parse.pulses[d][i] = (i16)pre2[d].pulses[f][i]; }
+            {
+                const i32* sc = (const i32*)&pre2[ndesc - 1].ctl[f];
+                i32* dc = (i32*)&w->u.parse.ctrl2[ndesc - 1];
+                SX_PAR(i, (int)(sizeof(SxDecCtrl) / 4)) dc[i] = sc[i];
             }
-            wv_sync();
-        }
+            static_assert(SX_LPC + 2 <= 32, "a row of 32 per description slot");
+            SX_PAR(t, ndesc * 32) {
+                const int d = t >> 5, i = t & 31;
+                const SxFrameSyms* y = &pre2[d].y[f];
+                SxDecDesc* m = &st->md[d];
+                i32* nl = &w->res_Q10[d * 2 * SX_LPC];
+                if (i < SX_LPC) {
+                    const i32 coef = fa ? 4 : y->NLSFInterpCoef_Q2;
+                    const i32 nq = y->NLSF_Q15[i], prev = m->prevNLSF_Q15[i];
+                    nl[SX_LPC + i] = nq;
+                    if (coef < 4) nl[i] = prev + (sx_mul(coef, nq - prev) >> 2);
+                    m->prevNLSF_Q15[i] = nq;
+                } else if (i == SX_LPC) {
+                    m->typeOffsetPrev = y->typeOffset;
+                    if (st->nFramesDecoded == 0) m->prevDeltaGainIndex = y->DeltaGainIndices;
+                    m->LastGainIndex = pre2[d].lastGain[f];
+                } else if (i == SX_LPC + 1) {
+                    w->u.parse.lane_out[d][0] = y->vadFlag;
+                    w->u.parse.lane_out[d][1] = y->FrameTermination;
+                    w->u.parse.lane_out[d][2] = y->left;
+                    w->u.parse.lane_out[d][3] = y->error;
+                    w->u.parse.lane_len[d] = y->bufferLength;
+                }
+            }
+            if (fa) { wv_sync(); w->u.parse.ctrl2[ndesc - 1].NLSFInterpCoef_Q2 = 4; }
+        } else {
         // the two descriptions are independent range-coded streams: description md is parsed by lane md
         SX_PAR(md, ndesc) {
             SxRangeDec* r = &rc[SX_NLANES == 1 ? md : 0];
-            if (pre2) {
-                sx_dequant_parameters(sx_dec_syms(w, md), st->nFramesDecoded, st->first_frame_after_reset, useMDIndex, &st->md[md], &w->u.parse.ctrl2[md],
-                                      w->u.parse.lane_out[md], &w->res_Q10[md * 2 * SX_LPC]);
-                w->u.parse.lane_len[md] = sx_dec_syms(w, md)->bufferLength;
-            } else {
+            {
                 if (st->nFramesDecoded == 0) {
                     r->tail = tails[md];
                     if (md == 0) sx_rc_dec_init(r, payload, nB0);
@@ -1132,6 +1170,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
                                      &w->res_Q10[4 * SX_LPC + md * 2 * (SX_FRAME / 16)], sx_dec_syms(w, md));
                 w->u.parse.lane_len[md] = r->bufferLength;
             }
+        }
         }
         wv_sync();
         SX_T(0)
@@ -1590,6 +1629,18 @@ SX_HD void sx_extract_desc(const u8* src, i32 len, int useMDIndex, const SxCdf* 
         { const i32* sq = (const i32*)&L->b[SX_EXTRACT_TMP]; i32* dq = (i32*)&rec->pulses[f][0]; for (int i = 0; i < SX_FRAME / 4; i++) dq[i] = sq[i]; }
     }
     if (r.ambiguous) return;
+    {   // the frames' side information de-quantised (see SxExtracted::ctl): blank description state, no first-frame override
+        SxDecDesc m;
+        SxDecCtrl c;
+        i32 lo_[4], nl_[2 * SX_LPC];
+        { i32* z = (i32*)&m; for (int i = 0; i < (int)(sizeof(SxDecDesc) / 4); i++) z[i] = 0; }
+        { i32* z = (i32*)&c; for (int i = 0; i < (int)(sizeof(SxDecCtrl) / 4); i++) z[i] = 0; }
+        for (int f = 0; f < 2; f++) {
+            sx_dequant_parameters_t<false>(&rec->y[f], f, 0, useMDIndex, &m, &c, lo_, nl_);
+            { const i32* sc = (const i32*)&c; i32* dc = (i32*)&rec->ctl[f]; for (int i = 0; i < (int)(sizeof(SxDecCtrl) / 4); i++) dc[i] = sc[i]; }
+            rec->lastGain[f] = m.LastGainIndex;
+        }
+    }
     if (sel) {
         // (private workspace: every lane of the wavefront is at the same place of its own copy, which is how scratch memory is laid out)
         i32 ws[SX_NLSF2A_WS], nl[SX_LPC];

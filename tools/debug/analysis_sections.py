@@ -69,7 +69,7 @@ def run(plan_path):
 
 DEC_NAMES = {0: "symbols staged, de-quantisation (two lanes)", 1: "merge + inverse NSQ (+ frame-0 NLSF -> LPC)", 2: "decode_core (LTP / LPC synthesis)",
              3: "PLC update", 4: "outBuf + glue frames", 5: "CNG", 8: "high band: side information", 6: "high band: finish", 7: "QMF synthesis",
-             9: "decode_core: excitation, subframe set-up", 10: "decode_core: LTP synthesis", 11: "decode_core: LPC synthesis", 12: "CNG: smoothing + excitation"}
+             9: "decode_core: excitation, subframe set-up", 10: "decode_core: LTP synthesis", 11: "decode_core: LPC synthesis", 12: "CNG: smoothing + excitation", 14: "(frame entry: glue between frames)", 13: "frame start .. shadow copy issued"}
 
 
 COD_NAMES = {57: "high band: buffers staged, LPC blocks", 23: "burg: sum_sqr_shift", 24: "burg: first row of correlations", 25: "burg: recursion", 58: "high band: burg tail, expand",

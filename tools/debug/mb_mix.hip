@@ -81,12 +81,52 @@ template <int A, int B> void run(const char* name, int* d_out, int ncu) {
     }
     printf("\n");
 }
+// ONE dependent chain per wave, W waves per SIMD: how well does the SIMD interleave the chains of its waves?
+template <int T>
+__global__ void __launch_bounds__(64) kdep(int* out, int seed) {
+    int a = threadIdx.x + seed, b = seed * 3 + threadIdx.x;
+    for (int r = 0; r < REPS; r++) {
+#pragma unroll
+        for (int u = 0; u < 64; u++) {
+            if (T == 0) asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b));
+            if (T == 1) asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a) : "v"(b));
+            if (T == 2) { asm volatile("v_mul_hi_i32 %0, %0, %1" : "+v"(a) : "v"(b)); asm volatile("v_add_u32 %0, %0, %1" : "+v"(a) : "v"(b)); }
+        }
+    }
+    out[blockIdx.x * 64 + threadIdx.x] = a;
+}
+template <int T> void rundep(const char* name, int* d_out, int ncu) {
+    printf("%-44s", name);
+    for (int wps = 1; wps <= 8; wps *= 2) {
+        const int nb = ncu * 4 * wps;
+        hipLaunchKernelGGL((kdep<T>), dim3(nb), dim3(64), 0, 0, d_out, 3);
+        hipDeviceSynchronize();
+        hipEvent_t e0, e1;
+        hipEventCreate(&e0); hipEventCreate(&e1);
+        float best = 1e9f;
+        for (int t = 0; t < 3; t++) {
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((kdep<T>), dim3(nb), dim3(64), 0, 0, d_out, 5 + t);
+            hipEventRecord(e1);
+            hipDeviceSynchronize();
+            float ms = 0;
+            hipEventElapsedTime(&ms, e0, e1);
+            if (ms < best) best = ms;
+        }
+        const double n = (T == 2 ? 2.0 : 1.0) * REPS * 64.0;
+        printf(" %dw: %5.2f ns/instr/wave %5.2f /SIMD |", wps, best * 1e6 / n, best * 1e6 / n / wps);
+    }
+    printf("\n");
+}
 int main() {
     hipDeviceProp_t p;
     hipGetDeviceProperties(&p, 0);
     const int ncu = p.multiProcessorCount;
     int* d_out;
     hipMalloc(&d_out, (size_t)ncu * 32 * 64 * sizeof(int));
+    rundep<0>("dependent v_add chain", d_out, ncu);
+    rundep<1>("dependent v_mul_hi chain", d_out, ncu);
+    rundep<2>("dependent mul_hi+add chain", d_out, ncu);
     run<0, 0>("empty loop", d_out, ncu);
     run<1, 0>("v_mul_hi", d_out, ncu);
     run<2, 0>("v_add", d_out, ncu);
