@@ -1339,8 +1339,11 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         const int row = SX_LANE >> 4, k = SX_LANE & 15, rowbase = SX_LANE & 48;
         const int srow = row < nb_subfr ? row : 0;            // rows past nb_subfr compute a copy of subframe 0 and are ignored
         const i16* xr = x + srow * L;
-        i32 Af_k = 0, Cf_k = bw->Cf[k], Cl_k = Cf_k;
-        i32 CAf_k = k == 0 ? CA0 : 0, CAb_k = CAf_k;
+        // The two correlation rows (first: Cf, last: Cl) are kept by rows 0 and 1 of the wave, the forward / backward correlations (CAf, CAb)
+        // by rows 2 and 3 -- P_k = Cf | CAf, Q_k = Cl | CAb: the four per-subframe terms of step (b) then reach the rows that keep their
+        // totals with three lane swaps (a transposing reduction) instead of two swaps each into every row.
+        const bool upper = row >= 2;
+        i32 Af_k = 0, P_k = upper ? (k == 0 ? CA0 : 0) : bw->Cf[k], Q_k = P_k;
         const bool hi = rshifts > -2;
         // element index of step (c)'s gather, gidx_a + (n & gidx_n): rows 0, 1: n - k - 1; row 2: n - k; row 3: k + 1
         const int gidx_a = row < 2 ? -k - 1 : (row == 2 ? -k : k + 1), gidx_n = row < 3 ? -1 : 0;
@@ -1389,15 +1392,22 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
                         dcab = sx_smulww(t2, sx_shl((i32)xs[L - n + kk - 1], -rshifts - 1));
                     }
                 }
-                dcf = wv_col_sum(dcf); dcl = wv_col_sum(dcl); dcaf = wv_col_sum(dcaf); dcab = wv_col_sum(dcab);
-                if (k < n) { Cf_k = sx_add(Cf_k, dcf); Cl_k = sx_add(Cl_k, dcl); }
-                if (k <= n) { CAf_k = sx_add(CAf_k, dcaf); CAb_k = sx_add(CAb_k, dcab); }
+                {   // v_permlane32_swap(X, Y): {X.lower | Y.lower}, {X.upper | Y.upper}: their sum holds X's half-sums in rows 0, 1 and Y's in
+                    // rows 2, 3; v_permlane16_swap of that with itself: the even row of each half in both of its rows, and the odd one
+                    auto p_ = __builtin_amdgcn_permlane32_swap(dcf, dcaf, false, false);
+                    auto q_ = __builtin_amdgcn_permlane32_swap(dcl, dcab, false, false);
+                    const i32 u_ = sx_add((i32)p_[0], (i32)p_[1]), v_ = sx_add((i32)q_[0], (i32)q_[1]);
+                    auto pu_ = __builtin_amdgcn_permlane16_swap(u_, u_, false, false);
+                    auto qv_ = __builtin_amdgcn_permlane16_swap(v_, v_, false, false);
+                    const i32 dP = sx_add((i32)pu_[0], (i32)pu_[1]), dQ = sx_add((i32)qv_[0], (i32)qv_[1]);
+                    if (upper ? k <= n : k < n) { P_k = sx_add(P_k, dP); Q_k = sx_add(Q_k, dQ); }
+                }
             }
             // (c) reflection coefficient: numerator / denominator terms of column k < n.  The four sums over k (against the reversed
             // Cl, Cf, CAb and the shifted CAb + CAf) are taken by the four rows, one each: the rows hold identical copies of the vectors
             i32 s1, s2, num, den;
             {
-                const i32 src = row < 2 ? (row == 0 ? Cl_k : Cf_k) : (row == 2 ? CAb_k : sx_add(CAb_k, CAf_k));
+                const i32 src = row < 2 ? (row == 0 ? Q_k : P_k) : (row == 2 ? Q_k : sx_add(Q_k, P_k));
                 const i32 g = SX_GATHER(src, gidx_a + (n & gidx_n));
                 i32 pq = 0;
                 if (k < n) {
@@ -1406,12 +1416,12 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
                     pq = sx_shl(sx_smmul(g, sx_shl(Af_k, lz)), 32 - QA - lz);
                 }
                 const i32 tot = wv_row_sum(pq);
-                s1 = sx_add(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(Cf_k, n));
-                s2 = sx_add(__builtin_amdgcn_readlane(tot, 16), __builtin_amdgcn_readlane(Cl_k, n));
+                s1 = sx_add(__builtin_amdgcn_readlane(tot, 0), __builtin_amdgcn_readlane(P_k, n));
+                s2 = sx_add(__builtin_amdgcn_readlane(tot, 16), __builtin_amdgcn_readlane(Q_k, n));
                 num = __builtin_amdgcn_readlane(tot, 32);
-                den = sx_add(__builtin_amdgcn_readlane(tot, 48), sx_add(__builtin_amdgcn_readlane(CAb_k, 0), __builtin_amdgcn_readlane(CAf_k, 0)));
+                den = sx_add(__builtin_amdgcn_readlane(tot, 48), sx_add(__builtin_amdgcn_readlane(Q_k, 32), __builtin_amdgcn_readlane(P_k, 32)));
             }
-            if (k == n + 1) { CAf_k = s1; CAb_k = s2; }
+            if (upper && k == n + 1) { P_k = s1; Q_k = s2; }
             num = sx_add(num, s2);
             num = sx_shl(sx_neg(num), 1);
             if (!(sx_abs(num) < den)) {
@@ -1422,11 +1432,11 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
             // (d) symmetric coefficient update and correlation update
             {
                 const i32 Af_r = SX_GATHER(Af_k, n - k - 1);
-                const i32 CAb_r = SX_GATHER(CAb_k, n + 1 - k), CAf_r = SX_GATHER(CAf_k, n + 1 - k);
+                const i32 CAb_r = SX_GATHER(Q_k, n + 1 - k), CAf_r = SX_GATHER(P_k, n + 1 - k);
                 if (k < n) Af_k = sx_add(Af_k, sx_shl(sx_smmul(Af_r, rc_Q31), 1));
-                if (k <= n + 1) {
-                    CAf_k = sx_add(CAf_k, sx_shl(sx_smmul(CAb_r, rc_Q31), 1));
-                    CAb_k = sx_add(CAb_k, sx_shl(sx_smmul(CAf_r, rc_Q31), 1));
+                if (upper && k <= n + 1) {
+                    P_k = sx_add(P_k, sx_shl(sx_smmul(CAb_r, rc_Q31), 1));
+                    Q_k = sx_add(Q_k, sx_shl(sx_smmul(CAf_r, rc_Q31), 1));
                 }
                 if (k == n) Af_k = rc_Q31 >> (31 - QA);
             }
@@ -1435,8 +1445,8 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         SX_T(25)
         // residual energy and output
         const i32 At = k < D ? sx_rshift_round(Af_k, QA - 16) : 0;
-        const i32 CAf_next = __shfl(CAf_k, rowbase | ((k + 1) & 15), 64);
-        nrg = sx_add(__builtin_amdgcn_readlane(CAf_k, 0), SX_UNI(wv_row_sum(k < D ? sx_smulww(CAf_next, At) : 0)));
+        const i32 CAf_next = __shfl(P_k, rowbase | ((k + 1) & 15), 64);
+        nrg = sx_add(__builtin_amdgcn_readlane(P_k, 32), __builtin_amdgcn_readlane(wv_row_sum(k < D ? sx_smulww(CAf_next, At) : 0), 32));
         tmp1 = sx_add(1 << 16, SX_UNI(wv_row_sum(sx_smulww(At, At))));
         if (SX_LANE < D) A_Q16[SX_LANE] = sx_neg(At);
     }
@@ -2000,8 +2010,12 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
     const i16* cb = (const i16*)(sigtype == 0 ? T_nlsf_cb0_Q15 : T_nlsf_cb1_Q15);
     const i16* rates = (const i16*)(sigtype == 0 ? T_nlsf_cb0_rates_Q5 : T_nlsf_cb1_rates_Q5);
 #endif
-    SX_PAR(i, S) x->Rate_Q5[i] = 0;
-    SX_PAR(i, SX_LPC) w->Res_Q15[i] = pNLSF_Q15[i];
+    // The survivors' residuals, rates and paths of consecutive stages alternate between two sets of arrays (the reference copies the
+    // new set over the old one after every stage: three passes and a round trip through LDS per stage)
+    i32 *res_cur = w->Res_Q15, *res_new = x->Res_new_Q15, *rate_cur = x->Rate_Q5, *rate_new = x->Rate_new_Q5;
+    u8 *path_cur = x->Path, *path_new = x->Path_new;
+    SX_PAR(i, S) rate_cur[i] = 0;
+    SX_PAR(i, SX_LPC) res_cur[i] = pNLSF_Q15[i];
     wv_sync();
     int prev_survivors = 1, cur_survivors = 0;
     const int min_survivors = S / 2;
@@ -2017,14 +2031,14 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         // rate-distortion of every (survivor, codebook vector) pair
         SX_PAR(t, total) {
             int n = t >> lgK, i = t - (n << lgK);
-            const i32* in = &w->Res_Q15[n * SX_LPC];
+            const i32* in = &res_cur[n * SX_LPC];
             const i16* cv = &cbs[i * SX_LPC];
             i32 sum_error = 0;
             for (int m = 0; m < SX_LPC; m++) {
                 i32 diff = in[m] - cv[m];
                 sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
             }
-            w->RateDist_Q18[t] = sx_smlabb(sum_error, x->Rate_Q5[n] + rts[i], mu_Q15);
+            w->RateDist_Q18[t] = sx_smlabb(sum_error, rate_cur[n] + rts[i], mu_Q15);
             w->taken[t] = 0;
         }
         // SKP_Silk_insertion_sort_increasing (the cur_survivors best of `total`, value ascending, first index wins ties)
@@ -2051,7 +2065,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
             const int t = SX_LANE + 64 * j;
             if (j * 64 < total && t < total) {
                 int n = t >> lgK, i = t - (n << lgK);
-                const i32* in = &w->Res_Q15[n * SX_LPC];
+                const i32* in = &res_cur[n * SX_LPC];
                 const i16* cv = &cbs[i * SX_LPC];
                 i32 sum_error = 0;
 #pragma unroll
@@ -2059,7 +2073,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                     i32 diff = in[m] - cv[m];
                     sum_error = sx_smlawb(sum_error, sx_smulbb(diff, diff), pW_Q6[m]);
                 }
-                const i32 rd = sx_smlabb(sum_error, x->Rate_Q5[n] + rts[i], mu_Q15);
+                const i32 rd = sx_smlabb(sum_error, rate_cur[n] + rts[i], mu_Q15);
                 const i64 key = (i64)(((u64)(u32)rd << 32) | (u32)t);
                 if (j == 0) k0 = key; else if (j == 1) k1 = key; else if (j == 2) k2 = key; else k3 = key;
             }
@@ -2106,17 +2120,16 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
                 input_index = cb_index >> lgK;
                 cb_index = cb_index - (input_index << lgK);
             }
-            if (i < SX_LPC) x->Res_new_Q15[k * SX_LPC + i] = w->Res_Q15[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
-            if (i == SX_LPC) x->Rate_new_Q5[k] = x->Rate_Q5[input_index] + rts[cb_index];
-            if (i > SX_LPC && i - SX_LPC - 1 < s) x->Path_new[k * nStages + (i - SX_LPC - 1)] = x->Path[input_index * nStages + (i - SX_LPC - 1)];
-            if (i == SX_MSVQ_ROW - 1) x->Path_new[k * nStages + s] = (u8)cb_index;
+            if (i < SX_LPC) res_new[k * SX_LPC + i] = res_cur[input_index * SX_LPC + i] - (i32)cbs[cb_index * SX_LPC + i];
+            if (i == SX_LPC) rate_new[k] = rate_cur[input_index] + rts[cb_index];
+            if (i > SX_LPC && i - SX_LPC - 1 < s) path_new[k * nStages + (i - SX_LPC - 1)] = path_cur[input_index * nStages + (i - SX_LPC - 1)];
+            if (i == SX_MSVQ_ROW - 1) path_new[k * nStages + s] = (u8)cb_index;
         }
         wv_sync();
-        if (s < nStages - 1) {
-            SX_PAR(i, cur_survivors * SX_LPC) w->Res_Q15[i] = x->Res_new_Q15[i];
-            SX_PAR(i, cur_survivors) x->Rate_Q5[i] = x->Rate_new_Q5[i];
-            SX_PAR(i, cur_survivors * nStages) x->Path[i] = x->Path_new[i];
-            wv_sync();
+        if (s < nStages - 1) {       // (after the last stage path_new stays the survivors' paths)
+            { i32* t_ = res_cur; res_cur = res_new; res_new = t_; }
+            { i32* t_ = rate_cur; rate_cur = rate_new; rate_new = t_; }
+            { u8* t_ = path_cur; path_cur = path_new; path_new = t_; }
         }
         prev_survivors = cur_survivors;
         cb_base += K;
@@ -2128,7 +2141,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
         SX_PAR(sv, cur_survivors) {
             i32* out = &w->Res_Q15[sv * SX_LPC];
-            sx_nlsf_msvq_decode_cb(out, &x->Path_new[sv * nStages], cb, nvec, w->ndelta);
+            sx_nlsf_msvq_decode_cb(out, &path_new[sv * nStages], cb, nvec, w->ndelta);
             i32 wsse_Q20 = 0;
             for (int i = 0; i < SX_LPC; i++) {
                 i32 se = out[i] - prev_q_Q15[i];
@@ -2141,7 +2154,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
         if (bv < bestRateDist_Q20) { bestRateDist_Q20 = bv; bestIndex = bi; }
         wv_sync();
     }
-    SX_PAR(i, nStages) NLSFIndices[i] = x->Path_new[bestIndex * nStages + i];
+    SX_PAR(i, nStages) NLSFIndices[i] = path_new[bestIndex * nStages + i];
     wv_sync();
     sx_nlsf_msvq_decode_cb(pNLSF_Q15, NLSFIndices, cb, nvec, w->ndelta);
     wv_sync();
