@@ -60,24 +60,24 @@ def load_ref(kind="fix"):
     return _libs[kind]
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000):
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000, framesize_ms=40):
     # defaults of the reference CLI: JC1_SDK_SRC_ARM/test/enc_main.c:92-99; joint=1: `-joint 1` (40 ms high-band frame);
     # samplerate=32000: `-Fs_API 32000` (16 kHz bands, SILK wide band)
     return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=samplerate, dtx_enable=1 if dtx else 0,
-                         framesize_ms=40, joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
+                         framesize_ms=framesize_ms, joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
-def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000):
-    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=40,
+def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000, framesize_ms=40):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=framesize_ms,
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
 class RefEncoder:
-    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0, samplerate=16000, use_md_index=0):
+    def __init__(self, kind="fix", rate=13600, joint=0, dtx=0, samplerate=16000, use_md_index=0, framesize_ms=40):
         # use_md_index = 1: every description starts with its range-coded index (SKP_Silk_encode_parameters.c:50-51)
         self.lib = load_ref(kind)
-        self.ctrl = default_enc_ctrl(rate, use_md_index=use_md_index, joint=joint, dtx=dtx, samplerate=samplerate)
-        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
+        self.ctrl = default_enc_ctrl(rate, use_md_index=use_md_index, joint=joint, dtx=dtx, samplerate=samplerate, framesize_ms=framesize_ms)
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000 * framesize_ms // 40
         self.h = self.lib.AGR_Sate_Encoder_Init(C.byref(self.ctrl))
         assert self.h
         self._bits = np.zeros(MAX_FRAME_BYTES, np.uint8)
@@ -101,11 +101,11 @@ class RefEncoder:
 
 
 class RefDecoder:
-    def __init__(self, kind="fix", joint=0, samplerate=16000, use_md_index=0):
+    def __init__(self, kind="fix", joint=0, samplerate=16000, use_md_index=0, framesize_ms=40):
         # use_md_index = 1: the decoder reads the description index first (SKP_Silk_decode_parameters.c:55-57)
         self.lib = load_ref(kind)
-        self.ctrl = default_dec_ctrl(use_md_index=use_md_index, joint=joint, samplerate=samplerate)
-        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
+        self.ctrl = default_dec_ctrl(use_md_index=use_md_index, joint=joint, samplerate=samplerate, framesize_ms=framesize_ms)
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000 * framesize_ms // 40
         self.h = self.lib.AGR_Sate_Decoder_Init(C.byref(self.ctrl))
         assert self.h
         self._pcm = np.zeros(1920, np.int16)

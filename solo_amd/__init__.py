@@ -141,15 +141,15 @@ def shader_clock_mhz():
     return float(v.value)
 
 
-def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000):
+def default_enc_ctrl(rate=13600, use_md_index=0, joint=0, dtx=0, samplerate=16000, framesize_ms=40):
     """Defaults of the reference CLI (JC1_SDK_SRC_ARM/test/enc_main.c:92-99); joint=1 is its `-joint 1`: one 40 ms high-band
     frame per packet (4 high-band bytes instead of 8)."""
-    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=samplerate, dtx_enable=1 if dtx else 0, framesize_ms=40,
+    return USER_Ctrl_enc(mode=2, targetRate_bps=rate, samplerate=samplerate, dtx_enable=1 if dtx else 0, framesize_ms=framesize_ms,
                          joint_enable=1 if joint else 0, joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
-def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000):
-    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=40, joint_enable=1 if joint else 0,
+def default_dec_ctrl(use_md_index=0, joint=0, samplerate=16000, framesize_ms=40):
+    return USER_Ctrl_dec(packetLoss_perc=0, samplerate=samplerate, framesize_ms=framesize_ms, joint_enable=1 if joint else 0,
                          joint_mode=1 if joint else 0, useMDIndex=use_md_index)
 
 
@@ -157,8 +157,10 @@ class SoloBatch:
     """N independent SOLO streams on the current HIP device (one wavefront per stream)."""
 
     def __init__(self, n_streams, rate=13600, encoder=True, decoder=True, slot_bytes=DEFAULT_SLOT_BYTES, use_md_index=0, joint=0, dtx=0,
-                 samplerate=16000):
-        """samplerate = 32000: the 32 kHz mode of the reference (`-Fs_API 32000`: 1280-sample packets, SILK wide band; rate >= 15600)."""
+                 samplerate=16000, framesize_ms=40):
+        """samplerate = 32000: the 32 kHz mode of the reference (`-Fs_API 32000`: 1280-sample packets, SILK wide band; rate >= 15600).
+        framesize_ms = 20 (`-framesize 20`, AGR_BWE_SDK_API.c:100-115): packets of ONE 20 ms SILK frame + one 4-byte high-band frame, half as
+        many samples per packet; not with joint=1 (its high-band frame is 40 ms)."""
         import torch
         if not torch.cuda.is_available():
             raise RuntimeError("solo_amd needs a HIP device (MI355X); there is no CPU path")
@@ -166,11 +168,13 @@ class SoloBatch:
         self.lib = load_library()
         self.n_streams = int(n_streams)
         self.slot = int(slot_bytes)
-        self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx, samplerate) if encoder else None
+        if framesize_ms not in (20, 40):
+            raise ValueError("framesize_ms must be 40 or 20")
+        self._enc = default_enc_ctrl(rate, use_md_index, joint, dtx, samplerate, framesize_ms) if encoder else None
         if samplerate not in (16000, 32000):
             raise ValueError("samplerate must be 16000 or 32000")
-        self.packet_samples = PACKET_SAMPLES * samplerate // 16000
-        self._dec = default_dec_ctrl(use_md_index, joint, samplerate) if decoder else None
+        self.packet_samples = PACKET_SAMPLES * samplerate // 16000 * framesize_ms // 40
+        self._dec = default_dec_ctrl(use_md_index, joint, samplerate, framesize_ms) if decoder else None
         self.h = self.lib.solo_batch_create(self.n_streams, C.byref(self._enc) if encoder else None,
                                             C.byref(self._dec) if decoder else None, self.slot)
         if not self.h:

@@ -127,7 +127,9 @@ struct solo_batch {
 // joint_enable = 0, or joint_mode 1 (one 40 ms high-band frame per packet, AGR_BWE_SDK_API.c:64-67); the other joint modes are
 // "reserved" in the reference as well
 static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
-    if (c->framesize_ms != 40 || !(c->joint_enable == 0 || c->joint_mode == 1)) return false;
+    // framesize_ms 40 (two SILK frames per packet) or 20 (one: AGR_BWE_SDK_API.c:100-115, test/enc_main.c:129); the 40 ms high-band frame of
+    // joint_mode 1 needs the 40 ms packet
+    if (!(c->framesize_ms == 40 || (c->framesize_ms == 20 && c->joint_enable == 0)) || !(c->joint_enable == 0 || c->joint_mode == 1)) return false;
     if (c->samplerate == 16000) return true;
     // 32 kHz input: SILK runs wide band.  Below WB2MB_BITRATE_BPS (14 kbps for SILK = 15.6 kbps total, 14.8 kbps with the 40 ms
     // high-band frame) the reference starts at, or switches down to, 12 / 8 kHz internally (SKP_Silk_control_audio_bandwidth.c:44-76):
@@ -138,9 +140,12 @@ static bool ctrl_enc_supported(const USER_Ctrl_enc* c) {
 }
 static bool ctrl_dec_supported(const USER_Ctrl_dec* c) {
     // 32000: the wide-band decoder (solo_api_wb.hip); a stream whose internal rate is not 16 kHz is rejected packet by packet
-    return (c->samplerate == 16000 || c->samplerate == 32000) && c->framesize_ms == 40 && (c->joint_enable == 0 || c->joint_mode == 1);
+    return (c->samplerate == 16000 || c->samplerate == 32000) && (c->framesize_ms == 40 || (c->framesize_ms == 20 && c->joint_enable == 0)) &&
+           (c->joint_enable == 0 || c->joint_mode == 1);
 }
 static int ctrl_hb_joint(int joint_enable, int joint_mode) { return joint_enable != 0 && joint_mode == 1; }
+// bytes of high band per packet: (QMF_HB_FrameSize / BWE_FrameSize) * HB_BYTE
+static int ctrl_hb_bytes(int joint_enable, int joint_mode, int framesize_ms) { return (ctrl_hb_joint(joint_enable, joint_mode) || framesize_ms == 20) ? SX_HB_BYTES / 2 : SX_HB_BYTES; }
 
 #ifdef SOLO_WITH_ENCODER
 static int32_t solo_enc_alloc(solo_batch* b) {
@@ -151,7 +156,7 @@ static int32_t solo_enc_reset(solo_batch* b, hipStream_t s) {
     // AGR_BWE_SDK_API.c:119: the SILK core gets the target rate minus the high-band share, 1600 * 20 / bwe_framesize_ms
     const int joint = ctrl_hb_joint(b->enc_ctrl.joint_enable, b->enc_ctrl.joint_mode);
     SOLO_CHECK(b->eops->init(b->d_enc_state, b->n_streams, b->enc_ctrl.targetRate_bps - (joint ? 800 : 1600), b->enc_ctrl.useMDIndex, joint,
-                             b->enc_ctrl.dtx_enable ? 1 : 0, s));
+                             b->enc_ctrl.dtx_enable ? 1 : 0, b->enc_ctrl.framesize_ms == 20 ? 1 : 2, s));
     return 0;
 }
 static void solo_enc_free(solo_batch* b) {
@@ -247,7 +252,7 @@ int32_t solo_batch_reset(solo_batch_t* b, void* hip_stream) {
             SOLO_CHECK(hipStreamWaitEvent(s, b->evDJoin, 0));
             SOLO_CHECK(hipStreamWaitEvent(s, b->evDJoin2, 0));
         }
-        const int hbj = ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode);
+        const int hbj = ctrl_hb_joint(b->dec_ctrl.joint_enable, b->dec_ctrl.joint_mode) | (b->dec_ctrl.framesize_ms == 20 ? 2 : 0);      // (sx_dec_state_init: bit 1 = one frame per packet)
         SOLO_CHECK(b->wb ? solo_wb_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s) : solo_dec_launch_init(b->d_dec_state, b->n_streams, hbj, s));
     }
 #ifdef SOLO_WITH_ENCODER
@@ -344,6 +349,7 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     if (!b->dec_pipe_ready) {
         const char* e = getenv("SOLO_DEC_SPLIT");
         b->dec_split = e ? atoi(e) : 1;
+        if (b->dec_ctrl.framesize_ms == 20) b->dec_split = 0;      // (the read-ahead records describe two-frame packets)
         e = getenv("SOLO_DEC_CHUNK");
         b->dec_chunk = e ? atoi(e) : SOLO_DEC_CHUNK_DEFAULT;
         if (b->dec_chunk <= 0) b->dec_chunk = 1 << 30;
@@ -626,7 +632,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
         const size_t pk0 = (size_t)s0 * (size_t)n_packets;                               // first packet record of the group
         void* g_states = (char*)states + (size_t)s0 * ops->state_bytes;
-        const int16_t* g_pcm = d_pcm + pk0 * (size_t)ops->packet_samples;
+        const int16_t* g_pcm = d_pcm + pk0 * (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples);
         void* g_nin = (char*)nin + pk0 * 2 * ops->nsq_in_bytes;
         void* g_nout = (char*)nout + pk0 * 2 * ops->nsq_out_bytes;
         void* g_cin = (char*)cin + pk0 * ops->code_in_bytes;
@@ -759,7 +765,7 @@ void* AGR_Sate_Encoder_Init(USER_Ctrl_enc* enc_Ctrl) {
 int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int32_t bufSize, int16_t* nBytesOut) {
     solo_single* h = (solo_single*)st;
     if (!h || !h->is_enc) return -1;
-    const size_t pcm_bytes = (size_t)h->b->eops->packet_samples * 2;                                             // JC1_FrameSize samples
+    const size_t pcm_bytes = (size_t)(h->b->enc_ctrl.framesize_ms == 20 ? h->b->eops->packet_samples / 2 : h->b->eops->packet_samples) * 2;      // JC1_FrameSize samples
     memcpy(h->h_blk + SOLO_SINGLE_PCM_OFF, pcm, pcm_bytes);
     if (hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
@@ -770,7 +776,7 @@ int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int
     memcpy(nb, h->h_blk + SOLO_SINGLE_NB_OFF, 4);
     int32_t n = nb[0];
     if (n == 0 && h->b->enc_ctrl.dtx_enable)                                 // DTX packet: the reference still returns the high-band bytes
-        n = ctrl_hb_joint(h->b->enc_ctrl.joint_enable, h->b->enc_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+        n = ctrl_hb_bytes(h->b->enc_ctrl.joint_enable, h->b->enc_ctrl.joint_mode, h->b->enc_ctrl.framesize_ms);
     if (n > bufSize) n = bufSize;                                            // AGR_Sate_bits_write truncates to max_nbytes
     if (n > h->b->slot) n = h->b->slot;
     if (n > 0) memcpy(bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n);
@@ -795,8 +801,8 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
     if (!h || h->is_enc) return -1;
     if (nBytes[0] <= 0) return -1;                                           // AGR_BWE_SDK_API.c:266 (state untouched, outputs unwritten)
     if (lostflag < 1 || lostflag > 4) return -1;
-    const int ns = h->b->wb ? 2 * SX_PACKET : SX_PACKET;                      // JC1_FrameSize (AGR_BWE_SDK_API.c:277)
-    const int32_t hbb = ctrl_hb_joint(h->b->dec_ctrl.joint_enable, h->b->dec_ctrl.joint_mode) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    const int ns = (h->b->wb ? 2 * SX_PACKET : SX_PACKET) / (h->b->dec_ctrl.framesize_ms == 20 ? 2 : 1);                      // JC1_FrameSize (AGR_BWE_SDK_API.c:277)
+    const int32_t hbb = ctrl_hb_bytes(h->b->dec_ctrl.joint_enable, h->b->dec_ctrl.joint_mode, h->b->dec_ctrl.framesize_ms);
     int32_t n0 = nBytes[0], n1 = nBytes[1];
     if (lostflag != 1) {
         // lengths that do not describe bytes inside the caller's buffer are refused before anything is read (the reference would
@@ -860,7 +866,7 @@ int32_t solo_debug_nsq(int32_t n_streams, int32_t n_packets, const void* h_in, v
     int32_t rc = -1;
     if (hipMalloc(&st, ops->state_bytes * (size_t)n_streams) == hipSuccess && hipMalloc(&d_in, sz_in) == hipSuccess && hipMalloc(&d_out, sz_out) == hipSuccess &&
         hipMalloc(&ring, ops->nsq_ring_bytes(n_streams)) == hipSuccess && hipMemset(d_out, 0, sz_out) == hipSuccess &&
-        ops->init(st, n_streams, 12000, 0, 0, 0, (hipStream_t)0) == hipSuccess && hipMemcpy(d_in, h_in, sz_in, hipMemcpyHostToDevice) == hipSuccess &&
+        ops->init(st, n_streams, 12000, 0, 0, 0, 2, (hipStream_t)0) == hipSuccess && hipMemcpy(d_in, h_in, sz_in, hipMemcpyHostToDevice) == hipSuccess &&
         ops->nsq(st, d_in, d_out, n_streams, n_packets, 0, n_packets, NULL, ring, NULL) == 0 && hipDeviceSynchronize() == hipSuccess &&
         hipMemcpy(h_out, d_out, sz_out, hipMemcpyDeviceToHost) == hipSuccess)
         rc = (int32_t)ops->nsq_out_bytes;                       // (the caller checks its idea of the record size)

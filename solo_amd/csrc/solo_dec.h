@@ -92,6 +92,9 @@ struct SxDecState {
     i32 hb_lossCnt;
     i32 hb_first;
     i32 hb_joint;                // joint_mode 1: ONE 40 ms high-band frame per packet (4 HB bytes instead of 8)
+    i32 fpp;                     // 2, or 1 with framesize_ms = 20: 320-sample packets, ONE 20 ms high-band frame (4 bytes) -- and, like the reference
+                                 // (HB2LB_NUM = 2 low-band decoder calls per packet whatever its size, AGR_BWE_decode_frame_FIX.c:173), the packet's one
+                                 // SILK frame decoded TWICE, the second time as a new packet whose output is dropped
     i32 HB_prev_NLSFq[SX_HB_LPC];
     i32 HB_synth_state[SX_HB_LPC];
     i32 HB_prev_Gain;
@@ -212,7 +215,9 @@ SX_HD SxFrameSyms* sx_dec_syms(SxDecWork* w, int md) { return (SxFrameSyms*)&w->
 // payload is parsed; every field touched by that switch has the same value here, so the state after
 // the first received packet is identical.  Packets LOST before that run the reference's 24 kHz concealment +
 // resampler: sx_silk_decode_frame models exactly what survives of it (first_frame_after_reset doubles as "still at 24 kHz").
-SX_HD void sx_dec_state_init(SxDecState* st, int hb_joint = 0) {
+// hb_mode: bit 0 = joint_mode 1, bit 1 = framesize_ms 20
+SX_HD void sx_dec_state_init(SxDecState* st, int hb_mode = 0) {
+    const int hb_joint = hb_mode & 1;
     u8* p = (u8*)st;
     SX_PAR(i, (int)sizeof(SxDecState)) p[i] = 0;
     wv_sync();
@@ -223,6 +228,7 @@ SX_HD void sx_dec_state_init(SxDecState* st, int hb_joint = 0) {
     st->md[1].LastGainIndex = 1;
     st->hb_first = 1;
     st->hb_joint = hb_joint;
+    st->fpp = (hb_mode & 2) ? 1 : 2;
     // CNG / PLC are (re)initialised on the first call because their fs_kHz field is 0
     wv_sync();
 }
@@ -1336,7 +1342,7 @@ SX_FN void sx_hb_decode_side(SxDecState* st, SxDecWork* w, const u8* hb, int los
     SX_IN_LDS(st); SX_IN_LDS(w);
     SxHbParams* hp = &w->hbp;
     const int lost = (lostflag == 1 || lostflag == 2);
-    const int nf = st->hb_joint ? 1 : 2;          // high-band frames per packet
+    const int nf = st->hb_joint ? 1 : st->fpp;    // high-band frames per packet
     if (pre && !lost && SX_UNI(pre->have_hb)) {
         SX_PAR(i, nf * SX_HB_LPC) { (&hp->lsp[0][0])[i] = (&pre->hb_lsp[0][0])[i]; (&hp->lpc[0][0])[i] = (&pre->hb_lpc[0][0])[i]; }
         SX_PAR(i, nf * 4) (&hp->gain[0][0])[i] = (&pre->hb_gain[0][0])[i];
@@ -1365,7 +1371,7 @@ SX_FN void sx_hb_finish(SxDecState* st, SxDecWork* w, int lostflag, int piggy_do
     SX_IN_LDS(st); SX_IN_LDS(w);
     SxHbParams* hp = &w->hbp;
     const int lost = (lostflag == 1 || lostflag == 2);
-    const int nf = st->hb_joint ? 1 : 2;
+    const int nf = st->hb_joint ? 1 : st->fpp;
     const int sub_len = st->hb_joint ? 2 * SX_SUBFR : SX_SUBFR;   // BWE_SubFrameSize
     SX_T_BEGIN
     if (!piggy_done) {
@@ -1417,7 +1423,7 @@ SX_FN void sx_hb_finish(SxDecState* st, SxDecWork* w, int lostflag, int piggy_do
     wv_sync();
     SX_PAR(i, SX_HB_LPC) st->HB_synth_state[i] = hp->S[i];
     SX_PAR(i, SX_QMF_HIST) w->u.hi[i] = st->qmf_hi_hist[i];      // (the high-band buffer of the QMF shares its LDS with the frame scratch)
-    SX_PAR(i, SX_BAND) w->u.hi[SX_QMF_HIST + i] = w->hi_out[i];
+    SX_PAR(i, st->fpp * SX_FRAME) w->u.hi[SX_QMF_HIST + i] = w->hi_out[i];
     wv_sync();
 }
 
@@ -1425,9 +1431,10 @@ SX_FN void sx_hb_finish(SxDecState* st, SxDecWork* w, int lostflag, int piggy_do
 //   y[2k]   = sat( pshr15( sum_m a[2m]   * s1[k-m] + (-a[2m]) * s2[k-m] ) )
 //   y[2k+1] = sat( pshr15( sum_m a[2m+1] * s1[k-m] +   a[2m+1] * s2[k-m] ) )      m = 0..31
 // lo/hi hold [32 history | 320 new] samples.  32-bit accumulation wraps, so summation order is free.
-SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
+SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y, int n = SX_BAND) {
     SX_IN_LDS(lo); SX_IN_LDS(hi);
-    SX_PAR(k, SX_BAND) {
+    n = SX_UNI(n);
+    SX_PAR(k, n) {
         i32 y0 = 0, y1 = 0;
         const i16* s1 = lo + SX_QMF_HIST + k;
         const i16* s2 = hi + SX_QMF_HIST + k;
@@ -1454,7 +1461,7 @@ SX_FN void sx_qmf_synth(const i16* lo, const i16* hi, i16* y) {
 // ext2: NULL, or the records of the packet's two description slots from the extraction kernel (batch path): used when the packet
 // is an ordinary one -- see sx_extracted_usable; otherwise the symbols are read here, serially, like without them.
 SX_HD bool sx_extracted_usable(const SxDecState* st, const SxExtracted* ext2, int lostflag) {
-    if (!ext2 || lostflag < 2) return false;
+    if (!ext2 || lostflag < 2 || SX_UNI(st->fpp) != 2) return false;
     // the packet starts a new range-coder buffer (no frames left over from a payload that announced more than it carried)
     if (SX_UNI(st->moreInternalDecoderFrames) != 0) return false;
     const int ndesc = lostflag == 4 ? 2 : 1;
@@ -1470,7 +1477,8 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
                            int useMDIndex, i16* pcm_out, const SxExtracted* ext2 = 0) {
     SxDecState* st = &w->st;
     if (nBytes0 <= 0) return -1;
-    const i32 hb_bytes = st->hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;     // (QMF_HB_FrameSize / BWE_FrameSize) * HB_BYTE
+    const int fpp = SX_UNI(st->fpp);
+    const i32 hb_bytes = st->hb_joint ? SX_HB_BYTES / 2 : (SX_HB_BYTES / 2) * fpp;     // (QMF_HB_FrameSize / BWE_FrameSize) * HB_BYTE
     i32 nB0 = (lostflag == 2) ? nBytes0 : nBytes0 - hb_bytes;
     i32 nB1 = nBytes1 ? nBytes1 - hb_bytes : 0;
     const i32 hb_pos = nB0;
@@ -1541,9 +1549,9 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
     for (int f = 0; f < 2; f++) {
         // a frame that is decoded (not concealed) runs the high band's synthesis filter next to its own (sx_decode_core)
         w->hbp.frame = f;
-        w->hbp.piggy = lostflag != 1;
+        w->hbp.piggy = lostflag != 1 && f < fpp;       // (framesize 20: the second decoder call of the packet has no high-band frame under it)
         wv_sync();
-        if (lostflag != 1) piggy_frames++;
+        if (lostflag != 1 && f < fpp) piggy_frames++;
         int ret = sx_silk_decode_frame(st, w, rc, lostflag, bits, nB0, nB1, useMDIndex, &w->lo[SX_QMF_HIST + f * SX_FRAME], pre2, f);
         wv_sync();
         if (!pre2) {
@@ -1567,11 +1575,11 @@ SX_HD int sx_decode_packet(SxDecWork* w, const u8* bits, i32 nBytes0, i32 nBytes
         wv_sync();
     }
     SX_T_BEGIN
-    sx_hb_finish(st, w, lostflag, piggy_frames == 2);
+    sx_hb_finish(st, w, lostflag, piggy_frames == fpp);
     SX_T(6)
-    sx_qmf_synth(w->lo, w->u.hi, pcm_out);
+    sx_qmf_synth(w->lo, w->u.hi, pcm_out, fpp * SX_FRAME);
     SX_T(7)
-    SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[SX_BAND + i]; st->qmf_hi_hist[i] = w->u.hi[SX_BAND + i]; }
+    SX_PAR(i, SX_QMF_HIST) { st->qmf_lo_hist[i] = w->lo[fpp * SX_FRAME + i]; st->qmf_hi_hist[i] = w->u.hi[fpp * SX_FRAME + i]; }
     wv_sync();
     return 0;
 }

@@ -5,10 +5,10 @@
 #include "solo_dec.h"
 #include "solo_recv.h"
 
-__global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecStream* states, int n_streams, int hb_joint) {
+__global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecStream* states, int n_streams, int hb_mode) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
-    sx_dec_state_init(&states[s].st, hb_joint);
+    sx_dec_state_init(&states[s].st, hb_mode);
     u32* sh = (u32*)&states[s].sh;
     SX_PAR(i, (int)(sizeof(SxDecShadow) / 4)) sh[i] = 0;
 }
@@ -72,11 +72,11 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* s
     i32 first_err = 0;
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint);
+        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint | (w.st.fpp == 1));
         const u8* ptr = bits + pk * (size_t)slot + a.ptr_off;
         const int lostflag = a.lostflag, bad = a.bad;
         const i32 a0 = a.a0, a1 = a.a1;
-        i16* out = pcm + pk * SX_PACKET;
+        i16* out = pcm + pk * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp));
         int ret = sx_decode_packet(&w, ptr, a0, a1, lostflag, useMDIndex, out);
         if (ret == 0 && bad) ret = bad;
         if (ret < 0 && first_err == 0) first_err = ret;
@@ -121,7 +121,7 @@ __global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_
     const size_t sp = idx >> 1;
     const int s = (int)(sp / (size_t)pc), p = p0 + (int)(sp % (size_t)pc);
     const size_t pk = (size_t)s * n_packets + p;
-    const int hb_joint = states[s].st.hb_joint;
+    const int hb_joint = states[s].st.hb_joint | (states[s].st.fpp == 1);      // (what matters here: four high-band bytes instead of eight)
     const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, hb_joint);
     SxExtracted* rec = &recs[idx];
     i32 off = 0, len = 0, hb_off = -1;
@@ -149,8 +149,8 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
     i32 first_err = 0;
     for (int p = p0; p < p0 + pc; p++) {
         const size_t pk = (size_t)s * n_packets + p;
-        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint);
-        int ret = sx_decode_packet(&w, bits + pk * (size_t)slot + a.ptr_off, a.a0, a.a1, a.lostflag, useMDIndex, pcm + pk * SX_PACKET,
+        const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint | (w.st.fpp == 1));
+        int ret = sx_decode_packet(&w, bits + pk * (size_t)slot + a.ptr_off, a.a0, a.a1, a.lostflag, useMDIndex, pcm + pk * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp)),
                                    recs + ((size_t)s * pc + (size_t)(p - p0)) * 2);
         if (ret == 0 && a.bad) ret = a.bad;
         if (ret < 0 && first_err == 0) first_err = ret;
@@ -184,7 +184,7 @@ __device__ __forceinline__ int SX_K(sx_decode_split_packet)(SxDecWork& w, const 
         if (ia == 0) { p1 = pa; l1 = la; } else if (ib == 0) { p1 = pb; l1 = lb; }
         if (ia == 1) { p2 = pa; l2 = la; } else if (ib == 1) { p2 = pb; l2 = lb; }
     }
-    const int hbb = w.st.hb_joint ? SX_HB_BYTES / 2 : SX_HB_BYTES;
+    const int hbb = (w.st.hb_joint | (w.st.fpp == 1)) ? SX_HB_BYTES / 2 : SX_HB_BYTES;
     if (l2 > 0 && l2 <= hbb) l2 = 0;                    // a second description always carries the high-band bytes
     if (l1 + l2 > SX_DEC_PAYLOAD_LDS) return -11;
     wv_sync();
@@ -211,7 +211,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecStr
     for (int p = 0; p < n_packets; p++) {
         const size_t pk = (size_t)s * n_packets + p;
         const int ret = SX_K(sx_decode_split_packet)(w, descA + pk * (size_t)slot, lenA[pk], descB + pk * (size_t)slot, lenB[pk], slot, useMDIndex,
-                                                     pcm + pk * SX_PACKET);
+                                                     pcm + pk * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp)));
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
     }
@@ -261,7 +261,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_ring_kernel)(SxDecStre
         const u32 lw = lens[e];
         const u8* pa = ring + e * 2 * (size_t)slot;
         const int ret = SX_K(sx_decode_split_packet)(w, pa, (i32)(lw & 0xFFFFu), pa + slot, (i32)(lw >> 16), slot, useMDIndex,
-                                                     pcm + ((size_t)s * n_packets + p) * SX_PACKET);
+                                                     pcm + ((size_t)s * n_packets + p) * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp)));
         if (ret < 0 && first_err == 0) first_err = ret;
         wv_sync();
         if (SX_LANE == 0) lens[e] = 0;

@@ -243,13 +243,15 @@ SX_HD void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* xp, int Seed, 
 // idx2: the two frames' indices (hand-over record of the analysis), Seed0 / Seed1: the dither seeds the quantiser chose,
 // q2: the description's pulses of frame 0 then frame 1 (LDS row).  Reports the byte count and the coder's error flag.
 SX_HD void sx_code_description(const SxFrameIdx* idx2, int Seed0, int Seed1, const i8* q2, int md, int writeMDIndex, const SxCdf* cdf, u8* pw,
-                               u8* buf, SxRcInfo* info) {
+                               u8* buf, SxRcInfo* info, int fpp = 2) {
     SxRangeEnc rc;
     sx_rc_enc_init(&rc, buf);
     const int prev = 2 * idx2[0].sigtype + idx2[0].QuantOffsetType;
     sx_encode_parameters(&rc, &idx2[0], Seed0, 0, md, writeMDIndex, 0, q2, cdf, pw);
-    sx_rc_enc(&rc, 1, cdf->cdf_frame_term);                      // SKP_SILK_MORE_FRAMES = 1
-    sx_encode_parameters(&rc, &idx2[1], Seed1, 1, md, writeMDIndex, prev, q2 + SX_FRAME, cdf, pw);
+    if (fpp > 1) {
+        sx_rc_enc(&rc, 1, cdf->cdf_frame_term);                  // SKP_SILK_MORE_FRAMES = 1
+        sx_encode_parameters(&rc, &idx2[1], Seed1, 1, md, writeMDIndex, prev, q2 + SX_FRAME, cdf, pw);
+    }
     sx_rc_enc(&rc, 0, cdf->cdf_frame_term);                      // SKP_SILK_LAST_FRAME = 0
     i32 nb;
     sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
@@ -498,7 +500,7 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     st->prev_sigtype = c->sigtype;
     st->prevLag = c->pitchL[SX_NB_SUBFR - 1];
     st->first_frame_after_reset = 0;
-    st->nFramesInPayloadBuf = frame == 0 ? 1 : 0;
+    st->nFramesInPayloadBuf = frame + 1 < st->fpp ? frame + 1 : 0;      // (the payload goes out after fpp frames: PacketSize_ms / 20)
     wv_sync();
     SX_T(8)
 }
@@ -520,10 +522,11 @@ SX_FNW void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsq
     SxEncHist* hist = &rec->hist;
     SX_T_BEGIN
     SX_STRETCH_DENSE();
-    sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, cin->hi);
+    const int fpp = SX_UNI(w->st.fpp);
+    sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, cin->hi, fpp * 2 * SX_FRAME);
     wv_sync();
     SX_T(0)
-    for (int frame = 0; frame < SX_EXP_ANALYSIS_FRAMES; frame++) {
+    for (int frame = 0; frame < (SX_EXP_ANALYSIS_FRAMES < 2 ? SX_EXP_ANALYSIS_FRAMES : fpp); frame++) {
         sx_enc_analyse_frame(rec, w, hist->lo + frame * SX_FRAME, frame, &in2[frame], &cin->idx[frame]);
         wv_sync();
     }
@@ -544,7 +547,8 @@ SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* ci
         wv_sync();
         SX_T(9)
     } else {
-        for (int frame = 0; frame < 2; frame++) {
+        const int fpp = SX_UNI(st->fpp);
+        for (int frame = 0; frame < fpp; frame++) {
             sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[4 * frame], SX_FRAME);
             wv_sync();
             SX_T(9)
@@ -554,7 +558,7 @@ SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* ci
 
 // the packet is dropped ("DTX simulation", SKP_Silk_enc_API.c:260-265): it was analysed, quantised and its high band encoded (all
 // states moved on), but nothing is sent
-SX_HD bool sx_enc_packet_in_dtx(int useDTX, const SxCodeIn* cin) { return useDTX && SX_UNI(cin->idx[1].inDTX); }
+SX_HD bool sx_enc_packet_in_dtx(int useDTX, const SxCodeIn* cin, int fpp = 2) { return useDTX && SX_UNI(cin->idx[fpp - 1].inDTX); }      // (the packet's LAST frame decides)
 
 // Returns the total byte count, or a negative status if the payload does not fit `buf_size`.  buf0 / buf1: the range coder's
 // bytes of MD1 / MD2 (HBM), info2: their byte counts and error flags.
@@ -563,8 +567,9 @@ SX_FN i32 sx_enc_stage_c_out(SxEncWork* w, const SxCodeIn* cin, const u8* buf0, 
     SX_IN_LDS(w);
     SxEncState* st = &w->st;
     SX_T_BEGIN
-    const int hb_bytes = st->hb_joint ? 4 : 8;
-    if (sx_enc_packet_in_dtx(st->useDTX, cin)) {
+    const int fpp = SX_UNI(st->fpp);
+    const int hb_bytes = st->hb_joint ? 4 : 4 * fpp;
+    if (sx_enc_packet_in_dtx(st->useDTX, cin, fpp)) {
         nBytesOut[0] = 0;                        // (The reference's bit buffer then holds just the high-band bytes and its Encode
         nBytesOut[1] = 0;                        // returns their count; mirrored: they sit at the start of the slot.)
         SX_PAR(i, hb_bytes) bits[i] = w->hb_bytes[i];
@@ -598,13 +603,14 @@ SX_FN i32 sx_enc_stage_c_out(SxEncWork* w, const SxCodeIn* cin, const u8* buf0, 
 SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2, u8* bits, i32 buf_size, i16* nBytesOut) {
     sx_enc_stage_c_hb(rec, w, cin, out2);
     SxRcInfo info[2] = {{0, 0}, {0, 0}};
-    if (!sx_enc_packet_in_dtx(w->st.useDTX, cin)) {
+    const int fpp = w->st.fpp;
+    if (!sx_enc_packet_in_dtx(w->st.useDTX, cin, fpp)) {
         sx_cdf_load(&w->u.code.cdf);
         i8 q2[2 * SX_FRAME];
         for (int md = 0; md < 2; md++) {
-            for (int i = 0; i < 2 * SX_FRAME; i++) q2[i] = out2[i / SX_FRAME].q[md][i % SX_FRAME];
+            for (int i = 0; i < fpp * SX_FRAME; i++) q2[i] = out2[i / SX_FRAME].q[md][i % SX_FRAME];
             sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, q2, md, w->st.useMDIndex, &w->u.code.cdf, w->u.code.pulses, w->u.code.buf[md],
-                                &info[md]);
+                                &info[md], fpp);
         }
     }
     return sx_enc_stage_c_out(w, cin, w->u.code.buf[0], w->u.code.buf[1], info, bits, buf_size, nBytesOut);
@@ -616,7 +622,7 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
 SX_FN i32 sx_encode_packet(SxEncStream* rec, SxEncWork* w, SxCodeIn* cin, const i16* pcm, u8* bits, i32 buf_size, i16* nBytesOut) {
     sx_enc_stage_a(rec, w, pcm, rec->nsq_in, cin);
     wv_sync();
-    for (int frame = 0; frame < 2; frame++) {
+    for (int frame = 0; frame < w->st.fpp; frame++) {
         sx_nsq_del_dec((char*)&rec->nsq, 0u, &rec->nsq_in[frame], (char*)&rec->nsq_out[frame], 0u, &w->u.nsq, w->u.nsq.ring_emu, 0u, 12);
         wv_sync();
     }

@@ -1200,7 +1200,7 @@ SX_FN1 void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_inde
     wv_sync();
 }
 
-// SKP_Silk_LTP_scale_ctrl_FIX, SKP_Silk_LTP_scale_ctrl_FIX.c:39 (PacketLoss_perc = 0, PacketSize_ms = 40)
+// SKP_Silk_LTP_scale_ctrl_FIX, SKP_Silk_LTP_scale_ctrl_FIX.c:39 (PacketLoss_perc = 0, PacketSize_ms = 20 x frames per packet)
 SX_HD void sx_LTP_scale_ctrl(SxEncState* st, SxEncCtrl* c) {
     st->HPLTPredCodGain_Q7 = sx_max(c->LTPredCodGain_Q7 - st->prevLTPredCodGain_Q7, 0) + sx_rshift_round(st->HPLTPredCodGain_Q7, 1);
     st->prevLTPredCodGain_Q7 = c->LTPredCodGain_Q7;
@@ -1208,7 +1208,7 @@ SX_HD void sx_LTP_scale_ctrl(SxEncState* st, SxEncCtrl* c) {
     i32 g_limit_Q15 = sx_sigm_Q15(g_out_Q5 - (3 << 5));
     c->LTP_scaleIndex = 0;
     if (st->nFramesInPayloadBuf == 0) {
-        int round_loss = 0 + (40 / 20) - 1;
+        int round_loss = 0 + st->fpp - 1;
         i32 thrld1 = T_ltp_scale_thresholds_Q15[sx_min(round_loss, 10)];
         i32 thrld2 = T_ltp_scale_thresholds_Q15[sx_min(round_loss + 1, 10)];
         if (g_limit_Q15 > thrld1) c->LTP_scaleIndex = 2;

@@ -12,12 +12,14 @@
 //   y1[k] = sat( pshr15( sum_{j<32} a[j] * (int16)( x[2k+j-63] + x[2k-j] ) ) )
 //   y2[k] = sat( pshr15( sum_{j<32} (j even ? -1 : +1) * a[j] * ( x[2k+j-63] - x[2k-j] ) ) )
 // `tl` is a 63+640 sample scratch timeline (LDS).
-SX_FN1 void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16* hi) {
+// n: samples of the packet (SX_PACKET, or half of it with framesize_ms = 20)
+SX_FN1 void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16* hi, int n = SX_PACKET) {
     SX_IN_LDS(tl);
+    n = SX_UNI(n);
     SX_PAR(i, 63) tl[i] = hist->qmf_hist[i];
-    SX_PAR(i, SX_PACKET) tl[63 + i] = (i16)(pcm[i] >> 1);
+    SX_PAR(i, n) tl[63 + i] = (i16)(pcm[i] >> 1);
     wv_sync();
-    SX_PAR(k, SX_BAND) {
+    SX_PAR(k, n >> 1) {
         i32 y1 = 0, y2 = 0;
         const i16* xa = tl + 2 * k;          // x[2k + j - 63]  -> tl[63 + 2k + j - 63]
         const i16* xb = tl + 63 + 2 * k;     // x[2k - j]
@@ -32,7 +34,7 @@ SX_FN1 void sx_qmf_decomp(SxEncHist* hist, const i16* pcm, i16* tl, i16* lo, i16
         hi[k] = (i16)sx_saturate(sx_pshr32(y2, 15), 32767);
     }
     wv_sync();
-    SX_PAR(i, 63) hist->qmf_hist[i] = tl[SX_PACKET + i];
+    SX_PAR(i, 63) hist->qmf_hist[i] = tl[n + i];
     wv_sync();
 }
 

@@ -11,10 +11,10 @@
 #endif
 #define SX_ENC_PER_WAVE (64 / SX_ENC_GROUP)
 
-__global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX) {
+__global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, int fpp) {
     const int s = blockIdx.x * SX_ENC_PER_WAVE + (int)(threadIdx.x / SX_ENC_GROUP);
     if (s >= n_streams) return;
-    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX);
+    sx_enc_state_init(&states[s], silk_rate_bps, useMDIndex, hb_joint, useDTX, fpp);
 }
 
 // Encoder, rows E0-E9, as a three-stage pipeline over HBM hand-over records:
@@ -84,7 +84,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
     SX_K(solo_enc_enter)(&w, rec);
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a call of n_packets
         const size_t pk = (size_t)s * n_packets + p;
-        sx_enc_stage_a(rec, &w, pcm + pk * SX_PACKET, nsq_in + pk * 2, code_in + pk);
+        sx_enc_stage_a(rec, &w, pcm + pk * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp)), nsq_in + pk * 2, code_in + pk);      // (a packet: fpp frames of 2 x SX_FRAME input samples)
         wv_sync();
     }
     SX_K(solo_enc_leave)(&w, rec);
@@ -123,22 +123,23 @@ __global__ void __launch_bounds__(64) SX_K(solo_enc_rc_kernel)(const SxEncStream
     const int s = blockIdx.x * 32 + (lane >> 1);
     if (s >= n_streams) return;
     const SxEncState* st = &states[s].core;
-    const int useDTX = st->useDTX, useMDIndex = st->useMDIndex;
+    const int useDTX = st->useDTX, useMDIndex = st->useMDIndex, fpp = st->fpp;
     for (int p = p0; p < p0 + pc; p++) {
         const size_t pk = (size_t)s * n_packets + p;
         const size_t slot = ((size_t)s * pc + (size_t)(p - p0)) * 2 + (size_t)md;
         const SxCodeIn* cin = code_in + pk;
         const SxNsqOut* out2 = nsq_out + pk * 2;
         SxRcInfo info = {0, 0};
-        if (!(useDTX && cin->idx[1].inDTX)) {
+        if (!(useDTX && cin->idx[fpp - 1].inDTX)) {
 #pragma unroll
             for (int f = 0; f < 2; f++) {
+                if (f >= fpp) break;
                 const u32* src = (const u32*)&out2[f].q[md][0];           // (4-byte aligned: SxNsqOut = {i32, i8[2][SX_FRAME], i32[]})
 #pragma unroll 8
                 for (int j = 0; j < SX_FRAME / 4; j++) w.q[lane][f * (SX_FRAME / 4) + j] = src[j];
             }
             sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, (const i8*)&w.q[lane][0], md, useMDIndex, &w.cdf, (u8*)&w.pw[lane][0],
-                                rcbuf + slot * SX_RC_BUF_STRIDE, &info);
+                                rcbuf + slot * SX_RC_BUF_STRIDE, &info, fpp);
         }
         rcinfo[slot] = info;
     }
@@ -187,8 +188,8 @@ extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
 extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams);
 
 #include "solo_enc_ops.h"
-static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s) {
-    hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3((n_streams + SX_ENC_PER_WAVE - 1) / SX_ENC_PER_WAVE), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX);
+static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, int fpp, hipStream_t s) {
+    hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3((n_streams + SX_ENC_PER_WAVE - 1) / SX_ENC_PER_WAVE), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX, fpp);
     return hipGetLastError();
 }
 static hipError_t SX_K(solo_enc_launch_analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in,

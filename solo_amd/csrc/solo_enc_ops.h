@@ -10,7 +10,7 @@
 struct solo_enc_ops {
     size_t state_bytes, nsq_in_bytes, nsq_out_bytes, code_in_bytes;      // sizeof SxEncStream / SxNsqIn / SxNsqOut / SxCodeIn
     int packet_samples;
-    hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, hipStream_t s);
+    hipError_t (*init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, int frames_per_packet, hipStream_t s);
     hipError_t (*analysis)(void* states, const int16_t* pcm, int n_streams, int n_packets, int p0, int pc, void* nsq_in, void* code_in, hipStream_t s);
     int (*nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started, void* ring, void* hip_stream);
     // entropy coding of the descriptions (lane per description) into rc_scratch, then high band + payload assembly

@@ -61,6 +61,7 @@ struct SxEncState {
     i32 useMDIndex;
     i32 useDTX;                      // dtx_enable: packets are not sent while inDTX
     i32 hb_joint;                    // joint_mode 1: ONE 40 ms high-band frame per packet (4 HB bytes instead of 8)
+    i32 fpp;                         // SILK frames per packet: 2 (framesize_ms = 40) or 1 (framesize_ms = 20: one frame, one 4-byte high-band frame)
     SxVAD vad;
     // shape / prefilter / prediction states (SKP_Silk_structs_FIX.h:44-73)
     i32 LastGainIndex, HarmBoost_smth_Q16, HarmShapeGain_smth_Q16, Tilt_smth_Q16;
@@ -155,7 +156,7 @@ struct SxEncCtrl {
 // SKP_Silk_init_encoder_FIX (SKP_Silk_init_encoder_FIX.c:33) + the first SKP_Silk_control_encoder_FIX
 // pass (control_codec_FIX.c:56-130: setup_fs(8), setup_rate, ...) + AGR_Sate_Encoder_Init
 // (libBWE/AGR_BWE_SDK_API.c:11-126).  `silk_rate_bps` = targetRate_bps - 1600.
-SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex, i32 hb_joint = 0, i32 useDTX = 0) {
+SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex, i32 hb_joint = 0, i32 useDTX = 0, i32 fpp = 2) {
     u8* p = (u8*)rec;
     SX_PAR(i, (int)sizeof(SxEncStream)) p[i] = 0;
     wv_sync();
@@ -166,6 +167,7 @@ SX_FN void sx_enc_state_init(SxEncStream* rec, i32 silk_rate_bps, i32 useMDIndex
     st->useMDIndex = useMDIndex;
     st->hb_joint = hb_joint;
     st->useDTX = useDTX;
+    st->fpp = fpp;
     // SKP_Silk_VAD_Init, SKP_Silk_VAD.c:39
     for (int b = 0; b < 4; b++) {
         st->vad.NoiseLevelBias[b] = sx_max(50 / (b + 1), 1);

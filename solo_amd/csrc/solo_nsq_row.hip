@@ -57,8 +57,9 @@ extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64) SX_K(solo_nsq_k
     const u32 pOff = (u32)g * (u32)sizeof(SxEncStream) + (u32)offsetof(SxEncStream, nsq);
     const u32 rec_stride = (u32)n_packets * 2u;                     // hand-over records between consecutive streams
     SxRowCell* rgu = ring + (size_t)blockIdx.x * SX_NSQ_RING_CELLS;
+    const int fpp = __builtin_amdgcn_readfirstlane(states[(size_t)blockIdx.x * SX_PER_WAVE].core.fpp);      // frames per packet: the same for every stream of a handle
     for (int p = p0; p < p0 + pc; p++) {          // packets [p0, p0 + pc) of a launch of n_packets (row stride of the records)
-        for (int f = 0; f < 2; f++) {
+        for (int f = 0; f < fpp; f++) {
             const size_t r0 = ((size_t)blockIdx.x * SX_PER_WAVE * n_packets + p) * 2 + f;       // record of the wavefront's first stream
             sx_nsq_del_dec(Pu, pOff, &in[r0 + (size_t)g * rec_stride], (char*)&out[r0], (u32)g * rec_stride * (u32)sizeof(SxNsqOut), &w[g], rgu,
                            (u32)(g * SX_GROUP), 64);

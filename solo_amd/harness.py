@@ -2,8 +2,8 @@
 test/enc_main.c and read by test/dec_main.c, and the loss simulator of the decoder CLI, so that files produced here
 interoperate with the stock reference binaries and their known-answer md5s can be matched end to end.
 
-  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1] [-Fs_API 32000]
-  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-dec_mode 1|2] [-MDI 0/1] [-joint 1] [-Fs_API 32000]
+  python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1] [-Fs_API 32000] [-framesize 20]
+  python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-dec_mode 1|2] [-MDI 0/1] [-joint 1] [-Fs_API 32000] [-framesize 20]
 
 Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per 40 ms packet  int16 total, int16 len(MD2)+8, `total` payload bytes
 (payload = MD1 || MD2 || HB(8)).  Loss simulator (test/dec_main.c:24,236-252): rand_seed = 1, the LCG
@@ -64,17 +64,17 @@ def recv_mask(pattern):
     return np.array([(0 if l1 else 1) | (0 if l2 else 2) for l1, l2 in pattern], np.uint8)
 
 
-def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0, samplerate=16000):
+def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0, samplerate=16000, framesize_ms=40):
     """int16 array (16 kHz mono, or 32 kHz with samplerate=32000) -> [(payload, total, len(MD2)+8)]; a trailing partial packet is dropped like the CLI does"""
     import torch
     from . import SoloBatch
     pcm = np.asarray(pcm, np.int16)
-    L = PACKET_SAMPLES * samplerate // 16000
+    L = PACKET_SAMPLES * samplerate // 16000 * framesize_ms // 40
     P = pcm.size // L
     if P == 0:
         return []
     b = SoloBatch(1, rate=rate, encoder=True, decoder=False, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, dtx=dtx,
-                  samplerate=samplerate)
+                  samplerate=samplerate, framesize_ms=framesize_ms)
     x = torch.from_numpy(np.ascontiguousarray(pcm[:P * L].reshape(1, P, L))).to(b.device)
     bits, nb, st = b.encode(x)
     torch.cuda.synchronize()
@@ -84,7 +84,7 @@ def encode_pcm(pcm, rate=13600, use_md_index=0, slot_bytes=1088, joint=0, dtx=0,
     return [(hb[p, :hn[p, 0]].tobytes(), int(hn[p, 0]), int(hn[p, 1])) for p in range(P)]
 
 
-def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, samplerate=16000, dec_mode=0):
+def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, samplerate=16000, dec_mode=0, framesize_ms=40):
     """[(payload, total, len(MD2)+8)] -> int16 PCM, with the CLI's loss simulation (samplerate 32000 = `-Fs_API 32000`).
 
     dec_mode (test/dec_main.c:123-145,341-361): 1 = decode ONLY the first description of every packet of the file, 2 = only the
@@ -101,7 +101,7 @@ def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, 
     P = len(recs)
     if P == 0:
         return np.zeros(0, np.int16)
-    ns = PACKET_SAMPLES * samplerate // 16000
+    ns = PACKET_SAMPLES * samplerate // 16000 * framesize_ms // 40
     if dec_mode not in (0, 1, 2):
         raise ValueError("dec_mode: 0, 1 or 2")
     if dec_mode and loss_perc > 0:
@@ -109,7 +109,7 @@ def decode_records(recs, loss_perc=0, use_md_index=0, slot_bytes=1088, joint=0, 
     mask = recv_mask(cli_loss_pattern(P, loss_perc, [(r[1], r[2]) for r in recs]))
     if dec_mode:
         mask[:] = dec_mode          # the override of dec_main.c:341-361 = "only that description arrived", whatever the packet's parity
-    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, samplerate=samplerate)
+    b = SoloBatch(1, encoder=False, decoder=True, slot_bytes=slot_bytes, use_md_index=use_md_index, joint=joint, samplerate=samplerate, framesize_ms=framesize_ms)
     out = np.zeros((P, ns), np.int16)
     p = 0
     while p < P:
@@ -157,12 +157,12 @@ def main(argv=None):
         return 2
     if argv[0] == "enc":
         recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi,
-                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0), samplerate=fs)
+                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0), samplerate=fs, framesize_ms=_opt(argv, "-framesize", 40))
         open(argv[2], "wb").write(write_bit_container(recs))
         print("%d packets, %.3f kbps" % (len(recs), sum(r[1] for r in recs) * 8 / max(len(recs), 1) / 40.0))
     else:
         pcm = decode_records(parse_bit_container(open(argv[1], "rb").read()), loss_perc=_opt(argv, "-loss", 0), use_md_index=mdi,
-                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0, samplerate=fs, dec_mode=_opt(argv, "-dec_mode", 0))
+                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0, samplerate=fs, dec_mode=_opt(argv, "-dec_mode", 0), framesize_ms=_opt(argv, "-framesize", 40))
         pcm.astype(np.int16).tofile(argv[2])
         print("%d packets decoded" % (pcm.size // (PACKET_SAMPLES * fs // 16000)))
     return 0

@@ -24,9 +24,9 @@ extern "C" {
 
 struct EmuDec { SxDecState st; SxDecWork w; SxDecShadow sh; int useMDIndex; SxExtractLane L; int two_step; };
 
-void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argument: joint_mode 1 (40 ms high-band frame)
+void* emu_dec_create(int useMDIndex) {                    // bit 1 of the argument: joint_mode 1 (40 ms high-band frame), bit 3: framesize_ms 20
     EmuDec* d = (EmuDec*)calloc(1, sizeof(EmuDec));
-    sx_dec_state_init(&d->st, (useMDIndex >> 1) & 1);
+    sx_dec_state_init(&d->st, ((useMDIndex >> 1) & 1) | (((useMDIndex >> 3) & 1) << 1));
     d->useMDIndex = useMDIndex & 1;
     return d;
 }
@@ -87,10 +87,10 @@ extern "C" const void* emu_dec_state_ptr(void* h) { return &((EmuDec*)h)->st; }
 // ---- encoder ----
 extern "C" {
 struct EmuEnc { SxEncStream rec; SxEncWork w; SxCodeIn cin; };
-void* emu_enc_create(int rate_bps, int useMDIndex) {        // bit 1 of the second argument: joint_mode 1, bit 2: DTX
+void* emu_enc_create(int rate_bps, int useMDIndex) {        // bit 1 of the second argument: joint_mode 1, bit 2: DTX, bit 3: framesize_ms 20
     EmuEnc* e = (EmuEnc*)calloc(1, sizeof(EmuEnc));
     const int joint = (useMDIndex >> 1) & 1;
-    sx_enc_state_init(&e->rec, rate_bps - (joint ? 800 : 1600), useMDIndex & 1, joint, (useMDIndex >> 2) & 1);   // AGR_BWE_SDK_API.c:119
+    sx_enc_state_init(&e->rec, rate_bps - (joint ? 800 : 1600), useMDIndex & 1, joint, (useMDIndex >> 2) & 1, ((useMDIndex >> 3) & 1) ? 1 : 2);   // AGR_BWE_SDK_API.c:119
     return e;
 }
 void emu_enc_destroy(void* h) { free(h); }
