@@ -547,7 +547,8 @@ def main():
                               "algorithmic_bytes_per_launch": int(alg[n] * packets_step / nl[n]),
                               "achieved_GBps": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9, 4),
                               "frac_of_hbm_peak": round(alg[n] * packets_step / (kavg[n] * 1e-3) / 1e9 / HBM_PEAK_GBS, 7),
-                              "traffic_bytes_per_launch": tr_launch(n)} for n in kavg}
+                              "traffic_bytes_per_launch": tr_launch(n),
+                              "valu_lane_utilisation": {k: (insts.get("valu_lane_utilisation") or {}).get(k) for k in stage_kernels[n]}} for n in kavg}
         dom = max(kavg, key=kavg.get)
         alg_launch = alg[dom] * packets_step / nl[dom]
         achieved = alg_launch / (kavg[dom] / nl[dom] * 1e-3) / 1e9
@@ -584,6 +585,8 @@ def main():
             "ranks": [{k: v for k, v in r.items() if k != "blocks"} for r in records],
             "roofline": {"kernel": kname[dom], "bound": "hbm", "achieved": round(achieved, 4), "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 7), "traffic": tr_launch(dom),
+                         "traffic_is": "L2 memory-side (fabric) bytes per launch, rocprofv3 FETCH_SIZE x 2 + WRITE_SIZE: Infinity-Cache hits are included (no counter "
+                                       "behind the Infinity Cache is exposed), so an UPPER bound of the HBM bytes; the 32 MB quantiser ring lives in the 256 MiB Infinity Cache",
                          "avg_launch_ms": round(kavg[dom] / nl[dom], 4), "launches_per_step": nl[dom],
                          "packets_per_launch": packets_step // nl[dom],
                          "algorithmic_bytes_per_packet": round(alg[dom], 2),
@@ -610,6 +613,8 @@ def main():
                                  "unit": "G wave-instructions/s (VALU)", "frac": round(v / peak_issue, 4),
                                  "valu_wave_instructions_per_packet": insts.get("valu_per_packet"),
                                  "all_wave_instructions_per_packet": insts.get("all_per_packet"),
+                                 "valu_lane_utilisation": insts.get("valu_lane_utilisation"),
+                                 "lane_utilisation_is": "SQ_THREAD_CYCLES_VALU / (64 x SQ_ACTIVE_INST_VALU): lanes switched on (EXEC) while a vector instruction executes",
                                  "source": insts.get("source"), "from_this_build": prof_ok,
                                  "note": "SQ_INSTS_VALU per packet of each kernel (rocprofv3 --pmc pass) x packets/s of this run, per GPU; "
                                          "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal).  Measured on gfx950 "

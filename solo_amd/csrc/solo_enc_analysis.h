@@ -2079,6 +2079,99 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
             }
         }
         SX_S(52)
+#if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64 && !defined(SX_MSVQ_SERIAL_SELECT)
+        // The cur_survivors smallest keys in ascending order = the head of the SORTED key set (keys are distinct: the pair index is part of
+        // them).  Instead of cur_survivors wave-minimum rounds -- each a chain of six dependent lane exchanges, a read-back, a vote and a
+        // queue shift, 400 cycles of a lone wave -- every register of keys (one key per lane) is sorted along its 16-lane rows with a
+        // bitonic network of ten compare-exchange stages (partner by DPP: i ^ 1, flip in 4, in 8, in 16, i ^ 2, i ^ 4), the sorted
+        // lists are merged pairwise keeping the lower sixteen (min against the mirrored partner list + four half-cleaner stages):
+        // first the registers of a lane, then the rows of a half (v_permlane16_swap), then the halves (v_permlane32_swap).  The
+        // registers' networks are independent instruction streams: the scheduler interleaves them.  (Network checked lane by lane
+        // against a sort in tools/debug/msvq_bitonic_model.py.)
+        {
+            // lanes that keep the SMALLER key of a pair, as wave masks: (lane & 1) == 0, & 2, & 4, & 8.  "take the partner's key" = (partner <
+            // mine) in these lanes, the opposite in the others: one s_xnor of the compare's mask, handed back to the select as a lane condition
+            const unsigned long long km1 = 0x5555555555555555ull, km2 = 0x3333333333333333ull, km4 = 0x0F0F0F0F0F0F0F0Full, km8 = 0x00FF00FF00FF00FFull;
+#define SXK_D(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+#define SXK_X4(v) __builtin_amdgcn_update_dpp(__builtin_amdgcn_update_dpp((v), (v), 0x104, 0xF, 0x5, false), (v), 0x114, 0xF, 0xA, false)
+#define SXK_CX_(K, PL, PH, KM) { const i32 pl_ = (PL), ph_ = (PH); const i64 pk_ = (i64)(((u64)(u32)ph_ << 32) | (u32)pl_);                     \
+            const bool take_ = __builtin_amdgcn_inverse_ballot_w64(~(__builtin_amdgcn_ballot_w64(pk_ < (K)) ^ (KM))); (K) = take_ ? pk_ : (K); }
+#define SXK_CXD(K, ctrl, KM) SXK_CX_(K, SXK_D((i32)(u32)(K), ctrl), SXK_D((i32)((u64)(K) >> 32), ctrl), KM)
+#define SXK_CX4(K) SXK_CX_(K, SXK_X4((i32)(u32)(K)), SXK_X4((i32)((u64)(K) >> 32)), km4)
+            // (one stage for several registers in a row: their chains are independent, the stages alternate in program order)
+#define SXK_ST1(A, OP) OP(A)
+#define SXK_ST2(A, B, OP) OP(A) OP(B)
+#define SXK_ST4(A, B, C, D, OP) OP(A) OP(B) OP(C) OP(D)
+#define SXK_S0(K) SXK_CXD(K, 0xB1, km1)
+#define SXK_S1(K) SXK_CXD(K, 0x1B, km2)
+#define SXK_S2(K) SXK_CXD(K, 0x141, km4)
+#define SXK_S3(K) SXK_CXD(K, 0x4E, km2)
+#define SXK_S4(K) SXK_CXD(K, 0x140, km8)
+#define SXK_S5(K) SXK_CX4(K)
+#define SXK_S6(K) SXK_CXD(K, 0x128, km8)
+#define SXK_SORT16_(ST) ST(SXK_S0) ST(SXK_S1) ST(SXK_S0) ST(SXK_S2) ST(SXK_S3) ST(SXK_S0) ST(SXK_S4) ST(SXK_S5) ST(SXK_S3) ST(SXK_S0)
+#define SXK_CLEAN16_(ST) ST(SXK_S6) ST(SXK_S5) ST(SXK_S3) ST(SXK_S0)
+            // A <- the lower sixteen of two sorted lists (B mirrored), as a bitonic sequence (the half-cleaners follow)
+#define SXK_MIN_MIRROR(A, BL, BH) { const i32 pl_ = SXK_D((BL), 0x140), ph_ = SXK_D((BH), 0x140); const i64 pk_ = (i64)(((u64)(u32)ph_ << 32) | (u32)pl_); \
+            (A) = pk_ < (A) ? pk_ : (A); }
+#define SXK_MERGE(A, BL, BH) { SXK_MIN_MIRROR(A, BL, BH) SXK_CLEAN16_(SXK_Z1) }
+#define SXK_Z1(OP) SXK_ST1(z, OP)
+#define SXK_Z2(OP) SXK_ST2(z, k1, OP)
+#define SXK_Z4(OP) SXK_ST4(z, k1, k2, k3, OP)
+#define SXK_ZK2(OP) SXK_ST2(z, k2, OP)
+            i64 z = k0;
+            if (total > 128) {
+                SXK_SORT16_(SXK_Z4)
+                SXK_MIN_MIRROR(z, (i32)(u32)k1, (i32)((u64)k1 >> 32)) SXK_MIN_MIRROR(k2, (i32)(u32)k3, (i32)((u64)k3 >> 32))
+                SXK_CLEAN16_(SXK_ZK2)
+                SXK_MERGE(z, (i32)(u32)k2, (i32)((u64)k2 >> 32))
+            } else if (total > 64) {
+                SXK_SORT16_(SXK_Z2)
+                SXK_MERGE(z, (i32)(u32)k1, (i32)((u64)k1 >> 32))
+            } else {
+                SXK_SORT16_(SXK_Z1)
+            }
+            {   // the rows of a half: element [0] = the even row's list in both rows, [1] = the odd row's
+                auto sl_ = __builtin_amdgcn_permlane16_swap((u32)z, (u32)z, false, false);
+                auto sh_ = __builtin_amdgcn_permlane16_swap((u32)((u64)z >> 32), (u32)((u64)z >> 32), false, false);
+                z = (i64)(((u64)(u32)sh_[0] << 32) | (u32)sl_[0]);
+                SXK_MERGE(z, (i32)sl_[1], (i32)sh_[1])
+            }
+            if (total > 32) {   // the halves ([0] = the lower half's list, [1] = the upper's); 32 pairs sit in the lower half alone
+                auto sl_ = __builtin_amdgcn_permlane32_swap((u32)z, (u32)z, false, false);
+                auto sh_ = __builtin_amdgcn_permlane32_swap((u32)((u64)z >> 32), (u32)((u64)z >> 32), false, false);
+                z = (i64)(((u64)(u32)sh_[0] << 32) | (u32)sl_[0]);
+                SXK_MERGE(z, (i32)sl_[1], (i32)sh_[1])
+            }
+            if (SX_LANE < cur_survivors) {
+                w->RateDist_Q18[SX_LANE] = (i32)((u64)z >> 32);
+                x->TempIndices[SX_LANE] = (i32)(u32)z;
+            }
+#undef SXK_D
+#undef SXK_X4
+#undef SXK_CX_
+#undef SXK_CXD
+#undef SXK_CX4
+#undef SXK_MERGE
+#undef SXK_MIN_MIRROR
+#undef SXK_ST1
+#undef SXK_ST2
+#undef SXK_ST4
+#undef SXK_S0
+#undef SXK_S1
+#undef SXK_S2
+#undef SXK_S3
+#undef SXK_S4
+#undef SXK_S5
+#undef SXK_S6
+#undef SXK_SORT16_
+#undef SXK_CLEAN16_
+#undef SXK_Z1
+#undef SXK_Z2
+#undef SXK_Z4
+#undef SXK_ZK2
+        }
+#else
         if (total > 64) { SX_KEY_CX(k0, k1) SX_KEY_CX(k2, k3) SX_KEY_CX(k0, k2) SX_KEY_CX(k1, k3) SX_KEY_CX(k1, k2) }
         // heads as (value, index) register pairs; one selection round = wave minimum of the values, then wave minimum of the
         // indices among the lanes that hold that value (two 32-bit DPP ladders instead of one 64-bit compare ladder)
@@ -2103,6 +2196,7 @@ SX_FN1 void sx_nlsf_msvq_encode(i32* NLSFIndices, i32* pNLSF_Q15, int sigtype, c
             w->RateDist_Q18[SX_LANE] = mine_v;
             x->TempIndices[SX_LANE] = mine_i;
         }
+#endif
 #endif
         SX_S(48)
         wv_sync();

@@ -85,7 +85,10 @@ json.dump(out, open(dst + "_summary.json", "w"), indent=1)
 open(dst + "_kernel_stats.csv", "w").write("Name,Calls,TotalDurationNs,AverageNs,Percentage\n" + "\n".join(lines) + "\n")
 if out["kernel_source_sha16"] != solo_amd.kernel_source_hash():
     print("WARNING: the profiled build (%s) is not the kernel source of this tree (%s)" % (out["kernel_source_sha16"], solo_amd.kernel_source_hash()))
-tr = {"note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per 40 ms packet and kernel; see "
+tr = {"what": "L2 memory-side (fabric) request bytes: TCC_EA0 read / write requests as rocprofv3 derives FETCH_SIZE / WRITE_SIZE from them. "
+              "Infinity-Cache (256 MiB) hits are NOT excluded and this rocprofv3 exposes no counter behind the Infinity Cache, so this is an upper "
+              "bound of the DRAM traffic (the quantiser's 32 MB emission ring and the stream states fit in the Infinity Cache)",
+      "note": "rocprofv3 FETCH_SIZE (x2, gfx950 correction) + WRITE_SIZE, KiB -> bytes, per 40 ms packet and kernel; see "
               + os.path.basename(dst) + "_summary.json", "kernel_source_sha16": out["kernel_source_sha16"], "git_head": git_head}
 for k, e in out["kernels"].items():
     if "hbm_bytes_per_packet_corrected" in e:
@@ -93,12 +96,14 @@ for k, e in out["kernels"].items():
 json.dump(tr, open(os.path.join(os.path.dirname(dst) or ".", "hbm_traffic.json"), "w"), indent=1)
 # VALU / all wave-instructions per packet (bench.py's valu_issue block reads this)
 wi = {"source": os.path.basename(dst) + "_summary.json (rocprofv3 --pmc SQ_INSTS_* pass)", "kernel_source_sha16": out["kernel_source_sha16"], "git_head": git_head,
-      "valu_per_packet": {}, "all_per_packet": {}}
+      "valu_per_packet": {}, "all_per_packet": {}, "valu_lane_utilisation": {}}
 for k, e in out["kernels"].items():
     w = e.get("wave_instructions_per_packet")
     if w and "gate" not in k and "debug" not in k:
         wi["valu_per_packet"][k] = round(w.get("VALU", 0.0), 1)
         wi["all_per_packet"][k] = round(sum(w.get(c, 0.0) for c in ("VALU", "SALU", "LDS", "SMEM", "VMEM_RD", "VMEM_WR")), 1)
+        if "valu_lane_utilisation" in e:
+            wi["valu_lane_utilisation"][k] = round(e["valu_lane_utilisation"], 4)
 if wi["valu_per_packet"]:
     wi["valu_per_packet_round_trip"] = round(sum(wi["valu_per_packet"].values()), 1)
     wi["all_per_packet_round_trip"] = round(sum(wi["all_per_packet"].values()), 1)
