@@ -724,6 +724,7 @@ struct solo_single {
     int16_t* d_nbytes;
     int32_t* d_status;
     int is_enc;
+    int zero_copy;                   // the kernels read / write the pinned host block directly (no staging copies): SOLO_LEGACY_ZEROCOPY=1
 };
 #define SOLO_SINGLE_PCM_OFF 16
 #define SOLO_SINGLE_NB_OFF (16 + 2 * SX_PACKET * 2)
@@ -731,7 +732,7 @@ struct solo_single {
 
 static void single_free(solo_single* h) {
     if (!h) return;
-    if (h->d_blk) (void)hipFree(h->d_blk);
+    if (h->d_blk && !h->zero_copy) (void)hipFree(h->d_blk);
     if (h->h_blk) (void)hipHostFree(h->h_blk);
     solo_batch_destroy(h->b);
     free(h);
@@ -743,12 +744,20 @@ static solo_single* single_new(const USER_Ctrl_enc* e, const USER_Ctrl_dec* d) {
     h->is_enc = e != NULL;
     h->b = solo_batch_create(1, e, d, 1024 + 64);   // MAX_FRAME_BYTES of the reference harness + slack
     const size_t blk = h->b ? (size_t)SOLO_SINGLE_BITS_OFF + (size_t)h->b->slot : 0;
-    if (!h->b || hipMalloc((void**)&h->d_blk, blk) != hipSuccess || hipHostMalloc((void**)&h->h_blk, blk, hipHostMallocDefault) != hipSuccess ||
-        hipMemset(h->d_blk, 0, blk) != hipSuccess) {
+    // A call moves ~1.4 KB each way.  Zero copy: the block is pinned host memory that the device addresses directly -- the analysis kernel
+    // reads the PCM, the coding kernel writes lengths + payload (the decoder: payload in, status + PCM out) over PCIe, and a call is the
+    // kernel launches + ONE synchronisation, without the two staging copies (each an enqueue + a DMA round trip of its own).
+    const char* zc = getenv("SOLO_LEGACY_ZEROCOPY");
+    h->zero_copy = zc ? atoi(zc) != 0 : 0;      // (measured: 0.214 ms per decode call either way -- the call is the single-wave kernel chain + one synchronisation; off by default)
+    if (!h->b || hipHostMalloc((void**)&h->h_blk, blk, hipHostMallocDefault) != hipSuccess) { single_free(h); return NULL; }
+    memset(h->h_blk, 0, blk);
+    if (h->zero_copy) {
+        if (hipHostGetDevicePointer((void**)&h->d_blk, h->h_blk, 0) != hipSuccess) { h->d_blk = NULL; h->zero_copy = 0; }
+    }
+    if (!h->zero_copy && (hipMalloc((void**)&h->d_blk, blk) != hipSuccess || hipMemset(h->d_blk, 0, blk) != hipSuccess)) {
         single_free(h);
         return NULL;
     }
-    memset(h->h_blk, 0, blk);
     h->d_status = (int32_t*)h->d_blk;
     h->d_pcm = (int16_t*)(h->d_blk + SOLO_SINGLE_PCM_OFF);
     h->d_nbytes = (int16_t*)(h->d_blk + SOLO_SINGLE_NB_OFF);
@@ -767,10 +776,10 @@ int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int
     if (!h || !h->is_enc) return -1;
     const size_t pcm_bytes = (size_t)(h->b->enc_ctrl.framesize_ms == 20 ? h->b->eops->packet_samples / 2 : h->b->eops->packet_samples) * 2;      // JC1_FrameSize samples
     memcpy(h->h_blk + SOLO_SINGLE_PCM_OFF, pcm, pcm_bytes);
-    if (hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
+    if (!h->zero_copy && hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
     // lengths + the whole payload slot in one copy (a payload is at most a few hundred bytes; the slot 1088)
-    if (hipMemcpyAsync(h->h_blk + SOLO_SINGLE_NB_OFF, h->d_blk + SOLO_SINGLE_NB_OFF, 16 + (size_t)h->b->slot, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (!h->zero_copy && hipMemcpyAsync(h->h_blk + SOLO_SINGLE_NB_OFF, h->d_blk + SOLO_SINGLE_NB_OFF, 16 + (size_t)h->b->slot, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int16_t nb[2];
     memcpy(nb, h->h_blk + SOLO_SINGLE_NB_OFF, 4);
@@ -810,12 +819,12 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
         if (n0 > h->b->slot) { *nSamplesOut = (int16_t)ns; return -11; }
         if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb) || (lostflag == 4 && n0 < hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
         memcpy(h->h_blk + SOLO_SINGLE_BITS_OFF, bits, (size_t)n0);
-        if (hipMemcpyAsync(h->d_bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n0, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
+        if (!h->zero_copy && hipMemcpyAsync(h->d_bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n0, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     }
     if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,
                                                                   h->d_status, (hipStream_t)0) != hipSuccess) return -1;
     // status + decoded packet in one copy, one synchronisation
-    if (hipMemcpyAsync(h->h_blk, h->d_blk, SOLO_SINGLE_PCM_OFF + (size_t)ns * 2, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (!h->zero_copy && hipMemcpyAsync(h->h_blk, h->d_blk, SOLO_SINGLE_PCM_OFF + (size_t)ns * 2, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int32_t ret = 0;
     memcpy(&ret, h->h_blk, 4);
