@@ -30,7 +30,7 @@ typedef struct {            /* AGR_JC1_SDK_API.h:11-21 */
     int32_t targetRate_bps; /* <=0 -> 15600 (AGR_BWE_SDK_API.c:35-37); CLI default 13600 */
     int32_t samplerate;     /* 16000, or 32000 (1280-sample packets, SILK wide band; targetRate_bps >= 15600) */
     int32_t dtx_enable;     /* 0 / 1                                                    */
-    int32_t framesize_ms;   /* 40                                                       */
+    int32_t framesize_ms;   /* 40, or 20 (one SILK frame + one 4-byte high-band frame per packet: half the samples; not with joint_mode 1) */
     int32_t joint_enable;   /* 0, or 1 with joint_mode 1 (one 40 ms high-band frame)   */
     int32_t joint_mode;
     int32_t useMDIndex;     /* 0/1: one extra description-index symbol per description  */
@@ -39,17 +39,17 @@ typedef struct {            /* AGR_JC1_SDK_API.h:11-21 */
 typedef struct {            /* AGR_JC1_SDK_API.h:23-31 */
     int32_t packetLoss_perc;
     int32_t samplerate;     /* 16000, or 32000 (1280-sample packets, SILK wide band at 16 kHz) */
-    int32_t framesize_ms;
+    int32_t framesize_ms;   /* 40 or 20, like the encoder's */
     int32_t joint_enable;
     int32_t joint_mode;
     int32_t useMDIndex;
 } USER_Ctrl_dec;
 
 /* AGR_JC1_SDK_API.h:33  (impl. libBWE/AGR_BWE_SDK_API.c:11).  NULL if the configuration is not the
- * supported one (samplerate 16000 or 32000, framesize 40, joint off or joint_mode 1) or no GPU is available. */
+ * supported one (samplerate 16000 or 32000, framesize 40 or 20, joint off or joint_mode 1 with framesize 40) or no GPU is available. */
 void *AGR_Sate_Encoder_Init(USER_Ctrl_enc *enc_Ctrl);
-/* AGR_JC1_SDK_API.h:37  (impl. AGR_BWE_SDK_API.c:129).  pcm: 640 samples (1280 at 32 kHz); returns total bytes,
- * nBytesOut[0] = total, nBytesOut[1] = len(MD2)+8 (MD1 = first nBytesOut[0]-nBytesOut[1] bytes). */
+/* AGR_JC1_SDK_API.h:37  (impl. AGR_BWE_SDK_API.c:129).  pcm: 640 samples (1280 at 32 kHz; half of that with framesize_ms 20); returns total bytes,
+ * nBytesOut[0] = total, nBytesOut[1] = len(MD2)+8 (+4 with framesize_ms 20 or joint_mode 1) (MD1 = first nBytesOut[0]-nBytesOut[1] bytes). */
 int32_t AGR_Sate_Encoder_Encode(void *SATEEnc_State, const int16_t *AGR_Sate_PCM, uint8_t *AGR_Sate_Bit,
                                 int32_t AGR_Sate_Buf_Size, int16_t *nBytesOut);
 /* AGR_JC1_SDK_API.h:45 */
@@ -70,7 +70,7 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
 /* ------------------------------------------------------------------------------------------------
  * Part 2: batched device API.  All d_* pointers are DEVICE pointers (HBM) of the current HIP device.
  *
- *   d_pcm      int16  [n_streams][n_packets][640]      stream-major 16 kHz PCM
+ *   d_pcm      int16  [n_streams][n_packets][640]      stream-major 16 kHz PCM (1280 samples per packet at 32 kHz; half as many with framesize_ms 20)
  *   d_bits     uint8  [n_streams][n_packets][slot]     one fixed-size slot per packet: MD1|MD2|HB
  *   d_nbytes   int16  [n_streams][n_packets][2]        {total, len(MD2)+8}  (the reference's nBytesOut[0..1])
  *   d_recv     uint8  [n_streams][n_packets]           bit0: MD1 arrived, bit1: MD2(+HB) arrived

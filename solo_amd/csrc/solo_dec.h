@@ -1065,6 +1065,49 @@ SX_FN void sx_cng(SxDecState* st, SxDecWork* w, i16* signal, int length) {
 // (SKP_Silk_errors.h) on a corrupt payload.
 // pre2: NULL = read the symbols off the range coder here (description md on lane md); else the records of the packet's description
 // slots from the extraction kernel, frame f of which holds this frame's symbols (the caller has checked that they can be used)
+// The batch path's records of one frame -> where the serial parse would have left them (a call of its own: inlined it takes the 32 kHz
+// build's synthesis kernel from 250 to 262 registers, i.e. from two waves per SIMD to one).
+SX_FN void sx_dec_stage_records(SxDecState* st, SxDecWork* w, const SxExtracted* pre2, int ndesc, int f) {
+    SX_IN_LDS(st); SX_IN_LDS(w);
+    ndesc = SX_UNI(ndesc); f = SX_UNI(f);
+    // The symbols were read ahead and de-quantised by the extraction kernel (SxExtracted::ctl): everything the frame takes from
+    // the records is requested here in ONE batch of loads -- the control block of the description in use, the pulses, and per
+    // description slot the few values its state moves on with (sx_dequant_parameters: the type offset, the delta-gain and
+    // last gain indices, the NLSF vector; frame 0 interpolates with the slot's previous vector, which only the decoder has).
+    const int fa = st->first_frame_after_reset == 1;
+    for (int d = 0; d < ndesc; d++) { SX_PAR(i, SX_FRAME) w->u.parse.pulses[d][i] = (i16)pre2[d].pulses[f][i]; }
+    {
+        const i32* sc = (const i32*)&pre2[ndesc - 1].ctl[f];
+        i32* dc = (i32*)&w->u.parse.ctrl2[ndesc - 1];
+        SX_PAR(i, (int)(sizeof(SxDecCtrl) / 4)) dc[i] = sc[i];
+    }
+    static_assert(SX_LPC + 2 <= 32, "a row of 32 per description slot");
+    SX_PAR(t, ndesc * 32) {
+        const int d = t >> 5, i = t & 31;
+        const SxFrameSyms* y = &pre2[d].y[f];
+        SxDecDesc* m = &st->md[d];
+        i32* nl = &w->res_Q10[d * 2 * SX_LPC];
+        if (i < SX_LPC) {
+            const i32 coef = fa ? 4 : y->NLSFInterpCoef_Q2;
+            const i32 nq = y->NLSF_Q15[i], prev = m->prevNLSF_Q15[i];
+            nl[SX_LPC + i] = nq;
+            if (coef < 4) nl[i] = prev + (sx_mul(coef, nq - prev) >> 2);
+            m->prevNLSF_Q15[i] = nq;
+        } else if (i == SX_LPC) {
+            m->typeOffsetPrev = y->typeOffset;
+            if (st->nFramesDecoded == 0) m->prevDeltaGainIndex = y->DeltaGainIndices;
+            m->LastGainIndex = pre2[d].lastGain[f];
+        } else if (i == SX_LPC + 1) {
+            w->u.parse.lane_out[d][0] = y->vadFlag;
+            w->u.parse.lane_out[d][1] = y->FrameTermination;
+            w->u.parse.lane_out[d][2] = y->left;
+            w->u.parse.lane_out[d][3] = y->error;
+            w->u.parse.lane_len[d] = y->bufferLength;
+        }
+    }
+    if (fa) { wv_sync(); w->u.parse.ctrl2[ndesc - 1].NLSFInterpCoef_Q2 = 4; }
+}
+
 SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int action, const u8* payload,
                                i32 nB0, i32 nB1, int useMDIndex, i16* pOut, const SxExtracted* pre2 = 0, int f = 0) {
     SX_IN_LDS(st); SX_IN_LDS(w); SX_IN_LDS(pOut);
@@ -1124,42 +1167,7 @@ SX_HD int sx_silk_decode_frame(SxDecState* st, SxDecWork* w, SxRangeDec* rc, int
         }
         SX_S(13)
         if (pre2) {
-            // The symbols were read ahead and de-quantised by the extraction kernel (SxExtracted::ctl): everything the frame takes from
-            // the records is requested here in ONE batch of loads -- the control block of the description in use, the pulses, and per
-            // description slot the few values its state moves on with (sx_dequant_parameters: the type offset, the delta-gain and
-            // last gain indices, the NLSF vector; frame 0 interpolates with the slot's previous vector, which only the decoder has).
-            const int fa = st->first_frame_after_reset == 1;
-            for (int d = 0; d < ndesc; d++) { SX_PAR(i, SX_FRAME) w->u.parse.pulses[d][i] = (i16)pre2[d].pulses[f][i]; }
-            {
-                const i32* sc = (const i32*)&pre2[ndesc - 1].ctl[f];
-                i32* dc = (i32*)&w->u.parse.ctrl2[ndesc - 1];
-                SX_PAR(i, (int)(sizeof(SxDecCtrl) / 4)) dc[i] = sc[i];
-            }
-            static_assert(SX_LPC + 2 <= 32, "a row of 32 per description slot");
-            SX_PAR(t, ndesc * 32) {
-                const int d = t >> 5, i = t & 31;
-                const SxFrameSyms* y = &pre2[d].y[f];
-                SxDecDesc* m = &st->md[d];
-                i32* nl = &w->res_Q10[d * 2 * SX_LPC];
-                if (i < SX_LPC) {
-                    const i32 coef = fa ? 4 : y->NLSFInterpCoef_Q2;
-                    const i32 nq = y->NLSF_Q15[i], prev = m->prevNLSF_Q15[i];
-                    nl[SX_LPC + i] = nq;
-                    if (coef < 4) nl[i] = prev + (sx_mul(coef, nq - prev) >> 2);
-                    m->prevNLSF_Q15[i] = nq;
-                } else if (i == SX_LPC) {
-                    m->typeOffsetPrev = y->typeOffset;
-                    if (st->nFramesDecoded == 0) m->prevDeltaGainIndex = y->DeltaGainIndices;
-                    m->LastGainIndex = pre2[d].lastGain[f];
-                } else if (i == SX_LPC + 1) {
-                    w->u.parse.lane_out[d][0] = y->vadFlag;
-                    w->u.parse.lane_out[d][1] = y->FrameTermination;
-                    w->u.parse.lane_out[d][2] = y->left;
-                    w->u.parse.lane_out[d][3] = y->error;
-                    w->u.parse.lane_len[d] = y->bufferLength;
-                }
-            }
-            if (fa) { wv_sync(); w->u.parse.ctrl2[ndesc - 1].NLSFInterpCoef_Q2 = 4; }
+            sx_dec_stage_records(st, w, pre2, ndesc, f);
         } else {
         // the two descriptions are independent range-coded streams: description md is parsed by lane md
         SX_PAR(md, ndesc) {

@@ -40,7 +40,9 @@ def test_vector_register_and_lds_budgets():
                 seen[name] = (v, lds)
     checked = 0
     for name, (v, lds) in seen.items():
-        if "_wb" in name:                 # the 32 kHz build: larger frames, its own budgets are not part of the plan
+        if "_wb" in name:                 # the 32 kHz build: larger frames, its own budgets are not part of the plan -- except the
+            if "solo_dec_synth_kernel" in name or "solo_decode_kernel" in name:      # decoder's two waves per SIMD (round 5: 262 registers = one wave, decode 45 % slower)
+                assert v <= 256, (name, "vector registers", v, "budget", 256)
             continue
         for frag, (vmax, lmax) in BUDGET.items():
             if frag in name:
