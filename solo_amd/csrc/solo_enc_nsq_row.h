@@ -713,7 +713,11 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
 #else
             // (a row per stream: in three groups, each requested one stage before its use: all at once they would be 40 live registers
             // at the point of the sample step where the filter states are live as well)
+#ifdef RW_NO_CF_FENCE
+#define RW_CF_STAGE(j0_, j1_) RW_CF_LOAD(j0_, j1_)
+#else
 #define RW_CF_STAGE(j0_, j1_) SX_SCHED_FENCE(); RW_CF_LOAD(j0_, j1_) SX_SCHED_FENCE();
+#endif
 #endif
             const i32 *Apre = cf + RW_CA, *ARpre = cf + RW_CAR, *Bpre = cf + RW_CB;
             constexpr int G1 = (RW_CAR + 3) / 4, G2 = (RW_CB + 3) / 4;      // 16-byte groups that hold A | the rest of AR | the rest
