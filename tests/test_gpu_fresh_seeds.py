@@ -3,8 +3,8 @@
 so a failure can be replayed with tools/debug/sweep_vs_reference.py / fuzz_decoder_gen.py.  Both tests compare the gfx950 library,
 through its C ABI, with the COMPILED REFERENCE running on the box's host cores (oracle/_ref travels with the snapshot).
 
-  * sweep: 1024 speech-like streams x 20 packets in four configurations (13.6 kbps / joint_mode 1 + useMDIndex / 24 kbps / DTX) and
-    256 un-speech-like `edge_stream`s x 20 packets in the same four: encoder payloads and lengths byte for byte, decoder PCM under
+  * sweep: 1024 speech-like streams x 20 packets in five configurations (13.6 kbps / joint_mode 1 + useMDIndex / 24 kbps / DTX /
+    framesize_ms 20 + useMDIndex) and 256 un-speech-like `edge_stream`s x 20 packets in the same five: encoder payloads and lengths byte for byte, decoder PCM under
     random description loss sample for sample;
   * decoder fuzz: 2000 freshly generated streams (random rate, 16 / 32 kHz mode, description index on / off, both high-band framings,
     speech-like and edge inputs) with corrupted packets (byte errors, bursts, bit flips, lying length records) under random description

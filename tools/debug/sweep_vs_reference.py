@@ -15,10 +15,13 @@ def ref_stream(args):
     seed, P, cfg, recv, edge = args
     from solo_amd.synth import edge_stream
     pcm = edge_stream(seed, P) if edge else R.synth_stream(seed, P)
-    e = R.RefEncoder("fix", rate=cfg["rate"], joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"])
+    fms = cfg.get("framesize", 40)
+    if fms == 20:                                       # the same signal as twice as many half-size packets
+        pcm = pcm.reshape(2 * P, -1)[:P]
+    e = R.RefEncoder("fix", rate=cfg["rate"], joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"], framesize_ms=fms)
     recs = [e.encode(pcm[p]) for p in range(P)]
     e.close()
-    d = R.RefDecoder("fix", joint=cfg["joint"], use_md_index=cfg["mdi"])
+    d = R.RefDecoder("fix", joint=cfg["joint"], use_md_index=cfg["mdi"], framesize_ms=fms)
     out = []
     for (pl, n0, n1), m in zip(recs, recv):
         if n0 <= 0 or m == 0:
@@ -31,7 +34,8 @@ def ref_stream(args):
 
 
 CFGS = [dict(rate=13600, joint=0, dtx=0, mdi=0, loss=0.3), dict(rate=13600, joint=1, dtx=0, mdi=1, loss=0.2),
-        dict(rate=24000, joint=0, dtx=0, mdi=0, loss=0.1), dict(rate=13600, joint=0, dtx=1, mdi=0, loss=0.15)]
+        dict(rate=24000, joint=0, dtx=0, mdi=0, loss=0.1), dict(rate=13600, joint=0, dtx=1, mdi=0, loss=0.15),
+        dict(rate=13600, joint=0, dtx=0, mdi=1, loss=0.2, framesize=20)]
 
 
 def sweep(N, P, seed0, edge=False, cfgs=CFGS, log=print):
@@ -43,9 +47,12 @@ def sweep(N, P, seed0, edge=False, cfgs=CFGS, log=print):
         t0 = time.time()
         s0 = seed0 + ci * 100000
         pcm = edge_batch(s0, N, P) if edge else synth_batch(s0, N, P, workers=16)
+        fms = cfg.get("framesize", 40)
+        if fms == 20:
+            pcm = np.ascontiguousarray(pcm.reshape(N, 2 * P, -1)[:, :P])
         rng = np.random.default_rng(s0)
         recv = ((rng.random((N, P)) >= cfg["loss"]).astype(np.uint8) | ((rng.random((N, P)) >= cfg["loss"]).astype(np.uint8) << 1))
-        b = solo_amd.SoloBatch(N, rate=cfg["rate"], encoder=True, decoder=True, slot_bytes=512, joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"])
+        b = solo_amd.SoloBatch(N, rate=cfg["rate"], encoder=True, decoder=True, slot_bytes=512, joint=cfg["joint"], dtx=cfg["dtx"], use_md_index=cfg["mdi"], framesize_ms=fms)
         bits, nb, st = b.encode(torch.from_numpy(pcm).cuda())
         out, st2 = b.decode(bits, nb, torch.from_numpy(recv).cuda())
         torch.cuda.synchronize()
