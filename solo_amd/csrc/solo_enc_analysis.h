@@ -1331,8 +1331,8 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64 && SX_FS_KHZ == 8
     // (orders <= 15: element k of every vector sits in column k of a 16-lane row; the order-16 analysis of the wide-band build needs
     // 17 correlation entries and takes the LDS form below)
-    // Register-resident recursion: lane (s, k) = (row, column) of the wave.  Column k of EVERY row holds coefficient / correlation
-    // element k (Af, first / last row correlations Cf / Cl, CAf, CAb: the rows are redundant copies), so the per-subframe terms
+    // Register-resident recursion: lane (s, k) = (row, column) of the wave.  Column k of a row holds coefficient / correlation
+    // element k (Af in every row; the correlation rows Cf / Cl in rows 0 - 1, CAf / CAb in rows 2 - 3), so the per-subframe terms
     // reduce inside a row (DPP) and index reversals n-1-k are one lane gather; nothing goes through LDS but the signal.
     i32 nrg, tmp1;
     {
