@@ -157,6 +157,9 @@ SX_HD i32 rwk_pick_(i32 v, i32 idx) { return rwk_or_((i32)(threadIdx.x & 3u) == 
 #define RWT_OR(dst, src) { (dst)[0] = (src)[0] | (src)[1] | (src)[2]; }
 #else
 // ---- a 16-lane row per stream: one (track, state) per lane ----
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(RW_CENTRE_SERIAL)
+#define RW_ROW_C 1                    // the centre's four combinations: one per quad of the row (phase C of the sample step)
+#endif
 #define RWK_GATHER(dst, src, idx) { (dst)[0] = rwk_sel((src)[0], (idx)[0]); }
 #define RWK_PICK(dst, src, idx) RWS_PICK(dst, src, idx)
 #define RWK_PERM(LV, idx) RWS_PERM(LV, idx)
@@ -176,6 +179,9 @@ SX_HD i32 rwt_from2(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW
 #define RWT_OR(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
         (dst)[0] = (v_ | RW_DPP(v_, RW_ROR(4))) | (RW_DPP(v_, RW_ROR(8)) | RW_DPP(v_, RW_ROR(12))); }
 #endif
+#endif
+#ifndef RW_ROW_C
+#define RW_ROW_C 0
 #endif
 
 // One cell of the emission ring: what ONE state slot of ONE track wrote at ONE ring position.  16 bytes, written / prefetched as
@@ -821,12 +827,48 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // phase C: Agora_Silk_CenterRD (NSQ_del_dec.c:1152) in the centre's lanes: the centre takes the best two of the four
             // combinations of side candidates; the side candidates are then re-ordered so that candidate j of every track belongs
             // to combination w_j
+            i32 wpk[RW_NS], ccInc[RW_NS][2], ccQ10[RW_NS][2];
+#if RW_ROW_C
+            // the row's FOUR quads evaluate the four combinations of a state side by side (quad c: combination c; member of MD1
+            // {0,1,0,1}, of MD2 {0,1,1,0}) instead of the centre's lanes evaluating all four: the members' values travel by
+            // bank-masked row shifts (MD1 lives in quad 1, MD2 in quad 2), the four costs come back as keys (cost << 2 | c) by three row
+            // rotations, and every lane of the row finds the two smallest on its own -- which also replaces the broadcast of the
+            // winners.  The costs are sums of three terms that each went through >> 10: |cost| < 2^23, the key cannot overflow; equal
+            // costs order by combination index, which is the reference's "first minimum".
+            {
+                const u32 t4_ = threadIdx.x & 12u;
+                const i32 q0_ = cQ10[0][0], q1_ = cQ10[0][1], r0_ = cInc[0][0], r1_ = cInc[0][1];
+                i32 x1q = q1_, x1r = r1_, x2q = q1_, x2r = r1_;       // (quad 1 / quad 2: the quad's own second candidate)
+                x1q = __builtin_amdgcn_update_dpp(x1q, q0_, RW_SHL(4), 0xf, 0x1, false);  x1r = __builtin_amdgcn_update_dpp(x1r, r0_, RW_SHL(4), 0xf, 0x1, false);
+                x2q = __builtin_amdgcn_update_dpp(x2q, q0_, RW_SHL(8), 0xf, 0x1, false);  x2r = __builtin_amdgcn_update_dpp(x2r, r0_, RW_SHL(8), 0xf, 0x1, false);
+                x1q = __builtin_amdgcn_update_dpp(x1q, q0_, RW_SHR(4), 0xf, 0x4, false);  x1r = __builtin_amdgcn_update_dpp(x1r, r0_, RW_SHR(4), 0xf, 0x4, false);
+                x2q = __builtin_amdgcn_update_dpp(x2q, q1_, RW_SHL(4), 0xf, 0x2, false);  x2r = __builtin_amdgcn_update_dpp(x2r, r1_, RW_SHL(4), 0xf, 0x2, false);
+                x1q = __builtin_amdgcn_update_dpp(x1q, q1_, RW_SHR(8), 0xf, 0x8, false);  x1r = __builtin_amdgcn_update_dpp(x1r, r1_, RW_SHR(8), 0xf, 0x8, false);
+                x2q = __builtin_amdgcn_update_dpp(x2q, q0_, RW_SHR(4), 0xf, 0x8, false);  x2r = __builtin_amdgcn_update_dpp(x2r, r0_, RW_SHR(4), 0xf, 0x8, false);
+                const i32 rc3_ = RW_DPP(rD[0], RW_SHR(12));                              // the centre's residual, for the fourth quad as well
+                const i32 r_temp = sx_sub(t4_ == 12u ? rc3_ : rC[0], offsum);
+                const i32 qx = sx_add(x1q, x2q);
+                const i32 rd_ = sx_add(sx_add(sx_nsq_center_rd1(qx, r_temp, offsum, Lambda_Q10), sx_mul_lambda(x1r)), sx_mul_lambda(x2r));
+                const i32 k0_ = (i32)(((u32)rd_ << 2) | (t4_ >> 2));
+                const i32 ka_ = RW_DPP(k0_, RW_ROR(4)), kb_ = RW_DPP(k0_, RW_ROR(8)), kc_ = RW_DPP(k0_, RW_ROR(12));
+                const i32 lo1 = sx_min(k0_, ka_), hi1 = sx_max(k0_, ka_), lo2 = sx_min(kb_, kc_), hi2 = sx_max(kb_, kc_);
+                const i32 m1 = sx_min(lo1, lo2), m2 = sx_min(sx_max(lo1, lo2), sx_min(hi1, hi2));
+                const u32 w1 = (u32)m1 & 3u, w2 = (u32)m2 & 3u;
+                tS[0] = (i32)(w1 | (w2 << 2));
+                // the centre's lanes: the winners' quantised values from their members (x1q / x2q hold the first candidates there)
+                const i32 p1q1_ = RW_DPP(q1_, RW_SHL(4)), p2q1_ = RW_DPP(q1_, RW_SHL(8));
+                ccInc[0][0] = m1 >> 2;
+                ccInc[0][1] = m2 >> 2;
+                ccQ10[0][0] = sx_add(((0xAu >> w1) & 1u) ? p1q1_ : x1q, ((0x6u >> w1) & 1u) ? p2q1_ : x2q);
+                ccQ10[0][1] = sx_add(((0xAu >> w2) & 1u) ? p1q1_ : x1q, ((0x6u >> w2) & 1u) ? p2q1_ : x2q);
+                (void)wpk;
+            }
+#else
             { i32 a_[RW_NL], b_[RW_NL], c_[RW_NL], d_[RW_NL];
 #pragma unroll
               for (int q_ = 0; q_ < RW_NL; q_++) { a_[q_] = cQ10[q_][0]; b_[q_] = cQ10[q_][1]; c_[q_] = cInc[q_][0]; d_[q_] = cInc[q_][1]; }
               RWT_TO0(p1q0, a_, 1) RWT_TO0(p1q1, b_, 1) RWT_TO0(p1r0, c_, 1) RWT_TO0(p1r1, d_, 1)
               RWT_TO0(p2q0, a_, 2) RWT_TO0(p2q1, b_, 2) RWT_TO0(p2r0, c_, 2) RWT_TO0(p2r1, d_, 2) }
-            i32 wpk[RW_NS], ccInc[RW_NS][2], ccQ10[RW_NS][2];
             RW_FORK(l) {
               if (RW_IS_C(l)) {
                 const int li = RW_LI(l), si = RW_SI(l);
@@ -859,6 +901,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
               }
             }
             RWT_FROM(tS, wpk, 0)
+#endif
             RW_FORK(l) {
                 const int li = RW_LI(l), si = RW_SI(l), t = RW_T(l);
                 // the reference's 12-way memcpy case table (NSQ_del_dec.c:1266-1336) is this selection;
