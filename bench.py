@@ -618,9 +618,12 @@ def main():
                                  "source": insts.get("source"), "from_this_build": prof_ok,
                                  "note": "SQ_INSTS_VALU per packet of each kernel (rocprofv3 --pmc pass) x packets/s of this run, per GPU; "
                                          "peak = 1024 SIMD-32 x 2.4 GHz / 2 cycles per wave64 VALU instruction (nominal).  Measured on gfx950 "
-                                         "(tools/debug/mb_valu.hip, profiles/r04_valu_microbench.txt): a SIMD retires one integer multiply / select / DPP / 3-operand "
-                                         "instruction per 2.36 cycles and one add / logic instruction per 1.33 at 8 waves; a single wave issues an independent instruction "
-                                         "every 4.8 cycles and a dependent one every 8.3"}
+                                         "(tools/debug/mb_mix.hip, profiles/r05_issue_model.txt; round 4: mb_valu.hip, r04_valu_microbench.txt): a SIMD retires one "
+                                         "add / sub / logic / arithmetic-shift instruction with register operands per 1.1 - 1.2 ns and one multiply / left shift / "
+                                         "min / max / select / DPP / 3-operand / SGPR-operand instruction per 1.8 - 1.9 ns (a v_mul_hi + v_add pair 3.0, v_mad_i64_i32 2.1); "
+                                         "scalar and LDS instructions of OTHER waves overlap with them (a type mix costs ~ the maximum, not the sum); one wave issues "
+                                         "a dependent instruction every 3.6 - 4.0 ns, two waves interleave perfectly, four saturate the unit.  The encoder pipeline "
+                                         "holds 5 waves per SIMD (registers and LDS full) and keeps the vector unit ~65 % busy: time follows the instruction count"}
         if world == 1 and not args.no_cpu_baseline:
             cb = cpu_baseline(args.cpu_seconds, args.cpu_packets_per_stream)
             if cb and cb.get("per_core_packets_per_s"):

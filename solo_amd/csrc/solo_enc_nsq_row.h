@@ -856,11 +856,18 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
                 const u32 w1 = (u32)m1 & 3u, w2 = (u32)m2 & 3u;
                 tS[0] = (i32)(w1 | (w2 << 2));
                 // the centre's lanes: the winners' quantised values from their members (x1q / x2q hold the first candidates there)
-                const i32 p1q1_ = RW_DPP(q1_, RW_SHL(4)), p2q1_ = RW_DPP(q1_, RW_SHL(8));
                 ccInc[0][0] = m1 >> 2;
                 ccInc[0][1] = m2 >> 2;
+#ifdef RW_CQ_SELECT
+                const i32 p1q1_ = RW_DPP(q1_, RW_SHL(4)), p2q1_ = RW_DPP(q1_, RW_SHL(8));
                 ccQ10[0][0] = sx_add(((0xAu >> w1) & 1u) ? p1q1_ : x1q, ((0x6u >> w1) & 1u) ? p2q1_ : x2q);
                 ccQ10[0][1] = sx_add(((0xAu >> w2) & 1u) ? p1q1_ : x1q, ((0x6u >> w2) & 1u) ? p2q1_ : x2q);
+#else
+                // (the winners' sums wait in the quads that evaluated them: one crossbar read each)
+                const u32 lb_ = (threadIdx.x & 0x33u) << 2;
+                ccQ10[0][0] = __builtin_amdgcn_ds_bpermute((int)((w1 << 4) | lb_), qx);
+                ccQ10[0][1] = __builtin_amdgcn_ds_bpermute((int)((w2 << 4) | lb_), qx);
+#endif
                 (void)wpk;
             }
 #else
