@@ -64,6 +64,13 @@ hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* 
 #ifdef SOLO_WITH_ENCODER
 #include "solo_enc_ops.h"
 extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq_row.hip
+#ifdef SX_EXPERIMENTS
+// (timing experiments only) one wavefront that waits `ticks` of the 100 MHz counter
+__global__ void __launch_bounds__(64) solo_exp_delay_kernel(int ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
+}
+#endif
 extern "C" const solo_enc_ops* solo_nb_enc_ops();                                                      // solo_enc_k.hip
 extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_enc_k_wb.hip
 #endif
@@ -102,7 +109,10 @@ struct solo_batch {
     // encoder pipeline: the packets of a call go through analysis -> quantiser -> coding in chunks on three streams
     int achunk;                      // analysis launches cover achunk chunks (env SOLO_ENC_ACHUNK, default 1)
     int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
-    hipStream_t sA, sB, sC;
+    hipStream_t sA, sB, sC, sD;      // (sD: the range coder's own stream, SOLO_ENC_RC_STREAM=1)
+    int rc_split;
+    int c_order;                     // third stage (SOLO_ENC_CORDER): 1 = high band, range coder + assembly (default); 0 = range coder, high band + assembly; 2 = high band, range coder, assembly kernel
+    hipEvent_t evR[SOLO_MAX_CHUNKS];
     hipEvent_t evFork, evJoinA[2], evJoinC[2], evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS], evC[SOLO_MAX_CHUNKS];
     int async_join;                  // solo_batch_set_async_join: encode returns without joining its streams into the caller's
     unsigned int enc_seq;            // encode calls so far (selects the join-event set)
@@ -321,6 +331,7 @@ void solo_batch_destroy(solo_batch_t* b) {
     if (b->pipe_ready) {
         (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC);
         (void)hipStreamDestroy(b->sA); (void)hipStreamDestroy(b->sB); (void)hipStreamDestroy(b->sC);
+        if (b->rc_split) { (void)hipStreamSynchronize(b->sD); (void)hipStreamDestroy(b->sD); for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evR[c]); }
         if (b->d_started) (void)hipFree(b->d_started);
         (void)hipEventDestroy(b->evFork);
         for (int i = 0; i < 2; i++) { (void)hipEventDestroy(b->evJoinA[i]); (void)hipEventDestroy(b->evJoinC[i]); }
@@ -519,7 +530,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
-        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); }
+        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); if (b->rc_split) (void)hipStreamSynchronize(b->sD); }
         if (b->d_enc_work) (void)hipFree(b->d_enc_work);
         b->d_enc_work = NULL;
         SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));
@@ -559,7 +570,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         } else {
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sA, hipStreamNonBlocking, lo));
         SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
-        SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, lo));
+        {   // SOLO_ENC_CPRIO=1: the third stage's stream at the quantiser's priority (its workgroups are short: first in line when slots come free)
+            const char* ep = getenv("SOLO_ENC_CPRIO");
+            SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, (ep && atoi(ep) > 0) ? hi : lo));
+        }
         }
         SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
         for (int i = 0; i < 2; i++) {
@@ -575,6 +589,14 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         b->chunk_packets = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_ACHUNK");
         b->achunk = (e && atoi(e) > 0) ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_CORDER");
+        b->c_order = e ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_RC_STREAM");
+        b->rc_split = (e && atoi(e) > 0 && cu_mod <= 1) ? atoi(e) : 0;      // (1: the coder after its chunk's high band; 2: beside it)
+        if (b->rc_split) {
+            SOLO_CHECK(hipStreamCreateWithPriority(&b->sD, hipStreamNonBlocking, lo));
+            for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evR[c], hipEventDisableTiming));
+        }
         e = getenv("SOLO_ENC_GATE");
         // residency gate (hold analysis chunk c + 1 until the quantiser launch of chunk c is resident): needed when the quantiser
         // was 1024 workgroups that had to find room between 4096 analysis workgroups; with 256 quantiser workgroups it costs 3 %
@@ -596,9 +618,10 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
     {   // scratch of one coding launch: the byte buffers of its descriptions
         const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
-        const size_t need = ops->rc_scratch_bytes(gs, cp);
+        const size_t need = ops->rc_scratch_bytes(gs, cp) * (b->rc_split ? 2 : 1);
         if (need > b->rc_scratch_bytes) {
             if (b->d_rc_scratch) {
+                if (b->rc_split) SOLO_CHECK(hipStreamSynchronize(b->sD));
                 SOLO_CHECK(hipStreamSynchronize(b->sC));             // (a coding launch of the previous call may still read the old one)
                 (void)hipFree(b->d_rc_scratch);
                 b->d_rc_scratch = NULL;
@@ -620,6 +643,13 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
+    if (b->rc_split) {
+        SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evFork, 0));
+        if (b->enc_seq > 0) {                    // (the previous call's assembly has read both scratch halves)
+            SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
+            SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
+        }
+    }
     // Streams beyond 8192 (SOLO_ENC_GROUP) are processed group after group; all per-stream arrays are stream-major, so a group is the
     // same launch on offset pointers.  (Round 1 measured groups of 4096 as the fastest shape; since the analysis kernel's workgroups
     // all fit beside the quantiser's -- round 3 -- 8192 streams in one group are 11 % faster than two groups of 4096.)
@@ -658,7 +688,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             } else if (tm) { (void)hipEventRecord(b->tev[0][c][0], b->sA); (void)hipEventRecord(b->tev[0][c][1], b->sA); }
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[a_slot], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-#ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding -- wrong output
+#ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding, bit 2 = no range coder -- wrong output
             static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;
 #else
             constexpr int exp_skip = 0;
@@ -671,8 +701,31 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
             SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
             if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-            if (!(exp_skip & 2))
-            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
+            if (!(exp_skip & 2)) {
+            if (b->rc_split) {
+                // SOLO_ENC_RC_STREAM=1: the high band of this chunk on sC, its range coder and the payload assembly on sD; the three of a chunk share
+                // one half of the scratch, which the high band of chunk c + 2 may only overwrite after this chunk's assembly
+                void* half = (char*)b->d_rc_scratch + (size_t)(idx & 1) * (b->rc_scratch_bytes / 2);
+                if (idx >= 2) SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evC[(idx - 2) % SOLO_MAX_CHUNKS], 0));
+                if ((lerr = ops->hb(g_states, g_cin, g_nout, ns, n_packets, p0, pc, half, b->sC)) != hipSuccess) goto launch_failed;
+                SOLO_CHECK(hipEventRecord(b->evR[c], b->sC));
+                // (the coder's 128 large workgroups start when the high band's 4096 are through: side by side they get in each other's way)
+                if (b->rc_split == 1) SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evR[c], 0));
+                else SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evB[c], 0));
+                if ((lerr = ops->rc(g_states, g_cin, g_nout, ns, n_packets, p0, pc, half, b->sD)) != hipSuccess) goto launch_failed;
+                if (b->rc_split != 1) SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evR[c], 0));
+                if ((lerr = ops->out(g_states, g_cin, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, half, b->sD)) != hipSuccess) goto launch_failed;
+                if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sD);
+                SOLO_CHECK(hipEventRecord(b->evC[c], b->sD));
+                continue;
+            } else if (exp_skip & 4) {      // (experiment: no range coder, the coding kernel assembles whatever the scratch holds; bit 3: a one-wave delay of 0.37 ms in its place)
+#ifdef SX_EXPERIMENTS
+                if (exp_skip & 8) hipLaunchKernelGGL(solo_exp_delay_kernel, dim3(1), dim3(64), 0, b->sC, 37000);
+#endif
+                if ((lerr = ops->hb_out(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
+            } else
+            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->c_order, b->sC)) != hipSuccess) goto launch_failed;
+            }
             if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
             SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
         }
@@ -686,18 +739,19 @@ launch_failed:
         b->evC_valid = 0;
         b->last_chunks = 0;
         (void)hipEventRecord(b->evJoinA[jf], b->sA);
-        (void)hipEventRecord(b->evJoinC[jf], b->sC);
+        (void)hipEventRecord(b->evJoinC[jf], b->rc_split ? b->sD : b->sC);
         (void)hipStreamWaitEvent(st, b->evJoinA[jf], 0);
         (void)hipStreamWaitEvent(st, b->evJoinC[jf], 0);
         (void)hipEventRecord(b->evFork, b->sB);
         (void)hipStreamWaitEvent(st, b->evFork, 0);
+        if (b->rc_split) (void)hipStreamSynchronize(b->sD);
         return -(int32_t)lerr;
     }
     b->evC_valid = ngroups == 1 ? nchunks : 0;       // chunk-wise hand-over guards only for single-group calls
     const int js = (int)(b->enc_seq & 1u);
     b->enc_seq++;
     SOLO_CHECK(hipEventRecord(b->evJoinA[js], b->sA));
-    SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->sC));
+    SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->rc_split ? b->sD : b->sC));      // (sD's last launch waits for sC's)
     if (!b->async_join) {
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA[js], 0));
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC[js], 0));

@@ -28,16 +28,18 @@ struct SxFrameIdx {
 // The entropy coder is a serial chain per description, so the GPU runs it lane-per-description: 64 descriptions (32 streams)
 // per wavefront, every lane with its own staged pulses and pulse work area in LDS.  The rows are an ODD number of dwords long
 // so that the 64 lanes, which mostly sit at the same offset of their own row, hit different LDS banks.
-#define SX_RC_Q_ROW (2 * SX_FRAME + 4)                          // staged pulses of both frames (+ pad: 81 dwords at 8 kHz)
-#define SX_RC_PW_ROW (SX_FRAME + 2 * (SX_FRAME / 16) + 8 - ((SX_FRAME + 2 * (SX_FRAME / 16)) & 7) + 4)   // |pulse|, block sums, block shifts
-static_assert(((SX_RC_Q_ROW / 4) & 1) == 1 && ((SX_RC_PW_ROW / 4) & 1) == 1 && SX_RC_Q_ROW % 4 == 0 && SX_RC_PW_ROW % 4 == 0, "odd dword rows");
+// work row of one description's pulse coder: |pulse| of the frame, block sums, block shifts (padded to a multiple of 8), the sign mask (one bit per
+// sample); an odd number of dwords per row (LDS banks of neighbouring lanes)
+#define SX_RC_PW_SIGNS (SX_FRAME + 2 * (SX_FRAME / 16) + 8 - ((SX_FRAME + 2 * (SX_FRAME / 16)) & 7))
+#define SX_RC_PW_ROW (SX_RC_PW_SIGNS + SX_FRAME / 8 + (((SX_RC_PW_SIGNS + SX_FRAME / 8) / 4) & 1 ? 0 : 4))
+static_assert(((SX_RC_PW_ROW / 4) & 1) == 1 && SX_RC_PW_ROW % 4 == 0, "odd dword rows");
 #define SX_RC_BUF_STRIDE (SX_MAX_ARITHM_BYTES + 16)             // HBM: byte buffer of one description
 struct SxRcInfo { i32 nBytes, error; };                        // HBM: what the coder of one description reports
 
 struct SxCodeWork {                  // host emulation of the coding kernels: both descriptions one after the other
 #if SX_NLANES == 1
     u8 buf[2][SX_RC_BUF_STRIDE];
-    u8 pulses[SX_RC_PW_ROW];
+    alignas(4) u8 pulses[SX_RC_PW_ROW];
     SxCdf cdf;
 #else
     i32 unused_;
@@ -93,9 +95,10 @@ SX_HD void sx_enc_split(SxRangeEnc* rc, int p_child1, int p, const u16* shell_ta
 }
 
 // SKP_Silk_shell_encoder, SKP_Silk_shell_coder.c:84
-SX_HD void sx_shell_encoder(SxRangeEnc* rc, const u8* p0, const SxCdf* cdf) {
-    i32 p1[8], p2[4], p3[2], p4;
-    for (int k = 0; k < 8; k++) p1[k] = (i32)p0[2 * k] + (i32)p0[2 * k + 1];
+SX_HD void sx_shell_encoder(SxRangeEnc* rc, const u8* pa, int sh, const SxCdf* cdf) {      // pa: the block's magnitudes, coded after >> sh
+    i32 p0[16], p1[8], p2[4], p3[2], p4;
+    for (int k = 0; k < 16; k++) p0[k] = (i32)pa[k] >> sh;
+    for (int k = 0; k < 8; k++) p1[k] = p0[2 * k] + p0[2 * k + 1];
     for (int k = 0; k < 4; k++) p2[k] = p1[2 * k] + p1[2 * k + 1];
     for (int k = 0; k < 2; k++) p3[k] = p2[2 * k] + p2[2 * k + 1];
     p4 = p3[0] + p3[1];
@@ -112,16 +115,37 @@ SX_HD void sx_shell_encoder(SxRangeEnc* rc, const u8* p0, const SxCdf* cdf) {
 }
 
 // SKP_Silk_encode_pulses + SKP_Silk_encode_signs, SKP_Silk_encode_pulses.c:55, SKP_Silk_code_signs.c:40
-// pw: SX_FRAME + 2 * (SX_FRAME / 16) bytes of work space (|pulse| <= 128 and the final block sums / shifts fit a byte; a block
-// sum that overflows one is followed by another pass over the block, which overwrites it)
+// q: the frame's pulses where the quantiser left them (4-byte aligned row; HBM on the GPU -- read once, four samples a load).
+// pw: SX_RC_PW_ROW bytes of work space (LDS on the GPU; 4-byte aligned): the UNSHIFTED magnitudes (|pulse| <= 128), the final block
+// sums / shifts (they fit a byte), the signs as a bit mask behind them.  A block's magnitudes are shifted where they are used (the
+// reference shifts its copy in place and goes back to the pulses for the bits it dropped), so the pulses need no row of their own.
 SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, const i8* q, const SxCdf* cdf, u8* pw) {
-    SX_IN_LDS(cdf); SX_IN_LDS(pw); SX_IN_LDS(q);
+    SX_IN_LDS(cdf); SX_IN_LDS(pw);
     const int iter = SX_FRAME / 16;
+#if defined(__HIP_DEVICE_COMPILE__)
+    pw = (u8*)__builtin_assume_aligned(pw, 4);                 // (rows of dwords: SxRcWork::pw, SxNsqOut::q)
+    q = (const i8*)__builtin_assume_aligned(q, 4);
+#endif
     u8 *abs_pulses = pw, *sum_pulses = pw + SX_FRAME, *nRshifts = pw + SX_FRAME + SX_FRAME / 16;
     const i32 maxp0 = T_max_pulses[0], maxp1 = T_max_pulses[1], maxp2 = T_max_pulses[2], maxp3 = T_max_pulses[3];
-    for (int i = 0; i < SX_FRAME; i++) abs_pulses[i] = (u8)(q[i] < 0 ? -(i32)q[i] : (i32)q[i]);
+    static_assert(SX_FRAME % 32 == 0 && SX_RC_PW_SIGNS % 4 == 0, "sign mask words");
+    u32* neg = (u32*)(void*)(pw + SX_RC_PW_SIGNS);
+    for (int w_ = 0; w_ < SX_FRAME / 32; w_++) {
+        u32 m = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            u32 v;
+            __builtin_memcpy(&v, q + 32 * w_ + 4 * j, 4);
+            const u32 sb = (v >> 7) & 0x01010101u;                      // 1 in the bytes that are negative
+            // per byte: negative ? -b : b = (b ^ 0xFF) + 1; a negative byte is not 0, so the + 1 never carries into its neighbour
+            const u32 a = (v ^ (sb * 0xFFu)) + sb;
+            __builtin_memcpy(abs_pulses + 32 * w_ + 4 * j, &a, 4);
+            m |= ((sb & 1u) | ((sb >> 7) & 2u) | ((sb >> 14) & 4u) | ((sb >> 21) & 8u)) << (4 * j);
+        }
+        neg[w_] = m;
+    }
     for (int i = 0; i < iter; i++) {
-        u8* ap = &abs_pulses[i * 16];
+        const u8* ap = &abs_pulses[i * 16];
         int nrs = 0;
         for (;;) {
             // combine_and_check: 1+1 (max 3), 2+2 (max 6), 4+4 (max 8), 8+8 (max 12); the reference aborts each level at
@@ -130,7 +154,7 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
             i32 c1[8], c2[4], c3[2];
             int scale_down = 0, bad;
             bad = 0;
-            for (int k = 0; k < 8; k++) { c1[k] = (i32)ap[2 * k] + (i32)ap[2 * k + 1]; bad |= c1[k] > maxp0; }
+            for (int k = 0; k < 8; k++) { c1[k] = ((i32)ap[2 * k] >> nrs) + ((i32)ap[2 * k + 1] >> nrs); bad |= c1[k] > maxp0; }
             scale_down += bad;
             bad = 0;
             for (int k = 0; k < 4; k++) { c2[k] = c1[2 * k] + c1[2 * k + 1]; bad |= c2[k] > maxp1; }
@@ -142,7 +166,6 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
             if (sum > maxp3) scale_down++;
             if (!scale_down) { sum_pulses[i] = (u8)sum; break; }
             nrs++;
-            for (int k = 0; k < 16; k++) ap[k] >>= 1;
         }
         nRshifts[i] = (u8)nrs;
     }
@@ -166,7 +189,7 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
         }
     }
     for (int i = 0; i < iter; i++)
-        if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16], cdf);
+        if (sum_pulses[i] > 0) sx_shell_encoder(rc, &abs_pulses[i * 16], nRshifts[i], cdf);
     // least significant bits of the blocks that were scaled down.  Few blocks are (at these rates), but some lane of a wavefront
     // nearly always has one: every lane walks ITS OWN list of (block, sample, bit) symbols, so the wavefront's trip count is the
     // longest list of a lane and not the union of the blocks
@@ -176,8 +199,7 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
         while (i < iter && nRshifts[i] == 0) i++;
         int k = 0, j = i < iter ? (int)nRshifts[i] - 1 : 0;
         while (i < iter) {
-            const i8 v = q[i * 16 + k];
-            const i32 abs_q = (i8)(v < 0 ? -v : v);
+            const i32 abs_q = abs_pulses[i * 16 + k];
             sx_rc_enc_bin(rc, (abs_q >> j) & 1, p_lsb);
             if (--j < 0) {
                 if (++k == 16) {
@@ -189,17 +211,19 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
         }
     }
     const u32 p_sign = cdf->cdf_sign[sx_smulbb(10 - 1, (sigtype << 1) + QuantOffsetType) + RateLevelIndex];
-    for (int i = 0; i < SX_FRAME; i++) {
-        const i32 v = q[i];
-        if (v != 0) sx_rc_enc_bin(rc, (v >> 15) + 1, p_sign);
+    for (int w_ = 0; w_ < SX_FRAME / 32; w_++) {
+        const u32 m = neg[w_];
+        for (int b_ = 0; b_ < 32; b_++)
+            if (abs_pulses[32 * w_ + b_] != 0) sx_rc_enc_bin(rc, (i32)(((m >> b_) & 1u) ^ 1u), p_sign);
     }
 }
+
 
 // SKP_Silk_encode_parameters, SKP_Silk_encode_parameters.c:33 (md_type = 1 description `md`).  x: the frame's indices (HBM record;
 // read once into registers)
 SX_HD void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* xp, int Seed, int frame, int md, int writeMDIndex, int typeOffsetPrev, const i8* q,
                                 const SxCdf* cdf, u8* pw) {
-    SX_IN_LDS(cdf); SX_IN_LDS(q);
+    SX_IN_LDS(cdf);
     const SxFrameIdx xv = *xp;
     const SxFrameIdx* x = &xv;
     if (frame == 0) {
@@ -241,16 +265,17 @@ SX_HD void sx_encode_parameters(SxRangeEnc* rc, const SxFrameIdx* xp, int Seed, 
 
 // The range coder of ONE description of one packet: both frames' parameters and pulses -> `buf` (SX_RC_BUF_STRIDE bytes of HBM).
 // idx2: the two frames' indices (hand-over record of the analysis), Seed0 / Seed1: the dither seeds the quantiser chose,
-// q2: the description's pulses of frame 0 then frame 1 (LDS row).  Reports the byte count and the coder's error flag.
-SX_HD void sx_code_description(const SxFrameIdx* idx2, int Seed0, int Seed1, const i8* q2, int md, int writeMDIndex, const SxCdf* cdf, u8* pw,
+// q0 / q1: the description's pulses of frame 0 / frame 1 where the quantiser left them (SxNsqOut::q rows).  Reports the byte count and the
+// coder's error flag.
+SX_HD void sx_code_description(const SxFrameIdx* idx2, int Seed0, int Seed1, const i8* q0, const i8* q1, int md, int writeMDIndex, const SxCdf* cdf, u8* pw,
                                u8* buf, SxRcInfo* info, int fpp = 2) {
     SxRangeEnc rc;
     sx_rc_enc_init(&rc, buf);
     const int prev = 2 * idx2[0].sigtype + idx2[0].QuantOffsetType;
-    sx_encode_parameters(&rc, &idx2[0], Seed0, 0, md, writeMDIndex, 0, q2, cdf, pw);
+    sx_encode_parameters(&rc, &idx2[0], Seed0, 0, md, writeMDIndex, 0, q0, cdf, pw);
     if (fpp > 1) {
         sx_rc_enc(&rc, 1, cdf->cdf_frame_term);                  // SKP_SILK_MORE_FRAMES = 1
-        sx_encode_parameters(&rc, &idx2[1], Seed1, 1, md, writeMDIndex, prev, q2 + SX_FRAME, cdf, pw);
+        sx_encode_parameters(&rc, &idx2[1], Seed1, 1, md, writeMDIndex, prev, q1, cdf, pw);
     }
     sx_rc_enc(&rc, 0, cdf->cdf_frame_term);                      // SKP_SILK_LAST_FRAME = 0
     i32 nb;
@@ -606,12 +631,9 @@ SX_FN i32 sx_enc_stage_c(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, co
     const int fpp = w->st.fpp;
     if (!sx_enc_packet_in_dtx(w->st.useDTX, cin, fpp)) {
         sx_cdf_load(&w->u.code.cdf);
-        i8 q2[2 * SX_FRAME];
-        for (int md = 0; md < 2; md++) {
-            for (int i = 0; i < fpp * SX_FRAME; i++) q2[i] = out2[i / SX_FRAME].q[md][i % SX_FRAME];
-            sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, q2, md, w->st.useMDIndex, &w->u.code.cdf, w->u.code.pulses, w->u.code.buf[md],
-                                &info[md], fpp);
-        }
+        for (int md = 0; md < 2; md++)
+            sx_code_description(cin->idx, out2[0].Seed, out2[1].Seed, out2[0].q[md], out2[1].q[md], md, w->st.useMDIndex, &w->u.code.cdf, w->u.code.pulses,
+                                w->u.code.buf[md], &info[md], fpp);
     }
     return sx_enc_stage_c_out(w, cin, w->u.code.buf[0], w->u.code.buf[1], info, bits, buf_size, nBytesOut);
 }

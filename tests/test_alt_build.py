@@ -61,10 +61,12 @@ def test_decoder_suite_with_small_decode_chunks():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{"SOLO_ENC_ACHUNK": "2"}, {"SOLO_ENC_CHUNK": "2"}, {"SOLO_ENC_CHUNK": "0"}, {"SOLO_ENC_GATE": "1"},
-                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}, {"SOLO_ENC_CORDER": "0"}, {"SOLO_ENC_CORDER": "2"}, {"SOLO_ENC_RC_STREAM": "1"},
+                                   {"SOLO_ENC_RC_STREAM": "1", "SOLO_ENC_CHUNK": "2", "SOLO_ENC_GROUP": "4"}], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_encoder_suite_under_the_pipeline_knobs(knobs):
     """The encoder's pipeline has run-time knobs that change how a call is cut into launches (chunks of several packets, one analysis
-    launch over several chunks, no pipeline at all, the residency gate, small launch groups) but must never change a bit of the
+    launch over several chunks, no pipeline at all, the residency gate, small launch groups, the order of the third stage's launches,
+    the range coder on a stream of its own) but must never change a bit of the
     output: the encoder parity tests (goldens, packet-wise vs batched calls, joint mode, DTX, both rates) once more under each."""
     env = dict(os.environ, **knobs)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
