@@ -594,7 +594,9 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         e = getenv("SOLO_ENC_RC_STREAM");
         b->rc_split = (e && atoi(e) > 0 && cu_mod <= 1) ? atoi(e) : 0;      // (1: the coder after its chunk's high band; 2: beside it)
         if (b->rc_split) {
-            SOLO_CHECK(hipStreamCreateWithPriority(&b->sD, hipStreamNonBlocking, lo));
+            const char* ed = getenv("SOLO_ENC_DPRIO");          // (experiment: 0 = lowest, 1 = middle, 2 = the quantiser's)
+            const int dp = ed ? atoi(ed) : 0;
+            SOLO_CHECK(hipStreamCreateWithPriority(&b->sD, hipStreamNonBlocking, dp == 2 ? hi : (dp == 1 ? (lo + hi) / 2 : lo)));
             for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evR[c], hipEventDisableTiming));
         }
         e = getenv("SOLO_ENC_GATE");
