@@ -64,13 +64,11 @@ hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* 
 #ifdef SOLO_WITH_ENCODER
 #include "solo_enc_ops.h"
 extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq_row.hip
-#ifdef SX_EXPERIMENTS
-// (timing experiments only) one wavefront that waits `ticks` of the 100 MHz counter
+// one wavefront that waits `ticks` of the 100 MHz counter (timing experiments; the stagger of SOLO_ENC_ASPLIT)
 __global__ void __launch_bounds__(64) solo_exp_delay_kernel(int ticks) {
     const unsigned long long t0 = wall_clock64();
     while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
 }
-#endif
 extern "C" const solo_enc_ops* solo_nb_enc_ops();                                                      // solo_enc_k.hip
 extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_enc_k_wb.hip
 #endif
@@ -110,6 +108,9 @@ struct solo_batch {
     int achunk;                      // analysis launches cover achunk chunks (env SOLO_ENC_ACHUNK, default 1)
     int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
     hipStream_t sA, sB, sC, sD;      // (sD: the range coder's own stream, SOLO_ENC_RC_STREAM=1)
+    hipStream_t sA2;                 // SOLO_ENC_ASPLIT=1: the analysis of the second half of the streams, as launches of its own
+    hipEvent_t evA2[SOLO_MAX_CHUNKS];
+    int a_split, a_stagger;
     int rc_split;
     int c_order;                     // third stage (SOLO_ENC_CORDER): 1 = high band, range coder + assembly (default); 0 = range coder, high band + assembly; 2 = high band, range coder, assembly kernel
     hipEvent_t evR[SOLO_MAX_CHUNKS];
@@ -331,6 +332,7 @@ void solo_batch_destroy(solo_batch_t* b) {
     if (b->pipe_ready) {
         (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC);
         (void)hipStreamDestroy(b->sA); (void)hipStreamDestroy(b->sB); (void)hipStreamDestroy(b->sC);
+        if (b->a_split) { (void)hipStreamSynchronize(b->sA2); (void)hipStreamDestroy(b->sA2); for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evA2[c]); }
         if (b->rc_split) { (void)hipStreamSynchronize(b->sD); (void)hipStreamDestroy(b->sD); for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evR[c]); }
         if (b->d_started) (void)hipFree(b->d_started);
         (void)hipEventDestroy(b->evFork);
@@ -530,7 +532,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
-        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); if (b->rc_split) (void)hipStreamSynchronize(b->sD); }
+        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); if (b->rc_split) (void)hipStreamSynchronize(b->sD); if (b->a_split) (void)hipStreamSynchronize(b->sA2); }
         if (b->d_enc_work) (void)hipFree(b->d_enc_work);
         b->d_enc_work = NULL;
         SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));
@@ -589,6 +591,14 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         b->chunk_packets = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_ACHUNK");
         b->achunk = (e && atoi(e) > 0) ? atoi(e) : 1;
+        e = getenv("SOLO_ENC_ASPLIT");
+        b->a_split = (e && atoi(e) > 0 && cu_mod <= 1) ? 1 : 0;
+        e = getenv("SOLO_ENC_ASTAGGER_US");
+        b->a_stagger = e ? atoi(e) : 0;
+        if (b->a_split) {
+            SOLO_CHECK(hipStreamCreateWithPriority(&b->sA2, hipStreamNonBlocking, (getenv("SOLO_ENC_A2PRIO") && atoi(getenv("SOLO_ENC_A2PRIO")) > 0) ? hi : lo));
+            for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evA2[c], hipEventDisableTiming));
+        }
         e = getenv("SOLO_ENC_CORDER");
         b->c_order = e ? atoi(e) : 1;
         e = getenv("SOLO_ENC_RC_STREAM");
@@ -637,12 +647,17 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp || b->evC_valid == 0)) {
         // the previous call laid its hand-over records out differently: no chunk-wise reuse, wait for all of its coding
         SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
+        if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
         b->evC_valid = 0;
     }
     b->last_np = n_packets;
     b->last_cp = cp;
     SOLO_CHECK(hipEventRecord(b->evFork, st));
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
+    if (b->a_split) {
+        SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evFork, 0));
+        if (b->a_stagger > 0) hipLaunchKernelGGL(solo_exp_delay_kernel, dim3(1), dim3(64), 0, b->sA2, b->a_stagger * 100);
+    }
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
     if (b->rc_split) {
@@ -659,6 +674,7 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     const int ngroups = (b->n_streams + G - 1) / G;
     const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
     int idx = 0, a_slot = 0;
+    bool a_split_now = false;
     hipError_t lerr = hipSuccess;
     for (int g = 0; g < ngroups; g++) {
         const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
@@ -674,21 +690,38 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         for (int cc = 0; cc < nchunks; cc++, idx++) {
             const int c = idx % SOLO_MAX_CHUNKS, cprev = (idx + SOLO_MAX_CHUNKS - 1) % SOLO_MAX_CHUNKS;     // event / counter slot
             const int p0 = cc * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
-            if (ngroups == 1 && cc < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));   // (previous call: its coding of this chunk's records is done)
+            if (ngroups == 1 && cc < b->evC_valid) {      // (previous call: its coding of this chunk's records is done)
+                SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));
+                if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evC[c], 0));
+            }
             if (idx > 0 && b->gate) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
             // SOLO_ENC_ACHUNK = a > 1: one analysis launch covers a chunks (the stream state is loaded and stored once per launch);
             // the quantiser / coding launches of those chunks stay chunk-wise and wait for that one launch
             if (cc % b->achunk == 0) {
-                if (ngroups == 1) for (int q = 1; q < b->achunk && cc + q < nchunks && cc + q < b->evC_valid; q++)
+                if (ngroups == 1) for (int q = 1; q < b->achunk && cc + q < nchunks && cc + q < b->evC_valid; q++) {
                     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[(idx + q) % SOLO_MAX_CHUNKS], 0));
+                    if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evC[(idx + q) % SOLO_MAX_CHUNKS], 0));
+                }
                 const int pa = (p0 + b->achunk * cp <= n_packets) ? b->achunk * cp : n_packets - p0;
+                // SOLO_ENC_ASPLIT=1: the two halves of the streams as launches of their own on two streams (each half's launches in order): the
+                // halves take their turns at different times, so the slots a turn frees come in two smaller portions per chunk
+                const int nh = (b->a_split && ns >= 128) ? ((ns / 2 + 63) & ~63) : ns;
                 if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-                if ((lerr = ops->analysis(g_states, g_pcm, ns, n_packets, p0, pa, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
+                if ((lerr = ops->analysis(g_states, g_pcm, nh, n_packets, p0, pa, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
                 if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
                 SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
+                if (nh < ns) {
+                    const size_t hk = (size_t)nh * (size_t)n_packets;
+                    if ((lerr = ops->analysis((char*)g_states + (size_t)nh * ops->state_bytes,
+                                              g_pcm + hk * (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples), ns - nh, n_packets, p0, pa,
+                                              (char*)g_nin + hk * 2 * ops->nsq_in_bytes, (char*)g_cin + hk * ops->code_in_bytes, b->sA2)) != hipSuccess) goto launch_failed;
+                    SOLO_CHECK(hipEventRecord(b->evA2[c], b->sA2));
+                }
+                a_split_now = nh < ns;
                 a_slot = c;
             } else if (tm) { (void)hipEventRecord(b->tev[0][c][0], b->sA); (void)hipEventRecord(b->tev[0][c][1], b->sA); }
             SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[a_slot], 0));
+            if (a_split_now) SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA2[a_slot], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
 #ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding, bit 2 = no range coder -- wrong output
             static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;
@@ -740,6 +773,7 @@ launch_failed:
         b->enc_seq++;
         b->evC_valid = 0;
         b->last_chunks = 0;
+        if (b->a_split) { (void)hipEventRecord(b->evA2[0], b->sA2); (void)hipStreamWaitEvent(b->sA, b->evA2[0], 0); }
         (void)hipEventRecord(b->evJoinA[jf], b->sA);
         (void)hipEventRecord(b->evJoinC[jf], b->rc_split ? b->sD : b->sC);
         (void)hipStreamWaitEvent(st, b->evJoinA[jf], 0);
@@ -752,6 +786,7 @@ launch_failed:
     b->evC_valid = ngroups == 1 ? nchunks : 0;       // chunk-wise hand-over guards only for single-group calls
     const int js = (int)(b->enc_seq & 1u);
     b->enc_seq++;
+    if (b->a_split) { SOLO_CHECK(hipEventRecord(b->evA2[0], b->sA2)); SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evA2[0], 0)); }      // (sA joins for both)
     SOLO_CHECK(hipEventRecord(b->evJoinA[js], b->sA));
     SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->rc_split ? b->sD : b->sC));      // (sD's last launch waits for sC's)
     if (!b->async_join) {

@@ -61,7 +61,7 @@ def test_decoder_suite_with_small_decode_chunks():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("knobs", [{"SOLO_ENC_ACHUNK": "2"}, {"SOLO_ENC_CHUNK": "2"}, {"SOLO_ENC_CHUNK": "0"}, {"SOLO_ENC_GATE": "1"},
-                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}, {"SOLO_ENC_CORDER": "0"}, {"SOLO_ENC_CORDER": "2"}, {"SOLO_ENC_RC_STREAM": "1"},
+                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}, {"SOLO_ENC_CORDER": "0"}, {"SOLO_ENC_CORDER": "2"}, {"SOLO_ENC_ASPLIT": "1", "SOLO_ENC_ASTAGGER_US": "300"}, {"SOLO_ENC_RC_STREAM": "1"},
                                    {"SOLO_ENC_RC_STREAM": "1", "SOLO_ENC_CHUNK": "2", "SOLO_ENC_GROUP": "4"}], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_encoder_suite_under_the_pipeline_knobs(knobs):
     """The encoder's pipeline has run-time knobs that change how a call is cut into launches (chunks of several packets, one analysis
