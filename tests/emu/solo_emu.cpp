@@ -109,6 +109,26 @@ int emu_nsq_frames(const void* in, int n, void* out) {
     emu_enc_destroy(e);
     return (int)sizeof(SxNsqOut);
 }
+// the pulse coder alone (tests/test_pulse_coder.py): one frame of pulses through a fresh range coder -> its bytes (SKP_Silk_encode_pulses.c:55)
+int emu_encode_pulses(int sigtype, int QuantOffsetType, const int8_t* q, uint8_t* out, int* error) {
+    static SxCdf cdf;
+    sx_cdf_load(&cdf);
+    alignas(4) u8 pw[SX_RC_PW_ROW];
+    alignas(4) i8 qa[SX_FRAME + 4];
+    memcpy(qa, q, SX_FRAME);
+    static u8 buf[SX_RC_BUF_STRIDE];
+    memset(buf, 0, sizeof(buf));
+    SxRangeEnc rc;
+    sx_rc_enc_init(&rc, buf);
+    sx_encode_pulses(&rc, sigtype, QuantOffsetType, qa, &cdf, pw);
+    i32 nb;
+    sx_rc_length_bits(rc.bufferIx, rc.range_Q16, &nb);
+    sx_rc_enc_wrap_up(&rc);
+    if (nb > 0 && nb <= (i32)sizeof(buf)) memcpy(out, buf, (size_t)nb);
+    *error = rc.error;
+    return nb;
+}
+int emu_frame_samples() { return SX_FRAME; }
 int emu_sizeof_nsq_in() { return (int)sizeof(SxNsqIn); }
 int emu_sizeof_enc_state() { return (int)sizeof(SxEncStream); }
 int emu_sizeof_enc_work() { return (int)sizeof(SxEncWork); }
