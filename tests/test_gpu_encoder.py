@@ -281,3 +281,31 @@ def test_stream_groups_of_the_pipeline(torch_cuda, monkeypatch):
             for p in range(P):
                 n0 = int(nh[i, p, 0])
                 assert np.array_equal(bh[i, p, :n0], z["bits"][i % 8, half * P + p, :n0]), (half, i, p)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("order", ["1", "0", "2"])
+def test_payload_larger_than_its_slot_is_reported_not_written(torch_cuda, monkeypatch, order):
+    """A payload that does not fit the caller's slot (AGR_Sate_Encoder_Encode's nBytesOut / buffer check, AGR_BWE_SDK_API.c:129 ->
+    sx_enc_stage_c_out): both byte counts of the packet are 0, the stream's status carries the first error of the call, every other
+    packet of the batch is unaffected -- under each launch order of the third stage (the assembly lives in a different kernel in each)."""
+    import solo_amd
+    torch = torch_cuda
+    monkeypatch.setenv("SOLO_ENC_CORDER", order)
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    P, S = 12, 80                                              # golden payloads of these packets: 56 .. 114 bytes
+    b = solo_amd.SoloBatch(8, encoder=True, decoder=False, slot_bytes=S)
+    bits, nb, st = b.encode(torch.from_numpy(np.ascontiguousarray(z["pcm"][:, :P])).to(b.device))
+    torch.cuda.synchronize()
+    bh, nh, sh = bits.cpu().numpy(), nb.cpu().numpy(), st.cpu().numpy()
+    too_big = z["nbytes"][:, :P, 0] > S
+    assert too_big.any() and (~too_big).any()
+    for i in range(8):
+        assert int(sh[i]) == (-1 if too_big[i].any() else 0), (i, int(sh[i]))
+        for p in range(P):
+            if too_big[i, p]:
+                assert nh[i, p, 0] == 0 and nh[i, p, 1] == 0, (i, p, nh[i, p])
+            else:
+                n0 = int(z["nbytes"][i, p, 0])
+                assert np.array_equal(nh[i, p], z["nbytes"][i, p]), (i, p)
+                assert np.array_equal(bh[i, p, :n0], z["bits"][i, p, :n0]), (i, p)
