@@ -64,11 +64,6 @@ hipError_t solo_wb_dec_launch_ring(void* states, const uint8_t* ring, uint32_t* 
 #ifdef SOLO_WITH_ENCODER
 #include "solo_enc_ops.h"
 extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, void* hip_stream);      // solo_nsq_row.hip
-// one wavefront that waits `ticks` of the 100 MHz counter (timing experiments; the stagger of SOLO_ENC_ASPLIT)
-__global__ void __launch_bounds__(64) solo_exp_delay_kernel(int ticks) {
-    const unsigned long long t0 = wall_clock64();
-    while (wall_clock64() - t0 < (unsigned long long)ticks) __builtin_amdgcn_s_sleep(16);
-}
 extern "C" const solo_enc_ops* solo_nb_enc_ops();                                                      // solo_enc_k.hip
 extern "C" const solo_enc_ops* solo_wb_enc_ops();                                                      // solo_enc_k_wb.hip
 #endif
@@ -104,27 +99,29 @@ struct solo_batch {
     int timing;                      // solo_batch_set_timing: bracket every kernel with HIP events on its launch stream
     hipEvent_t ev[6];                // decode: 4|D|5  (0..3: unused since the encoder is pipelined)
     int ev_ready, ev_enc, ev_dec;
-    // encoder pipeline: the packets of a call go through analysis -> quantiser -> coding in chunks on three streams
-    int achunk;                      // analysis launches cover achunk chunks (env SOLO_ENC_ACHUNK, default 1)
-    int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
-    hipStream_t sA, sB, sC, sD;      // (sD: the range coder's own stream, SOLO_ENC_RC_STREAM=1)
-    hipStream_t sA2;                 // SOLO_ENC_ASPLIT=1: the analysis of the second half of the streams, as launches of its own
-    hipEvent_t evA2[SOLO_MAX_CHUNKS];
-    int a_split, a_stagger;
-    int rc_split;
-    int c_order;                     // third stage (SOLO_ENC_CORDER): 1 = high band, range coder + assembly (default); 0 = range coder, high band + assembly; 2 = high band, range coder, assembly kernel
-    hipEvent_t evR[SOLO_MAX_CHUNKS];
+    // encoder: three internal streams (analysis / front kernel: sA, quantiser: sB, third stage of the launch-per-chunk schedule: sC)
+    int pipe_ready, chunk_packets;   // chunk_packets: packets per chunk of the launch-per-chunk schedule (env SOLO_ENC_CHUNK, default 1; 0 = one chunk)
+    hipStream_t sA, sB, sC;
     hipEvent_t evFork, evJoinA[2], evJoinC[2], evA[SOLO_MAX_CHUNKS], evB[SOLO_MAX_CHUNKS], evC[SOLO_MAX_CHUNKS];
     int async_join;                  // solo_batch_set_async_join: encode returns without joining its streams into the caller's
     unsigned int enc_seq;            // encode calls so far (selects the join-event set)
     int evC_valid;                   // chunks of the previous call whose coding-done events are recorded
     int last_np, last_cp;            // packets / packets per chunk of the previous call (layout of the hand-over records)
-    hipEvent_t tev[3][SOLO_MAX_CHUNKS][2];   // timing brackets per kernel type / chunk (created with set_timing)
+    hipEvent_t tev[3][SOLO_MAX_CHUNKS][2];   // timing brackets per kernel type / launch (created with set_timing)
     int tev_ready, last_chunks;
-    unsigned int* d_started;         // per chunk slot: workgroups of the quantiser launches that have started (running count)
+    unsigned int* d_started;         // per launch slot: workgroups of the quantiser launches that have started (running count)
     unsigned int started_target[SOLO_MAX_CHUNKS];
-    int group_streams;               // env SOLO_ENC_GROUP (default 4096): streams per launch group of the encoder pipeline (0 = all)
-    int gate;                        // env SOLO_ENC_GATE (default 1): analysis of chunk c+1 starts once the quantiser of chunk c is resident
+    int group_streams;               // streams per launch group (env SOLO_ENC_GROUP; default: launch per chunk 8192, persistent = what is resident at once)
+    int gate;                        // env SOLO_ENC_GATE: the front / next analysis launch starts once the quantiser's workgroups are resident
+    // persistent schedule (calls of two or more packets; env SOLO_ENC_PERSIST=0 turns it off): per-stream hand-over flags, tickets
+    int persist;
+    int persist_group;               // streams per launch group: all of a group's front workgroups are resident beside its quantiser's
+    unsigned int* d_flags;           // ana[n_streams] | nsq[n_streams / 4 + 1] | prog[n_streams] | err[4]
+    unsigned int ticket;             // packets encoded by persistent calls so far (mod 2^32): the flag words are never reset
+    unsigned int final_wait_ticks;   // env SOLO_ENC_FINAL_WAIT_US: bound of the front kernel's wait for the quantiser's last packets (100 MHz ticks)
+    int front_defer;                 // SOLO_ENC_FINAL_WAIT_US=-1
+    void* d_nsq_stage;               // the persistent quantiser's staging records (one launch group)
+    void* d_front_scratch;           // byte buffers of the front kernel's in-wave range coder (one launch group)
     void* d_dec_state;               // SxDecState[n_streams] of the build that matches `wb`
     // receiver staging ring (solo_recv.h): payload [N][D][2][slot] | length words [N][D] | play-out positions [N] | statistics
     uint8_t* d_recv_ring;
@@ -177,6 +174,12 @@ static void solo_enc_free(solo_batch* b) {
     b->d_nsq_ring = NULL;
     if (b->d_rc_scratch) (void)hipFree(b->d_rc_scratch);
     b->d_rc_scratch = NULL;
+    if (b->d_flags) (void)hipFree(b->d_flags);
+    b->d_flags = NULL;
+    if (b->d_front_scratch) (void)hipFree(b->d_front_scratch);
+    b->d_front_scratch = NULL;
+    if (b->d_nsq_stage) (void)hipFree(b->d_nsq_stage);
+    b->d_nsq_stage = NULL;
     b->d_enc_state = NULL;
     b->d_enc_work = NULL;
 }
@@ -332,8 +335,6 @@ void solo_batch_destroy(solo_batch_t* b) {
     if (b->pipe_ready) {
         (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC);
         (void)hipStreamDestroy(b->sA); (void)hipStreamDestroy(b->sB); (void)hipStreamDestroy(b->sC);
-        if (b->a_split) { (void)hipStreamSynchronize(b->sA2); (void)hipStreamDestroy(b->sA2); for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evA2[c]); }
-        if (b->rc_split) { (void)hipStreamSynchronize(b->sD); (void)hipStreamDestroy(b->sD); for (int c = 0; c < SOLO_MAX_CHUNKS; c++) (void)hipEventDestroy(b->evR[c]); }
         if (b->d_started) (void)hipFree(b->d_started);
         (void)hipEventDestroy(b->evFork);
         for (int i = 0; i < 2; i++) { (void)hipEventDestroy(b->evJoinA[i]); (void)hipEventDestroy(b->evJoinC[i]); }
@@ -517,6 +518,156 @@ int32_t solo_recv_stats(solo_batch_t* b, uint32_t* out8, void* hip_stream) {
 }
 
 #ifdef SOLO_WITH_ENCODER
+// one-time set-up of a handle's encoder pipeline: internal streams, events, knobs (documented in INTEGRATION.md section 5), scratch
+static int32_t solo_enc_pipe_setup(solo_batch* b) {
+    const solo_enc_ops* ops = b->eops;
+    int lo = 0, hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&lo, &hi);            // hi = numerically lowest = greatest priority
+    SOLO_CHECK(hipStreamCreateWithPriority(&b->sA, hipStreamNonBlocking, lo));
+    SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
+    SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, lo));
+    SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
+    for (int i = 0; i < 2; i++) {
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA[i], hipEventDisableTiming));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinC[i], hipEventDisableTiming));
+    }
+    for (int c = 0; c < SOLO_MAX_CHUNKS; c++) {
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evA[c], hipEventDisableTiming));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evB[c], hipEventDisableTiming));
+        SOLO_CHECK(hipEventCreateWithFlags(&b->evC[c], hipEventDisableTiming));
+    }
+    int dev = 0, ncu = 0;
+    SOLO_CHECK(hipGetDevice(&dev));
+    SOLO_CHECK(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev));
+    // SOLO_ENC_PERSIST=1: the persistent schedule (two kernels per call that hand packets over through flags) instead of one launch per
+    // chunk and stage.  Bit-exact and deadlock-free by construction, but measured SLOWER (54 - 60 against 50.5 ms per 4096 x 50 packets:
+    // DESIGN.md section 9 has the trace): it removes the launch tails, but it also fixes the SIMD's population at five dependent
+    // chains, where the launch-per-chunk schedule reaches nine.  Off unless asked for.
+    const char* e = getenv("SOLO_ENC_PERSIST");
+    b->persist = e ? (atoi(e) != 0) : 0;
+    e = getenv("SOLO_ENC_CHUNK");
+    b->chunk_packets = e ? atoi(e) : 1;
+    if (b->chunk_packets < 0) b->chunk_packets = 1;
+    // launch per chunk: the residency gate (hold analysis chunk c + 1 until the quantiser launch of chunk c is resident) costs 3 % with 256
+    // quantiser workgroups per chunk: off unless asked for.  Persistent: ONE gate per launch group, in front of the front kernel -- the
+    // quantiser's wavefronts have to be resident before 4096 front workgroups take every register of the device: on unless turned off.
+    e = getenv("SOLO_ENC_GATE");
+    b->gate = e ? (atoi(e) != 0) : -1;                          // (-1: the schedule's default)
+    // streams per launch group.  Launch per chunk: 8192 (one group of 8192 takes 120 ms per 50 packets, two of 4096 take 134).  Persistent:
+    // what is resident at once -- front workgroups per compute unit (LDS-bound: 16 at the 16 kHz rate, 9 at 32 kHz) x compute units, a
+    // multiple of the quantiser's four streams per wavefront: a larger group's last workgroups would only start when the first ones have
+    // finished ALL their packets, while their quantiser wavefronts held registers from the start
+    e = getenv("SOLO_ENC_GROUP");
+    const int g_env = e ? atoi(e) : -1;
+    b->group_streams = g_env >= 0 ? g_env : 8192;
+    b->persist_group = g_env > 0 ? ((g_env + 3) & ~3) : ((ops->front_per_cu * (ncu > 0 ? ncu : 256)) & ~3);
+    if (b->persist_group < 4) b->persist_group = 4;
+    e = getenv("SOLO_ENC_FINAL_WAIT_US");
+    {
+        // (-1, tests: the front launch codes nothing -- no look at the quantiser's flags at all --, the second launch every packet)
+        const long us = e ? atol(e) : 20000;
+        b->front_defer = us < 0;
+        b->final_wait_ticks = (unsigned int)((us < 0 ? 0 : (us > 10000000 ? 10000000 : us)) * 100);
+    }
+    {   // the quantiser launches of a call run one after the other on sB: one ring, sized for the largest launch group
+        int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
+        if (b->persist && b->persist_group > gs) gs = b->persist_group < b->n_streams ? b->persist_group : b->n_streams;
+        SOLO_CHECK(hipMalloc(&b->d_nsq_ring, ops->nsq_ring_bytes(gs)));
+    }
+    SOLO_CHECK(hipMalloc((void**)&b->d_started, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
+    SOLO_CHECK(hipMemset(b->d_started, 0, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
+    memset(b->started_target, 0, sizeof(b->started_target));
+    if (b->persist) {
+        const size_t nflags = (size_t)b->n_streams * 2 + (size_t)b->n_streams / 4 + 1 + 4;
+        SOLO_CHECK(hipMalloc((void**)&b->d_flags, nflags * sizeof(unsigned int)));
+        SOLO_CHECK(hipMemset(b->d_flags, 0, nflags * sizeof(unsigned int)));
+        const int gs = b->persist_group < b->n_streams ? b->persist_group : b->n_streams;
+        SOLO_CHECK(hipMalloc(&b->d_front_scratch, ops->front_scratch_bytes(gs)));
+        SOLO_CHECK(hipMalloc(&b->d_nsq_stage, ops->nsq_stage_bytes(gs)));
+    }
+    b->ticket = 0;
+    b->pipe_ready = 1;
+    return 0;
+}
+
+// Persistent schedule of one call: per launch group ONE quantiser launch (sB) and ONE front launch (sA) that hand packets to each other
+// through flags while they run (solo_enc_kernels.h), then the front kernel once more behind the quantiser (mode 1: what a bounded wait
+// left undone -- nothing, normally).
+static int32_t solo_encode_persist(solo_batch* b, const int16_t* d_pcm, int32_t n_packets, uint8_t* d_bits, int16_t* d_nbytes, int32_t* d_status,
+                                   hipStream_t st, void* nin, void* nout, void* cin) {
+    const solo_enc_ops* ops = b->eops;
+    const int G = b->persist_group, ngroups = (b->n_streams + G - 1) / G;
+    const bool tm = b->timing && b->tev_ready && ngroups <= SOLO_MAX_CHUNKS;
+    unsigned int* ana = b->d_flags;
+    unsigned int* nsqf = ana + b->n_streams;
+    unsigned int* prog = nsqf + (size_t)b->n_streams / 4 + 1;
+    unsigned int* err = prog + b->n_streams;
+    const unsigned int ticket0 = b->ticket;
+    b->ticket += (unsigned int)n_packets;
+    const size_t frame_samples = (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples);
+    SOLO_CHECK(hipEventRecord(b->evFork, st));
+    SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
+    SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
+    if (b->enc_seq > 0) {          // the previous call (of either schedule) has read its hand-over records to the end
+        const int jp = (int)((b->enc_seq - 1u) & 1u);
+        SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evJoinC[jp], 0));
+        SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evJoinC[jp], 0));
+        SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evJoinA[jp], 0));
+    }
+    b->evC_valid = 0;
+    b->last_np = n_packets;
+    b->last_cp = 0;
+    hipError_t lerr = hipSuccess;
+    for (int g = 0; g < ngroups && lerr == hipSuccess; g++) {
+        const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0, c = g % SOLO_MAX_CHUNKS;
+        const size_t pk0 = (size_t)s0 * (size_t)n_packets;
+        void* g_states = (char*)b->d_enc_state + (size_t)s0 * ops->state_bytes;
+        void* g_nin = (char*)nin + pk0 * 2 * ops->nsq_in_bytes;
+        void* g_nout = (char*)nout + pk0 * 2 * ops->nsq_out_bytes;
+        void* g_cin = (char*)cin + pk0 * ops->code_in_bytes;
+        const int16_t* g_pcm = d_pcm + pk0 * frame_samples;
+        uint8_t* g_bits = d_bits + pk0 * (size_t)b->slot;
+        int16_t* g_nbytes = d_nbytes + pk0 * 2;
+        int32_t* g_status = d_status ? d_status + s0 : NULL;
+        // the front kernel first; the quantiser's launch is held until the front workgroups have started (they fill every compute unit
+        // up to one 128-register hole per SIMD, which is where the quantiser's wavefronts then go: solo_nsq_row.hip, "Residency")
+        // (sB comes up to where sA stands -- behind the previous group's last launch -- before it starts counting)
+        if ((lerr = hipEventRecord(b->evA[c], b->sA)) != hipSuccess) break;
+        if ((lerr = hipStreamWaitEvent(b->sB, b->evA[c], 0)) != hipSuccess) break;
+        if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
+        lerr = ops->front(g_states, g_pcm, ns, n_packets, g_nin, g_cin, g_nout, ana + s0, nsqf + s0 / 4, prog + s0, ticket0, b->front_defer ? 2 : 0, b->final_wait_ticks, b->slot,
+                          g_bits, g_nbytes, g_status, b->d_front_scratch, &b->d_started[c], b->sA);
+        if (lerr != hipSuccess) break;
+        b->started_target[c] += (unsigned int)((ns + ops->front_waves - 1) / ops->front_waves);
+        if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
+        if (b->gate != 0) (void)solo_launch_gate(&b->d_started[c], b->started_target[c], b->sB);
+        if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
+        lerr = (hipError_t)ops->nsq_persist(g_states, g_nin, g_nout, ns, n_packets, NULL, b->d_nsq_ring, ana + s0, nsqf + s0 / 4, ticket0, err, b->d_nsq_stage, b->sB);
+        if (lerr != hipSuccess) break;
+        if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
+        if ((lerr = hipEventRecord(b->evB[c], b->sB)) != hipSuccess) break;
+        if ((lerr = hipStreamWaitEvent(b->sA, b->evB[c], 0)) != hipSuccess) break;
+        if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sA);
+        lerr = ops->front(g_states, g_pcm, ns, n_packets, g_nin, g_cin, g_nout, ana + s0, nsqf + s0 / 4, prog + s0, ticket0, 1, 0u, b->slot, g_bits, g_nbytes,
+                          g_status, b->d_front_scratch, NULL, b->sA);
+        if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sA);
+    }
+    // join (also after a refused launch: whatever was enqueued still runs, nothing of this call stays forked)
+    const int js = (int)(b->enc_seq & 1u);
+    b->enc_seq++;
+    (void)hipEventRecord(b->evJoinA[js], b->sA);
+    (void)hipEventRecord(b->evJoinC[js], b->sB);
+    if (!b->async_join || lerr != hipSuccess) {
+        (void)hipStreamWaitEvent(st, b->evJoinA[js], 0);
+        (void)hipStreamWaitEvent(st, b->evJoinC[js], 0);
+    }
+    b->last_chunks = (lerr == hipSuccess && (tm || ngroups <= SOLO_MAX_CHUNKS)) ? ngroups : 0;
+    if (tm && lerr == hipSuccess) b->ev_enc = 1;
+    SOLO_CHECK(lerr);
+    SOLO_CHECK(hipGetLastError());
+    return 0;
+}
+
 int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packets, uint8_t* d_bits, int16_t* d_nbytes,
                           int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_enc || !d_pcm || !d_bits || !d_nbytes || n_packets <= 0) return -1;
@@ -526,13 +677,12 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     // the quantiser addresses the hand-over records of its wavefront's four streams with 32-bit offsets from a wave-uniform base
     // (solo_nsq_row.hip): the records of 3 streams x 2 n_packets, plus one more record for the offsets inside the last one, must stay
     // below 4 GiB (~700 k packets per call at the 16 kHz API rate)
-    // (streams per wavefront of THIS build's quantiser: four in the row layout, sixteen with -DRW_TPL=3)
     const unsigned long long per_wave = 64ull / (unsigned long long)ops->nsq_workgroups(64);
     if (((per_wave - 1ull) * 2ull * (unsigned long long)n_packets + 1ull) * (unsigned long long)ops->nsq_out_bytes >= (1ull << 32)) return -1;
     const size_t sz_in = np * 2 * ops->nsq_in_bytes, sz_out = np * 2 * ops->nsq_out_bytes, sz_code = np * ops->code_in_bytes;
     if (n_packets > b->enc_work_packets) {          // grow the hand-over area (synchronises; steady-state launches do not)
         SOLO_CHECK(hipStreamSynchronize(st));
-        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); if (b->rc_split) (void)hipStreamSynchronize(b->sD); if (b->a_split) (void)hipStreamSynchronize(b->sA2); }
+        if (b->pipe_ready) { (void)hipStreamSynchronize(b->sA); (void)hipStreamSynchronize(b->sB); (void)hipStreamSynchronize(b->sC); }
         if (b->d_enc_work) (void)hipFree(b->d_enc_work);
         b->d_enc_work = NULL;
         SOLO_CHECK(hipMalloc(&b->d_enc_work, sz_in + sz_out + sz_code + 256));
@@ -542,98 +692,25 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     void* nout = (char*)b->d_enc_work + ((sz_in + 63) & ~(size_t)63);
     void* cin = (char*)nout + ((sz_out + 63) & ~(size_t)63);
     void* states = b->d_enc_state;
-    // Pipeline: chunk c of the call's packets goes analysis (stream sA) -> quantiser (sB) -> coding (sC).  A_c follows A_{c-1},
-    // B_c follows A_c and B_{c-1}, C_c follows B_c and C_{c-1}; so the quantiser of chunk c (one wave per SIMD, latency bound)
-    // runs next to the analysis of chunk c + 1 and the coding of chunk c - 1 (instruction bound): they share the SIMDs.  The
-    // kernels of different types touch disjoint parts of the stream records.  The caller's stream is forked / joined by events.
     if (!b->pipe_ready) {
-        int lo = 0, hi = 0;
-        (void)hipDeviceGetStreamPriorityRange(&lo, &hi);            // hi = numerically lowest = greatest priority
-        // SOLO_ENC_CUMASK = m > 0: spatial split -- the quantiser's stream runs on every m-th compute unit only (its one wave per
-        // stream group takes a whole SIMD: four of them fill a CU), the analysis / coding streams on all the others
-        const char* em = getenv("SOLO_ENC_CUMASK");
-        const int cu_mod = em ? atoi(em) : 0;
-        if (cu_mod > 1) {
-            hipDeviceProp_t prop;
-            int dev = 0;
-            SOLO_CHECK(hipGetDevice(&dev));
-            SOLO_CHECK(hipGetDeviceProperties(&prop, dev));
-            const int ncu = prop.multiProcessorCount, nw = (ncu + 31) / 32;
-            const char* eo = getenv("SOLO_ENC_CUMASK_PHASE");
-            const int phase = eo ? atoi(eo) : 0;
-            std::vector<uint32_t> mq(nw, 0u), mo(nw, 0u);
-            for (int i = 0; i < ncu; i++) {
-                if (i % cu_mod == phase) mq[i >> 5] |= 1u << (i & 31);
-                else mo[i >> 5] |= 1u << (i & 31);
-            }
-            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sA, (uint32_t)nw, mo.data()));
-            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sB, (uint32_t)nw, mq.data()));
-            SOLO_CHECK(hipExtStreamCreateWithCUMask(&b->sC, (uint32_t)nw, mo.data()));
-        } else {
-        SOLO_CHECK(hipStreamCreateWithPriority(&b->sA, hipStreamNonBlocking, lo));
-        SOLO_CHECK(hipStreamCreateWithPriority(&b->sB, hipStreamNonBlocking, hi));
-        {   // SOLO_ENC_CPRIO=1: the third stage's stream at the quantiser's priority (its workgroups are short: first in line when slots come free)
-            const char* ep = getenv("SOLO_ENC_CPRIO");
-            SOLO_CHECK(hipStreamCreateWithPriority(&b->sC, hipStreamNonBlocking, (ep && atoi(ep) > 0) ? hi : lo));
-        }
-        }
-        SOLO_CHECK(hipEventCreateWithFlags(&b->evFork, hipEventDisableTiming));
-        for (int i = 0; i < 2; i++) {
-            SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinA[i], hipEventDisableTiming));
-            SOLO_CHECK(hipEventCreateWithFlags(&b->evJoinC[i], hipEventDisableTiming));
-        }
-        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evC[c], hipEventDisableTiming));
-        for (int c = 0; c < SOLO_MAX_CHUNKS; c++) {
-            SOLO_CHECK(hipEventCreateWithFlags(&b->evA[c], hipEventDisableTiming));
-            SOLO_CHECK(hipEventCreateWithFlags(&b->evB[c], hipEventDisableTiming));
-        }
-        const char* e = getenv("SOLO_ENC_CHUNK");
-        b->chunk_packets = e ? atoi(e) : 1;
-        e = getenv("SOLO_ENC_ACHUNK");
-        b->achunk = (e && atoi(e) > 0) ? atoi(e) : 1;
-        e = getenv("SOLO_ENC_ASPLIT");
-        b->a_split = (e && atoi(e) > 0 && cu_mod <= 1) ? 1 : 0;
-        e = getenv("SOLO_ENC_ASTAGGER_US");
-        b->a_stagger = e ? atoi(e) : 0;
-        if (b->a_split) {
-            SOLO_CHECK(hipStreamCreateWithPriority(&b->sA2, hipStreamNonBlocking, (getenv("SOLO_ENC_A2PRIO") && atoi(getenv("SOLO_ENC_A2PRIO")) > 0) ? hi : lo));
-            for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evA2[c], hipEventDisableTiming));
-        }
-        e = getenv("SOLO_ENC_CORDER");
-        b->c_order = e ? atoi(e) : 1;
-        e = getenv("SOLO_ENC_RC_STREAM");
-        b->rc_split = (e && atoi(e) > 0 && cu_mod <= 1) ? atoi(e) : 0;      // (1: the coder after its chunk's high band; 2: beside it)
-        if (b->rc_split) {
-            const char* ed = getenv("SOLO_ENC_DPRIO");          // (experiment: 0 = lowest, 1 = middle, 2 = the quantiser's)
-            const int dp = ed ? atoi(ed) : 0;
-            SOLO_CHECK(hipStreamCreateWithPriority(&b->sD, hipStreamNonBlocking, dp == 2 ? hi : (dp == 1 ? (lo + hi) / 2 : lo)));
-            for (int c = 0; c < SOLO_MAX_CHUNKS; c++) SOLO_CHECK(hipEventCreateWithFlags(&b->evR[c], hipEventDisableTiming));
-        }
-        e = getenv("SOLO_ENC_GATE");
-        // residency gate (hold analysis chunk c + 1 until the quantiser launch of chunk c is resident): needed when the quantiser
-        // was 1024 workgroups that had to find room between 4096 analysis workgroups; with 256 quantiser workgroups it costs 3 %
-        // (measured 72.3 vs 69.9 ms per 204 800 packets), so it is off unless asked for
-        b->gate = e ? atoi(e) : 0;
-        e = getenv("SOLO_ENC_GROUP");
-        b->group_streams = e ? atoi(e) : 8192;        // (8192 streams: one group of 8192 takes 120 ms per 50 packets, two of 4096 take 134 ms)
-        {   // the quantiser launches of a call run one after the other on sB: one ring, sized for the largest launch group
-            const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
-            SOLO_CHECK(hipMalloc(&b->d_nsq_ring, ops->nsq_ring_bytes(gs)));
-        }
-        SOLO_CHECK(hipMalloc((void**)&b->d_started, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
-        SOLO_CHECK(hipMemset(b->d_started, 0, SOLO_MAX_CHUNKS * sizeof(unsigned int)));
-        memset(b->started_target, 0, sizeof(b->started_target));
-        b->pipe_ready = 1;
+        const int32_t r = solo_enc_pipe_setup(b);
+        if (r) return r;
     }
+    // SOLO_ENC_PERSIST=1: calls of two or more packets run the persistent schedule (a single packet has nothing to pipeline inside the call)
+    if (b->persist && n_packets >= 2) return solo_encode_persist(b, d_pcm, n_packets, d_bits, d_nbytes, d_status, st, nin, nout, cin);
+
+    // Launch per chunk: chunk c of the call's packets goes analysis (stream sA) -> quantiser (sB) -> high band, range coder (sC).  A_c
+    // follows A_{c-1}, B_c follows A_c and B_{c-1}, C_c follows B_c and C_{c-1}; so the quantiser of chunk c (one wave per SIMD, latency
+    // bound) runs next to the analysis of chunk c + 1 and the coding of chunk c - 1 (instruction bound): they share the SIMDs.  The
+    // kernels of different types touch disjoint parts of the stream records.  The caller's stream is forked / joined by events.
     int cp = b->chunk_packets > 0 ? b->chunk_packets : n_packets;
     int nchunks = (n_packets + cp - 1) / cp;
     if (nchunks > SOLO_MAX_CHUNKS) { cp = (n_packets + SOLO_MAX_CHUNKS - 1) / SOLO_MAX_CHUNKS; nchunks = (n_packets + cp - 1) / cp; }
     {   // scratch of one coding launch: the byte buffers of its descriptions
         const int gs = (b->group_streams > 0 && b->group_streams < b->n_streams) ? b->group_streams : b->n_streams;
-        const size_t need = ops->rc_scratch_bytes(gs, cp) * (b->rc_split ? 2 : 1);
+        const size_t need = ops->rc_scratch_bytes(gs, cp);
         if (need > b->rc_scratch_bytes) {
             if (b->d_rc_scratch) {
-                if (b->rc_split) SOLO_CHECK(hipStreamSynchronize(b->sD));
                 SOLO_CHECK(hipStreamSynchronize(b->sC));             // (a coding launch of the previous call may still read the old one)
                 (void)hipFree(b->d_rc_scratch);
                 b->d_rc_scratch = NULL;
@@ -645,42 +722,30 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
     }
     const bool tm_req = b->timing && b->tev_ready;
     if (b->enc_seq > 0 && (b->last_np != n_packets || b->last_cp != cp || b->evC_valid == 0)) {
-        // the previous call laid its hand-over records out differently: no chunk-wise reuse, wait for all of its coding
+        // the previous call laid its hand-over records out differently (or ran the persistent schedule): no chunk-wise reuse, wait for all of it
         SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
-        if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
+        SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evJoinA[(b->enc_seq - 1u) & 1u], 0));
         b->evC_valid = 0;
     }
     b->last_np = n_packets;
     b->last_cp = cp;
     SOLO_CHECK(hipEventRecord(b->evFork, st));
     SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evFork, 0));
-    if (b->a_split) {
-        SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evFork, 0));
-        if (b->a_stagger > 0) hipLaunchKernelGGL(solo_exp_delay_kernel, dim3(1), dim3(64), 0, b->sA2, b->a_stagger * 100);
-    }
     SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evFork, 0));
     SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evFork, 0));
-    if (b->rc_split) {
-        SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evFork, 0));
-        if (b->enc_seq > 0) {                    // (the previous call's assembly has read both scratch halves)
-            SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
-            SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evJoinC[(b->enc_seq - 1u) & 1u], 0));
-        }
-    }
-    // Streams beyond 8192 (SOLO_ENC_GROUP) are processed group after group; all per-stream arrays are stream-major, so a group is the
-    // same launch on offset pointers.  (Round 1 measured groups of 4096 as the fastest shape; since the analysis kernel's workgroups
-    // all fit beside the quantiser's -- round 3 -- 8192 streams in one group are 11 % faster than two groups of 4096.)
+    // Streams beyond the launch group (SOLO_ENC_GROUP) are processed group after group; all per-stream arrays are stream-major, so a
+    // group is the same launch on offset pointers.
     const int G = b->group_streams > 0 ? b->group_streams : b->n_streams;
     const int ngroups = (b->n_streams + G - 1) / G;
     const bool tm = tm_req && (size_t)ngroups * (size_t)nchunks <= SOLO_MAX_CHUNKS;     // (per-launch timing brackets: one per event slot)
-    int idx = 0, a_slot = 0;
-    bool a_split_now = false;
+    const size_t frame_samples = (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples);
+    int idx = 0;
     hipError_t lerr = hipSuccess;
     for (int g = 0; g < ngroups; g++) {
         const int s0 = g * G, ns = (s0 + G <= b->n_streams) ? G : b->n_streams - s0;
         const size_t pk0 = (size_t)s0 * (size_t)n_packets;                               // first packet record of the group
         void* g_states = (char*)states + (size_t)s0 * ops->state_bytes;
-        const int16_t* g_pcm = d_pcm + pk0 * (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples);
+        const int16_t* g_pcm = d_pcm + pk0 * frame_samples;
         void* g_nin = (char*)nin + pk0 * 2 * ops->nsq_in_bytes;
         void* g_nout = (char*)nout + pk0 * 2 * ops->nsq_out_bytes;
         void* g_cin = (char*)cin + pk0 * ops->code_in_bytes;
@@ -690,77 +755,21 @@ int32_t solo_batch_encode(solo_batch_t* b, const int16_t* d_pcm, int32_t n_packe
         for (int cc = 0; cc < nchunks; cc++, idx++) {
             const int c = idx % SOLO_MAX_CHUNKS, cprev = (idx + SOLO_MAX_CHUNKS - 1) % SOLO_MAX_CHUNKS;     // event / counter slot
             const int p0 = cc * cp, pc = (p0 + cp <= n_packets) ? cp : n_packets - p0;
-            if (ngroups == 1 && cc < b->evC_valid) {      // (previous call: its coding of this chunk's records is done)
-                SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));
-                if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evC[c], 0));
-            }
-            if (idx > 0 && b->gate) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
-            // SOLO_ENC_ACHUNK = a > 1: one analysis launch covers a chunks (the stream state is loaded and stored once per launch);
-            // the quantiser / coding launches of those chunks stay chunk-wise and wait for that one launch
-            if (cc % b->achunk == 0) {
-                if (ngroups == 1) for (int q = 1; q < b->achunk && cc + q < nchunks && cc + q < b->evC_valid; q++) {
-                    SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[(idx + q) % SOLO_MAX_CHUNKS], 0));
-                    if (b->a_split) SOLO_CHECK(hipStreamWaitEvent(b->sA2, b->evC[(idx + q) % SOLO_MAX_CHUNKS], 0));
-                }
-                const int pa = (p0 + b->achunk * cp <= n_packets) ? b->achunk * cp : n_packets - p0;
-                // SOLO_ENC_ASPLIT=1: the two halves of the streams as launches of their own on two streams (each half's launches in order): the
-                // halves take their turns at different times, so the slots a turn frees come in two smaller portions per chunk
-                const int nh = (b->a_split && ns >= 128) ? ((ns / 2 + 63) & ~63) : ns;
-                if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
-                if ((lerr = ops->analysis(g_states, g_pcm, nh, n_packets, p0, pa, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
-                if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
-                SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
-                if (nh < ns) {
-                    const size_t hk = (size_t)nh * (size_t)n_packets;
-                    if ((lerr = ops->analysis((char*)g_states + (size_t)nh * ops->state_bytes,
-                                              g_pcm + hk * (size_t)(b->enc_ctrl.framesize_ms == 20 ? ops->packet_samples / 2 : ops->packet_samples), ns - nh, n_packets, p0, pa,
-                                              (char*)g_nin + hk * 2 * ops->nsq_in_bytes, (char*)g_cin + hk * ops->code_in_bytes, b->sA2)) != hipSuccess) goto launch_failed;
-                    SOLO_CHECK(hipEventRecord(b->evA2[c], b->sA2));
-                }
-                a_split_now = nh < ns;
-                a_slot = c;
-            } else if (tm) { (void)hipEventRecord(b->tev[0][c][0], b->sA); (void)hipEventRecord(b->tev[0][c][1], b->sA); }
-            SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[a_slot], 0));
-            if (a_split_now) SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA2[a_slot], 0));
+            if (ngroups == 1 && cc < b->evC_valid) SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evC[c], 0));      // (previous call: its coding of this chunk's records is done)
+            if (idx > 0 && b->gate > 0) (void)solo_launch_gate(&b->d_started[cprev], b->started_target[cprev], b->sA);
+            if (tm) (void)hipEventRecord(b->tev[0][c][0], b->sA);
+            if ((lerr = ops->analysis(g_states, g_pcm, ns, n_packets, p0, pc, g_nin, g_cin, b->sA)) != hipSuccess) goto launch_failed;
+            if (tm) (void)hipEventRecord(b->tev[0][c][1], b->sA);
+            SOLO_CHECK(hipEventRecord(b->evA[c], b->sA));
+            SOLO_CHECK(hipStreamWaitEvent(b->sB, b->evA[c], 0));
             if (tm) (void)hipEventRecord(b->tev[1][c][0], b->sB);
-#ifdef SX_EXPERIMENTS     // builds for timing experiments only (tools/debug): SOLO_EXP_SKIP bit 0 = no quantiser, bit 1 = no coding, bit 2 = no range coder -- wrong output
-            static const int exp_skip = getenv("SOLO_EXP_SKIP") ? atoi(getenv("SOLO_EXP_SKIP")) : 0;
-#else
-            constexpr int exp_skip = 0;
-#endif
-            if (!(exp_skip & 1)) {
             if ((lerr = (hipError_t)ops->nsq(g_states, g_nin, g_nout, ns, n_packets, p0, pc, &b->d_started[c], b->d_nsq_ring, b->sB)) != hipSuccess) goto launch_failed;
             b->started_target[c] += (unsigned int)ops->nsq_workgroups(ns);     // workgroups of this launch, counted once it is enqueued
-            }
             if (tm) (void)hipEventRecord(b->tev[1][c][1], b->sB);
             SOLO_CHECK(hipEventRecord(b->evB[c], b->sB));
             SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evB[c], 0));
             if (tm) (void)hipEventRecord(b->tev[2][c][0], b->sC);
-            if (!(exp_skip & 2)) {
-            if (b->rc_split) {
-                // SOLO_ENC_RC_STREAM=1: the high band of this chunk on sC, its range coder and the payload assembly on sD; the three of a chunk share
-                // one half of the scratch, which the high band of chunk c + 2 may only overwrite after this chunk's assembly
-                void* half = (char*)b->d_rc_scratch + (size_t)(idx & 1) * (b->rc_scratch_bytes / 2);
-                if (idx >= 2) SOLO_CHECK(hipStreamWaitEvent(b->sC, b->evC[(idx - 2) % SOLO_MAX_CHUNKS], 0));
-                if ((lerr = ops->hb(g_states, g_cin, g_nout, ns, n_packets, p0, pc, half, b->sC)) != hipSuccess) goto launch_failed;
-                SOLO_CHECK(hipEventRecord(b->evR[c], b->sC));
-                // (the coder's 128 large workgroups start when the high band's 4096 are through: side by side they get in each other's way)
-                if (b->rc_split == 1) SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evR[c], 0));
-                else SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evB[c], 0));
-                if ((lerr = ops->rc(g_states, g_cin, g_nout, ns, n_packets, p0, pc, half, b->sD)) != hipSuccess) goto launch_failed;
-                if (b->rc_split != 1) SOLO_CHECK(hipStreamWaitEvent(b->sD, b->evR[c], 0));
-                if ((lerr = ops->out(g_states, g_cin, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, half, b->sD)) != hipSuccess) goto launch_failed;
-                if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sD);
-                SOLO_CHECK(hipEventRecord(b->evC[c], b->sD));
-                continue;
-            } else if (exp_skip & 4) {      // (experiment: no range coder, the coding kernel assembles whatever the scratch holds; bit 3: a one-wave delay of 0.37 ms in its place)
-#ifdef SX_EXPERIMENTS
-                if (exp_skip & 8) hipLaunchKernelGGL(solo_exp_delay_kernel, dim3(1), dim3(64), 0, b->sC, 37000);
-#endif
-                if ((lerr = ops->hb_out(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
-            } else
-            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->c_order, b->sC)) != hipSuccess) goto launch_failed;
-            }
+            if ((lerr = ops->coding(g_states, g_cin, g_nout, ns, n_packets, p0, pc, b->slot, g_bits, g_nbytes, g_status, b->d_rc_scratch, b->sC)) != hipSuccess) goto launch_failed;
             if (tm) (void)hipEventRecord(b->tev[2][c][1], b->sC);
             SOLO_CHECK(hipEventRecord(b->evC[c], b->sC));
         }
@@ -773,22 +782,19 @@ launch_failed:
         b->enc_seq++;
         b->evC_valid = 0;
         b->last_chunks = 0;
-        if (b->a_split) { (void)hipEventRecord(b->evA2[0], b->sA2); (void)hipStreamWaitEvent(b->sA, b->evA2[0], 0); }
         (void)hipEventRecord(b->evJoinA[jf], b->sA);
-        (void)hipEventRecord(b->evJoinC[jf], b->rc_split ? b->sD : b->sC);
+        (void)hipEventRecord(b->evJoinC[jf], b->sC);
         (void)hipStreamWaitEvent(st, b->evJoinA[jf], 0);
         (void)hipStreamWaitEvent(st, b->evJoinC[jf], 0);
         (void)hipEventRecord(b->evFork, b->sB);
         (void)hipStreamWaitEvent(st, b->evFork, 0);
-        if (b->rc_split) (void)hipStreamSynchronize(b->sD);
         return -(int32_t)lerr;
     }
     b->evC_valid = ngroups == 1 ? nchunks : 0;       // chunk-wise hand-over guards only for single-group calls
     const int js = (int)(b->enc_seq & 1u);
     b->enc_seq++;
-    if (b->a_split) { SOLO_CHECK(hipEventRecord(b->evA2[0], b->sA2)); SOLO_CHECK(hipStreamWaitEvent(b->sA, b->evA2[0], 0)); }      // (sA joins for both)
     SOLO_CHECK(hipEventRecord(b->evJoinA[js], b->sA));
-    SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->rc_split ? b->sD : b->sC));      // (sD's last launch waits for sC's)
+    SOLO_CHECK(hipEventRecord(b->evJoinC[js], b->sC));      // (sC's last launch waits for sB's)
     if (!b->async_join) {
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinA[js], 0));
         SOLO_CHECK(hipStreamWaitEvent(st, b->evJoinC[js], 0));
@@ -815,7 +821,6 @@ struct solo_single {
     int16_t* d_nbytes;
     int32_t* d_status;
     int is_enc;
-    int zero_copy;                   // the kernels read / write the pinned host block directly (no staging copies): SOLO_LEGACY_ZEROCOPY=1
 };
 #define SOLO_SINGLE_PCM_OFF 16
 #define SOLO_SINGLE_NB_OFF (16 + 2 * SX_PACKET * 2)
@@ -823,7 +828,7 @@ struct solo_single {
 
 static void single_free(solo_single* h) {
     if (!h) return;
-    if (h->d_blk && !h->zero_copy) (void)hipFree(h->d_blk);
+    if (h->d_blk) (void)hipFree(h->d_blk);
     if (h->h_blk) (void)hipHostFree(h->h_blk);
     solo_batch_destroy(h->b);
     free(h);
@@ -835,17 +840,12 @@ static solo_single* single_new(const USER_Ctrl_enc* e, const USER_Ctrl_dec* d) {
     h->is_enc = e != NULL;
     h->b = solo_batch_create(1, e, d, 1024 + 64);   // MAX_FRAME_BYTES of the reference harness + slack
     const size_t blk = h->b ? (size_t)SOLO_SINGLE_BITS_OFF + (size_t)h->b->slot : 0;
-    // A call moves ~1.4 KB each way.  Zero copy: the block is pinned host memory that the device addresses directly -- the analysis kernel
-    // reads the PCM, the coding kernel writes lengths + payload (the decoder: payload in, status + PCM out) over PCIe, and a call is the
-    // kernel launches + ONE synchronisation, without the two staging copies (each an enqueue + a DMA round trip of its own).
-    const char* zc = getenv("SOLO_LEGACY_ZEROCOPY");
-    h->zero_copy = zc ? atoi(zc) != 0 : 0;      // (measured: 0.214 ms per decode call either way -- the call is the single-wave kernel chain + one synchronisation; off by default)
+    // A call moves ~1.4 KB each way through one pinned host block and one device block of the same layout.  (Letting the kernels address the
+    // pinned block directly -- no staging copies -- measured the same 0.21 ms per decode call: the call is its single-wave kernel chain + one
+    // synchronisation.)
     if (!h->b || hipHostMalloc((void**)&h->h_blk, blk, hipHostMallocDefault) != hipSuccess) { single_free(h); return NULL; }
     memset(h->h_blk, 0, blk);
-    if (h->zero_copy) {
-        if (hipHostGetDevicePointer((void**)&h->d_blk, h->h_blk, 0) != hipSuccess) { h->d_blk = NULL; h->zero_copy = 0; }
-    }
-    if (!h->zero_copy && (hipMalloc((void**)&h->d_blk, blk) != hipSuccess || hipMemset(h->d_blk, 0, blk) != hipSuccess)) {
+    if (hipMalloc((void**)&h->d_blk, blk) != hipSuccess || hipMemset(h->d_blk, 0, blk) != hipSuccess) {
         single_free(h);
         return NULL;
     }
@@ -867,10 +867,10 @@ int32_t AGR_Sate_Encoder_Encode(void* st, const int16_t* pcm, uint8_t* bits, int
     if (!h || !h->is_enc) return -1;
     const size_t pcm_bytes = (size_t)(h->b->enc_ctrl.framesize_ms == 20 ? h->b->eops->packet_samples / 2 : h->b->eops->packet_samples) * 2;      // JC1_FrameSize samples
     memcpy(h->h_blk + SOLO_SINGLE_PCM_OFF, pcm, pcm_bytes);
-    if (!h->zero_copy && hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->d_pcm, h->h_blk + SOLO_SINGLE_PCM_OFF, pcm_bytes, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     if (solo_batch_encode(h->b, h->d_pcm, 1, h->d_bits, h->d_nbytes, h->d_status, NULL) != 0) return -1;
     // lengths + the whole payload slot in one copy (a payload is at most a few hundred bytes; the slot 1088)
-    if (!h->zero_copy && hipMemcpyAsync(h->h_blk + SOLO_SINGLE_NB_OFF, h->d_blk + SOLO_SINGLE_NB_OFF, 16 + (size_t)h->b->slot, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->h_blk + SOLO_SINGLE_NB_OFF, h->d_blk + SOLO_SINGLE_NB_OFF, 16 + (size_t)h->b->slot, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int16_t nb[2];
     memcpy(nb, h->h_blk + SOLO_SINGLE_NB_OFF, 4);
@@ -910,12 +910,12 @@ int32_t AGR_Sate_Decoder_Decode(void* st, int16_t* pcm, int16_t* nSamplesOut, co
         if (n0 > h->b->slot) { *nSamplesOut = (int16_t)ns; return -11; }
         if (n1 < 0 || n1 > n0 || (n1 > 0 && n1 < hbb) || (lostflag == 3 && n0 <= hbb) || (lostflag == 4 && n0 < hbb)) { *nSamplesOut = (int16_t)ns; return -12; }
         memcpy(h->h_blk + SOLO_SINGLE_BITS_OFF, bits, (size_t)n0);
-        if (!h->zero_copy && hipMemcpyAsync(h->d_bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n0, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
+        if (hipMemcpyAsync(h->d_bits, h->h_blk + SOLO_SINGLE_BITS_OFF, (size_t)n0, hipMemcpyHostToDevice, (hipStream_t)0) != hipSuccess) return -1;
     }
     if ((h->b->wb ? solo_wb_dec_launch_raw : solo_dec_launch_raw)(h->b->d_dec_state, h->d_bits, n0, n1, lostflag, h->b->dec_ctrl.useMDIndex, h->d_pcm,
                                                                   h->d_status, (hipStream_t)0) != hipSuccess) return -1;
     // status + decoded packet in one copy, one synchronisation
-    if (!h->zero_copy && hipMemcpyAsync(h->h_blk, h->d_blk, SOLO_SINGLE_PCM_OFF + (size_t)ns * 2, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
+    if (hipMemcpyAsync(h->h_blk, h->d_blk, SOLO_SINGLE_PCM_OFF + (size_t)ns * 2, hipMemcpyDeviceToHost, (hipStream_t)0) != hipSuccess) return -1;
     if (hipStreamSynchronize((hipStream_t)0) != hipSuccess) return -1;
     int32_t ret = 0;
     memcpy(&ret, h->h_blk, 4);

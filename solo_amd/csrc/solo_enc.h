@@ -69,12 +69,16 @@ struct SxHbWork {                    // LDS scratch of the high-band encoder
     SxLpcWork lpc;
 };
 
+// high-band bytes of the packets whose descriptions are not range-coded yet: the persistent pipeline's front kernel (solo_enc_kernels.h) runs
+// its coder once per SX_HB_Q packets, one lane per (packet, description); everywhere else slot 0 is the only one used.  (The slots fit
+// into what the LDS allocation granularity of 512 bytes leaves behind the work area: 8 632 of 8 704, 12 200 of 12 288 bytes.)
+#define SX_HB_Q (SX_FS_KHZ == 8 ? 10 : 8)
 struct SxEncWork {
     // persistent over the launch / packet
     SxEncState st;                   // the stream's compact state (HBM record -> LDS at launch start, back at the end)
     SxEncCtrl ctrl;
     i16 xfw[SX_FRAME];
-    u8 hb_bytes[8];
+    u8 hb_bytes[8 * SX_HB_Q];
     // phase-local
     union {
         i16 qmf_tl[63 + SX_PACKET];
@@ -135,7 +139,7 @@ SX_HD void sx_encode_pulses(SxRangeEnc* rc, int sigtype, int QuantOffsetType, co
 #pragma unroll
         for (int j = 0; j < 8; j++) {
             u32 v;
-            __builtin_memcpy(&v, q + 32 * w_ + 4 * j, 4);
+            v = sx_pub_ld((const u32*)(const void*)(q + 32 * w_ + 4 * j));       // (written by the quantiser's kernel, possibly while this one runs: solo_wave.h)
             const u32 sb = (v >> 7) & 0x01010101u;                      // 1 in the bytes that are negative
             // per byte: negative ? -b : b = (b ^ 0xFF) + 1; a negative byte is not 0, so the + 1 never carries into its neighbour
             const u32 a = (v ^ (sb * 0xFFu)) + sb;
@@ -396,7 +400,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
             const int n = sub * sub_len + i;
             const i32 e = exc[n];
             res_nrg0 = sx_add(res_nrg0, sx_mul(e, e));
-            i32 tmp = (n < SX_FRAME ? residue0[n] : residue1[n - SX_FRAME]) >> 10;
+            i32 tmp = sx_pub_ld(n < SX_FRAME ? &residue0[n] : &residue1[n - SX_FRAME]) >> 10;      // (the quantiser's output: solo_wave.h "publish / consume")
             res_nrg1 = sx_smlabb(res_nrg1, tmp, tmp);
         }
         res_nrg0 = wv_sum(res_nrg0);
@@ -485,18 +489,21 @@ SX_FNW void sx_enc_analyse_frame(SxEncStream* rec, SxEncWork* w, const i16* pIn,
     // the history of the next frame leaves LDS before the quantiser takes over the union
     SX_PAR(i, SX_FRAME + SX_LA_SHAPE) hist->x_buf[i] = f->x_buf[SX_FRAME + i];
     wv_sync();
-    // hand-over record for the quantiser
+    // hand-over record for the quantiser.  In the persistent pipeline the quantiser's wavefront reads it while this kernel still runs: every
+    // word of it is stored write-through (sx_pub_st, solo_wave.h); the caller drains the stores and raises the stream's flag
     {
-        in->sigtype = c->sigtype; in->QuantOffsetType = c->QuantOffsetType; in->NLSFInterpCoef_Q2 = c->NLSFInterpCoef_Q2;
-        in->Seed = c->Seed; in->Lambda_Q10 = c->Lambda_Q10; in->LTP_scale_Q14 = c->LTP_scale_Q14; in->DeltaGains_Q16 = c->DeltaGains_Q16;
-        SX_PAR(i, SX_NB_SUBFR) {
-            in->pitchL[i] = c->pitchL[i]; in->Gains_Q16[i] = c->Gains_Q16[i]; in->LF_shp_Q14[i] = c->LF_shp_Q14[i];
-            in->Tilt_Q14[i] = c->Tilt_Q14[i]; in->HarmShapeGain_Q14[i] = c->HarmShapeGain_Q14[i];
+        if (SX_LANE == 0) {
+            sx_pub_st(&in->sigtype, c->sigtype); sx_pub_st(&in->QuantOffsetType, c->QuantOffsetType); sx_pub_st(&in->NLSFInterpCoef_Q2, c->NLSFInterpCoef_Q2);
+            sx_pub_st(&in->Seed, c->Seed); sx_pub_st(&in->Lambda_Q10, c->Lambda_Q10); sx_pub_st(&in->LTP_scale_Q14, c->LTP_scale_Q14); sx_pub_st(&in->DeltaGains_Q16, c->DeltaGains_Q16);
         }
-        SX_PAR(i, 2 * SX_MAX_LPC) (&in->PredCoef_Q12[0][0])[i] = (&c->PredCoef_Q12[0][0])[i];
-        SX_PAR(i, SX_LTP_ORDER * SX_NB_SUBFR) in->LTPCoef_Q14[i] = c->LTPCoef_Q14[i];
-        SX_PAR(i, SX_NB_SUBFR * SX_SHAPE_ORDER) in->AR2_Q13[i] = c->AR2_Q13[i];
-        SX_PAR(i, SX_FRAME) in->xfw[i] = w->xfw[i];
+        SX_PAR(i, SX_NB_SUBFR) {
+            sx_pub_st(&in->pitchL[i], c->pitchL[i]); sx_pub_st(&in->Gains_Q16[i], c->Gains_Q16[i]); sx_pub_st(&in->LF_shp_Q14[i], c->LF_shp_Q14[i]);
+            sx_pub_st(&in->Tilt_Q14[i], c->Tilt_Q14[i]); sx_pub_st(&in->HarmShapeGain_Q14[i], c->HarmShapeGain_Q14[i]);
+        }
+        SX_PAR(i, 2 * SX_MAX_LPC) sx_pub_st(&(&in->PredCoef_Q12[0][0])[i], (&c->PredCoef_Q12[0][0])[i]);
+        SX_PAR(i, SX_LTP_ORDER * SX_NB_SUBFR) sx_pub_st(&in->LTPCoef_Q14[i], c->LTPCoef_Q14[i]);
+        SX_PAR(i, SX_NB_SUBFR * SX_SHAPE_ORDER) sx_pub_st(&in->AR2_Q13[i], c->AR2_Q13[i]);
+        SX_PAR(i, SX_FRAME) sx_pub_st(&in->xfw[i], w->xfw[i]);
         wv_sync();
     }
     SX_T(7)
@@ -562,19 +569,19 @@ SX_FNW void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsq
 // On the GPU the stage is two kernels: the range coder is a serial chain per description and runs LANE-per-description
 // (sx_code_description; 32 streams per wavefront, solo_enc_rc_kernel), the high-band encoder and the payload assembly run
 // wavefront-per-stream (sx_enc_stage_c_hb, sx_enc_stage_c_out; solo_enc_coding_kernel).  The host emulation calls the three in a row.
-SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2) {
+SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* cin, const SxNsqOut* out2, int hb_slot = 0) {      // (hb_slot: see SX_HB_Q)
     SX_IN_LDS(w);
     SxEncHist* hist = &rec->hist;
     SxEncState* st = &w->st;
     SX_T_BEGIN
     if (st->hb_joint) {
-        sx_hb_encode_frame(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[0], 2 * SX_FRAME);
+        sx_hb_encode_frame(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[8 * hb_slot], 2 * SX_FRAME);
         wv_sync();
         SX_T(9)
     } else {
         const int fpp = SX_UNI(st->fpp);
         for (int frame = 0; frame < fpp; frame++) {
-            sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[4 * frame], SX_FRAME);
+            sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[8 * hb_slot + 4 * frame], SX_FRAME);
             wv_sync();
             SX_T(9)
         }

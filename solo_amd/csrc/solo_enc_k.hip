@@ -1,15 +1,8 @@
-// solo_enc_k.hip -- the encoder's analysis / range-coding / high-band + payload kernels and the launch table of the build
-// (solo_enc_kernels.h).  A translation unit of their own, so that the lanes-per-stream model of the analysis / coding kernels is a
-// compile-time choice apart from the decoder's: SX_ENC_GROUP = 64 (one wavefront per stream: what runs) or 32 (TWO streams per
-// wavefront, a 32-lane half each -- solo_wave.h: "wave-uniform" then means uniform within the half).  The 32-lane model is NOT
-// finished: it compiles (kernel wrappers, reductions and the energy scan have their 32-lane forms) but the stages that lay four
-// subframes out on the four rows of a wavefront (warped autocorrelation, shape rows, Burg) still assume 64 lanes; see DESIGN.md.
-#ifndef SX_ENC_GROUP
-#define SX_ENC_GROUP 64
-#endif
-#if SX_ENC_GROUP != 64
-#define SX_GROUP SX_ENC_GROUP
-#endif
+// solo_enc_k.hip -- the encoder's analysis / front / high-band / range-coding kernels and the launch table of the build
+// (solo_enc_kernels.h).  A translation unit of their own, apart from the decoder's.
+// wv_sync() of this translation unit is wave-local (solo_wave.h): the front kernel's workgroups hold several wavefronts that each follow
+// their own stream and never meet at a barrier
+#define SX_SYNC_WAVE_ONLY 1
 #include <hip/hip_runtime.h>
 #include "solo_enc_kernels.h"
 #if SX_FS_KHZ == 8
@@ -50,5 +43,11 @@ extern "C" int32_t solo_debug_site_hits(unsigned long long* out64, int32_t reset
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_sx_site_hits), z, sizeof(z)) != hipSuccess) return -1;
     }
     return 0;
+}
+#endif
+
+#if defined(SX_PIPE_TRACE) && SX_FS_KHZ == 8
+extern "C" int32_t solo_debug_front_trace(unsigned long long* out, int32_t n_streams) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sx_front_trace), (size_t)n_streams * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
 }
 #endif

@@ -37,8 +37,10 @@
 // (under hipcc these are __host__ __device__ so that the host pass of a .hip file still parses
 // kernels that call them; the host bodies are the 1-lane identities used by the emulation build)
 SX_HD void wv_sync() {
-#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_SYNC_LDS_ONLY)
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // (timing experiment: no wait for outstanding global memory operations)
+#if defined(__HIP_DEVICE_COMPILE__) && defined(SX_SYNC_WAVE_ONLY)
+    // workgroups of several wavefronts that each own their streams (solo_nsq_row.hip): what a single-wave __syncthreads() leaves once
+    // the compiler has dropped its barrier -- all memory operations of the wavefront done, nothing moved across
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
 #elif defined(__HIP_DEVICE_COMPILE__)
     __syncthreads();
 #endif
@@ -234,6 +236,34 @@ SX_HD int sx_vzero() { int z; asm volatile("v_mov_b32 %0, 0" : "=v"(z)); return 
 #define SX_LANE_STREAM 1
 #define SX_RDLANE(v, i) ((i32)__builtin_amdgcn_readlane((i32)(v), (i)))
 #define SX_WRLANE(v, i, val) (v) = (SX_LANE == (i)) ? (i32)(val) : (v)
+#endif
+
+// Hand-over INSIDE a launch (the persistent encoder pipeline, solo_enc_kernels.h / solo_nsq_row.hip): a record one workgroup writes and
+// another reads while both kernels run.  gfx950 has eight XCDs with private L2s and a vector L1 per compute unit that other units'
+// stores never refresh, so (guide: "publish / consume"): the PAYLOAD is stored write-through (sc1: sx_pub_st, <= 8 bytes a store), every
+// storing wave drains its stores (sx_pub_drain), ONE lane stores the flag (sx_flag_st); the consumer polls the flag relaxed
+// (sx_flag_ld), then reads the payload with sc1 loads (sx_pub_ld: served by the L2 / memory, never by the unit's L1, which may hold a
+// stale line -- neighbouring records share cache lines).  No release fence (a buffer_wbl2 per hand-over would sweep the XCD's L2
+// thousands of times a millisecond) and NO acquire fence: buffer_inv sc1 drops the whole L1 of the compute unit, and with twenty
+// wavefronts per unit doing that once per packet the analysis chains' table reads all went to the L2 (measured: + 0.24 ms per packet,
+// 65 instead of 53 ms per 4096 x 50).  The host emulation: plain stores and loads.
+#if defined(__HIP_DEVICE_COMPILE__)
+typedef __attribute__((address_space(1))) unsigned int sx_gu32;
+template <typename T, typename V>
+__device__ __forceinline__ void sx_pub_st(T* p, V v) { __hip_atomic_store(p, (T)v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void sx_pub_drain() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void sx_flag_st(unsigned int* p, unsigned int v) { __hip_atomic_store((sx_gu32*)p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ unsigned int sx_flag_ld(const unsigned int* p) { return __hip_atomic_load((sx_gu32*)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <typename T>
+__device__ __forceinline__ T sx_pub_ld(const T* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+#else
+template <typename T, typename V>
+SX_HD void sx_pub_st(T* p, V v) { *p = (T)v; }
+SX_HD void sx_pub_drain() {}
+SX_HD void sx_flag_st(unsigned int* p, unsigned int v) { *p = v; }
+SX_HD unsigned int sx_flag_ld(const unsigned int* p) { return *p; }
+template <typename T>
+SX_HD T sx_pub_ld(const T* p) { return *p; }
 #endif
 
 // lane-strided parallel loop

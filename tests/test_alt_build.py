@@ -60,17 +60,19 @@ def test_decoder_suite_with_small_decode_chunks():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("knobs", [{"SOLO_ENC_ACHUNK": "2"}, {"SOLO_ENC_CHUNK": "2"}, {"SOLO_ENC_CHUNK": "0"}, {"SOLO_ENC_GATE": "1"},
-                                   {"SOLO_ENC_GROUP": "4", "SOLO_ENC_ACHUNK": "3"}, {"SOLO_ENC_CORDER": "0"}, {"SOLO_ENC_CORDER": "2"}, {"SOLO_ENC_ASPLIT": "1", "SOLO_ENC_ASTAGGER_US": "300"}, {"SOLO_ENC_RC_STREAM": "1"},
-                                   {"SOLO_ENC_RC_STREAM": "1", "SOLO_ENC_CHUNK": "2", "SOLO_ENC_GROUP": "4"}], ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
+@pytest.mark.parametrize("knobs", [{"SOLO_ENC_CHUNK": "2"}, {"SOLO_ENC_CHUNK": "0"}, {"SOLO_ENC_GATE": "1"}, {"SOLO_ENC_GROUP": "4", "SOLO_ENC_CHUNK": "3"},
+                                   {"SOLO_ENC_PERSIST": "1"}, {"SOLO_ENC_PERSIST": "1", "SOLO_ENC_FINAL_WAIT_US": "0"},
+                                   {"SOLO_ENC_PERSIST": "1", "SOLO_ENC_FINAL_WAIT_US": "-1"}, {"SOLO_ENC_PERSIST": "1", "SOLO_ENC_GROUP": "8", "SOLO_ENC_GATE": "0"}],
+                         ids=lambda k: ",".join("%s=%s" % kv for kv in k.items()))
 def test_encoder_suite_under_the_pipeline_knobs(knobs):
-    """The encoder's pipeline has run-time knobs that change how a call is cut into launches (chunks of several packets, one analysis
-    launch over several chunks, no pipeline at all, the residency gate, small launch groups, the order of the third stage's launches,
-    the range coder on a stream of its own) but must never change a bit of the
-    output: the encoder parity tests (goldens, packet-wise vs batched calls, joint mode, DTX, both rates) once more under each."""
+    """The encoder's host-side schedule has run-time knobs that change how a call is cut into launches -- chunks of
+    several packets, no pipeline at all, the residency gate, small launch groups, and the PERSISTENT schedule (two kernels per call that hand
+    packets to each other through flags in HBM while they run; with its bounded final wait set to zero, or with every packet left to its
+    second launch, or cut into several launch groups without the gate) -- but must never change a bit of the output: the encoder parity tests
+    (goldens, packet-wise vs batched calls, joint mode, DTX, both rates, framesize 20) once more under each."""
     env = dict(os.environ, **knobs)
     r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-m", "gpu", "-x", "-p", "no:cacheprovider",
-                        os.path.join(T.ROOT, "tests", "test_gpu_encoder.py")],
+                        os.path.join(T.ROOT, "tests", "test_gpu_encoder.py"), os.path.join(T.ROOT, "tests", "test_framesize20.py"), os.path.join(T.ROOT, "tests", "test_wb.py")],
                        env=env, cwd=T.ROOT, capture_output=True, text=True, timeout=1500)
     tail = (r.stdout + r.stderr)[-1500:]
     assert r.returncode == 0, tail

@@ -4,42 +4,41 @@ beside a quantiser wave), a quantiser wave at 128, the decoder's kernels at 128 
 one register more and the allocation granularity of 8 takes a whole wave per SIMD away without any test noticing (it happened to
 the decoder when the encoder kernels moved to their own translation unit)."""
 import os
-import re
-import shutil
-import subprocess
-import tempfile
+import sys
 
 import pytest
 
 import solo_amd
+import solo_testlib as T
+
+sys.path.insert(0, os.path.join(T.ROOT, "tools"))
+from kernel_resources import kernel_resources      # noqa: E402
 
 LLVM = "/opt/rocm/lib/llvm/bin"
-BUDGET = {                        # kernel name fragment -> (max vector registers, max LDS bytes)
+BUDGET = {                        # kernel name fragment -> (max vector registers ALLOCATED per wavefront, max static LDS bytes)
     "solo_enc_analysis_kernel": (96, 8704), "solo_enc_coding_kernel": (96, 8704), "solo_nsq_kernel": (128, 6144),
     "solo_dec_synth_kernel": (128, 10240), "solo_decode_kernel": (128, 10240), "solo_decode_split_kernel": (128, 10240),
-    "solo_decode_ring_kernel": (128, 10240), "solo_dec_extract_kernel": (96, 14336),
+    "solo_decode_ring_kernel": (128, 10240),
+    # (the extraction kernel uses 96 registers, but its 14 KB of static LDS make the backend pad the descriptor to 136: harmless for the
+    # kernel itself -- LDS bounds it to eleven wavefronts per unit either way --, noted here because the padding is invisible in the notes)
+    "solo_dec_extract_kernel": (136, 14336),
+    # the persistent schedule: ONE front workgroup (sixteen wavefronts of 96 registers, 135 KB of DYNAMIC LDS: a static allocation makes the
+    # backend pad the descriptor to 104 registers) and ONE quantiser workgroup (four wavefronts of 128, 24 KB) per compute unit
+    "solo_enc_front_kernel": (96, 0), "solo_nsq_persist_kernel": (128, 24576),
 }
 
 
 @pytest.mark.skipif(not os.path.exists(os.path.join(LLVM, "llvm-objdump")), reason="no LLVM binutils on this box")
 def test_vector_register_and_lds_budgets():
+    """What the kernel DESCRIPTOR allocates per wavefront (tools/kernel_resources.py), not what the metadata notes count: the two differ
+    when the backend pads an allocation (it did, for the front kernel with static LDS: notes 96, descriptor 104 -- and not one quantiser
+    wavefront fitted beside four such wavefronts on a SIMD)."""
     assert os.path.exists(solo_amd.LIB_PATH)
-    seen = {}
-    with tempfile.TemporaryDirectory() as d:
-        lib = os.path.join(d, "lib.so")
-        shutil.copy(solo_amd.LIB_PATH, lib)
-        subprocess.check_call([os.path.join(LLVM, "llvm-objdump"), "--offloading", lib], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, cwd=d)
-        for f in sorted(os.listdir(d)):
-            if "amdgcn" not in f:
-                continue
-            notes = subprocess.check_output([os.path.join(LLVM, "llvm-readelf"), "--notes", os.path.join(d, f)], text=True)
-            for blk in notes.split("- .agpr_count:")[1:]:
-                name = re.search(r"\.name:\s+(\S+)", blk).group(1)
-                v = int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) + int(blk.split()[0])
-                lds = int(re.search(r"\.group_segment_fixed_size:\s+(\d+)", blk).group(1))
-                seen[name] = (v, lds)
+    seen = kernel_resources(solo_amd.LIB_PATH)
     checked = 0
-    for name, (v, lds) in seen.items():
+    for name, r in seen.items():
+        v, lds = r["vgpr_alloc"], r["lds"]
+        assert v is not None and v >= r["vgpr"] + r["agpr"], (name, r)
         if "_wb" in name:                 # the 32 kHz build: larger frames, its own budgets are not part of the plan -- except the
             if "solo_dec_synth_kernel" in name or "solo_decode_kernel" in name:      # decoder's two waves per SIMD (round 5: 262 registers = one wave, decode 45 % slower)
                 assert v <= 256, (name, "vector registers", v, "budget", 256)
