@@ -609,7 +609,11 @@ def main():
         peak_issue = N_SIMD * CLOCK_HZ / CYCLES_PER_VALU
         if insts.get("valu_per_packet_round_trip"):
             v = insts["valu_per_packet_round_trip"] * (value / world)
-            res["valu_issue"] = {"bound": "valu_issue", "achieved": round(v / 1e9, 2), "peak": round(peak_issue / 1e9, 1),
+            # share of the time a SIMD's vector unit is executing: VALU wave-instructions of this run per SIMD and second (SQ_INSTS_VALU of the
+            # committed counter pass x this run's packet rate) x the measured cost of an instruction of this path's class mix (a third of them
+            # full rate at 1.15 ns, two thirds half rate at 1.85 ns per SIMD: profiles/r05_issue_model.txt, tools/debug/nsq_row_mix.py)
+            busy = v / N_SIMD * (1.15e-9 / 3.0 + 2.0 * 1.85e-9 / 3.0)
+            res["valu_issue"] = {"bound": "valu_issue", "achieved": round(v / 1e9, 2), "peak": round(peak_issue / 1e9, 1), "valu_busy_frac": round(busy, 3),
                                  "unit": "G wave-instructions/s (VALU)", "frac": round(v / peak_issue, 4),
                                  "valu_wave_instructions_per_packet": insts.get("valu_per_packet"),
                                  "all_wave_instructions_per_packet": insts.get("all_per_packet"),
@@ -629,12 +633,54 @@ def main():
             if cb and cb.get("per_core_packets_per_s"):
                 cb["gpu_equals_reference_cores"] = round(value / cb["per_core_packets_per_s"], 1)
             res["cpu_baseline"] = cb
-        print(json.dumps(res), flush=True)
+        print(json.dumps(compact_line(res), separators=(",", ":")), flush=True)
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if checked is False:
         raise SystemExit("bench.py: the first step does NOT equal the compiled reference's hashes (rank %d, first stream %d)" % (rank, first))
+
+
+# ---- the line as printed: under ~6 KB, the fields a reader looks for first at its END (a driver keeps the tail of stdout) -------------
+# What the numbers mean (formulae, where the counters come from, how the CPU sample was taken) is DESIGN.md section 6, not the line.
+_DROP = {"note", "parity_note", "clock_note", "formula", "what", "profile_source", "lane_utilisation_is", "kernels_of_the_stage",
+         "worker_cpu_seconds", "host", "whole_node_packets_per_s", "per_gpu_packets_per_s", "source", "from_this_build", "algorithmic_bytes_per_launch",
+         "packets_per_launch", "achieved_GBps"}
+_TAIL = ("kernel_source_sha16", "profile_matches_head", "third_step_pipelined_checked", "shader_clock_mhz_under_vector_load", "valu_busy_frac", "parity_checked")
+
+
+def _squeeze(o, depth=0):
+    if isinstance(o, dict):
+        out = {}
+        for k, v in o.items():
+            if k in _DROP:
+                continue
+            if k.endswith("_md5") and isinstance(v, str):
+                v = v[:12]
+            elif k in ("workload", "sample", "build", "schedule", "launch", "traffic_is") and isinstance(v, str) and len(v) > 150:
+                v = v[:147] + "..."
+            out[k] = _squeeze(v, depth + 1)
+        return out
+    if isinstance(o, list):
+        return [_squeeze(v, depth + 1) for v in o]
+    return o
+
+
+def compact_line(res):
+    r = _squeeze(res)
+    r.pop("launches_per_step", None)              # (each entry of `kernels` carries its own)
+    if isinstance(r.get("parity"), dict):
+        r["third_step_pipelined_checked"] = r["parity"].get("third_step_pipelined_checked")
+        ranks = r["parity"].get("ranks") or []
+        r["parity"] = {"third_step_pipelined_checked": r["third_step_pipelined_checked"], "blocks_checked": sum(len(x.get("blocks") or []) for x in ranks),
+                       "first_block": (ranks[0]["blocks"][0] if ranks and ranks[0].get("blocks") else None)}
+    vi = r.get("valu_issue")
+    if isinstance(vi, dict) and vi.get("valu_busy_frac") is not None:
+        r["valu_busy_frac"] = vi["valu_busy_frac"]
+    for k in _TAIL:                                # re-insert at the end, in this order
+        if k in r:
+            r[k] = r.pop(k)
+    return r
 
 
 if __name__ == "__main__":
