@@ -7,6 +7,10 @@
  * a batch of ONE stream whose codec state lives in HBM; every call launches the same gfx950 kernels
  * as the batched API (there is no host-side codec arithmetic and no CPU fallback: if no HIP device is
  * usable, Init returns NULL and Encode/Decode return -1).
+ * THESE SIX SYMBOLS ARE A CONFORMANCE AND MIGRATION PATH, NOT A REPLACEMENT FOR THE REFERENCE'S PER-CALL SPEED: a call is the
+ * single-wavefront kernel chain of one packet end to end plus two small copies and one synchronisation -- Encode 1.06 ms (2.7 x the
+ * reference's 0.39 ms on one host core), Decode 0.21 ms (8.8 x its 0.024 ms); tools/legacy_api_cost.py measures both.  One stream is
+ * 1 / 4096 of what the device does in that time: throughput comes from Part 2.
  *
  * Part 2 is the additive batched API: N independent streams per handle, device pointers in,
  * device pointers out, one wavefront per stream.  This is what a server-side integration binds
@@ -91,10 +95,11 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  * Return value: 0 or a negative hipError_t.  solo_batch_encode returns -1 for n_packets >= ~700 000 (16 kHz) / ~350 000 (32 kHz) per
  * call -- split longer (offline) inputs over several calls; state carries over.
  * Device memory a handle holds besides the stream states: encode -- the hand-over records of one call, 4.3 KB per packet of the call
- * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 1952 B per
- * packet of a CHUNK (16 kHz API rate): a call is cut into chunks of min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 1952)) packets but never
- * less than ONE, so one buffer holds max(n_streams x 1952 B, at most SOLO_DEC_SCRATCH_CAP bytes) (environment, read when the handle
- * decodes for the first time; default -- also for 0 or an unparsable value -- 1 GiB).
+ * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 2208 B per
+ * packet of a CHUNK (16 kHz API rate; 2 x sizeof(SxExtracted): solo_api.hip asserts the figure): a call is cut into chunks of
+ * min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 2208)) packets but never less than ONE, so one buffer holds max(n_streams x 2208 B, at most
+ * SOLO_DEC_SCRATCH_CAP bytes) (environment, read when the handle decodes for the first time; default -- also for 0 or an unparsable
+ * value -- 1 GiB: 4096 streams x 64 packets are 579 MB, 8192 streams get chunks of 59 packets).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct solo_batch solo_batch_t;
 

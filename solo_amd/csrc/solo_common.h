@@ -403,70 +403,6 @@ SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, i
     *shift = shft;
     *energy = (i32)nrg;
 }
-#elif defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 32
-// ... and with two streams per wavefront (a 32-lane half each): the same rounds, the scan and the look-ups inside the half
-SX_HD u32 sx_uadd_sat(u32 a, u32 b) { const u32 r = a + b; return r < a ? 0xFFFFFFFFu : r; }
-SX_HD u32 wv_scan_sat(u32 v) {      // inclusive saturating prefix sum over the 32 lanes of the half
-    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x111, 0xF, 0xF, true));
-    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x112, 0xF, 0xF, true));
-    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x114, 0xF, 0xF, true));
-    v = sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x118, 0xF, 0xF, true));
-    // the second row of the half adds the first row's total (row_bcast:15 into rows 1 and 3; the other rows get 0)
-    return sx_uadd_sat(v, (u32)__builtin_amdgcn_update_dpp(0, (i32)v, 0x142, 0xA, 0xF, false));
-}
-SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
-    const int start = odd_start ? 1 : 0;
-    const int npairs = (len - start) >> 1;
-    const int tail = (len - start) & 1;
-    if (npairs > 8 * 32) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); return; }
-    u32 nrg = odd_start ? (u32)sx_smulbb(x[0], x[0]) : 0u;
-    const int C = (npairs + 31) >> 5;
-    u32 P[8];
-#pragma unroll
-    for (int j = 0; j < 8; j++) {
-        const int m = SX_LANE * C + j;
-        u32 v = 0;
-        if (j < C && m < npairs) {
-            const i32 a = x[start + 2 * m], b = x[start + 2 * m + 1];
-            v = (u32)(a * a) + (u32)(b * b);
-        }
-        P[j] = v;
-    }
-    int cur = 0, shft = 0;
-    const int hsh = (int)(threadIdx.x & 32u);
-    for (;;) {
-        u32 sl = 0;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int m = SX_LANE * C + j;
-            if (m >= cur) sl = sx_uadd_sat(sl, P[j] >> shft);
-        }
-        const u32 pre = wv_scan_sat(sl);
-        const u32 tot = sx_uadd_sat(nrg, pre);
-        const u32 cross = (u32)(__builtin_amdgcn_ballot_w64(tot >= 0x80000000u) >> hsh);
-        if (!cross) { nrg = (u32)__shfl((i32)tot, 31, 32); break; }
-        const int Lc = __builtin_ctz(cross);
-        u32 base = nrg;
-        const u32 before = (u32)__shfl((i32)pre, Lc > 0 ? Lc - 1 : 0, 32);
-        if (Lc > 0) base += before;
-        bool found = false;
-#pragma unroll
-        for (int j = 0; j < 8; j++) {
-            const int m = Lc * C + j;
-            const u32 pj = (u32)__shfl((i32)P[j], Lc, 32);
-            if (!found && j < C && m >= cur) {
-                base += pj >> shft;
-                if (base >= 0x80000000u) { found = true; cur = m + 1; }
-            }
-        }
-        nrg = base >> 2;
-        shft += 2;
-    }
-    if (tail) nrg += (u32)sx_smulbb(x[len - 1], x[len - 1]) >> shft;
-    if (nrg & 0xC0000000u) { nrg >>= 2; shft += 2; }
-    *shift = shft;
-    *energy = (i32)nrg;
-}
 #else
 SX_HD void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
 #endif

@@ -35,14 +35,10 @@
 #define SX_DD_MASK (SX_DD_DELAY - 1)
 
 // ---- the lanes of a stream ---------------------------------------------------------------------------------------------------
-// RW_TPL: tracks per lane on the GPU.  1: the row layout above.  3: ONE LANE = ONE STATE carrying its THREE tracks, a stream is a
-// DPP quad, sixteen streams per wavefront (256 wavefronts per 4096 streams): a third of the row layout's instructions per stream --
-// the decision phases are executed once per sixteen streams instead of once per four -- but a three times longer chain per sample.
-// Same source: the loop over "the lanes of a stream" (RW_FORK) then walks the three tracks of the lane's state, per-track values
-// live in arrays of three, per-state values in arrays of one, and the cross-track exchanges are register moves.
-#ifndef RW_TPL
-#define RW_TPL 1
-#endif
+// On the GPU one lane is one (track, state) pair (the row layout above); the host emulation walks twelve virtual lanes in loops.  The loop
+// over "the lanes of a stream" (RW_FORK), per-(track, state) values in arrays of RW_NL, per-state values in arrays of RW_NS.  (Round 3's
+// layout -- one lane = one state carrying its three tracks, sixteen streams per wavefront, a third of the instructions per stream but a
+// three times longer chain per sample and ONE such wavefront per compute unit -- was measured slower and is gone: DESIGN_NOTES.md section 9.)
 #if SX_NLANES == 1
 #define RW_NL 12                                 // per (track, state) values
 #define RW_NS 12                                 // per state values (the emulation keeps a copy per virtual lane)
@@ -52,15 +48,6 @@
 #define RW_ONCE(l) 1                             // per-state work: every virtual lane maintains its copy
 #define RW_IS_C(l) 1                             // centre-only / side-only work: done by every lane, used where it applies
 #define RW_IS_S(l) 1
-#elif RW_TPL == 3
-#define RW_NL 3
-#define RW_NS 1
-#define RW_FORK(l) _Pragma("unroll") for (int t_ = 0; t_ < 3; t_++) for (int l = 4 * t_ + (int)(threadIdx.x & 3u), once_ = 1; once_; once_ = 0)
-#define RW_LI(l) ((l) >> 2)
-#define RW_SI(l) 0
-#define RW_ONCE(l) (((l) >> 2) == 0)
-#define RW_IS_C(l) (((l) >> 2) == 0)
-#define RW_IS_S(l) (((l) >> 2) != 0)
 #else
 #define RW_NL 1
 #define RW_NS 1
@@ -144,18 +131,6 @@ SX_HD i32 rwk_pick_(i32 v, i32 idx) { return rwk_or_((i32)(threadIdx.x & 3u) == 
 #define RWS_PICK(dst, src, idx) { (dst)[0] = rwk_pick_((src)[0], (idx)[0]); }
 #define RWS_SUM(val, out) { (out)[0] = rwk_sum_((val)[0]); }
 #define RWS_PERM(LV, idx) { LV(0) = rwk_from(LV(0), (idx)[0]); }
-#if RW_TPL == 3
-// ---- a quad per stream: per-track values are three registers of the lane ----
-#define RWK_GATHER(dst, src, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (dst)[q_] = rwk_sel((src)[q_], (idx)[0]); }
-#define RWK_PICK(dst, src, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) (dst)[q_] = rwk_pick_((src)[q_], (idx)[0]); }
-#define RWK_PERM(LV, idx) { _Pragma("unroll") for (int q_ = 0; q_ < 3; q_++) LV(q_) = rwk_from(LV(q_), (idx)[0]); }
-#define RWK_ARGMIN(val, mv, mi) RWS_ARGMIN(val, mv, mi)
-#define RWK_ARGMAX(val, mv, mi) RWS_ARGMAX(val, mv, mi)
-#define RWT_FROM(dst, src, T) { (dst)[0] = (src)[T]; }
-#define RWT_TO0(dst, src, T) { (dst)[0] = (src)[T]; }
-#define RWT_SUM(dst, src) { (dst)[0] = sx_add(sx_add((src)[0], (src)[1]), (src)[2]); }
-#define RWT_OR(dst, src) { (dst)[0] = (src)[0] | (src)[1] | (src)[2]; }
-#else
 // ---- a 16-lane row per stream: one (track, state) per lane ----
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(RW_CENTRE_SERIAL)
 #define RW_ROW_C 1                    // the centre's four combinations: one per quad of the row (phase C of the sample step)
@@ -178,7 +153,6 @@ SX_HD i32 rwt_from2(i32 v) { const u32 t_ = threadIdx.x & 12u; const i32 a_ = RW
         (dst)[0] = sx_add(sx_add(v_, RW_DPP(v_, RW_ROR(4))), sx_add(RW_DPP(v_, RW_ROR(8)), RW_DPP(v_, RW_ROR(12)))); }
 #define RWT_OR(dst, src) { const i32 v_ = (threadIdx.x & 12u) == 12u ? 0 : (src)[0]; \
         (dst)[0] = (v_ | RW_DPP(v_, RW_ROR(4))) | (RW_DPP(v_, RW_ROR(8)) | RW_DPP(v_, RW_ROR(12))); }
-#endif
 #endif
 #ifndef RW_ROW_C
 #define RW_ROW_C 0
@@ -346,11 +320,7 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
         decisionDelay = sx_min(decisionDelay, lagC - SX_LTP_ORDER / 2 - 1);
     }
     const int LSF_interpolation_flag = c->NLSFInterpCoef_Q2 == 4 ? 0 : 1;
-#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
-#define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)(((pos_) * 3 + RW_T(lane_)) * rstride) + rlane + (u32)RW_K(lane_)) * (u32)sizeof(SxRowCell))
-#else
 #define RW_CELL(pos_, lane_) SX_AT(SxRowCell, ringu, ((u32)((pos_) * rstride) + rlane + (u32)(lane_)) * (u32)sizeof(SxRowCell))
-#endif
     // the sample loop's own ring traffic (every cell is written once and read once, a decision delay later) with the non-temporal
     // cache policy: 32 MB of ring per 4096 streams otherwise sweep everything else -- the stream histories the subframe prologues
     // wait for -- out of the 32 MB of L2
@@ -713,17 +683,12 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             const SxRowV4* cv = (const SxRowV4*)__builtin_assume_aligned((const char*)w->coef + co_, 16);
             i32 cf[RW_NCOEF];
 #define RW_CF_LOAD(j0_, j1_) _Pragma("unroll") for (int j = (j0_); j < (j1_); j++) { const SxRowV4 v_ = cv[j]; cf[4 * j] = v_.x; cf[4 * j + 1] = v_.y; cf[4 * j + 2] = v_.z; cf[4 * j + 3] = v_.w; }
-#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
-            RW_CF_LOAD(0, RW_NCOEF / 4)                // (a quad per stream: once for the lane's three tracks; the register budget is 256)
-#define RW_CF_STAGE(j0_, j1_)
-#else
             // (a row per stream: in three groups, each requested one stage before its use: all at once they would be 40 live registers
             // at the point of the sample step where the filter states are live as well)
 #ifdef RW_NO_CF_FENCE
 #define RW_CF_STAGE(j0_, j1_) RW_CF_LOAD(j0_, j1_)
 #else
 #define RW_CF_STAGE(j0_, j1_) SX_SCHED_FENCE(); RW_CF_LOAD(j0_, j1_) SX_SCHED_FENCE();
-#endif
 #endif
             const i32 *Apre = cf + RW_CA, *ARpre = cf + RW_CAR, *Bpre = cf + RW_CB;
             constexpr int G1 = (RW_CAR + 3) / 4, G2 = (RW_CB + 3) / 4;      // 16-byte groups that hold A | the rest of AR | the rest
@@ -760,26 +725,21 @@ SX_NSQ_FN void sx_nsq_del_dec(char* Pu, u32 pOff, const SxNsqIn* c, char* Ou, u3
             // Agora_Silk_STS (Agora_SILK_func.c:85): warped shaping filter, state updated in place.  One all-pass section is
             // difference -> multiply -> add, each waiting for the one before; RW_STEP issues one such operation for every track of
             // the lane before the next (three tracks per lane: the order is pinned, the tracks hide each other's result latency)
-#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 3
-#define RW_TIE(a_) asm volatile("" : "+v"(a_[0]), "+v"(a_[1]), "+v"(a_[2]));
-#else
-#define RW_TIE(a_)
-#endif
 #define RW_STEP(body_) { RW_FORK(l) { const int li = RW_LI(l); body_ } }
             i32 dd_[RW_NL], mm_[RW_NL];
-            RW_STEP(dd_[li] = sx_smulw_pre(sAR2[li][0], warp_pre);) RW_TIE(dd_)
-            RW_STEP(tmp2[li] = sx_add(sLPC[li][0], dd_[li]);) RW_TIE(tmp2)
-            RW_STEP(dd_[li] = sx_sub(sAR2[li][1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[0]);) RW_TIE(dd_) RW_TIE(mm_)
-            RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = mm_[li];) RW_TIE(dd_)
-            RW_STEP(tmp1[li] = sx_add(sAR2[li][0], dd_[li]); sAR2[li][0] = tmp2[li];) RW_TIE(tmp1)
+            RW_STEP(dd_[li] = sx_smulw_pre(sAR2[li][0], warp_pre);)
+            RW_STEP(tmp2[li] = sx_add(sLPC[li][0], dd_[li]);)
+            RW_STEP(dd_[li] = sx_sub(sAR2[li][1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[0]);)
+            RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = mm_[li];)
+            RW_STEP(tmp1[li] = sx_add(sAR2[li][0], dd_[li]); sAR2[li][0] = tmp2[li];)
 #pragma unroll
             for (int j = 2; j < SX_SHAPE_ORDER; j += 2) {
-                RW_STEP(dd_[li] = sx_sub(sAR2[li][j], tmp1[li]); mm_[li] = sx_smulw_pre(tmp1[li], ARpre[j - 1]);) RW_TIE(dd_) RW_TIE(mm_)
-                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);) RW_TIE(dd_) RW_TIE(nAR_)
-                RW_STEP(tmp2[li] = sx_add(sAR2[li][j - 1], dd_[li]); sAR2[li][j - 1] = tmp1[li];) RW_TIE(tmp2)
-                RW_STEP(dd_[li] = sx_sub(sAR2[li][j + 1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[j]);) RW_TIE(dd_) RW_TIE(mm_)
-                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);) RW_TIE(dd_) RW_TIE(nAR_)
-                RW_STEP(tmp1[li] = sx_add(sAR2[li][j], dd_[li]); sAR2[li][j] = tmp2[li];) RW_TIE(tmp1)
+                RW_STEP(dd_[li] = sx_sub(sAR2[li][j], tmp1[li]); mm_[li] = sx_smulw_pre(tmp1[li], ARpre[j - 1]);)
+                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);)
+                RW_STEP(tmp2[li] = sx_add(sAR2[li][j - 1], dd_[li]); sAR2[li][j - 1] = tmp1[li];)
+                RW_STEP(dd_[li] = sx_sub(sAR2[li][j + 1], tmp2[li]); mm_[li] = sx_smulw_pre(tmp2[li], ARpre[j]);)
+                RW_STEP(dd_[li] = sx_smulw_pre(dd_[li], warp_pre); nAR_[li] = sx_add(nAR_[li], mm_[li]);)
+                RW_STEP(tmp1[li] = sx_add(sAR2[li][j], dd_[li]); sAR2[li][j] = tmp2[li];)
             }
             RW_FORK(l) {
                 const int li = RW_LI(l), si = RW_SI(l);

@@ -5,16 +5,7 @@
 // order: packet by packet, two frames each.  4096 streams = 1024 wavefronts = one per SIMD: the quantiser's wave is a dependent
 // chain that issues every ~5 cycles; the analysis / coding kernels of the neighbouring chunks of the pipeline fill the rest of
 // every SIMD's issue slots.
-// -DRW_TPL=3: the other layout of the same source (solo_enc_nsq_row.h): one lane = one state carrying its three tracks, a DPP quad per
-// stream, SIXTEEN streams per wavefront, 256 wavefronts per 4096 streams.
-#ifndef RW_TPL
-#define RW_TPL 1
-#endif
-#if RW_TPL == 3
-#define SX_GROUP 4
-#else
 #define SX_GROUP 16
-#endif
 #define SX_PER_WAVE (64 / SX_GROUP)
 // wavefronts per workgroup of the persistent kernel (4: one workgroup per compute unit, one wavefront per SIMD; > 1: wv_sync() of this translation unit must not contain a workgroup
 // barrier -- the wavefronts' control flow differs, each follows its own streams -- see solo_wave.h)
@@ -34,9 +25,7 @@
 // wave still takes four analysis waves of 96 (128 + 4 x 96 = 512), so all sixteen analysis workgroups of a compute unit stay
 // resident beside its four quantiser waves.
 #ifndef SX_NSQ_VGPR_CAP
-#if RW_TPL == 3
-#define SX_NSQ_VGPR_CAP 128          // (three tracks per lane: 256 registers; one such wave per compute unit)
-#elif SX_FS_KHZ == 16
+#if SX_FS_KHZ == 16
 #define SX_NSQ_VGPR_CAP 80           // (32 kHz build: order-16 prediction spills inside the sample loop at 128 registers -- 160: encode 72.0 -> 67.0 ms
                                      // per 4096 x 25 packets; its analysis workgroups are LDS-bound to nine per compute unit, the registers are free)
 #else
@@ -49,7 +38,7 @@
 #define SX_NSQ_CAP_ATTR
 #endif
 // ring: SX_DD_DELAY rows of 64 cells per workgroup and track-per-lane (the emission ring of its streams, rows of 64 lanes = 1 KB)
-#define SX_NSQ_RING_CELLS (SX_DD_DELAY * 64 * RW_TPL)
+#define SX_NSQ_RING_CELLS (SX_DD_DELAY * 64)
 extern "C" __global__ void SX_NSQ_CAP_ATTR __launch_bounds__(64) SX_K(solo_nsq_kernel)(SxEncStream* states, const SxNsqIn* __restrict__ in,
                                                                  SxNsqOut* __restrict__ out, int n_streams, int n_packets, int p0, int pc,
                                                                  unsigned int* started, SxRowCell* __restrict__ ring) {
@@ -192,7 +181,7 @@ extern "C" int solo_launch_gate(const unsigned int* flag, unsigned int target, v
 
 // Unit check of the row exchanges (tests/test_gpu_nsq_row.py): out[0..7][lane] = the primitives applied to in[lane]
 extern "C" __global__ void __launch_bounds__(64) solo_debug_rowops_kernel(const i32* in, const i32* idx, i32* out) {
-#if defined(__HIP_DEVICE_COMPILE__) && RW_TPL == 1
+#if defined(__HIP_DEVICE_COMPILE__)
     const int lane = threadIdx.x;
     i32 v[1] = {in[lane]}, ix[1] = {idx[lane] & 3}, d[1] = {-1}, mv[1], mi[1];
     RWT_FROM(d, v, 0) out[0 * 64 + lane] = d[0];

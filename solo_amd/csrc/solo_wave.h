@@ -17,7 +17,7 @@
 #include "solo_fix.h"
 
 #if defined(__HIP_DEVICE_COMPILE__) && defined(SX_GROUP)
-// quantiser kernel: SEVERAL streams per wavefront, SX_GROUP (16 or 32) lanes each ("wave-uniform" then means uniform within
+// quantiser kernel: SEVERAL streams per wavefront, SX_GROUP (16) lanes each ("wave-uniform" then means uniform within
 // the lane group; the hardware's exec masking serialises groups that take different branches)
 #define SX_NLANES SX_GROUP
 #define SX_LANE ((int)(threadIdx.x & (SX_GROUP - 1)))
@@ -51,7 +51,7 @@ SX_HD void wv_sync_lds() {
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #endif
 }
-#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 32 || SX_NLANES == 16)
+#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 16)
 // Reductions without the LDS crossbar: four DPP steps (quad_perm [1,0,3,2], [2,3,0,1], row_half_mirror, row_mirror) leave the
 // result of each 16-lane row in all of its lanes; the four rows are then combined on the scalar unit (v_readlane), which also
 // makes the result provably wave-uniform.  Wrapping adds / min / max are order-independent, so this equals the serial scan.
@@ -64,13 +64,6 @@ SX_HD void wv_sync_lds() {
     { i32 a_ = __builtin_amdgcn_readlane(v, 0), b_ = __builtin_amdgcn_readlane(v, 16),           \
           c_ = __builtin_amdgcn_readlane(v, 32), d_ = __builtin_amdgcn_readlane(v, 48);          \
       { i32 t_ = b_; v = a_; a_ = OP; } { i32 t_ = d_; v = c_; c_ = OP; } { i32 t_ = c_; v = a_; v = OP; } }
-#elif SX_NLANES == 32
-// two streams per wavefront, a 32-lane half each: the half's two rows exchange their results with the gfx950 row swap
-// (v_permlane16_swap: the odd rows of one operand <-> the even rows of the other; with both operands the same value, element [0] of
-// the result holds the half's EVEN row in both of its rows, element [1] its odd row -- measured, tools/debug)
-#define SX_ROWS_COMBINE(v, OP)                                                                   \
-    { auto sw_ = __builtin_amdgcn_permlane16_swap((v), (v), false, false);                       \
-      const i32 t_ = (i32)sw_[1]; v = (i32)sw_[0]; v = OP; }
 #else
 #define SX_ROWS_COMBINE(v, OP)
 #endif
@@ -123,12 +116,6 @@ SX_HD i64 wv_sum64(i64 v) {
     for (int row = 0; row < 4; row++)
         acc += ((u64)(u32)__builtin_amdgcn_readlane((i32)hi, row * 16) << 32) | (u32)__builtin_amdgcn_readlane((i32)lo, row * 16);
     r = acc;
-#elif SX_NLANES == 32
-    {
-        auto sl_ = __builtin_amdgcn_permlane16_swap(lo, lo, false, false);
-        auto sh_ = __builtin_amdgcn_permlane16_swap(hi, hi, false, false);
-        r = (((u64)(u32)sh_[0] << 32) | (u32)sl_[0]) + (((u64)(u32)sh_[1] << 32) | (u32)sl_[1]);
-    }
 #endif
     return (i64)r;
 }
@@ -147,7 +134,7 @@ SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
 #endif
 }
 // (value, index) arg-min with "first index wins on ties" (matches a serial `<` scan)
-#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 32 || SX_NLANES == 16)
+#if defined(__HIP_DEVICE_COMPILE__) && (SX_NLANES == 64 || SX_NLANES == 16)
 #define SX_ARG_STEP(CTRL, CMP)                                                                   \
     { i32 tv = SX_DPP_(bv, CTRL), ti = SX_DPP_(bi, CTRL);                                        \
       const bool take_ = (tv CMP bv) | ((tv == bv) & (ti < bi));                                 \
@@ -160,13 +147,6 @@ SX_HD i32 wv_bcast(i32 v, int src) {   // broadcast lane `src`'s value
           const bool take_ = (tv CMP rv) | ((tv == rv) & (ti < ri));                             \
           rv = take_ ? tv : rv; ri = take_ ? ti : ri; }                                          \
       bv = rv; bi = ri; }
-#elif SX_NLANES == 32
-#define SX_ARG_ROWS(CMP)                                                                         \
-    { auto sv_ = __builtin_amdgcn_permlane16_swap(bv, bv, false, false);                         \
-      auto si_ = __builtin_amdgcn_permlane16_swap(bi, bi, false, false);                         \
-      const i32 rv = (i32)sv_[0], ri = (i32)si_[0], tv = (i32)sv_[1], ti = (i32)si_[1];          \
-      const bool take_ = (tv CMP rv) | ((tv == rv) & (ti < ri));                                 \
-      bv = take_ ? tv : rv; bi = take_ ? ti : ri; }
 #else
 #define SX_ARG_ROWS(CMP)
 #endif

@@ -5,8 +5,8 @@ interoperate with the stock reference binaries and their known-answer md5s can b
   python -m solo_amd.harness enc in.pcm out.bit [-rate bps] [-MDI 0/1] [-joint 1] [-DTX 1] [-Fs_API 32000] [-framesize 20]
   python -m solo_amd.harness dec in.bit out.pcm [-loss perc] [-dec_mode 1|2] [-MDI 0/1] [-joint 1] [-Fs_API 32000] [-framesize 20]
 
-Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per 40 ms packet  int16 total, int16 len(MD2)+8, `total` payload bytes
-(payload = MD1 || MD2 || HB(8)).  Loss simulator (test/dec_main.c:24,236-252): rand_seed = 1, the LCG
+Record format (JC1_SDK_SRC_ARM/test/enc_main.c:243-249): per packet (40 ms; 20 ms with -framesize 20)  int16 total,
+int16 len(MD2)+HB, `total` payload bytes (payload = MD1 || MD2 || HB; HB = 8 bytes, 4 with -framesize 20 or -joint 1).  Loss simulator (test/dec_main.c:24,236-252): rand_seed = 1, the LCG
 seed <- 907633515 + seed * 196314165 (mod 2^32) is drawn twice (MD1, MD2) on every EVEN packet and the pair of decisions is
 reused for the following odd packet; a description is lost when ((seed >> 16) + 32768) / 65535 < loss / 100 in float32.
 The receiver-side mapping of the decisions to (ptr, nBytes, lostflag) (dec_main.c:255-378) runs on the GPU inside
@@ -155,16 +155,20 @@ def main(argv=None):
     if fs not in (16000, 32000):
         print("-Fs_API: 16000 or 32000")
         return 2
+    framesize = _opt(argv, "-framesize", 40)
+    if framesize not in (20, 40):
+        print("-framesize: 40 or 20")
+        return 2
     if argv[0] == "enc":
         recs = encode_pcm(np.fromfile(argv[1], np.int16), rate=_opt(argv, "-rate", 13600), use_md_index=mdi,
-                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0), samplerate=fs, framesize_ms=_opt(argv, "-framesize", 40))
+                          joint=1 if _opt(argv, "-joint", 0) == 1 else 0, dtx=_opt(argv, "-DTX", 0), samplerate=fs, framesize_ms=framesize)
         open(argv[2], "wb").write(write_bit_container(recs))
-        print("%d packets, %.3f kbps" % (len(recs), sum(r[1] for r in recs) * 8 / max(len(recs), 1) / 40.0))
+        print("%d packets of %d ms, %.3f kbps" % (len(recs), framesize, sum(r[1] for r in recs) * 8 / max(len(recs), 1) / float(framesize)))
     else:
         pcm = decode_records(parse_bit_container(open(argv[1], "rb").read()), loss_perc=_opt(argv, "-loss", 0), use_md_index=mdi,
-                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0, samplerate=fs, dec_mode=_opt(argv, "-dec_mode", 0), framesize_ms=_opt(argv, "-framesize", 40))
+                             joint=1 if _opt(argv, "-joint", 0) == 1 else 0, samplerate=fs, dec_mode=_opt(argv, "-dec_mode", 0), framesize_ms=framesize)
         pcm.astype(np.int16).tofile(argv[2])
-        print("%d packets decoded" % (pcm.size // (PACKET_SAMPLES * fs // 16000)))
+        print("%d packets of %d ms decoded" % (pcm.size // (PACKET_SAMPLES * fs // 16000 * framesize // 40), framesize))
     return 0
 
 
