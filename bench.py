@@ -271,7 +271,11 @@ def main():
     first = args.first_stream if args.first_stream >= 0 else sdist.stream_range(rank, N)[0]
     ncpu, _ = effective_cores()
     workers = max(1, min(16, ncpu // max(1, min(world, 8))))
+    # (outside the timed region.  The generator costs ~19 ms per stream of 50 packets on one host core: a rank of the 8-GPU job -- 8192
+    # streams, 16 usable CPUs / 8 ranks = 2 workers -- spends ~80 s here, the one-GPU run ~5 s; reported as config.input_generation_s)
+    t_gen = time.perf_counter()
     pcm_host = synth_batch(first, N, P, workers=workers)
+    t_gen = time.perf_counter() - t_gen
     import torch
     import solo_amd
 
@@ -564,6 +568,7 @@ def main():
                                    ("BASELINE configs[4]: %d synthetic 16 kHz WB streams sharded evenly across %d x MI355X (%d per GPU), encode + "
                                     "decode per rank, RCCL gather only, 13.6 kbps, %d packets/stream/step" % (N * world, world, N, P)),
                        "streams_per_gpu": N, "packets_per_stream_per_step": P, "mean_payload_bytes": round(mean_payload, 2),
+                       "input_generation_s": round(t_gen, 1), "input_workers": workers,
                        "launch": "torch.distributed.run, one rank per GPU" + (" (started by bench.py itself)" if os.environ.get("SOLO_SELF_LAUNCHED") else "") if world > 1 else "single process",
                        "runtime_env": {k: os.environ[k] for k in ("GPU_MAX_HW_QUEUES", "SOLO_DEC_SPLIT", "SOLO_DEC_CHUNK", "SOLO_DEC_FIRST_CHUNK", "SOLO_ENC_CHUNK") if k in os.environ},
                        "schedule": ("consecutive steps pipelined: encode of step k+1 issued before the decode of step k "
