@@ -136,10 +136,6 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
                                                             int n_streams, int n_packets, int p0, int pc, int slot, int useMDIndex,
                                                             const SxExtracted* __restrict__ recs, i16* __restrict__ pcm, i32* status) {
     __shared__ SxDecWork w;
-#ifdef SX_EXP_PAD
-    __shared__ volatile char exp_pad_[SX_EXP_PAD];
-    exp_pad_[threadIdx.x] = 0;
-#endif
     const int s = blockIdx.x;
     if (s >= n_streams) return;
 #if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)

@@ -543,9 +543,6 @@ struct SxCodeIn {
     i16 hi[SX_BAND];                 // high band of the packet (QMF output) for the BWE encoder
 };
 
-#ifndef SX_EXP_ANALYSIS_FRAMES
-#define SX_EXP_ANALYSIS_FRAMES 2      // (timing experiments: 1 = only the first frame of a packet is analysed -- wrong output)
-#endif
 // Stage A of AGR_Sate_Encoder_Encode (AGR_BWE_SDK_API.c:129): QMF split and the analysis chain of both 20 ms frames.
 // Nothing here depends on the quantiser's output (DISABLE_BUF_RD, SKP_Silk_define.h:53), so a whole launch of packets
 // can be analysed before any is quantised.
@@ -558,7 +555,7 @@ SX_FNW void sx_enc_stage_a(SxEncStream* rec, SxEncWork* w, const i16* pcm, SxNsq
     sx_qmf_decomp(hist, pcm, w->u.qmf_tl, hist->lo, cin->hi, fpp * 2 * SX_FRAME);
     wv_sync();
     SX_T(0)
-    for (int frame = 0; frame < (SX_EXP_ANALYSIS_FRAMES < 2 ? SX_EXP_ANALYSIS_FRAMES : fpp); frame++) {
+    for (int frame = 0; frame < fpp; frame++) {
         sx_enc_analyse_frame(rec, w, hist->lo + frame * SX_FRAME, frame, &in2[frame], &cin->idx[frame]);
         wv_sync();
     }

@@ -1,8 +1,5 @@
-// solo_enc_k.hip -- the encoder's analysis / front / high-band / range-coding kernels and the launch table of the build
+// solo_enc_k.hip -- the encoder's analysis / high-band / range-coding kernels and the launch table of the build
 // (solo_enc_kernels.h).  A translation unit of their own, apart from the decoder's.
-// wv_sync() of this translation unit is wave-local (solo_wave.h): the front kernel's workgroups hold several wavefronts that each follow
-// their own stream and never meet at a barrier
-#define SX_SYNC_WAVE_ONLY 1
 #include <hip/hip_runtime.h>
 #include "solo_enc_kernels.h"
 #if SX_FS_KHZ == 8
@@ -46,8 +43,3 @@ extern "C" int32_t solo_debug_site_hits(unsigned long long* out64, int32_t reset
 }
 #endif
 
-#if defined(SX_PIPE_TRACE) && SX_FS_KHZ == 8
-extern "C" int32_t solo_debug_front_trace(unsigned long long* out, int32_t n_streams) {
-    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sx_front_trace), (size_t)n_streams * 6 * sizeof(unsigned long long)) == hipSuccess ? 0 : -1;
-}
-#endif

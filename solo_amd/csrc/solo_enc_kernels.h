@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 #include "solo_enc.h"
 
+#ifndef SX_TU_FRONT       // (the front kernel lives in a translation unit of its own, solo_enc_front_k.hip: see there)
 __global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, int fpp) {
     const int s = blockIdx.x;
     if (s >= n_streams) return;
@@ -22,6 +23,7 @@ __global__ void __launch_bounds__(64) SX_K(solo_enc_init_kernel)(SxEncStream* st
 //    ONE launch of solo_nsq_persist_kernel (solo_nsq_row.hip); the two hand packets to each other through per-stream flags in HBM while
 //    they run (solo_wave.h: "publish / consume"), so no launch ever waits for the stragglers of another.  Measured slower than the
 //    launch-per-chunk schedule, kept as the measured answer to "remove the launch tails".
+#endif
 #ifdef SX_OUTLINE_WRAPPERS
 #define SX_ENTER_FN static __device__ __attribute__((noinline))
 #else
@@ -50,6 +52,7 @@ SX_ENTER_FN void SX_K(solo_enc_leave)(SxEncWork* w, SxEncStream* rec) {
 #ifndef SX_ANALYSIS_PRIO
 #define SX_ANALYSIS_PRIO 3
 #endif
+#ifndef SX_TU_FRONT
 __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_kernel)(SxEncStream* states, const i16* __restrict__ pcm, int n_streams,
                                                                   int n_packets, int p0, int pc, SxNsqIn* __restrict__ nsq_in,
                                                                   SxCodeIn* __restrict__ code_in) {
@@ -83,6 +86,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_analysis_
 #endif
 }
 
+#endif
 // Entropy coding, LANE per description: lane l of workgroup g codes description (l & 1) of stream 32 g + (l >> 1).  The coder is a
 // serial chain of table look-ups and byte writes; 64 of them advance together.  rcbuf / rcinfo: the launch's scratch, indexed
 // [(stream * pc + (p - p0)) * 2 + md]; hbout: the high band's bytes of the launch before this one on the same HIP stream.
@@ -133,6 +137,7 @@ __device__ __forceinline__ i32 SX_K(sx_rc_code_and_assemble)(const SxFrameIdx* i
     return total;
 }
 
+#ifndef SX_TU_FRONT
 __global__ void __launch_bounds__(64) SX_K(solo_enc_rc_kernel)(const SxEncStream* states, const SxCodeIn* __restrict__ code_in,
                                                                const SxNsqOut* __restrict__ nsq_out, int n_streams, int n_packets, int p0, int pc,
                                                                u8* __restrict__ rcbuf, SxRcInfo* __restrict__ rcinfo, const u8* __restrict__ hbout,
@@ -184,6 +189,7 @@ __global__ void __launch_bounds__(64, SX_ANALYSIS_WAVES) SX_K(solo_enc_coding_ke
     }
 }
 
+#endif
 // ---------------------------------------------------------------------------------------------------------------------------------------
 // The PERSISTENT pipeline's front kernel: one wavefront per stream, ONE launch per call and launch group (mode 0), beside one launch of
 // solo_nsq_persist_kernel (solo_nsq_row.hip).  The wavefront analyses its stream's packets one after the other; after each it publishes
@@ -242,6 +248,7 @@ static __device__ unsigned long long g_sx_front_trace[8192][6];
 static_assert(sizeof(SxEncWork) == SX_FRONT_WORK_BYTES, "SX_FRONT_WORK_BYTES = sizeof(SxEncWork) of the device pass");
 #endif
 #define SX_FRONT_PER_CU (SX_FS_KHZ == 8 ? 16 : 9)       // front wavefronts a compute unit holds beside the quantiser's four (LDS-bound)
+#ifdef SX_TU_FRONT
 // Registers: 96 of a SIMD's 512, like the analysis kernel (the waves-per-SIMD hint of __launch_bounds__).  The work areas are DYNAMIC
 // shared memory on purpose: with 136 KB of static LDS the backend concludes that no more than four wavefronts of this kernel ever share a
 // SIMD and pads the kernel's register allocation up to the largest size that still allows four (97 -> 104 registers in the kernel
@@ -349,6 +356,7 @@ __global__ void __launch_bounds__(64 * SX_FRONT_WAVES, SX_ANALYSIS_WAVES) SX_K(s
     }
 }
 
+#endif
 extern "C" int SX_K(solo_launch_nsq)(void* states, const void* in, void* out, int n_streams, int n_packets, int p0, int pc, unsigned int* started,
                                      void* ring, void* hip_stream);   // solo_nsq_row.hip / solo_nsq_row_wb.hip
 extern "C" int SX_K(solo_launch_nsq_persist)(void* states, const void* in, void* out, int n_streams, int n_packets, unsigned int* started, void* ring,
@@ -360,6 +368,7 @@ extern "C" int SX_K(solo_nsq_workgroups)(int n_streams);
 extern "C" size_t SX_K(solo_nsq_ring_bytes)(int n_streams);
 
 #include "solo_enc_ops.h"
+#ifndef SX_TU_FRONT
 static hipError_t SX_K(solo_enc_launch_init)(void* states, int n_streams, int silk_rate_bps, int useMDIndex, int hb_joint, int useDTX, int fpp, hipStream_t s) {
     hipLaunchKernelGGL(SX_K(solo_enc_init_kernel), dim3(n_streams), dim3(64), 0, s, (SxEncStream*)states, n_streams, silk_rate_bps, useMDIndex, hb_joint, useDTX, fpp);
     return hipGetLastError();
@@ -394,9 +403,11 @@ static hipError_t SX_K(solo_enc_launch_coding)(void* states, const void* code_in
                        (const u8*)SX_K(solo_enc_hbout_of)(rcbuf, n_streams, pc), slot, bits, nbytes, status);
     return hipGetLastError();
 }
+#endif
+#ifdef SX_TU_FRONT
 // persistent pipeline: scratch of the in-wave coder (2 SX_FRONT_RB byte buffers per stream) and the front kernel's launch
-static size_t SX_K(solo_enc_front_scratch_bytes)(int n_streams) { return (size_t)n_streams * (2 * SX_FRONT_RB) * SX_RC_BUF_STRIDE + 128; }
-static hipError_t SX_K(solo_enc_launch_front)(void* states, const int16_t* pcm, int n_streams, int n_packets, void* nsq_in, void* code_in, const void* nsq_out,
+extern "C" size_t SX_K(solo_enc_front_scratch_bytes)(int n_streams) { return (size_t)n_streams * (2 * SX_FRONT_RB) * SX_RC_BUF_STRIDE + 128; }
+extern "C" hipError_t SX_K(solo_enc_launch_front)(void* states, const int16_t* pcm, int n_streams, int n_packets, void* nsq_in, void* code_in, const void* nsq_out,
                                               unsigned int* ana_flag, const unsigned int* nsq_flag, unsigned int* prog, unsigned int ticket0, int mode,
                                               unsigned int final_wait_ticks, int slot, uint8_t* bits, int16_t* nbytes, int32_t* status, void* scratch,
                                               unsigned int* started, hipStream_t s) {
@@ -411,8 +422,16 @@ static hipError_t SX_K(solo_enc_launch_front)(void* states, const int16_t* pcm, 
                        (u8*)scratch, started);
     return hipGetLastError();
 }
+#else
+extern "C" size_t SX_K(solo_enc_front_scratch_bytes)(int n_streams);                                            // solo_enc_front_k.hip
+extern "C" hipError_t SX_K(solo_enc_launch_front)(void* states, const int16_t* pcm, int n_streams, int n_packets, void* nsq_in, void* code_in, const void* nsq_out,
+                                                  unsigned int* ana_flag, const unsigned int* nsq_flag, unsigned int* prog, unsigned int ticket0, int mode,
+                                                  unsigned int final_wait_ticks, int slot, uint8_t* bits, int16_t* nbytes, int32_t* status, void* scratch,
+                                                  unsigned int* started, hipStream_t s);
 static const solo_enc_ops SX_K(solo_enc_ops_table) = {
     sizeof(SxEncStream), sizeof(SxNsqIn), sizeof(SxNsqOut), sizeof(SxCodeIn), SX_PACKET,
     SX_K(solo_enc_launch_init), SX_K(solo_enc_launch_analysis), SX_K(solo_launch_nsq), SX_K(solo_enc_launch_coding), SX_K(solo_enc_rc_scratch_bytes),
     SX_K(solo_nsq_workgroups), SX_K(solo_nsq_ring_bytes), SX_K(solo_enc_launch_front), SX_K(solo_launch_nsq_persist), SX_K(solo_enc_front_scratch_bytes), SX_K(solo_nsq_persist_workgroups), SX_K(solo_nsq_stage_bytes),
     SX_FRONT_WAVES, SX_FRONT_PER_CU};
+
+#endif

@@ -7,5 +7,5 @@ mkdir -p build/var_prof
 F="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-pass-failed -DSOLO_WITH_ENCODER -DSX_PROF"
 for f in solo_api solo_enc_k; do hipcc $F -c solo_amd/csrc/$f.hip -o build/var_prof/$f.o & done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC build/var_prof/solo_api.o build/obj/solo_api_wb.o build/var_prof/solo_enc_k.o build/obj/solo_enc_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_prof.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/var_prof/solo_api.o build/obj/solo_api_wb.o build/var_prof/solo_enc_k.o build/obj/solo_enc_k_wb.o build/obj/solo_enc_front_k.o build/obj/solo_enc_front_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_prof.so
 ls -la build/libsolo_prof.so

@@ -8,5 +8,5 @@ F="--offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-pass-failed -DSOLO_WITH_ENCOD
 hipcc $F -DSX_EXPERIMENTS -DSX_STOPS -c solo_amd/csrc/solo_api.hip -o build/var_stops/solo_api.o &
 hipcc $F -DSX_STOPS "$@" -c solo_amd/csrc/solo_enc_k.hip -o build/var_stops/solo_enc_k.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC build/var_stops/solo_api.o build/obj/solo_api_wb.o build/var_stops/solo_enc_k.o build/obj/solo_enc_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_stops.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/var_stops/solo_api.o build/obj/solo_api_wb.o build/var_stops/solo_enc_k.o build/obj/solo_enc_k_wb.o build/obj/solo_enc_front_k.o build/obj/solo_enc_front_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_stops.so
 ls -la build/libsolo_stops.so

@@ -10,6 +10,6 @@ for f in solo_nsq_row solo_nsq_row_wb; do
   hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-pass-failed -DSOLO_WITH_ENCODER "$@" -c solo_amd/csrc/$f.hip -o build/var_$name/$f.o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC build/obj/solo_api.o build/obj/solo_api_wb.o build/obj/solo_enc_k.o build/obj/solo_enc_k_wb.o build/var_$name/solo_nsq_row.o build/var_$name/solo_nsq_row_wb.o -o build/libsolo_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/obj/solo_api.o build/obj/solo_api_wb.o build/obj/solo_enc_k.o build/obj/solo_enc_k_wb.o build/obj/solo_enc_front_k.o build/obj/solo_enc_front_k_wb.o build/var_$name/solo_nsq_row.o build/var_$name/solo_nsq_row_wb.o -o build/libsolo_$name.so
 echo "$@" > build/libsolo_$name.flags
 ls -la build/libsolo_$name.so

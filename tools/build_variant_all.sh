@@ -5,7 +5,7 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/var_$name
-for f in solo_api solo_api_wb solo_enc_k solo_enc_k_wb solo_nsq_row solo_nsq_row_wb; do
+for f in solo_api solo_api_wb solo_enc_k solo_enc_k_wb solo_enc_front_k solo_enc_front_k_wb solo_nsq_row solo_nsq_row_wb; do
   hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-pass-failed -DSOLO_WITH_ENCODER "$@" -c solo_amd/csrc/$f.hip -o build/var_$name/$f.o &
 done
 wait

@@ -6,10 +6,10 @@ set -e
 cd "$(dirname "$0")/.."
 name=$1; shift
 mkdir -p build/var_$name
-for f in solo_enc_k solo_enc_k_wb; do
+for f in solo_enc_k solo_enc_k_wb solo_enc_front_k solo_enc_front_k_wb; do
   hipcc --offload-arch=gfx950 -O2 -std=c++17 -fPIC -Wno-pass-failed -DSOLO_WITH_ENCODER "$@" -c solo_amd/csrc/$f.hip -o build/var_$name/$f.o &
 done
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC build/obj/solo_api.o build/obj/solo_api_wb.o build/var_$name/solo_enc_k.o build/var_$name/solo_enc_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_$name.so
+hipcc --offload-arch=gfx950 -shared -fPIC build/obj/solo_api.o build/obj/solo_api_wb.o build/var_$name/solo_enc_k.o build/var_$name/solo_enc_k_wb.o build/var_$name/solo_enc_front_k.o build/var_$name/solo_enc_front_k_wb.o build/obj/solo_nsq_row.o build/obj/solo_nsq_row_wb.o -o build/libsolo_$name.so
 echo "$@" > build/libsolo_$name.flags
 ls -la build/libsolo_$name.so
