@@ -15,6 +15,10 @@ __global__ void __launch_bounds__(64) SX_K(solo_dec_init_kernel)(SxDecStream* st
 
 // Decoder: rows D0-D8.  blockIdx.x = stream.
 // state record HBM <-> LDS (whole launch) and the entropy tables
+// ONE work area for all decoder kernels of the build (a file-scope LDS variable): the stage functions are real calls, and a function whose
+// callers all pass the address of the same variable is compiled with that address as a constant -- LDS offsets become immediates.  With a
+// __shared__ variable per kernel the five kernels passed five different variables and the functions they share got a run-time base.
+static __shared__ SxDecWork SX_K(g_sx_dec_work);
 __device__ __forceinline__ void SX_K(solo_dec_enter)(SxDecWork* w, SxDecStream* rec) {
     const i32* src = (const i32*)&rec->st;
     i32* dst = (i32*)&w->st;
@@ -65,7 +69,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_kernel)(SxDecStream* s
                                                          const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                          int n_streams, int n_packets, int slot, int useMDIndex,
                                                          i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
+    SxDecWork& w = SX_K(g_sx_dec_work);
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SX_K(solo_dec_enter)(&w, &states[s]);
@@ -135,7 +139,7 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
                                                             const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                             int n_streams, int n_packets, int p0, int pc, int slot, int useMDIndex,
                                                             const SxExtracted* __restrict__ recs, i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
+    SxDecWork& w = SX_K(g_sx_dec_work);
     const int s = blockIdx.x;
     if (s >= n_streams) return;
 #if defined(SX_STOPS) && defined(__HIP_DEVICE_COMPILE__)
@@ -199,7 +203,7 @@ __device__ __forceinline__ int SX_K(sx_decode_split_packet)(SxDecWork& w, const 
 __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_split_kernel)(SxDecStream* states, const u8* __restrict__ descA, const i16* __restrict__ lenA,
                                                                const u8* __restrict__ descB, const i16* __restrict__ lenB, int n_streams,
                                                                int n_packets, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
+    SxDecWork& w = SX_K(g_sx_dec_work);
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SX_K(solo_dec_enter)(&w, &states[s]);
@@ -246,7 +250,7 @@ __global__ void __launch_bounds__(64) SX_K(solo_recv_reset_kernel)(u32* lens, i3
 // the next n_packets sequence numbers of every stream: merge what has arrived (as the split kernel does), decode, free the entries
 __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_ring_kernel)(SxDecStream* states, const u8* ring, u32* lens, i32* play, int n_streams, int n_packets,
                                                               int depth, int slot, int useMDIndex, i16* __restrict__ pcm, i32* status) {
-    __shared__ SxDecWork w;
+    SxDecWork& w = SX_K(g_sx_dec_work);
     const int s = blockIdx.x;
     if (s >= n_streams) return;
     SX_K(solo_dec_enter)(&w, &states[s]);
@@ -270,9 +274,9 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_decode_ring_kernel)(SxDecStre
 }
 
 // single-packet decode with the reference's raw (ptr, nBytes, lostflag) convention
-__global__ void __launch_bounds__(64) SX_K(solo_decode_raw_kernel)(SxDecStream* st, const u8* bits, int n0, int n1, int lostflag,
+__global__ void __launch_bounds__(64, 4) SX_K(solo_decode_raw_kernel)(SxDecStream* st, const u8* bits, int n0, int n1, int lostflag,
                                                              int useMDIndex, i16* pcm, i32* status) {
-    __shared__ SxDecWork w;
+    SxDecWork& w = SX_K(g_sx_dec_work);
     SX_K(solo_dec_enter)(&w, st);
     int ret = sx_decode_packet(&w, bits, n0, n1, lostflag, useMDIndex, pcm);
     SX_K(solo_dec_leave)(&w, st);

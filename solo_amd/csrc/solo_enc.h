@@ -298,7 +298,9 @@ SX_HD void sx_code_description(const SxFrameIdx* idx2, int Seed0, int Seed1, con
 // high-band frame takes residue0[n] for n < 160, residue1[n - 160] after)
 #define SX_HB_DELAY (5 * SX_FS_KHZ)                 // lb_Delay * hb_KHz: the high band is delayed 5 ms to stay in step with SILK
 #define SX_HB_LPCBLK (10 * SX_FS_KHZ + SX_HB_LPC)   // BWE_LPCFrameSize + BWE_LPCOrder: one 10 ms analysis block with its history
-SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue0, const i32* residue1, SxHbWork* hw, u8* out4, int N) {
+// (N is a template parameter: one instance per frame length -- 160, or 320 with joint_mode 1 -- each with constant loop bounds and divisors)
+template <int N>
+SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* residue0, const i32* residue1, SxHbWork* hw, u8* out4) {
     SX_IN_LDS(hw); SX_IN_LDS(out4);
     i16* xb = hw->x_hb_buf;
     i16* lpc_in = hw->lpc_in;
@@ -320,11 +322,11 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     i32* a_Q16 = hw->lpc.a_Q16;
     i32* NLSF_Q15 = hw->NLSF_Q15;
     SX_S(57)
-    sx_burg_modified(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, SX_HB_LPCBLK, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
+    sx_burg_modified<2>(&res_nrg, &res_nrg_Q, a_Q16, lpc_in, SX_HB_LPCBLK, 4, K_FIND_LPC_COND_FAC_Q32, SX_HB_LPC, &hw->lpc.burg);
     sx_bwexpander_32(a_Q16, SX_HB_LPC, K_FIND_LPC_CHIRP_Q16);
     wv_sync();
     SX_S(58)
-    sx_a2nlsf(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q, &hw->lpc.u.grid);
+    sx_a2nlsf<2>(NLSF_Q15, a_Q16, SX_HB_LPC, hw->lpc.P, hw->lpc.Q, &hw->lpc.u.grid);
     wv_sync();
     SX_S(59)
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
@@ -572,13 +574,13 @@ SX_FNW void sx_enc_stage_c_hb(SxEncStream* rec, SxEncWork* w, const SxCodeIn* ci
     SxEncState* st = &w->st;
     SX_T_BEGIN
     if (st->hb_joint) {
-        sx_hb_encode_frame(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[8 * hb_slot], 2 * SX_FRAME);
+        sx_hb_encode_frame<2 * SX_FRAME>(hist, cin->hi, out2[0].r, out2[1].r, &w->u.hb, &w->hb_bytes[8 * hb_slot]);
         wv_sync();
         SX_T(9)
     } else {
         const int fpp = SX_UNI(st->fpp);
         for (int frame = 0; frame < fpp; frame++) {
-            sx_hb_encode_frame(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[8 * hb_slot + 4 * frame], SX_FRAME);
+            sx_hb_encode_frame<SX_FRAME>(hist, cin->hi + frame * SX_FRAME, out2[frame].r, out2[frame].r, &w->u.hb, &w->hb_bytes[8 * hb_slot + 4 * frame]);
             wv_sync();
             SX_T(9)
         }

@@ -1268,6 +1268,9 @@ struct SxLpcWork {
 // SKP_Silk_burg_modified, SKP_Silk_burg_modified.c:49.  The reference's scalar loops over the coefficient index k are
 // spread over lanes (all its accumulations are wrapping int32 sums of independent terms, so lane order is immaterial):
 // lane (s, k) builds the per-subframe prediction terms, lane k owns row / correlation element k.
+// (SITE: one instance per call site -- a stage function that several sites call with different work areas, lengths and orders is compiled
+// for none of them; an instance with ONE caller gets that caller's constants: LDS addresses as immediates, loop bounds, the filter order)
+template <int SITE = 0>
 SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16* x, int subfr_length, int nb_subfr, i32 WhiteNoiseFrac_Q32,
                             int D, SxBurgWork* bw) {
     SX_IN_LDS(x); SX_IN_LDS(bw); SX_IN_LDS(A_Q16);
@@ -1625,6 +1628,7 @@ SX_HD void sx_a2nlsf_init(const i32* a_Q16, i32* P, i32* Q, int dd) {
 // SKP_Silk_A2NLSF, SKP_Silk_A2NLSF.c:127.  The reference walks the cosine grid evaluating one polynomial per step; here
 // both polynomials are evaluated on the whole grid up front, lane-parallel, and the (inherently serial) root scan reads
 // those values from LDS -- only the three bisection points per root are evaluated on the spot.
+template <int SITE = 0>
 SX_FN void sx_a2nlsf(i32* NLSF, i32* a_Q16, int d, i32* P, i32* Q, SxA2nlsfGrid* g) {
     SX_IN_LDS(NLSF); SX_IN_LDS(a_Q16); SX_IN_LDS(P); SX_IN_LDS(Q); SX_IN_LDS(g);
     d = SX_UNI(d);                           // (an argument of a real call arrives in a vector register: the root scan below is scalar code)
@@ -1830,7 +1834,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
     wv_sync();
     SX_T_BEGIN
     if (useInterp == 1) {
-        sx_burg_modified(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
+        sx_burg_modified<1>(&res_tmp_nrg, &res_tmp_nrg_Q, a_tmp_Q16, x + 2 * subfr_length, subfr_length, 2, K_FIND_LPC_COND_FAC_Q32, order, &lw->burg);
         sx_bwexpander_32(a_tmp_Q16, order, K_FIND_LPC_CHIRP_Q16);
         wv_sync();
         SX_T(22)
@@ -1841,7 +1845,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
             res_nrg = (res_nrg >> (-shift)) - res_tmp_nrg;
             res_nrg_Q = res_tmp_nrg_Q;
         }
-        sx_a2nlsf(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q, &lw->u.grid);
+        sx_a2nlsf<1>(NLSF_Q15, a_tmp_Q16, order, lw->P, lw->Q, &lw->u.grid);
         wv_sync();
         SX_T(21)
         // the four interpolation candidates (SKP_Silk_find_LPC_FIX.c:81-140) are evaluated side by side: candidate k on lane k
