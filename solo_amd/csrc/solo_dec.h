@@ -544,16 +544,25 @@ SX_FN void sx_decode_parameters(int nFramesDecoded, int first_frame_after_reset,
 }
 
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
-// All-pole recursion with ONE TAP PER LANE (see sx_decode_core): lane j of every 16-lane row holds the output of time t - 1 - j (hj)
-// and coefficient j, pre-shifted (aj; zero past the order).  step(i, p) turns the prediction p of sample i into the filter value v
-// (and stores whatever the caller wants of it); the new state sample is v << 4, saturating if SAT.  Returns the lane's final history.
+// All-pole recursion with ONE TAP PER LANE, in its transposed form (see sx_decode_core): lane j of every 16-lane row holds coefficient j,
+// pre-shifted (aj; zero past the order), and the partial sum r_j = sum over m of a_(j+m) h[t - m], seeded from the history the caller
+// hands over (hj = the output of time t0 - 1 - j).  step(i, p) turns the prediction p = r_0 of sample i into the filter value v (and
+// stores whatever the caller wants of it); the new state sample is v << 4, saturating if SAT.  Returns the lane's final history (the
+// output of time t_end - j): kept beside the sums by a one-lane shift of the row per sample.
+#define SX_IIR_SEED_(m_) r = sx_add(r, sx_smulw_pre(__builtin_amdgcn_update_dpp(0, hj, 0x150 + (m_), 0xF, 0xF, false), \
+                                                   (m_) == 0 ? aj : __builtin_amdgcn_update_dpp(0, aj, 0x100 + ((m_) == 0 ? 1 : (m_)), 0xF, 0xF, true)));
+#define SX_IIR_SEED(r, hj, aj) { SX_IIR_SEED_(0) SX_IIR_SEED_(1) SX_IIR_SEED_(2) SX_IIR_SEED_(3) SX_IIR_SEED_(4) SX_IIR_SEED_(5) SX_IIR_SEED_(6) SX_IIR_SEED_(7) \
+                                 SX_IIR_SEED_(8) SX_IIR_SEED_(9) SX_IIR_SEED_(10) SX_IIR_SEED_(11) SX_IIR_SEED_(12) SX_IIR_SEED_(13) SX_IIR_SEED_(14) SX_IIR_SEED_(15) }
 template <bool SAT, typename F>
 __device__ __forceinline__ i32 sx_iir_rows(i32 hj, const i32 aj, int n, F step) {
     const int j = SX_LANE & 15;
+    i32 r = 0;
+    SX_IIR_SEED(r, hj, aj)
     for (int i = 0; i < n; i++) {
-        const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
+        const i32 p = __builtin_amdgcn_update_dpp(0, r, 0x150, 0xF, 0xF, false);            // row_newbcast:0
         const i32 v = step(i, p);
         const i32 hn = SAT ? sx_lshift_sat32(v, 4) : sx_shl(v, 4);
+        r = sx_add(sx_smulw_pre(hn, aj), __builtin_amdgcn_update_dpp(0, r, 0x101, 0xF, 0xF, true));   // row_shl:1, zero into the row's last lane
         const i32 sh = __builtin_amdgcn_update_dpp(0, hj, 0x111, 0xF, 0xF, true);          // row_shr:1
         hj = j == 0 ? hn : sh;
     }
@@ -658,10 +667,15 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
             const i32 hbGain_Q16 = sx_mul(-2867, (i32)hp->gain[hf][hk]);
             i16* hb_out = &w->hi_out[hp->frame * SX_FRAME + k * SX_SUBFR];
 #if defined(__HIP_DEVICE_COMPILE__) && SX_NLANES == 64
-            // GPU form: ONE TAP PER LANE.  Lane (row, j) of the wavefront holds coefficient j and the output of time t - 1 - j of the
-            // row's filter: row 1 = the high band's, every other row a copy of the low band's.  A sample is then one high-word
-            // multiply, a sum over the 16-lane row (four DPP adds; the 32-bit sums wrap, so the order is free), the role's output
-            // arithmetic, and a one-lane shift of the row (DPP row_shr:1) -- instead of SX_LPC multiply-adds per filter in every lane.
+            // GPU form: the TRANSPOSED recursion, one tap per lane.  Lane (row, j) of the wavefront holds coefficient a_j of the row's filter
+            // (row 1 = the high band's, every other row a copy of the low band's) and the partial sum
+            //     r_j[t] = sum over m >= 0 of a_(j+m) h[t - m]            (h: the filter's outputs, scaled; wrapping 32-bit sums)
+            // which obeys  r_j[t] = a_j h[t] + r_(j+1)[t - 1]  and whose lane 0 IS the prediction of the next sample, p[t + 1] = r_0[t].
+            // A sample is then: lane 0's sum to the row (one DPP row broadcast), the role's output arithmetic, ONE high-word multiply
+            // and ONE add that takes the neighbour's sum (DPP row_shl:1) -- ~11 instructions.  (Until round 6 lane j held the output of time
+            // t - 1 - j and every sample summed sixteen products across the row: a multiply, four dependent DPP adds with their wait states,
+            // a one-lane shift of the row: ~18 instructions.  The products are the same sixteen, each rounded on its own; only the order of
+            // the wrapping additions differs.)
             {
                 const int row = SX_LANE >> 4, j = SX_LANE & 15;
                 const bool hbl = piggy && row == 1;
@@ -670,7 +684,11 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 const i32 hl = w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j];                    // (all 16 lanes carry true history; taps past the order meet zeros)
                 const i32 hh = j < SX_HB_LPC ? hp->S[SX_HB_LPC - 1 - (j < SX_HB_LPC ? j : 0)] : 0;
                 const i32 aj = hbl ? ah : al;
-                i32 hj = hbl ? hh : hl;
+                const i32 hj = hbl ? hh : hl;                                            // h[t0 - 1 - j]
+                // the sums the subframe starts from: r_j = sum over m of a_(j+m) h[t0 - 1 - m] -- lane m's history to the row, lane j + m's
+                // coefficient to lane j (zero past the row's end)
+                i32 r = 0;
+                SX_IIR_SEED(r, hj, aj)
                 // What a sample step does NOT need stays outside the recursion: the high band's excitation is scaled for the whole
                 // subframe beforehand (xs: the tail of sLPC_Q14, which only the other builds use), the filter values v are left
                 // where their inputs were (the low band's residual, xs), and gain / rounding / saturation of both bands' outputs
@@ -684,11 +702,11 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                 i32 clo = hbl ? (SX_I32_MIN >> 4) : SX_I32_MIN, chi = hbl ? (SX_I32_MAX >> 4) : SX_I32_MAX;   // lshift_sat32(v, 4) = clamp, then shift
                 SX_VEC(clo); SX_VEC(chi);
                 for (int i = 0; i < SX_SUBFR; i++) {
-                    const i32 p = wv_row_sum(sx_smulw_pre(hj, aj));
+                    const i32 p = __builtin_amdgcn_update_dpp(0, r, 0x150, 0xF, 0xF, false);       // row_newbcast:0: r_0 = the prediction of this sample
                     const i32 x = io[i];
                     const i32 v = hbl ? sx_add_sat32(p, x) : sx_add(x, p);
                     const i32 hn = sx_shl(sx_max(sx_min(v, chi), clo), 4);
-                    hj = __builtin_amdgcn_update_dpp(hn, hj, 0x111, 0xF, 0xF, false);              // row_shr:1: lane j takes lane j - 1, lane 0 the new sample
+                    r = sx_add(sx_smulw_pre(hn, aj), __builtin_amdgcn_update_dpp(0, r, 0x101, 0xF, 0xF, true));   // r_j = a_j h[t] + r_(j+1); the row's last lane takes 0
                     io[i] = v;
                 }
                 wv_sync();
@@ -698,9 +716,12 @@ SX_FN void sx_decode_core(SxDecState* st, SxDecWork* w, i16* xq) {
                     const i32 o = hb ? xs[i] : sx_smulww(pres_Q10[i], Gain_Q16);
                     (hb ? hb_out : pxq)[i] = (i16)sx_sat16(sx_rshift_round(o, 10));
                 }
+                // the last SX_MAX_LPC outputs, as the state's history (the next subframe starts from them): from the values just left in io
+                static_assert(SX_SUBFR >= SX_MAX_LPC, "a subframe holds the whole history");
+                const i32 hlast = sx_shl(sx_max(sx_min(io[SX_SUBFR - 1 - j], chi), clo), 4);
                 wv_sync();
-                if (row == 0) w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j] = hj;                // the last SX_MAX_LPC outputs: the next subframe starts from them
-                if (hbl && j < SX_HB_LPC) w->hbp.S[SX_HB_LPC - 1 - j] = hj;
+                if (row == 0) w->u.syn.sLPC_Q14[SX_MAX_LPC - 1 - j] = hlast;
+                if (hbl && j < SX_HB_LPC) w->hbp.S[SX_HB_LPC - 1 - j] = hlast;
             }
 #else
 #if SX_NLANES == 1
