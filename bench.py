@@ -673,7 +673,6 @@ def _squeeze(o, depth=0):
 
 def compact_line(res):
     r = _squeeze(res)
-    r.pop("launches_per_step", None)              # (each entry of `kernels` carries its own)
     if isinstance(r.get("parity"), dict):
         r["third_step_pipelined_checked"] = r["parity"].get("third_step_pipelined_checked")
         ranks = r["parity"].get("ranks") or []
