@@ -573,10 +573,9 @@ SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pit
     i32 Tilt_Q16;
     if (c->sigtype == 0) {
         i32 fs_kHz_inv = K_0p2_Q14 / SX_FS_KHZ;
-        for (int k = 0; k < SX_NB_SUBFR; k++) {
+        SX_PAR(k, SX_NB_SUBFR) {                     // (one division per subframe: side by side)
             i32 b_Q14 = fs_kHz_inv + K_3p0_Q14 / c->pitchL[k];
-            c->LF_shp_Q14[k] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, b_Q14), 16);
-            c->LF_shp_Q14[k] |= (i32)(u16)(b_Q14 - K_1p0_Q14);
+            c->LF_shp_Q14[k] = sx_shl(K_1p0_Q14 - b_Q14 - sx_smulwb(strength_Q16, b_Q14), 16) | (i32)(u16)(b_Q14 - K_1p0_Q14);
         }
         Tilt_Q16 = -K_HP_NOISE_COEF_Q16 - sx_smulwb(K_1p0_Q16 - K_HP_NOISE_COEF_Q16, sx_smulwb(K_HARM_HP_NOISE_COEF_Q24, st->speech_activity_Q8));
     } else {
@@ -1347,10 +1346,14 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
         // totals with three lane swaps (a transposing reduction) instead of two swaps each into every row.
         const bool upper = row >= 2;
         i32 Af_k = 0, P_k = upper ? (k == 0 ? CA0 : 0) : bw->Cf[k], Q_k = P_k;
-        const bool hi = rshifts > -2;
         // element index of step (c)'s gather, gidx_a + (n & gidx_n): rows 0, 1: n - k - 1; row 2: n - k; row 3: k + 1
         const int gidx_a = row < 2 ? -k - 1 : (row == 2 ? -k : k + 1), gidx_n = row < 3 ? -1 : 0;
 #define SX_GATHER(v, idx) __shfl((v), rowbase | ((idx) & 15), 64)
+        // (the recursion exists twice, once per scaling regime of the input -- `hi` = rshifts > -2, the usual one -- so that the regime is
+        // a compile-time constant inside the loop: a wave-uniform condition nested in the per-column conditions below is otherwise
+        // carried as an execution mask through every step)
+        auto recursion = [&](auto regime) {
+        constexpr bool hi = decltype(regime)::value;
         for (int n = 0; n < D; n++) {
             // (a) forward / backward prediction errors at the two edges of subframe `row`
             i32 a = 0, b = 0;
@@ -1444,6 +1447,8 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
                 if (k == n) Af_k = rc_Q31 >> (31 - QA);
             }
         }
+        };
+        if (rshifts > -2) recursion(SxConst<bool, true>{}); else recursion(SxConst<bool, false>{});
 #undef SX_GATHER
         SX_T(25)
         // residual energy and output
@@ -2372,14 +2377,13 @@ SX_FN1 void sx_find_pred_coefs(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     i32 *invGains_Q16 = w->invGains_Q16, *local_gains = w->local_gains, *Wght_Q15 = w->Wght_Q15;
     i32* NLSF_Q15 = w->NLSF_Q15;
     SX_T_BEGIN
-    i32 min_gain_Q16 = SX_I32_MAX >> 6;
-    for (int i = 0; i < 4; i++) min_gain_Q16 = sx_min(min_gain_Q16, c->Gains_Q16[i]);
-    for (int i = 0; i < 4; i++) {
-        invGains_Q16[i] = sx_div32_varQ(min_gain_Q16, c->Gains_Q16[i], 16 - 2);
-        invGains_Q16[i] = sx_max(invGains_Q16[i], 363);
-        i32 tmp = sx_smulwb(invGains_Q16[i], invGains_Q16[i]);
-        Wght_Q15[i] = tmp >> 1;
-        local_gains[i] = (1 << 16) / invGains_Q16[i];
+    SX_PAR(i, 4) {                               // (the four subframes side by side: two divisions each)
+        i32 min_gain_Q16 = SX_I32_MAX >> 6;
+        for (int k = 0; k < 4; k++) min_gain_Q16 = sx_min(min_gain_Q16, c->Gains_Q16[k]);
+        const i32 inv = sx_max(sx_div32_varQ(min_gain_Q16, c->Gains_Q16[i], 16 - 2), 363);
+        invGains_Q16[i] = inv;
+        Wght_Q15[i] = sx_smulwb(inv, inv) >> 1;
+        local_gains[i] = (1 << 16) / inv;
     }
     wv_sync();
     SX_STRETCH_DENSE();
@@ -2438,8 +2442,10 @@ SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditiona
     }
     inv_gain_Q16 += 32767;
     *DeltaGains_Q16 = sx_inverse32_varQ(sx_max(inv_gain_Q16, 1), 32);
+    // the logarithms of the four gains and the four quantised gains side by side; the index chain between them is the serial part
+    SX_PAR(k, SX_NB_SUBFR) ind[k] = sx_smulwb(SCALE_Q16, sx_lin2log(gain_Q16[k]) - OFFSET);
+    wv_sync();
     for (int k = 0; k < SX_NB_SUBFR; k++) {
-        ind[k] = sx_smulwb(SCALE_Q16, sx_lin2log(gain_Q16[k]) - OFFSET);
         if (ind[k] < *prev_ind) ind[k]++;
         if (k == 0 && conditional == 0) {
             ind[k] = sx_limit(ind[k], 0, 63);
@@ -2450,20 +2456,22 @@ SX_HD void sx_gains_quant(i32* ind, i32* gain_Q16, i32* prev_ind, int conditiona
             *prev_ind += ind[k];
             ind[k] -= -4;
         }
-        gain_Q16[k] = sx_log2lin(sx_min(sx_smulwb(INV_SCALE_Q16, *prev_ind) + OFFSET, 3967));
+        gain_Q16[k] = *prev_ind;
     }
+    wv_sync();
+    SX_PAR(k, SX_NB_SUBFR) gain_Q16[k] = sx_log2lin(sx_min(sx_smulwb(INV_SCALE_Q16, gain_Q16[k]) + OFFSET, 3967));
+    wv_sync();
 }
 
 // SKP_Silk_process_gains_FIX, SKP_Silk_process_gains_FIX.c:32
 SX_FN1 void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
     SX_IN_LDS(st); SX_IN_LDS(c);
     st = SX_VPTR(st); c = SX_VPTR(c);            // wave-uniform scalar stage: on the vector unit (SX_VPTR)
-    if (c->sigtype == 0) {
-        i32 s_Q16 = -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4));
-        for (int k = 0; k < 4; k++) c->Gains_Q16[k] = sx_smlawb(c->Gains_Q16[k], c->Gains_Q16[k], s_Q16);
-    }
+    const bool voiced = c->sigtype == 0;
+    const i32 s_Q16 = voiced ? -sx_sigm_Q15(sx_rshift_round(c->LTPredCodGain_Q7 - K_12p0_Q7, 4)) : 0;
     i32 InvMaxSqrVal_Q16 = sx_log2lin(sx_smulwb(K_70p0_Q7 - c->current_SNR_dB_Q7, K_0p33_Q16)) / SX_SUBFR;
-    for (int k = 0; k < 4; k++) {
+    SX_PAR(k, 4) {                               // (the four subframes side by side)
+        if (voiced) c->Gains_Q16[k] = sx_smlawb(c->Gains_Q16[k], c->Gains_Q16[k], s_Q16);
         i32 ResNrg = c->ResNrg[k];
         i32 ResNrgPart = sx_smulww(ResNrg, InvMaxSqrVal_Q16);
         if (c->ResNrgQ[k] > 0) {
@@ -2484,6 +2492,7 @@ SX_FN1 void sx_process_gains(SxEncState* st, SxEncCtrl* c) {
             c->Gains_Q16[k] = sx_lshift_sat32(gain, 16);
         }
     }
+    wv_sync();
     // MD delta gain: float / double island (process_gains_FIX.c:90-92)
     float tmp_float = sx_fdiv(1.0f, c->md_delta_gain_par);
     tmp_float = tmp_float * 65536.0f;

@@ -1009,6 +1009,23 @@ SX_FN1 int sx_pitch_analysis_core(const i16* signal, i32* pitch_out, i32* lagInd
 #endif
 }
 
+#ifdef SX_LANE_STREAM
+// steps K .. ORDER - 1 of SKP_Silk_k2a (SKP_Silk_k2a.c:40) on a coefficient vector held one element per lane of a 16-lane row
+template <int K, int ORDER>
+SX_HD void sx_row_k2a_steps(i32& A, i32 rcv, int j) {
+    if constexpr (K < ORDER) {
+        const i32 rck = SX_RDLANE(rcv, K);
+        if constexpr (K > 0) {
+            const i32 m = SX_DPP_(A, 0x140);                         // row_mirror: element 15 - j
+            const i32 g = SX_DPP_(m, 0x100 + (16 - K));              // row_shl 16 - K: element K - 1 - j (lanes j < K)
+            if (j < K) A = sx_smlawb(A, sx_shl(g, 1), rck);
+        }
+        if (j == K) A = sx_neg(sx_shl(rck, 9));
+        sx_row_k2a_steps<K + 1, ORDER>(A, rcv, j);
+    }
+}
+#endif
+
 // SKP_Silk_find_pitch_lags_FIX, SKP_Silk_find_pitch_lags_FIX.c:32.  x = x_buf + frame_length.
 // res: 336 samples (LDS).  Wsig: 192 samples scratch.
 SX_FN1 void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i16* res, i16* Wsig, SxPitchWork* pw) {
@@ -1021,6 +1038,80 @@ SX_FN1 void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     SX_PAR(i, SX_PITCH_LPC_WIN - 2 * SX_LA_PITCH) Wsig[SX_LA_PITCH + i] = x_ptr[SX_LA_PITCH + i];
     sx_apply_sine_window(Wsig + SX_PITCH_LPC_WIN - SX_LA_PITCH, x_ptr + SX_PITCH_LPC_WIN - SX_LA_PITCH, 2, SX_LA_PITCH);
     wv_sync();
+#if defined(SX_LANE_STREAM) && SX_PITCH_LPC_ORDER <= 15
+    // Autocorrelation, Schur recursion, step-up and bandwidth expansion with one vector element per lane of a 16-lane row (the four rows
+    // hold copies after the autocorrelation): lane (chunk, lag) sums a quarter of the window's products for its lag exactly, in 64 bits
+    // -- the reference's wrapping 32-bit sums (autocorr.c:58) are the low words of the exact ones --, the order-n inner loops of
+    // SKP_Silk_schur / SKP_Silk_k2a are one step each, the quotient of a Schur step is computed once per wave.
+    {
+        constexpr int ORD = SX_PITCH_LPC_ORDER, CH = SX_PITCH_LPC_WIN / 4;
+        static_assert(SX_PITCH_LPC_WIN % 4 == 0 && CH > ORD && sizeof(pw->tmp32) >= 2 * 64 * sizeof(i32), "chunks of the pitch LPC window");
+        i32 *part_lo = pw->tmp32, *part_hi = pw->tmp32 + 64;
+        const int j = SX_LANE & 15, cch = SX_LANE >> 4;
+        {
+            i64 acc = 0;
+            if (j <= ORD) {
+                const i16 *xa = Wsig + cch * CH, *xb = xa + j;
+                const int len = cch == 3 ? CH - j : CH;          // the lag's products end with the window
+#pragma unroll 8
+                for (int u = 0; u < CH - ORD; u++) acc += (i64)((i32)xa[u] * (i32)xb[u]);
+                for (int u = CH - ORD; u < CH; u++) {            // (past the window: a factor of zero; the read stays inside the work area)
+                    const i32 bv = (i32)xb[u];
+                    acc += (i64)((i32)xa[u] * (u < len ? bv : 0));
+                }
+            }
+            part_lo[SX_LANE] = (i32)acc;
+            part_hi[SX_LANE] = (i32)(acc >> 32);
+        }
+        wv_sync();
+        i64 S = 0;
+        for (int r = 0; r < 4; r++) S += (i64)(((u64)(u32)part_hi[16 * r + j] << 32) | (u64)(u32)part_lo[16 * r + j]);
+        wv_sync();
+        const i64 corr64 = (i64)(((u64)(u32)SX_RDLANE((i32)(S >> 32), 0) << 32) | (u64)(u32)SX_RDLANE((i32)S, 0)) + 1;
+        const int nRightShifts = 35 - sx_clz64(corr64);
+        if (j == 0) S = corr64;
+        i32 cj = nRightShifts <= 0 ? sx_shl((i32)S, -nRightShifts) : (i32)(S >> nRightShifts);
+        if (j > ORD) cj = 0;
+        if (j == 0) cj = sx_smlawb(cj, cj, K_FIND_PITCH_WHITE_NOISE_FRACTION_Q16);
+        const i32 c0 = SX_RDLANE(cj, 0);
+        // SKP_Silk_schur: lane n keeps C[n][1] and, at step k, C[n + k + 1][0]
+        {
+            const int lz = sx_clz32(c0);
+            if (lz < 2) cj = cj >> 1;
+            else if (lz > 2) cj = sx_shl(cj, lz - 2);
+        }
+        i32 C1 = cj, D = SX_ROW_NEXT(cj), rcv = 0;
+#pragma unroll
+        for (int k = 0; k < ORD; k++) {
+            const i32 b0 = SX_RDLANE(D, 0), c01 = SX_RDLANE(C1, 0);
+            const i32 rc = sx_sat16(sx_neg(b0 / sx_max(c01 >> 15, 1)));
+            if (j == k) rcv = rc;
+            const bool in = j < ORD - k;
+            const i32 Dn = in ? sx_smlawb(D, sx_shl(C1, 1), rc) : D;
+            if (in) C1 = sx_smlawb(C1, sx_shl(D, 1), rc);
+            D = SX_ROW_NEXT(Dn);
+        }
+        const i32 res_nrg = SX_RDLANE(C1, 0);
+        c->predGain_Q16 = sx_div32_varQ(c0, sx_max(res_nrg, 1), 16);
+        // SKP_Silk_k2a: A[n] += (A[k - 1 - n] << 1) * rc[k] for n < k -- the reversed row is the mirrored row shifted by 16 - k lanes
+        i32 A = 0;
+        sx_row_k2a_steps<0, ORD>(A, rcv, j);
+        // Q12, SKP_Silk_bwexpander: coefficient j is scaled by the chirp factor after j of its updates
+        i32 a = sx_sat16(A >> 12);
+        {
+            i32 chirp_Q16 = K_FIND_PITCH_BANDWITH_EXPANSION_Q16, mine = chirp_Q16;
+            const i32 chirp_minus_one_Q16 = chirp_Q16 - 65536;
+            for (int i = 1; i < ORD; i++) {
+                chirp_Q16 = sx_add(chirp_Q16, sx_rshift_round(sx_mul(chirp_Q16, chirp_minus_one_Q16), 16));
+                if (j == i) mine = chirp_Q16;
+            }
+            a = (i16)sx_rshift_round(sx_mul(mine, a), 16);
+        }
+#pragma unroll
+        for (int d = 0; d < ORD; d++) A_Q12[d] = (i16)SX_RDLANE(a, d);
+        (void)auto_corr; (void)A_Q24; (void)rc_Q15; (void)scale;
+    }
+#else
     sx_autocorr(auto_corr, &scale, Wsig, SX_PITCH_LPC_WIN, SX_PITCH_LPC_ORDER + 1);
     auto_corr[0] = sx_smlawb(auto_corr[0], auto_corr[0], K_FIND_PITCH_WHITE_NOISE_FRACTION_Q16);
     i32 res_nrg = sx_schur(rc_Q15, auto_corr, SX_PITCH_LPC_ORDER);
@@ -1028,6 +1119,7 @@ SX_FN1 void sx_find_pitch_lags(SxEncState* st, SxEncCtrl* c, const i16* x_buf, i
     sx_k2a(A_Q24, rc_Q15, SX_PITCH_LPC_ORDER);
     for (int i = 0; i < SX_PITCH_LPC_ORDER; i++) A_Q12[i] = (i16)sx_sat16(A_Q24[i] >> 12);
     sx_bwexpander(A_Q12, SX_PITCH_LPC_ORDER, K_FIND_PITCH_BANDWITH_EXPANSION_Q16);
+#endif
     // MA_Prediction with zero state over the whole buffer (SKP_Silk_MA.c:40), FIR form, then zero the first `order` outputs
     SX_PAR(k, buf_len) {
         i32 acc = 0;

@@ -195,6 +195,10 @@ SX_HD void wv_argmax(i32* v, i32* idx) {
 #define SX_UNI(x) ((i32)(x))
 #endif
 
+// a value as a type: argument of a generic lambda whose body is compiled once per value (a loop specialised on a wave-uniform regime)
+template <typename T, T V>
+struct SxConst { static constexpr T value = V; };
+
 // SX_VPTR(p): the same pointer, but opaque to the compiler's uniformity analysis (an offset of zero that lives in a vector
 // register).  Wave-uniform straight-line arithmetic on values loaded through it is emitted for the VECTOR unit instead of the
 // scalar unit: one wave pays one issue slot per instruction either way, but the scalar unit takes one instruction per four cycles
