@@ -135,6 +135,22 @@ __global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_
     sx_extract_desc(pkt + off, len, useMDIndex, (const SxCdf*)&w.cdf, &w.lane[threadIdx.x], rec, sel, hb_off >= 0 ? pkt + hb_off : 0, hb_joint);
 }
 
+#if !defined(SX_DEC_NO_PREFETCH) && defined(__HIP_DEVICE_COMPILE__)
+// The records of a packet (2 x sizeof(SxExtracted), written by the extraction kernel: 0.45 GB per 4096 streams x 50 packets, so they
+// come from HBM) are read in several dependent batches while the packet is decoded.  The wavefront therefore touches every 128-byte
+// line of the NEXT packet's records when it starts a packet: one dword per line through the LDS-DMA path (global_load_lds), whose
+// destination is a strip of LDS nobody reads -- no register waits for the data, the loads a packet later find their lines in L2
+// (5.43 -> 5.30 ms per 4096 x 50 packets; profiles/r06_decoder_prefetch.txt).
+#define SX_PF_LINES ((int)((2 * sizeof(SxExtracted) + 127 + 127) / 128))
+static_assert(SX_PF_LINES <= 64, "one line per lane");
+static __shared__ u32 SX_K(g_sx_dec_pf)[SX_PF_LINES];
+static __device__ __forceinline__ void sx_prefetch_records(const SxExtracted* next2, u32* sink) {
+    const unsigned long long a = (unsigned long long)next2, mine = (a & ~127ull) + (unsigned long long)SX_LANE * 128ull;
+    if (mine < a + 2 * sizeof(SxExtracted))
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)mine, (__attribute__((address_space(3))) void*)sink, 4, 0, 0);
+}
+#endif
+
 __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream* states, const u8* __restrict__ bits,
                                                             const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                             int n_streams, int n_packets, int p0, int pc, int slot, int useMDIndex,
@@ -149,6 +165,9 @@ __global__ void __launch_bounds__(64, 4) SX_K(solo_dec_synth_kernel)(SxDecStream
     i32 first_err = 0;
     for (int p = p0; p < p0 + pc; p++) {
         const size_t pk = (size_t)s * n_packets + p;
+#if !defined(SX_DEC_NO_PREFETCH) && defined(__HIP_DEVICE_COMPILE__)
+        if (p + 1 < p0 + pc) sx_prefetch_records(recs + ((size_t)s * pc + (size_t)(p + 1 - p0)) * 2, SX_K(g_sx_dec_pf));
+#endif
         const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, w.st.hb_joint | (w.st.fpp == 1));
         int ret = sx_decode_packet(&w, bits + pk * (size_t)slot + a.ptr_off, a.a0, a.a1, a.lostflag, useMDIndex, pcm + pk * (size_t)(SX_FRAME * 2 * SX_UNI(w.st.fpp)),
                                    recs + ((size_t)s * pc + (size_t)(p - p0)) * 2);
