@@ -1157,16 +1157,30 @@ SX_HD i32 sx_vq_wmat_ec_one(const i16* in_Q14, const i32* W, const i16* row, i32
 SX_FN1 void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_index, const i32* W_Q18, i32 mu_Q8, i32* rd /* [3][4][40] LDS */,
                               i32* best /* [3][4][2] LDS */) {
     SX_IN_LDS(B_Q14); SX_IN_LDS(cbk_index); SX_IN_LDS(periodicity_index); SX_IN_LDS(W_Q18); SX_IN_LDS(rd); SX_IN_LDS(best);
-    SX_PAR(t, 3 * 4 * 40) {
-        const int k = t / 160, j = (t - k * 160) / 40, e = t % 40;
-        const int L = T_ltp_vq_sizes[k];
-        if (e < L) {
-            const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
-            const i16* cbk = k == 0 ? T_ltp_vq0_Q14 : (k == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
-            rd[t] = sx_vq_wmat_ec_one(&B_Q14[j * 5], &W_Q18[j * 25], &cbk[e * 5], cl[e], mu_Q8);
-        }
+    // (the three codebooks hold 10 + 20 + 40 = 70 entries: the 4 x 70 evaluations are numbered densely, five rounds of the wave)
+    SX_PAR(t, 4 * 70) {
+        const int j = t / 70, r = t - j * 70;
+        const int k = r < 10 ? 0 : (r < 30 ? 1 : 2), e = r - (r < 10 ? 0 : (r < 30 ? 10 : 30));
+        const i16* cl = k == 0 ? T_bits_ltp_gain0_Q6 : (k == 1 ? T_bits_ltp_gain1_Q6 : T_bits_ltp_gain2_Q6);
+        const i16* cbk = k == 0 ? T_ltp_vq0_Q14 : (k == 1 ? T_ltp_vq1_Q14 : T_ltp_vq2_Q14);
+        rd[k * 160 + j * 40 + e] = sx_vq_wmat_ec_one(&B_Q14[j * 5], &W_Q18[j * 25], &cbk[e * 5], cl[e], mu_Q8);
     }
     wv_sync();
+#ifdef SX_LANE_STREAM
+    {   // a (codebook, subframe) pair on the four lanes of a quad, ten entries each; the quad's first minimum by two DPP steps
+        const int kj = SX_LANE >> 2, q = SX_LANE & 3;
+        i32 bv = SX_I32_MAX, bi = 0;
+        if (kj < 12) {
+            const int L = T_ltp_vq_sizes[kj >> 2];
+            for (int e = 10 * q; e < 10 * q + 10; e++) {
+                const i32 v = e < L ? rd[kj * 40 + e] : SX_I32_MAX;
+                if (v < bv) { bv = v; bi = e; }
+            }
+        }
+        SX_ARG_STEP(0xB1, <) SX_ARG_STEP(0x4E, <)
+        if (kj < 12 && q == 0) { best[kj * 2] = bv; best[kj * 2 + 1] = bi; }
+    }
+#else
     SX_PAR(kj, 12) {
         const int k = kj >> 2;
         const int L = T_ltp_vq_sizes[k];
@@ -1178,6 +1192,7 @@ SX_FN1 void sx_quant_LTP_gains(i16* B_Q14, i32* cbk_index, i32* periodicity_inde
         best[kj * 2] = bv;
         best[kj * 2 + 1] = bi;
     }
+#endif
     wv_sync();
     i32 min_rate_dist = SX_I32_MAX;
     int per = 0;

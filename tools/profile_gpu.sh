@@ -27,7 +27,7 @@ for p in $PASSES; do
     scalar) ARGS="--pmc SQ_INST_CYCLES_SALU SQ_INSTS_SALU SQ_INSTS_SMEM SQC_DCACHE_REQ SQC_DCACHE_MISSES SQ_WAVE_CYCLES" ;;
     *) echo "unknown pass $p"; continue ;;
   esac
-  timeout -k 5 240 rocprofv3 $ARGS -d "$OUT/$p" -o r01 --output-format csv -- $CMD > "$OUT/bench_$p.log" 2>&1
+  timeout -k 5 ${PASS_TIMEOUT:-300} rocprofv3 $ARGS -d "$OUT/$p" -o r01 --output-format csv -- $CMD > "$OUT/bench_$p.log" 2>&1
   echo "pass $p: rc=$?"
 done
 grep -h '"metric"' "$OUT/bench_trace.log" 2>/dev/null | tail -1 | cut -c1-300
