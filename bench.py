@@ -650,7 +650,7 @@ def main():
 # What the numbers mean (formulae, where the counters come from, how the CPU sample was taken) is DESIGN.md section 6, not the line.
 _DROP = {"note", "parity_note", "clock_note", "formula", "what", "profile_source", "lane_utilisation_is", "kernels_of_the_stage",
          "worker_cpu_seconds", "host", "whole_node_packets_per_s", "per_gpu_packets_per_s", "source", "from_this_build", "algorithmic_bytes_per_launch",
-         "packets_per_launch", "achieved_GBps"}
+         "packets_per_launch", "achieved_GBps", "traffic_is"}
 _TAIL = ("kernel_source_sha16", "profile_matches_head", "third_step_pipelined_checked", "shader_clock_mhz_under_vector_load", "valu_busy_frac", "parity_checked")
 
 
@@ -662,8 +662,8 @@ def _squeeze(o, depth=0):
                 continue
             if k.endswith("_md5") and isinstance(v, str):
                 v = v[:12]
-            elif k in ("workload", "sample", "build", "schedule", "launch", "traffic_is") and isinstance(v, str) and len(v) > 150:
-                v = v[:147] + "..."
+            elif k in ("workload", "sample", "build", "schedule", "launch", "traffic_is") and isinstance(v, str) and len(v) > 100:
+                v = v[:97] + "..."
             out[k] = _squeeze(v, depth + 1)
         return out
     if isinstance(o, list):
@@ -678,6 +678,9 @@ def compact_line(res):
         ranks = r["parity"].get("ranks") or []
         r["parity"] = {"third_step_pipelined_checked": r["third_step_pipelined_checked"], "blocks_checked": sum(len(x.get("blocks") or []) for x in ranks),
                        "first_block": (ranks[0]["blocks"][0] if ranks and ranks[0].get("blocks") else None)}
+    for kv in (r.get("kernels") or {}).values():      # (the lane utilisation of every kernel is in valu_issue)
+        if isinstance(kv, dict):
+            kv.pop("valu_lane_utilisation", None)
     vi = r.get("valu_issue")
     if isinstance(vi, dict) and vi.get("valu_busy_frac") is not None:
         r["valu_busy_frac"] = vi["valu_busy_frac"]
