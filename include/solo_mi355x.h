@@ -95,11 +95,11 @@ int32_t AGR_Sate_Decoder_Uninit(void *SATEDec_State);
  * Return value: 0 or a negative hipError_t.  solo_batch_encode returns -1 for n_packets >= ~700 000 (16 kHz) / ~350 000 (32 kHz) per
  * call -- split longer (offline) inputs over several calls; state carries over.
  * Device memory a handle holds besides the stream states: encode -- the hand-over records of one call, 4.3 KB per packet of the call
- * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 2208 B per
- * packet of a CHUNK (16 kHz API rate; 2 x sizeof(SxExtracted): solo_api.hip asserts the figure): a call is cut into chunks of
- * min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 2208)) packets but never less than ONE, so one buffer holds max(n_streams x 2208 B, at most
+ * (n_streams x n_packets), and 32 KB of quantiser ring per four streams; decode -- up to two buffers of extraction records, 2216 B per
+ * packet of a CHUNK (16 kHz API rate; 2 x sizeof(SxExtracted) + two entries of the list of slots that carry bytes: solo_api.hip asserts the figure): a call is cut into chunks of
+ * min(64, SOLO_DEC_SCRATCH_CAP / (n_streams x 2216)) packets but never less than ONE, so one buffer holds max(n_streams x 2216 B, at most
  * SOLO_DEC_SCRATCH_CAP bytes) (environment, read when the handle decodes for the first time; default -- also for 0 or an unparsable
- * value -- 1 GiB: 4096 streams x 64 packets are 579 MB, 8192 streams get chunks of 59 packets).
+ * value -- 1 GiB: 4096 streams x 64 packets are 581 MB, 8192 streams get chunks of 59 packets).
  * ---------------------------------------------------------------------------------------------- */
 typedef struct solo_batch solo_batch_t;
 

@@ -352,10 +352,10 @@ void solo_batch_destroy(solo_batch_t* b) {
 // boundary only costs: a synthesis launch reloads and stores 4096 stream states, and its last workgroups run in a thinly populated
 // tail.  Measured (4096 streams x 50 packets): chunks of 24 packets after a first one of 4: 9.0 ms; 6 + 44: 7.7 ms; ONE chunk:
 // 7.4 ms (8192 streams, 30 % description loss: 17.5 / 16.2 / 16.0 ms).  So a call is one chunk up to 64 packets (the extraction
-// records of a chunk are 2208 B per packet: 579 MB for 4096 streams x 64 packets), longer calls are cut into chunks of 64.
+// records of a chunk are 2216 B per packet: 581 MB for 4096 streams x 64 packets), longer calls are cut into chunks of 64.
 #define SOLO_DEC_FIRST_CHUNK 64
 #define SOLO_DEC_CHUNK_DEFAULT 64
-static_assert(2 * sizeof(SxExtracted) == 2208, "include/solo_mi355x.h documents 2208 bytes of extraction records per packet (16 kHz API rate)");
+static_assert(2 * sizeof(SxExtracted) + 8 == 2216, "include/solo_mi355x.h documents 2216 bytes of extraction records (2 x 1104 B + two list entries) per packet (16 kHz API rate)");
 int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t* d_nbytes, const uint8_t* d_recv,
                           int32_t n_packets, int16_t* d_pcm, int32_t* d_status, void* hip_stream) {
     if (!b || !b->have_dec || !d_bits || !d_nbytes || !d_pcm || n_packets <= 0) return -1;
@@ -402,17 +402,17 @@ int32_t solo_batch_decode(solo_batch_t* b, const uint8_t* d_bits, const int16_t*
     // two alternating buffers.  X_c follows X_{c-1} and D_{c-2} (buffer free), D_c follows X_c and D_{c-1}.
     // (a short first chunk -- its extraction has nothing to hide behind -- then long ones: every decoder launch reloads the stream states)
     // packets per chunk: the knob, capped so that ONE buffer of extraction records stays below SOLO_DEC_SCRATCH_CAP bytes (default 1 GiB;
-    // the records are 2208 B per packet at the 16 kHz API rate: 4096 streams x 64 packets = 579 MB, 65536 streams -> 7 packets per chunk).
+    // the records are 2216 B per packet at the 16 kHz API rate: 4096 streams x 64 packets = 581 MB, 65536 streams -> 7 packets per chunk).
     // A handle holds at most two such buffers (calls longer than one chunk); include/solo_mi355x.h states the footprint.
     const size_t rec_bytes = b->wb ? solo_wb_dec_extracted_bytes() : solo_dec_extracted_bytes();
     int cp = n_packets < b->dec_chunk ? n_packets : b->dec_chunk;
-    {   // (floor: one packet per chunk -- a handle with more than cap / 2208 streams holds n_streams x 2208 B per buffer, see the header)
+    {   // (floor: one packet per chunk -- a handle with more than cap / 2216 streams holds n_streams x 2216 B per buffer, see the header)
         const size_t fit = b->dec_scratch_cap / ((size_t)b->n_streams * rec_bytes);
         if ((size_t)cp > fit) cp = fit < 1 ? 1 : (int)fit;
     }
     const int c0 = (n_packets > 2 * b->dec_first && cp > b->dec_first) ? b->dec_first : cp;      // (never larger than the buffers: c0 <= cp)
     const int nchunks = 1 + (n_packets - c0 + cp - 1) / cp;
-    const size_t need = (size_t)b->n_streams * (size_t)cp * rec_bytes;
+    const size_t need = (size_t)b->n_streams * (size_t)cp * rec_bytes + 256;      // (+ the count of the listed description slots)
     if (need > b->parsed_bytes || (nchunks > 1 && !b->parsed_two)) {
         SOLO_CHECK(hipStreamSynchronize(st));
         (void)hipStreamSynchronize(b->sP);

@@ -106,12 +106,53 @@ struct SxExtractWork {
     SxCdfDec cdf;
     SxExtractLane lane[SX_EXTRACT_LANES];
 };
-// recs: [(stream * pc + (p - p0)) * 2 + slot]; one lane per record
+// recs: [(stream * pc + (p - p0)) * 2 + slot]; one lane per record.
+// Which records there is something to read for is decided first (solo_dec_list_kernel): the description slots that carry bytes are
+// numbered densely -- a wavefront's count by ballot, its place in the list by one atomic add --, the others get their `usable = 0` there.
+// The extraction kernel's lane i then takes list entry i: with descriptions lost on the way (BASELINE configs[3]: 30 % of them) the
+// wavefronts of 64 lock-stepped coders are all full and fewer, instead of each running with the lost slots' lanes switched off.
+// (The order of the list depends on the order the wavefronts' atomic adds arrive in; every entry is extracted into its own record
+// whatever lane takes it.)
+static __device__ __forceinline__ bool SX_K(sx_extract_slot)(const SxDecStream* states, const i16* __restrict__ nbytes, const u8* __restrict__ recv, size_t idx, int n_packets,
+                                                            int p0, int pc, int slot, size_t* pk_out, int* hb_joint_out, SxDecArgs* a_out, i32* off, i32* len, int* sel,
+                                                            i32* hb_off) {
+    const int md = (int)(idx & 1);
+    const size_t sp = idx >> 1;
+    const int s = (int)(sp / (size_t)pc), p = p0 + (int)(sp % (size_t)pc);
+    const size_t pk = (size_t)s * n_packets + p;
+    const int hb_joint = states[s].st.hb_joint | (states[s].st.fpp == 1);      // (what matters here: four high-band bytes instead of eight)
+    const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, hb_joint);
+    *pk_out = pk; *hb_joint_out = hb_joint; *a_out = a;
+    *off = 0; *len = 0; *hb_off = -1; *sel = 0;
+    return sx_desc_span(a.lostflag, a.a0, a.a1, hb_joint, md, off, len, sel, hb_off);
+}
+// list: n_streams * pc * 2 entries, count: one word behind them, zeroed before the launch
+__global__ void __launch_bounds__(64) SX_K(solo_dec_list_kernel)(const SxDecStream* states, const i16* __restrict__ nbytes, const u8* __restrict__ recv, int n_streams,
+                                                                int n_packets, int p0, int pc, int slot, SxExtracted* __restrict__ recs, u32* __restrict__ list,
+                                                                u32* __restrict__ count) {
+    const size_t idx = (size_t)blockIdx.x * 64 + threadIdx.x;
+    bool present = false;
+    if (idx < (size_t)n_streams * (size_t)pc * 2) {
+        size_t pk; int hb_joint, sel; SxDecArgs a; i32 off, len, hb_off;
+        present = SX_K(sx_extract_slot)(states, nbytes, recv, idx, n_packets, p0, pc, slot, &pk, &hb_joint, &a, &off, &len, &sel, &hb_off);
+        if (!present) recs[idx].usable = 0;
+    }
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(present);
+    if (m == 0) return;
+    u32 base = 0;
+    if (threadIdx.x == 0) base = atomicAdd(count, (u32)__builtin_popcountll(m));
+    base = (u32)__builtin_amdgcn_readfirstlane((int)base);
+    if (present) list[base + (u32)__builtin_popcountll(m & ((1ull << threadIdx.x) - 1ull))] = (u32)idx;
+}
 __global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_dec_extract_kernel)(const SxDecStream* states, const u8* __restrict__ bits,
                                                                                  const i16* __restrict__ nbytes, const u8* __restrict__ recv,
                                                                                  int n_streams, int n_packets, int p0, int pc, int slot,
-                                                                                 int useMDIndex, SxExtracted* __restrict__ recs) {
+                                                                                 int useMDIndex, SxExtracted* __restrict__ recs, const u32* __restrict__ list,
+                                                                                 const u32* __restrict__ count) {
     __shared__ SxExtractWork w;
+    // (without a list -- the caller passed no reception flags, so nearly every slot carries bytes -- lane i takes slot i)
+    const size_t n_listed = list ? (size_t)*count : (size_t)n_streams * (size_t)pc * 2;
+    if ((size_t)blockIdx.x * SX_EXTRACT_LANES >= n_listed) return;                  // (the grid is sized for "every slot carries bytes")
     {
         SxCdfDec* c = &w.cdf;
 #define X(type, name, n) for (int i = threadIdx.x; i < (n); i += SX_EXTRACT_LANES) c->name[i] = T_##name[i];
@@ -119,18 +160,12 @@ __global__ void __launch_bounds__(SX_EXTRACT_LANES, SX_EXTRACT_WAVES) SX_K(solo_
 #undef X
     }
     __syncthreads();
-    const size_t idx = (size_t)blockIdx.x * SX_EXTRACT_LANES + threadIdx.x;
-    if (idx >= (size_t)n_streams * (size_t)pc * 2) return;
-    const int md = (int)(idx & 1);
-    const size_t sp = idx >> 1;
-    const int s = (int)(sp / (size_t)pc), p = p0 + (int)(sp % (size_t)pc);
-    const size_t pk = (size_t)s * n_packets + p;
-    const int hb_joint = states[s].st.hb_joint | (states[s].st.fpp == 1);      // (what matters here: four high-band bytes instead of eight)
-    const SxDecArgs a = sx_dec_map_record(nbytes[pk * 2 + 0], nbytes[pk * 2 + 1], slot, recv ? (int)recv[pk] : 3, hb_joint);
+    const size_t li = (size_t)blockIdx.x * SX_EXTRACT_LANES + threadIdx.x;
+    if (li >= n_listed) return;
+    const size_t idx = list ? (size_t)list[li] : li;
+    size_t pk; int hb_joint, sel; SxDecArgs a; i32 off, len, hb_off;
     SxExtracted* rec = &recs[idx];
-    i32 off = 0, len = 0, hb_off = -1;
-    int sel = 0;
-    if (!sx_desc_span(a.lostflag, a.a0, a.a1, hb_joint, md, &off, &len, &sel, &hb_off)) { rec->usable = 0; return; }
+    if (!SX_K(sx_extract_slot)(states, nbytes, recv, idx, n_packets, p0, pc, slot, &pk, &hb_joint, &a, &off, &len, &sel, &hb_off)) { rec->usable = 0; return; }
     const u8* pkt = bits + pk * (size_t)slot + a.ptr_off;
     sx_extract_desc(pkt + off, len, useMDIndex, (const SxCdf*)&w.cdf, &w.lane[threadIdx.x], rec, sel, hb_off >= 0 ? pkt + hb_off : 0, hb_joint);
 }
@@ -313,11 +348,21 @@ static inline hipError_t SX_K(solo_dec_launch)(void* states, const uint8_t* bits
                        n_packets, slot, useMDIndex, pcm, status);
     return hipGetLastError();
 }
+// recs: solo_dec_extracted_bytes() x n_streams x pc bytes + 256: the records, behind them the list of the slots that carry bytes and its count
 static inline hipError_t SX_K(solo_dec_launch_extract)(const void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
                                                        int n_packets, int p0, int pc, int slot, int useMDIndex, void* recs, hipStream_t s) {
     const size_t lanes = (size_t)n_streams * (size_t)pc * 2;
+    u32* list = recv ? (u32*)((SxExtracted*)recs + lanes) : (u32*)0;     // (reception flags given: descriptions may be missing)
+    u32* count = list ? list + lanes : (u32*)0;
+    if (list) {
+        hipError_t e = hipMemsetAsync(count, 0, sizeof(u32), s);
+        if (e != hipSuccess) return e;
+        hipLaunchKernelGGL(SX_K(solo_dec_list_kernel), dim3((unsigned)((lanes + 63) / 64)), dim3(64), 0, s, (const SxDecStream*)states, nbytes, recv, n_streams,
+                           n_packets, p0, pc, slot, (SxExtracted*)recs, list, count);
+        if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
     hipLaunchKernelGGL(SX_K(solo_dec_extract_kernel), dim3((unsigned)((lanes + SX_EXTRACT_LANES - 1) / SX_EXTRACT_LANES)), dim3(SX_EXTRACT_LANES), 0, s,
-                       (const SxDecStream*)states, bits, nbytes, recv, n_streams, n_packets, p0, pc, slot, useMDIndex, (SxExtracted*)recs);
+                       (const SxDecStream*)states, bits, nbytes, recv, n_streams, n_packets, p0, pc, slot, useMDIndex, (SxExtracted*)recs, list, count);
     return hipGetLastError();
 }
 static inline hipError_t SX_K(solo_dec_launch_synth)(void* states, const uint8_t* bits, const int16_t* nbytes, const uint8_t* recv, int n_streams,
@@ -327,7 +372,7 @@ static inline hipError_t SX_K(solo_dec_launch_synth)(void* states, const uint8_t
                        n_packets, p0, pc, slot, useMDIndex, (const SxExtracted*)recs, pcm, status);
     return hipGetLastError();
 }
-static inline size_t SX_K(solo_dec_extracted_bytes)() { return 2 * sizeof(SxExtracted); }      // per packet
+static inline size_t SX_K(solo_dec_extracted_bytes)() { return 2 * sizeof(SxExtracted) + 2 * sizeof(u32); }      // per packet: two records, two list entries
 static inline hipError_t SX_K(solo_dec_launch_split)(void* states, const uint8_t* descA, const int16_t* lenA, const uint8_t* descB,
                                                      const int16_t* lenB, int n_streams, int n_packets, int slot, int useMDIndex,
                                                      int16_t* pcm, int32_t* status, hipStream_t s) {
