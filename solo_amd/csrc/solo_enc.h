@@ -396,6 +396,32 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     }
     wv_sync();
     SX_S(62)
+#ifdef SX_LANE_STREAM
+    {   // the four sub-frames side by side, one per 16-lane row: energies by row sums (wrapping adds: the order is free), the 32-entry
+        // gain codebook two entries per lane, the row's first minimum by four DPP steps
+        const int sub = SX_LANE >> 4, jl = SX_LANE & 15;
+        i32 res_nrg0 = 0, res_nrg1 = 0;
+        for (int i = jl; i < sub_len; i += 16) {
+            const int n = sub * sub_len + i;
+            const i32 e = exc[n];
+            res_nrg0 = sx_add(res_nrg0, sx_mul(e, e));
+            i32 tmp = sx_pub_ld(n < SX_FRAME ? &residue0[n] : &residue1[n - SX_FRAME]) >> 10;
+            res_nrg1 = sx_smlabb(res_nrg1, tmp, tmp);
+        }
+        res_nrg0 = sx_sqrt_approx(wv_row_sum(res_nrg0));
+        res_nrg1 = sx_sqrt_approx(wv_row_sum(res_nrg1));
+        const i16 gain = (i16)(sx_shl(res_nrg0 + 1, 4) / (res_nrg1 + 1));
+        i32 bv = SX_I32_MAX, bi = SX_I32_MAX;
+        for (int i = jl; i < 32; i += 16) {
+            i16 tmp = (i16)(gain - T_hb_gain_cb[i]);
+            const i32 dist = sx_smulbb(tmp, tmp);
+            if (dist < bv) { bv = dist; bi = i; }
+        }
+        SX_ARG_STEP(0xB1, <) SX_ARG_STEP(0x4E, <) SX_ARG_STEP(0x141, <) SX_ARG_STEP(0x140, <)
+#pragma unroll
+        for (int r = 0; r < 4; r++) word |= (u32)__builtin_amdgcn_readlane(bi, 16 * r) << (15 - 5 * r);
+    }
+#else
     for (int sub = 0; sub < 4; sub++) {
         i32 res_nrg0 = 0, res_nrg1 = 0;
         SX_PAR(i, sub_len) {
@@ -420,6 +446,7 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
         wv_argmin(&min_dist, &gidx);
         word |= (u32)gidx << (15 - 5 * sub);
     }
+#endif
     SX_S(45)
     out4[0] = (u8)(word >> 24); out4[1] = (u8)(word >> 16); out4[2] = (u8)(word >> 8); out4[3] = (u8)word;
     // slide the buffer: the last 200 samples are the next frame's history
