@@ -444,6 +444,19 @@ SX_HD i32 sx_sigm_Q15(i32 in_Q5) {
 #define SX_ROWG(v, idx) __shfl((v), (SX_LANE & 48) | ((idx) & 15), 64)          // element idx (per lane) of the own row
 #define SX_ROW_NEXT(v) SX_DPP_((v), 0x101)                                      // element j + 1 (row_shl:1; 0 beyond the row)
 
+// SKP_Silk_NLSF_VQ_weights_laroia (sx_nlsf_weights_laroia above) with one division per lane: weight k is the sum of the inverses of the two
+// intervals next to coefficient k, lane k <= D <= 15 of a row divides for the interval below coefficient k (the last one for the interval up to 2^15)
+SX_HD void sx_row_nlsf_weights_laroia(i32* pW_Q6, const i32* pNLSF_Q15, int D, bool row_active) {
+    const int k = SX_LANE & 15;
+    i32 inv = 0;
+    if (row_active && k <= D) {
+        const i32 lo = k > 0 ? pNLSF_Q15[k - 1] : 0, hi = k < D ? pNLSF_Q15[k] : (1 << 15);
+        inv = (1 << 21) / sx_max(hi - lo, 3);
+    }
+    const i32 nx = SX_ROW_NEXT(inv);
+    if (row_active && k < D) pW_Q6[k] = sx_min(inv + nx, 32767);
+}
+
 // SKP_Silk_LPC_inverse_pred_gain_Q24 (SKP_Silk_LPC_inv_pred_gain.c:134 -> :43): a = coefficient j in Q16; returns invGain_Q30 as
 // the reference leaves it (also when it bails out on an unstable filter)
 template <int ORDER>

@@ -330,7 +330,11 @@ SX_FN void sx_hb_encode_frame(SxEncHist* hist, const i16* high, const i32* resid
     wv_sync();
     SX_S(59)
     // AGR_Sate_lsp_quant_highband (AGR_BWE_quant_highband.c:91): 256-entry first stage, weighted 16-entry second stage
-    if (SX_LANE == 0) sx_nlsf_weights_laroia(SX_VPTR(weight), SX_VPTR(NLSF_Q15), SX_HB_LPC);      // (one lane, vector unit: SX_VPTR)
+#ifdef SX_LANE_STREAM
+    sx_row_nlsf_weights_laroia(weight, NLSF_Q15, SX_HB_LPC, SX_LANE < 16);                       // (one division per lane of row 0)
+#else
+    if (SX_LANE == 0) sx_nlsf_weights_laroia(SX_VPTR(weight), SX_VPTR(NLSF_Q15), SX_HB_LPC);
+#endif
     wv_sync();
     int idx1 = 0;
     {

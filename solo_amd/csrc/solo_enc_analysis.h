@@ -2303,7 +2303,14 @@ SX_FN1 void sx_process_NLSFs(SxEncState* st, SxEncCtrl* c, i32* pNLSF_Q15, SxMsv
         SX_PAR(i, SX_LPC) w->NLSF0[i] = st->prev_NLSFq_Q15[i] + (sx_mul(pNLSF_Q15[i] - st->prev_NLSFq_Q15[i], interp_Q2) >> 2);
         wv_sync();
     }
+#if defined(SX_LANE_STREAM) && SX_LPC <= 15
+    {   // (vector v on row v, one division per lane)
+        const int v = SX_LANE >> 4;
+        sx_row_nlsf_weights_laroia(v ? w->W0_Q6 : pNLSFW_Q6, v ? w->NLSF0 : pNLSF_Q15, SX_LPC, v < (doInterpolate ? 2 : 1));
+    }
+#else
     SX_PAR(v, doInterpolate ? 2 : 1) sx_nlsf_weights_laroia(v ? w->W0_Q6 : pNLSFW_Q6, v ? w->NLSF0 : pNLSF_Q15, SX_LPC);
+#endif
     wv_sync();
     if (doInterpolate) {
         const i32 i_sqr_Q15 = sx_shl(sx_smulbb(interp_Q2, interp_Q2), 11);
