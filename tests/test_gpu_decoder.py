@@ -36,6 +36,24 @@ def test_synthetic_goldens_clean_and_lossy(torch_cuda):
     assert np.array_equal(out, z["dec_loss"])
 
 
+def test_listed_and_unlisted_extraction_agree(torch_cuda):
+    """The extraction kernel takes its description slots from a dense list when reception flags are passed (solo_dec_list_kernel) and by
+    position when they are not: all-received flags must give the clean decode, and a mask that leaves a number of slots that is no multiple
+    of 64 (the last wavefront of the list is ragged, some are empty) must give the golden lossy decode stream by stream."""
+    z = np.load(T.GOLDEN + "/synth8x25.npz")
+    N, P = z["recv"].shape
+    out = _gpu_decode(torch_cuda, z["bits"], z["nbytes"], np.full((N, P), 3, np.uint8))
+    assert np.array_equal(out, z["dec_clean"])
+    # five of the eight streams, tiled to 325 streams: 325 x 25 packets with the golden masks
+    reps = 65
+    idx = np.tile(np.arange(5), reps)
+    bits, nb, recv = (np.ascontiguousarray(z[k][idx]) for k in ("bits", "nbytes", "recv"))
+    carried = int(((recv & 1) != 0).sum() + ((recv & 2) != 0).sum())
+    assert carried % 64 != 0
+    out = _gpu_decode(torch_cuda, bits, nb, recv)
+    assert np.array_equal(out, z["dec_loss"][idx])
+
+
 def test_old_buffers_of_both_slots_after_a_record_path_packet(torch_cuda):
     """tests/golden/nb_stale_coder.npz on the GPU (tests/test_emu_decoder.py has the story): the packets before the rejected one equal
     the reference's PCM and the stream's status is the reference's return code, in one call and packet by packet."""
