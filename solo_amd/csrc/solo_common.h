@@ -352,16 +352,18 @@ SX_HD u32 wv_scan_sat(u32 v) {      // inclusive saturating prefix sum over the 
     const u32 off = row == 0 ? 0u : (row == 1 ? r0 : (row == 2 ? s01 : s012));
     return sx_uadd_sat(v, off);
 }
+// (MAXC: pairs per lane the instance is built for -- a caller whose vectors are at most 128 samples long passes 1 and gets a third of the code)
+template <int MAXC = 4>
 SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
     const int start = odd_start ? 1 : 0;
     const int npairs = (len - start) >> 1;
     const int tail = (len - start) & 1;
-    if (npairs > 4 * 64) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); return; }
+    if (npairs > MAXC * 64) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); return; }
     u32 nrg = odd_start ? (u32)sx_smulbb(x[0], x[0]) : 0u;
-    const int C = (npairs + 63) >> 6;
-    u32 P[4];
+    const int C = MAXC == 1 ? 1 : (npairs + 63) >> 6;
+    u32 P[MAXC];
 #pragma unroll
-    for (int j = 0; j < 4; j++) {
+    for (int j = 0; j < MAXC; j++) {
         const int m = SX_LANE * C + j;
         u32 v = 0;
         if (j < C && m < npairs) {
@@ -374,7 +376,7 @@ SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, i
     for (;;) {
         u32 sl = 0;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < MAXC; j++) {
             const int m = SX_LANE * C + j;
             if (m >= cur) sl = sx_uadd_sat(sl, P[j] >> shft);
         }
@@ -387,7 +389,7 @@ SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, i
         if (Lc > 0) base += (u32)__builtin_amdgcn_readlane((i32)pre, Lc - 1);
         bool found = false;
 #pragma unroll
-        for (int j = 0; j < 4; j++) {
+        for (int j = 0; j < MAXC; j++) {
             const int m = Lc * C + j;
             const u32 pj = (u32)__builtin_amdgcn_readlane((i32)P[j], Lc);
             if (!found && j < C && m >= cur) {
@@ -404,6 +406,7 @@ SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, i
     *energy = (i32)nrg;
 }
 #else
+template <int MAXC = 4>
 SX_HD void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
 #endif
 
