@@ -334,6 +334,34 @@ SX_FN void sx_sum_sqr_shift(i32* energy, i32* shift, const i16* x, int len, int 
     *energy = nrg;
 }
 
+// the same with the length known at compile time, inlined at the call site (a lane-serial call inside SX_PAR: the loops unroll)
+template <int LEN>
+SX_HD void sx_sum_sqr_shift_n(i32* energy, i32* shift, const i16* x, int odd_start) {
+    i32 nrg, nrg_tmp;
+    int i, shft = 0;
+    if (odd_start) { nrg = sx_smulbb(x[0], x[0]); i = 1; } else { nrg = 0; i = 0; }
+    constexpr int len = LEN - 1;
+    while (i < len) {
+        nrg = sx_add(nrg, sx_smulbb(x[i], x[i]));
+        nrg = sx_add(nrg, sx_smulbb(x[i + 1], x[i + 1]));
+        i += 2;
+        if (nrg < 0) { nrg = (i32)((u32)nrg >> 2); shft = 2; break; }
+    }
+    for (; i < len; i += 2) {
+        nrg_tmp = sx_smulbb(x[i], x[i]);
+        nrg_tmp = sx_add(nrg_tmp, sx_smulbb(x[i + 1], x[i + 1]));
+        nrg = (i32)((u32)nrg + ((u32)nrg_tmp >> shft));
+        if (nrg < 0) { nrg = (i32)((u32)nrg >> 2); shft += 2; }
+    }
+    if (i == len) {
+        nrg_tmp = sx_smulbb(x[i], x[i]);
+        nrg = (i32)((u32)nrg + ((u32)nrg_tmp >> shft));
+    }
+    if (nrg & 0xC0000000) { nrg = (i32)((u32)nrg >> 2); shft += 2; }
+    *shift = shft;
+    *energy = nrg;
+}
+
 // The same function for wave-uniform callers: all lanes cooperate.  The reference's loop is a state machine (nrg, shift):
 // add the next pair of squares >> shift; when bit 31 gets set, nrg >>= 2 and shift += 2.  Between two such events the
 // accumulation is a plain sum, so each round takes one saturating prefix scan over the remaining pairs (lane l owns C

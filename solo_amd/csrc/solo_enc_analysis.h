@@ -850,7 +850,7 @@ SX_FN1 void sx_prefilter(SxEncState* st, const SxEncCtrl* c, i16* xw, const i16*
 // part 1: energy of x, the right shift of all correlations of the subframe, the main diagonal
 SX_HD int sx_corr_matrix_diag(const i16* x, int L, int order, int head_room, i32* XX, int rshifts_in, int x_odd) {
     i32 energy, rshifts_local;
-    sx_sum_sqr_shift(&energy, &rshifts_local, x, L + order - 1, x_odd);
+    sx_sum_sqr_shift_n<SX_SUBFR + SX_LTP_ORDER - 1>(&energy, &rshifts_local, x, x_odd);      // (L + order - 1 of the one caller, sx_find_LTP)
     int head_room_rshifts = sx_max(head_room - sx_clz32(energy), 0);
     energy = energy >> head_room_rshifts;
     rshifts_local += head_room_rshifts;
@@ -1005,7 +1005,7 @@ SX_FN1 void sx_find_LTP(i16* b_Q14, i32* WLTP, i32* LTPredCodGain_Q7, const i16*
         const i16* r_ptr = res_pitch + mem_offset + k * subfr_length;     // r_first / r_last of the reference address one timeline
         const i16* lag_ptr = r_ptr - (lag[k] + SX_LTP_ORDER / 2);
         i32 rr_shifts, rrk;
-        sx_sum_sqr_shift(&rrk, &rr_shifts, r_ptr, subfr_length, 0);
+        sx_sum_sqr_shift_n<SX_SUBFR>(&rrk, &rr_shifts, r_ptr, 0);
         int LZs = sx_clz32(rrk);
         if (LZs < HEAD) {
             rrk = sx_rshift_round(rrk, HEAD - LZs);
@@ -1912,7 +1912,7 @@ SX_FN1 void sx_find_LPC(i32* NLSF_Q15, i32* interpIndex, const i32* prev_NLSFq_Q
         SX_PAR(kh, 8) {
             const int k = kh >> 1, h = kh & 1;
             i32 e, sh;
-            sx_sum_sqr_shift(&e, &sh, lw->u.it.res[k] + order + h * subfr_length, subfr_length - order, 0);
+            sx_sum_sqr_shift_n<SX_SUBFR>(&e, &sh, lw->u.it.res[k] + order + h * subfr_length, 0);      // (subfr_length - order = SX_SUBFR: the one caller)
             lw->u.it.nrg[k][h] = e;
             lw->u.it.rsh[k][h] = sh;
         }
