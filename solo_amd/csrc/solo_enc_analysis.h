@@ -442,7 +442,7 @@ SX_FN1 void sx_noise_shape_analysis(SxEncState* st, SxEncCtrl* c, const i16* pit
                       "scratch of the sparseness measure");
         SX_PAR(k, 10) {
             i32 e, sh;
-            sx_sum_sqr_shift(&e, &sh, pitch_res + k * nSamples, nSamples, 0);
+            sx_sum_sqr_shift_n<2 * SX_FS_KHZ>(&e, &sh, pitch_res + k * nSamples, 0);
             e += nSamples >> sh;
             lg[k] = sx_lin2log(e);
         }
