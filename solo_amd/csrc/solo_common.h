@@ -381,8 +381,8 @@ SX_HD u32 wv_scan_sat(u32 v) {      // inclusive saturating prefix sum over the 
     return sx_uadd_sat(v, off);
 }
 // (MAXC: pairs per lane the instance is built for -- a caller whose vectors are at most 128 samples long passes 1 and gets a third of the code)
-template <int MAXC = 4>
-SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
+template <int MAXC>
+SX_HD void sx_sum_sqr_shift_wv_inl(i32* energy, i32* shift, const i16* x, int len, int odd_start) {
     const int start = odd_start ? 1 : 0;
     const int npairs = (len - start) >> 1;
     const int tail = (len - start) & 1;
@@ -433,9 +433,14 @@ SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, i
     *shift = shft;
     *energy = (i32)nrg;
 }
+// (a call of its own; short vectors in a loop of the caller: the _inl form)
+template <int MAXC = 4>
+SX_FN void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift_wv_inl<MAXC>(energy, shift, x, len, odd_start); }
 #else
 template <int MAXC = 4>
 SX_HD void sx_sum_sqr_shift_wv(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
+template <int MAXC>
+SX_HD void sx_sum_sqr_shift_wv_inl(i32* energy, i32* shift, const i16* x, int len, int odd_start) { sx_sum_sqr_shift(energy, shift, x, len, odd_start); }
 #endif
 
 // SKP_Silk_LPC_analysis_filter, SKP_Silk_MA.c:70 with a ZERO initial state, as a direct-form FIR:

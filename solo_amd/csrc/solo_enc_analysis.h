@@ -1297,7 +1297,7 @@ SX_FN void sx_burg_modified(i32* res_nrg, i32* res_nrg_Q, i32* A_Q16, const i16*
     SX_T_BEGIN
     // (pairs of samples per lane at this call site: the frame's 4 x (SX_SUBFR + SX_LPC) samples, the high band's 4 x SX_HB_LPCBLK)
     constexpr int PAIRS_PER_LANE = SITE == 2 ? (4 * (10 * SX_FS_KHZ + SX_HB_LPC) / 2 + 63) / 64 : (4 * (SX_SUBFR + SX_MAX_LPC) / 2 + 63) / 64;
-    sx_sum_sqr_shift_wv<PAIRS_PER_LANE>(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
+    sx_sum_sqr_shift_wv_inl<PAIRS_PER_LANE>(&C0, &rshifts, x, nb_subfr * subfr_length, 0);
     C0 = SX_UNI(C0); rshifts = SX_UNI(rshifts);
     SX_T(23)
     if (rshifts > MAX_RSHIFTS) {
@@ -2365,7 +2365,7 @@ SX_FN1 void sx_residual_energy(i32* nrgs, i32* nrgsQ, const i16* x, i16 a_Q12[2]
         for (int j = 0; j < 2; j++) {
             i32 rshift;
             static_assert(SX_SUBFR <= 128, "one pair of samples per lane");
-            sx_sum_sqr_shift_wv<1>(&nrgs[i * 2 + j], &rshift, LPC_res + SX_LPC + j * offset, SX_SUBFR, 0);
+            sx_sum_sqr_shift_wv_inl<1>(&nrgs[i * 2 + j], &rshift, LPC_res + SX_LPC + j * offset, SX_SUBFR, 0);
             nrgsQ[i * 2 + j] = -rshift;
         }
         x_ptr += 2 * offset;
